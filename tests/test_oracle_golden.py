@@ -1,0 +1,79 @@
+"""Pins the CPU oracle (oracle/*.py) to outputs of the real reference scripts.
+
+The expected files under tests/golden/ were produced by tools/make_golden.py, which ran
+/root/reference/scripts/{alignments_augmentation_from_gaf,call}.py in the build container.
+"""
+import collections
+import io
+import json
+import os
+
+import pytest
+
+import augment_oracle
+import call_oracle
+from conftest import CASES, GOLDEN
+
+
+def _flags_to_opts(flags):
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rca", type=int, default=-1)
+    ap.add_argument("--novel", action="store_true")
+    ap.add_argument("--no-annotated", dest="no_annotated", action="store_true")
+    ap.add_argument("--events", nargs="+", default=["ES", "SS", "IR"])
+    ap.add_argument("--isw", type=int, default=5)
+    ap.add_argument("--minintronsize", type=int, default=100)
+    ap.add_argument("--junction", default=None)
+    return vars(ap.parse_args(flags))
+
+
+def check_rows(rows, golden_call):
+    """rows == reference rows as a multiset, allowing only the reference's own
+    hash-seed-dependent alternatives for the non-stable remainder."""
+    mine = collections.Counter(call_oracle.normalise_row(r) for r in rows)
+    stable = collections.Counter(golden_call["stable"])
+    variants = set(golden_call["variants"])
+    assert sum(mine.values()) == golden_call["n_rows"]
+    missing = stable - mine
+    assert not missing, f"rows every reference run prints are missing: {list(missing)[:3]}"
+    extra = mine - stable
+    bad = [r for r in extra if r not in variants]
+    assert not bad, f"rows the reference never prints: {bad[:3]}"
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_augment_oracle_bytes(case):
+    d = os.path.join(GOLDEN, case)
+    out = io.StringIO()
+    a = augment_oracle.augment(f"{d}/in.gaf", f"{d}/in.gfa", out)
+    with open(f"{d}/expected.aug.gfa") as f:
+        expected = f.read()
+    assert out.getvalue() == expected
+    meta = json.load(open(f"{d}/expected.json"))
+    assert a.rejected == meta["rejected"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_call_oracle_rows(case):
+    d = os.path.join(GOLDEN, case)
+    meta = json.load(open(f"{d}/expected.json"))
+    for gc in meta["calls"]:
+        rows = call_oracle.call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", None, **_flags_to_opts(gc["flags"]))
+        check_rows(rows, gc)
+
+
+def test_oracle_crashes_where_reference_crashes():
+    crashes = json.load(open(os.path.join(GOLDEN, "crashes.json")))
+    cd = os.path.join(GOLDEN, "crashes")
+    assert len(crashes) >= 10
+    for c in crashes:
+        if c["stage"] == "augment":
+            with pytest.raises(augment_oracle.ReferenceCrash) as ei:
+                augment_oracle.augment(f"{cd}/{c['name']}.gaf", f"{cd}/{c['name']}.gfa", io.StringIO())
+        else:
+            with pytest.raises(augment_oracle.ReferenceCrash) as ei:
+                call_oracle.call(f"{cd}/{c['call_input']}", f"{cd}/{c['name']}.gtf", None,
+                                 **_flags_to_opts(c["flags"]))
+        if c["name"] != "aug_tilde_first":
+            assert ei.value.kind == c["exception"], (c["name"], ei.value.kind, c["exception"])
