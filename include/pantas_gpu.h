@@ -1,0 +1,114 @@
+/* libpantas_gpu -- C ABI of the MI355X augment+call engine.
+ *
+ * The reference (AlgoLab/pantas) has no in-process plugin interface; its hot path is reached
+ * through two command lines (`pantas augment`, `pantas call`; reference `pantas:114-175`) that
+ * spawn `scripts/alignments_augmentation_from_gaf.py` and `scripts/call.py`.  This header is
+ * the boundary a maintainer would bind (ctypes) to replace the bodies of
+ * those two scripts.  Every entry point names the reference code it stands in for.
+ *
+ * Conventions: plain C types only; every function that can fail returns 0 on success and a
+ * negative status otherwise, with the reason available from pantas_last_error() (thread
+ * local, library-owned).  PANTAS_E_REFERENCE means "the reference script raises a Python
+ * exception on this input" (pantas_last_error_kind() names the exception class); nothing
+ * has then been written to the output descriptor, as in the reference.  One host thread
+ * drives one handle.  The kernels have NO CPU fallback: without a HIP device every
+ * device entry point fails with PANTAS_E_NODEVICE.
+ */
+#ifndef PANTAS_GPU_H
+#define PANTAS_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANTAS_OK 0
+#define PANTAS_E_REFERENCE (-1) /* the reference raises on this input */
+#define PANTAS_E_UNSUPPORTED (-2)
+#define PANTAS_E_NODEVICE (-3)
+#define PANTAS_E_HIP (-4)
+#define PANTAS_E_IO (-5)
+#define PANTAS_E_INTERNAL (-6)
+#define PANTAS_E_ARG (-7)
+
+typedef struct pantas_graph pantas_graph; /* GFA as CSR, host + HBM copy, + run results */
+typedef struct pantas_batch pantas_batch; /* tokenised GAF records resident in HBM */
+
+const char* pantas_last_error(void);
+const char* pantas_last_error_kind(void);
+const char* pantas_version(void);
+int pantas_device_count(void);
+
+/* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
+typedef struct {
+  uint64_t segments;       /* distinct S names (V) */
+  uint64_t link_slots;     /* L lines with both ends known (A) */
+  uint64_t lines, s_lines, l_lines, p_lines;
+  uint64_t text_bytes;
+  uint32_t max_segment_len;
+  uint32_t dense_names;    /* 1: names are canonical decimals in a compact range */
+  double load_seconds;
+} pantas_graph_stats;
+
+/* alignments_augmentation_from_gaf.py:121-126 (first GFA pass) / call.py:145-181 */
+int pantas_graph_load(const char* gfa_path, pantas_graph** out);
+void pantas_graph_free(pantas_graph* g);
+int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out);
+/* copies node_len / row_ptr / col to the HBM of `device` and allocates the counters */
+int pantas_graph_to_device(pantas_graph* g, int device);
+
+/* ---- augment: alignments_augmentation_from_gaf.py main() :110-427 ------------------------- */
+typedef struct {
+  uint64_t lines;          /* GAF lines read */
+  uint64_t rejected;       /* mapq < thr            (:143-146, "Rejected alignments: N") */
+  uint64_t skipped;        /* '*' path or dv > 0.1  (:147-148, :179-180) */
+  uint64_t records;        /* lines that reach the walk */
+  uint64_t path_nodes;     /* sum of path lengths of those */
+  uint64_t cs_ops;
+  uint64_t del_records;    /* records with a '-' op */
+  uint64_t text_bytes;
+  uint64_t alg_bytes;      /* algorithmic bytes of one launch over this batch */
+  double tokenize_seconds, upload_seconds;
+} pantas_batch_stats;
+
+typedef struct {
+  float rare_ms;           /* augment_rare_kernel, HIP events on the launch stream */
+  float main_ms;           /* augment_main_kernel */
+} pantas_launch_stats;
+
+/* zero NC/RC/IL/OL and the sparse tables (start of a run) */
+int pantas_augment_reset(pantas_graph* g);
+/* :142-197 + :10-50: tokenise GAF bytes [begin,end) of the file (end = 0: to EOF; ranges must
+ * fall on line starts, see pantas_gaf_split) into binary records and upload them.
+ * first_line = index of the range's first line in the whole file (first-seen ordering). */
+int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,
+                            uint64_t first_line, pantas_batch** out, pantas_batch_stats* stats);
+/* byte range of shard `rank` of `world` (cut at line starts) and the number of lines before it */
+int pantas_gaf_split(const char* gaf_path, int rank, int world, uint64_t* begin, uint64_t* end,
+                     uint64_t* lines_before);
+void pantas_batch_free(pantas_batch* b);
+/* :209-363 on the GPU: both kernels over a resident batch, accumulating into g's counters */
+int pantas_augment_launch(pantas_graph* g, pantas_batch* b, pantas_launch_stats* out);
+/* device address of the dense counters [NC V | IL0 V | OLL V | RC A] (uint32) for a
+ * caller-run all-reduce (RCCL through torch.distributed); words = 3V + A */
+int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words);
+/* sparse side results (links absent from the GFA, rare IL/OL keys): export from one rank /
+ * merge into another.  Rows are 4 x uint64: {key, count, first_seen, kind (0 hist, 1 novel)} */
+int pantas_augment_sparse_count(pantas_graph* g, uint64_t* rows);
+int pantas_augment_sparse_export(pantas_graph* g, uint64_t* rows_out, uint64_t capacity);
+int pantas_augment_sparse_import(pantas_graph* g, const uint64_t* rows, uint64_t n);
+/* reports lines the kernels flagged (reference IndexError / '~'), downloads the results */
+int pantas_augment_finish(pantas_graph* g);
+/* host copies of the dense counters after finish (for tests): any pointer may be NULL */
+int pantas_augment_read(pantas_graph* g, uint32_t* nc, uint32_t* il0, uint32_t* oll, uint32_t* rc);
+/* :377-427 second GFA pass: echo + NC/IL/OL/RC tags + novel links, to fd */
+int pantas_augment_write_gfa(pantas_graph* g, int fd);
+/* whole script: reset, load, launch, finish, write.  stats may be NULL */
+int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
+                       pantas_launch_stats* launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

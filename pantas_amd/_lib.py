@@ -1,0 +1,91 @@
+"""ctypes binding of libpantas_gpu.so (include/pantas_gpu.h).
+
+The library holds the HIP kernels; there is no Python or CPU substitute for it.  Importing
+this module without the built library raises ImportError (run ``python -c 'import
+__graft_entry__ as g; g.build()'`` or ``make -C pantas_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
+
+
+class PantasError(RuntimeError):
+    """A failed libpantas_gpu call.  ``kind`` is the library's error class; for inputs the
+    reference script dies on it is the name of the Python exception the reference raises."""
+
+    def __init__(self, status: int, kind: str, message: str):
+        super().__init__(message)
+        self.status = status
+        self.kind = kind
+
+
+class GraphStats(C.Structure):
+    _fields_ = [("segments", C.c_uint64), ("link_slots", C.c_uint64), ("lines", C.c_uint64),
+                ("s_lines", C.c_uint64), ("l_lines", C.c_uint64), ("p_lines", C.c_uint64),
+                ("text_bytes", C.c_uint64), ("max_segment_len", C.c_uint32), ("dense_names", C.c_uint32),
+                ("load_seconds", C.c_double)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("lines", C.c_uint64), ("rejected", C.c_uint64), ("skipped", C.c_uint64),
+                ("records", C.c_uint64), ("path_nodes", C.c_uint64), ("cs_ops", C.c_uint64),
+                ("del_records", C.c_uint64), ("text_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
+                ("tokenize_seconds", C.c_double), ("upload_seconds", C.c_double)]
+
+
+class LaunchStats(C.Structure):
+    _fields_ = [("rare_ms", C.c_float), ("main_ms", C.c_float)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is not built: the pantas_amd engine is a HIP library and has no "
+                          "fallback.  Build it with `make -C pantas_amd/csrc` (needs /opt/rocm/bin/hipcc).")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    P = C.POINTER
+    sig = {
+        "pantas_last_error": (C.c_char_p, []),
+        "pantas_last_error_kind": (C.c_char_p, []),
+        "pantas_version": (C.c_char_p, []),
+        "pantas_device_count": (i32, []),
+        "pantas_graph_load": (i32, [C.c_char_p, P(vp)]),
+        "pantas_graph_free": (None, [vp]),
+        "pantas_graph_get_stats": (i32, [vp, P(GraphStats)]),
+        "pantas_graph_to_device": (i32, [vp, i32]),
+        "pantas_augment_reset": (i32, [vp]),
+        "pantas_augment_load_gaf": (i32, [vp, C.c_char_p, i32, u64, u64, u64, P(vp), P(BatchStats)]),
+        "pantas_gaf_split": (i32, [C.c_char_p, i32, i32, P(u64), P(u64), P(u64)]),
+        "pantas_batch_free": (None, [vp]),
+        "pantas_augment_launch": (i32, [vp, vp, P(LaunchStats)]),
+        "pantas_augment_counters": (i32, [vp, P(vp), P(u64)]),
+        "pantas_augment_sparse_count": (i32, [vp, P(u64)]),
+        "pantas_augment_sparse_export": (i32, [vp, P(u64), u64]),
+        "pantas_augment_sparse_import": (i32, [vp, P(u64), u64]),
+        "pantas_augment_finish": (i32, [vp]),
+        "pantas_augment_read": (i32, [vp, vp, vp, vp, vp]),
+        "pantas_augment_write_gfa": (i32, [vp, i32]),
+        "pantas_augment_run": (i32, [vp, C.c_char_p, i32, i32, P(BatchStats), P(LaunchStats)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sig
+
+
+lib, SIGNATURES = _load()
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise PantasError(status, (lib.pantas_last_error_kind() or b"").decode(),
+                          (lib.pantas_last_error() or b"").decode())
+
+
+def device_count() -> int:
+    return lib.pantas_device_count()

@@ -1,0 +1,72 @@
+// Augment engine: device state, kernels' host entry points, result assembly and the GFA
+// writer.  Reference: scripts/alignments_augmentation_from_gaf.py (hot loop :135-371 on the
+// GPU, second GFA pass :377-427 in write_augmented_gfa).
+#pragma once
+#include "common.h"
+#include "gaf.h"
+#include "graph.h"
+
+namespace pantas {
+
+struct HistEntry {      // one key of a node's IL or OL histogram that needs explicit ordering
+  uint32_t node;
+  uint32_t side;        // SIDE_IL / SIDE_OL
+  int32_t pos;          // histogram key; for is_common the key is 0 (IL) / len(node) (OL)
+  uint32_t count;       // increments (0 for is_common: the dense array holds the count)
+  uint64_t first;       // first-seen order (walk.h event_order)
+  bool is_common;
+};
+
+struct NovelLink {
+  uint32_t u, v, count;
+  uint64_t first;
+};
+
+struct AugmentResult {
+  std::vector<uint32_t> nc;        // [V]
+  std::vector<uint32_t> rc;        // [A] per adjacency slot (first slot of a duplicated link gets the count)
+  std::vector<uint32_t> il0, oll;  // [V] IL[0] and OL[len] counts
+  std::vector<HistEntry> hist;     // sorted by (node, side, first)
+  std::vector<NovelLink> novel;    // sorted by first
+  uint64_t lines_total = 0, rejected = 0, skipped = 0, used = 0;
+};
+
+// Second GFA pass (:377-427): echoes the mapped GFA with NC/IL/OL on S lines, RC on L lines and
+// the novel links appended.  Writes to fd.
+void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigned threads = 0);
+
+// sorts hist / novel into the orders documented above
+void finalize_result(AugmentResult& r);
+
+struct AugmentTimes {
+  double tokenize_s = 0, h2d_s = 0, kernel_ms = 0, d2h_s = 0;
+  double kernel_rare_ms = 0, kernel_main_ms = 0;
+};
+
+// Device side (augment.hip).  Opaque to the rest of the host code.
+struct DeviceGraph;
+struct DeviceBatch;
+
+struct DeviceGraphDeleter { void operator()(DeviceGraph*) const; };
+struct DeviceBatchDeleter { void operator()(DeviceBatch*) const; };
+using DeviceGraphPtr = std::unique_ptr<DeviceGraph, DeviceGraphDeleter>;
+using DeviceBatchPtr = std::unique_ptr<DeviceBatch, DeviceBatchDeleter>;
+
+int device_count();                                   // 0 when no HIP device is usable
+DeviceGraphPtr upload_graph(const Graph& g, int device);
+void reset_counters(DeviceGraph& dg);                 // zero NC/RC/IL/OL, clear flags and tables
+DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);
+// Launches the two augment kernels over a resident batch; accumulates into dg's counters.
+// Returns the device time of the two kernels in ms (HIP events on the launch stream).
+float launch_augment(DeviceGraph& dg, DeviceBatch& db, float* ms_rare = nullptr, float* ms_main = nullptr);
+// Raises Error if a kernel reported a line the reference would have died on.
+void check_device_status(DeviceGraph& dg, const DeviceBatch* db);
+void boost_novel_table(DeviceGraph& dg);              // next sizing of the novel-link table is 4x larger
+void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
+// device pointers of the dense counters, for collectives run by the caller (RCCL via torch.distributed)
+struct CounterPtrs { void* nc; void* rc; void* il0; void* oll; uint64_t V, A; };
+CounterPtrs counter_ptrs(DeviceGraph& dg);
+uint64_t batch_lines(const DeviceBatch& db);
+uint64_t batch_alg_bytes(const DeviceBatch& db);      // algorithmic bytes of the main kernel
+
+}  // namespace pantas

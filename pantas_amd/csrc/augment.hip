@@ -1,0 +1,482 @@
+// HIP kernels (gfx950) of the augment path and their host-side launchers.
+//
+// Two kernels per batch of tokenised GAF lines, one thread per line, both built on
+// walk_line() of walk.h (reference scripts/alignments_augmentation_from_gaf.py:209-363):
+//
+//   augment_rare_kernel   only lines whose cs holds a '-' op.  Records the IL/OL keys that
+//                         come from deletions (key, count, first-seen order) in a device hash
+//                         table and flags the node (two top bits of its node_len word).
+//   augment_main_kernel   every line.  NC[node]++, IL[0]/OL[len] dense counters, RC[slot]++ by
+//                         scanning the node's CSR row, links missing from the graph into a
+//                         second hash table (count + first-seen order); on flagged nodes also
+//                         the first-seen order of the dense key, which the writer needs to
+//                         interleave it with the rare keys of that node.
+//
+// All counters are uint32 device-scope atomics (no-return global_atomic_add).  The dense
+// counters sit in ONE allocation [NC | IL0 | OLL | RC] so a multi-GPU run needs a single
+// all-reduce.
+#include <hip/hip_runtime.h>
+
+#include "augment.h"
+#include "walk.h"
+
+namespace pantas {
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      throw Error("HipError", std::string(#expr) + ": " + hipGetErrorString(e__));                     \
+  } while (0)
+
+constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr uint32_t COMMON_POS = 0x7FFFFFFFu;
+
+struct TableView {
+  uint64_t* keys;
+  uint32_t* cnt;
+  uint64_t* first;
+  uint32_t mask;        // capacity - 1 (capacity is a power of two)
+  uint32_t* n_keys;     // distinct keys inserted
+  uint32_t* overflow;   // set when an insert found no free slot
+};
+
+struct GraphView {
+  uint32_t* word;             // [V] segment length | FLAG_IL | FLAG_OL
+  const uint32_t* row_ptr;    // [V+1]
+  const uint32_t* col;        // [A]
+  uint32_t* nc;               // [V]
+  uint32_t* il0;              // [V]
+  uint32_t* oll;              // [V]
+  uint32_t* rc;               // [A]
+  TableView hist, novel;
+  unsigned long long* status; // min over failing lines of (line_id << 8 | code)
+};
+
+struct BatchView {
+  const LineHdr* hdr;
+  const uint32_t* node_off;
+  const uint32_t* op_off;
+  const uint32_t* nodes;
+  const uint32_t* ops;
+  const uint32_t* del_idx;    // records holding a '-' op
+  uint32_t n, n_del;
+};
+
+__device__ __forceinline__ uint32_t mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return uint32_t(k);
+}
+
+// count += add, first = min(first, order) for `key`; inserts the key if absent.
+__device__ __forceinline__ void table_update(const TableView& t, uint64_t key, uint32_t add, uint64_t order) {
+  uint32_t h = mix64(key) & t.mask;
+  for (uint32_t probe = 0; probe <= t.mask && probe < 8192u; ++probe) {
+    uint64_t cur = t.keys[h];
+    if (cur == EMPTY_KEY) {
+      cur = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]), EMPTY_KEY, key);
+      if (cur == EMPTY_KEY) { atomicAdd(t.n_keys, 1u); cur = key; }
+    }
+    if (cur == key) {
+      if (add) atomicAdd(&t.cnt[h], add);
+      atomicMin(reinterpret_cast<unsigned long long*>(&t.first[h]), order);
+      return;
+    }
+    h = (h + 1) & t.mask;
+  }
+  atomicExch(t.overflow, 1u);
+}
+
+__device__ __forceinline__ uint64_t hist_key(uint32_t node, uint32_t side, uint32_t pos_code) {
+  return (uint64_t(node) << 32) | (uint64_t(side) << 31) | pos_code;
+}
+
+struct RareSink {
+  const GraphView& g;
+  __device__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
+  __device__ void nc(uint32_t) const {}
+  __device__ void common(uint32_t, uint32_t, uint32_t, uint32_t, uint64_t) const {}
+  __device__ void rare(uint32_t n, uint32_t side, int32_t pos, uint64_t order) const {
+    table_update(g.hist, hist_key(n, side, uint32_t(pos + 1) & 0x7FFFFFFFu), 1u, order);
+    atomicOr(&g.word[n], side == SIDE_IL ? FLAG_IL : FLAG_OL);
+  }
+  __device__ void edge(uint32_t, uint32_t, uint64_t) const {}
+};
+
+struct MainSink {
+  const GraphView& g;
+  __device__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
+  __device__ void nc(uint32_t n) const { atomicAdd(&g.nc[n], 1u); }
+  __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
+    atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
+    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+  }
+  __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
+  __device__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
+    const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
+    for (uint32_t s = lo; s < hi; ++s) {
+      if (g.col[s] == b) { atomicAdd(&g.rc[s], 1u); return; }
+    }
+    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
+  }
+};
+
+template <class Sink>
+__device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b, uint32_t i) {
+  const LineHdr h = b.hdr[i];
+  const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
+  const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
+  Sink sink{g};
+  const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+  if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+}
+
+__global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchView b) {
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < b.n_del; t += gridDim.x * 256u)
+    run_line<RareSink>(g, b, b.del_idx[t]);
+}
+
+__global__ __launch_bounds__(256) void augment_main_kernel(GraphView g, BatchView b) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < b.n; i += gridDim.x * 256u)
+    run_line<MainSink>(g, b, i);
+}
+
+__global__ void clear_flags_kernel(uint32_t* word, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) word[i] &= LEN_MASK;
+}
+
+__global__ void compact_table_kernel(TableView t, uint64_t* keys, uint32_t* cnt, uint64_t* first, uint32_t* cursor) {
+  const uint32_t cap = t.mask + 1u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cap; i += gridDim.x * 256u) {
+    const uint64_t k = t.keys[i];
+    if (k != EMPTY_KEY) {
+      const uint32_t o = atomicAdd(cursor, 1u);
+      keys[o] = k;
+      cnt[o] = t.cnt[i];
+      first[o] = t.first[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Table {
+  TableView v{};
+  uint32_t cap = 0;
+  void free_all() {
+    if (v.keys) (void)hipFree(v.keys);
+    if (v.cnt) (void)hipFree(v.cnt);
+    if (v.first) (void)hipFree(v.first);
+    v.keys = nullptr; v.cnt = nullptr; v.first = nullptr; cap = 0;
+  }
+};
+
+struct DeviceGraph {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  uint32_t V = 0;
+  uint64_t A = 0;
+  uint32_t* word = nullptr;
+  uint32_t* row_ptr = nullptr;
+  uint32_t* col = nullptr;
+  uint32_t* counters = nullptr;   // [NC V | IL0 V | OLL V | RC A]
+  uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
+  Table hist, novel;
+  uint64_t novel_boost = 1;       // grown after a TableOverflow("novel") retry
+  GraphView view() const {
+    GraphView g{};
+    g.word = word; g.row_ptr = row_ptr; g.col = col;
+    g.nc = counters; g.il0 = counters + V; g.oll = counters + 2 * size_t(V); g.rc = counters + 3 * size_t(V);
+    g.hist = hist.v; g.novel = novel.v;
+    g.status = reinterpret_cast<unsigned long long*>(small);
+    return g;
+  }
+};
+
+struct DeviceBatch {
+  LineHdr* hdr = nullptr;
+  uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
+  uint32_t n = 0, n_del = 0;
+  uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
+  std::vector<uint32_t> first_line_ids;   // unused placeholder for error reports
+};
+
+void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (void* p : {(void*)d->word, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small})
+    if (p) (void)hipFree(p);
+  d->hist.free_all();
+  d->novel.free_all();
+  for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
+  if (!b) return;
+  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx})
+    if (p) (void)hipFree(p);
+  delete b;
+}
+
+int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static uint32_t pow2_at_least(uint64_t x) {
+  uint64_t c = 1024;
+  while (c < x && c < (1ull << 31)) c <<= 1;
+  return uint32_t(c);
+}
+
+static void table_alloc(Table& t, uint32_t cap, uint32_t* n_keys, uint32_t* overflow) {
+  if (t.cap >= cap) { t.v.n_keys = n_keys; t.v.overflow = overflow; return; }
+  t.free_all();
+  HIP_OK(hipMalloc(&t.v.keys, size_t(cap) * 8));
+  HIP_OK(hipMalloc(&t.v.cnt, size_t(cap) * 4));
+  HIP_OK(hipMalloc(&t.v.first, size_t(cap) * 8));
+  t.cap = cap;
+  t.v.mask = cap - 1;
+  t.v.n_keys = n_keys;
+  t.v.overflow = overflow;
+}
+
+static void table_clear(Table& t, hipStream_t s) {
+  if (!t.cap) return;
+  HIP_OK(hipMemsetAsync(t.v.keys, 0xFF, size_t(t.cap) * 8, s));
+  HIP_OK(hipMemsetAsync(t.v.cnt, 0, size_t(t.cap) * 4, s));
+  HIP_OK(hipMemsetAsync(t.v.first, 0xFF, size_t(t.cap) * 8, s));
+}
+
+DeviceGraphPtr upload_graph(const Graph& g, int device) {
+  if (device_count() <= device) throw Error("NoDevice", "no HIP device " + std::to_string(device) + " (the augment kernels have no CPU path)");
+  HIP_OK(hipSetDevice(device));
+  DeviceGraphPtr d(new DeviceGraph());
+  d->device = device;
+  d->V = g.V;
+  d->A = g.A;
+  HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  for (auto& e : d->ev) HIP_OK(hipEventCreate(&e));
+  HIP_OK(hipMalloc(&d->word, std::max<size_t>(1, g.V) * 4));
+  HIP_OK(hipMalloc(&d->row_ptr, (size_t(g.V) + 1) * 4));
+  HIP_OK(hipMalloc(&d->col, std::max<size_t>(1, g.A) * 4));
+  HIP_OK(hipMalloc(&d->counters, std::max<size_t>(1, 3 * size_t(g.V) + g.A) * 4));
+  HIP_OK(hipMalloc(&d->small, 64));
+  HIP_OK(hipMemcpyAsync(d->word, g.seg_len.data(), size_t(g.V) * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_OK(hipMemcpyAsync(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_OK(hipMemcpyAsync(d->col, g.col.data(), size_t(g.A) * 4, hipMemcpyHostToDevice, d->stream));
+  table_alloc(d->hist, 1024, d->small + 2, d->small + 3);
+  table_alloc(d->novel, 1024, d->small + 4, d->small + 5);
+  HIP_OK(hipStreamSynchronize(d->stream));
+  reset_counters(*d);
+  return d;
+}
+
+void reset_counters(DeviceGraph& d) {
+  HIP_OK(hipSetDevice(d.device));
+  HIP_OK(hipMemsetAsync(d.counters, 0, (3 * size_t(d.V) + d.A) * 4, d.stream));
+  HIP_OK(hipMemsetAsync(d.small, 0xFF, 8, d.stream));
+  HIP_OK(hipMemsetAsync(d.small + 2, 0, 56, d.stream));
+  table_clear(d.hist, d.stream);
+  table_clear(d.novel, d.stream);
+  if (d.V) {
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(d.V) + 255) / 256, 4096));
+    hipLaunchKernelGGL(clear_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.V);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipStreamSynchronize(d.stream));
+}
+
+template <class T>
+static T* to_device(const std::vector<T>& v, hipStream_t s) {
+  T* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
+  if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return p;
+}
+
+// Grows the two tables for the batch about to run.  Only legal while they are empty.
+static void size_tables(DeviceGraph& d, uint64_t hist_keys_bound, uint64_t novel_keys_guess) {
+  const uint32_t hc = pow2_at_least(2 * hist_keys_bound + 1024);
+  const uint32_t nc = pow2_at_least(2 * novel_keys_guess + 1024);
+  bool grew = false;
+  if (hc > d.hist.cap) { table_alloc(d.hist, hc, d.small + 2, d.small + 3); grew = true; }
+  if (nc > d.novel.cap) { table_alloc(d.novel, nc, d.small + 4, d.small + 5); grew = true; }
+  if (grew) { table_clear(d.hist, d.stream); table_clear(d.novel, d.stream); }
+}
+
+DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
+  HIP_OK(hipSetDevice(d.device));
+  if (b.size() >= NONE32) throw Error("Unsupported", "more than 2^32-2 records in one batch");
+  // host-side shape check before any kernel sees the batch (a fault can take the whole node down)
+  for (size_t i = 0; i < b.nodes.size(); ++i)
+    if (b.nodes[i] >= d.V) throw Error("InternalError", "batch names a node outside the graph");
+  if (b.node_off.size() != b.size() + 1 || b.op_off.size() != b.size() + 1 || b.node_off.back() != b.nodes.size() ||
+      b.op_off.back() != b.ops.size())
+    throw Error("InternalError", "batch offsets do not match its arrays");
+  DeviceBatchPtr p(new DeviceBatch());
+  p->n = uint32_t(b.size());
+  p->n_nodes = b.nodes.size();
+  p->n_ops = b.ops.size();
+  p->del_nodes = b.del_nodes;
+  std::vector<uint32_t> del;
+  del.reserve(b.del_lines);
+  for (size_t i = 0; i < b.size(); ++i) if (b.hdr[i].flags & LINE_HAS_DEL) del.push_back(uint32_t(i));
+  p->n_del = uint32_t(del.size());
+  p->hdr = to_device(b.hdr, d.stream);
+  p->node_off = to_device(b.node_off, d.stream);
+  p->op_off = to_device(b.op_off, d.stream);
+  p->nodes = to_device(b.nodes, d.stream);
+  p->ops = to_device(b.ops, d.stream);
+  p->del_idx = to_device(del, d.stream);
+  HIP_OK(hipStreamSynchronize(d.stream));
+  return p;
+}
+
+uint64_t batch_lines(const DeviceBatch& db) { return db.n; }
+
+uint64_t batch_alg_bytes(const DeviceBatch& db) {
+  // B_line = 16 + 16 k + 4 c + 21 (k - 1)
+  const uint64_t n = db.n;
+  return 16 * n + 16 * db.n_nodes + 4 * db.n_ops + 21 * (db.n_nodes - std::min<uint64_t>(n, db.n_nodes));
+}
+
+static BatchView batch_view(const DeviceBatch& b) {
+  BatchView v{};
+  v.hdr = b.hdr; v.node_off = b.node_off; v.op_off = b.op_off; v.nodes = b.nodes; v.ops = b.ops; v.del_idx = b.del_idx;
+  v.n = b.n; v.n_del = b.n_del;
+  return v;
+}
+
+void boost_novel_table(DeviceGraph& d) { d.novel_boost *= 4; }
+
+float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_main) {
+  HIP_OK(hipSetDevice(d.device));
+  // capacity: every rare event and every flagged dense key is at most one key per (node, side) visit
+  const uint64_t hist_bound = 4 * b.del_nodes;
+  const uint64_t edges = b.n_nodes > b.n ? b.n_nodes - b.n : 0;
+  const uint64_t novel_guess = std::min<uint64_t>(edges, std::max<uint64_t>(1u << 16, edges / 4 * d.novel_boost));
+  if (hist_bound * 2 + 1024 > d.hist.cap || novel_guess * 2 + 1024 > d.novel.cap) {
+    // growing drops what the tables hold: only allowed right after a reset
+    uint32_t nk[4];
+    HIP_OK(hipMemcpy(nk, d.small + 2, 16, hipMemcpyDeviceToHost));
+    if (nk[0] || nk[2]) throw Error("InternalError", "device tables must be sized before the first batch of a run");
+    size_tables(d, hist_bound, novel_guess);
+  }
+  const GraphView g = d.view();
+  const BatchView bv = batch_view(b);
+  HIP_OK(hipEventRecord(d.ev[0], d.stream));
+  if (b.n_del) {
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n_del) + 255) / 256, 1u << 20));
+    hipLaunchKernelGGL(augment_rare_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipEventRecord(d.ev[1], d.stream));
+  if (b.n) {
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
+    hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipEventRecord(d.ev[2], d.stream));
+  HIP_OK(hipEventSynchronize(d.ev[2]));
+  float a = 0, m = 0;
+  HIP_OK(hipEventElapsedTime(&a, d.ev[0], d.ev[1]));
+  HIP_OK(hipEventElapsedTime(&m, d.ev[1], d.ev[2]));
+  if (ms_rare) *ms_rare = a;
+  if (ms_main) *ms_main = m;
+  return a + m;
+}
+
+void check_device_status(DeviceGraph& d, const DeviceBatch*) {
+  HIP_OK(hipSetDevice(d.device));
+  uint32_t s[8];
+  HIP_OK(hipMemcpy(s, d.small, 32, hipMemcpyDeviceToHost));
+  const uint64_t st = uint64_t(s[0]) | (uint64_t(s[1]) << 32);
+  if (st != ~0ull) {
+    const uint64_t line = (st >> 8) + 1;
+    const unsigned code = unsigned(st & 0xFF);
+    if (code == WALK_OPS_EXHAUSTED)
+      throw Error("IndexError", "GAF line " + std::to_string(line) + ": cs ops exhausted before the path end");
+    throw Error("Unsupported", "GAF line " + std::to_string(line) + ": '~' op reached by the walk");
+  }
+  if (s[3]) throw Error("TableOverflow", "hist");
+  if (s[5]) throw Error("TableOverflow", "novel");
+}
+
+static void download_table(DeviceGraph& d, Table& t, uint32_t n_keys, std::vector<uint64_t>& keys,
+                           std::vector<uint32_t>& cnt, std::vector<uint64_t>& first) {
+  keys.resize(n_keys);
+  cnt.resize(n_keys);
+  first.resize(n_keys);
+  if (!n_keys) return;
+  uint64_t *dk = nullptr, *df = nullptr;
+  uint32_t* dc = nullptr;
+  HIP_OK(hipMalloc(&dk, size_t(n_keys) * 8));
+  HIP_OK(hipMalloc(&df, size_t(n_keys) * 8));
+  HIP_OK(hipMalloc(&dc, size_t(n_keys) * 4));
+  HIP_OK(hipMemsetAsync(d.small + 6, 0, 4, d.stream));
+  const uint32_t blocks = std::min<uint32_t>((t.cap + 255) / 256, 8192);
+  hipLaunchKernelGGL(compact_table_kernel, dim3(blocks), dim3(256), 0, d.stream, t.v, dk, dc, df, d.small + 6);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(keys.data(), dk, size_t(n_keys) * 8, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipMemcpyAsync(cnt.data(), dc, size_t(n_keys) * 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipMemcpyAsync(first.data(), df, size_t(n_keys) * 8, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  (void)hipFree(dk); (void)hipFree(df); (void)hipFree(dc);
+}
+
+void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
+  HIP_OK(hipSetDevice(d.device));
+  const size_t V = d.V;
+  r.nc.resize(V); r.il0.resize(V); r.oll.resize(V); r.rc.resize(d.A);
+  if (V) {
+    HIP_OK(hipMemcpyAsync(r.nc.data(), d.counters, V * 4, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(r.il0.data(), d.counters + V, V * 4, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(r.oll.data(), d.counters + 2 * V, V * 4, hipMemcpyDeviceToHost, d.stream));
+  }
+  if (d.A) HIP_OK(hipMemcpyAsync(r.rc.data(), d.counters + 3 * V, size_t(d.A) * 4, hipMemcpyDeviceToHost, d.stream));
+  uint32_t s[8];
+  HIP_OK(hipMemcpyAsync(s, d.small, 32, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  std::vector<uint64_t> keys, first;
+  std::vector<uint32_t> cnt;
+  download_table(d, d.hist, s[2], keys, cnt, first);
+  r.hist.clear();
+  r.hist.reserve(keys.size());
+  for (size_t i = 0; i < keys.size(); ++i) {
+    const uint32_t node = uint32_t(keys[i] >> 32);
+    const uint32_t side = uint32_t(keys[i] >> 31) & 1u;
+    const uint32_t pc = uint32_t(keys[i]) & 0x7FFFFFFFu;
+    const bool common = pc == COMMON_POS;
+    r.hist.push_back(HistEntry{node, side, common ? 0 : int32_t(pc) - 1, cnt[i], first[i], common});
+  }
+  download_table(d, d.novel, s[4], keys, cnt, first);
+  r.novel.clear();
+  r.novel.reserve(keys.size());
+  for (size_t i = 0; i < keys.size(); ++i)
+    r.novel.push_back(NovelLink{uint32_t(keys[i] >> 32), uint32_t(keys[i]), cnt[i], first[i]});
+  (void)g;
+  finalize_result(r);
+}
+
+CounterPtrs counter_ptrs(DeviceGraph& d) {
+  CounterPtrs p{};
+  p.nc = d.counters;
+  p.il0 = d.counters + d.V;
+  p.oll = d.counters + 2 * size_t(d.V);
+  p.rc = d.counters + 3 * size_t(d.V);
+  p.V = d.V;
+  p.A = d.A;
+  return p;
+}
+
+}  // namespace pantas

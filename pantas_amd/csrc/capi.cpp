@@ -1,0 +1,341 @@
+// extern "C" boundary of libpantas_gpu (include/pantas_gpu.h).  No C++ exception leaves it.
+#include "../../include/pantas_gpu.h"
+
+#include "augment.h"
+
+#include <string>
+
+using namespace pantas;
+
+struct pantas_graph {
+  std::unique_ptr<Graph> g;
+  DeviceGraphPtr dev;
+  AugmentResult res;
+  bool have_result = false;
+  uint64_t lines = 0, rejected = 0, skipped = 0;
+  double load_s = 0;
+};
+
+struct pantas_batch {
+  DeviceBatchPtr dev;
+  pantas_batch_stats st{};
+};
+
+namespace {
+
+thread_local std::string g_err, g_kind;
+
+int fail(const Error& e) {
+  g_err = e.what();
+  g_kind = e.kind;
+  if (e.kind == "Unsupported") return PANTAS_E_UNSUPPORTED;
+  if (e.kind == "NoDevice") return PANTAS_E_NODEVICE;
+  if (e.kind == "HipError") return PANTAS_E_HIP;
+  if (e.kind == "OSError" || e.kind == "FileNotFoundError") return PANTAS_E_IO;
+  if (e.kind == "InternalError" || e.kind == "TableOverflow") return PANTAS_E_INTERNAL;
+  if (e.kind == "ArgumentError") return PANTAS_E_ARG;
+  return PANTAS_E_REFERENCE;
+}
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return PANTAS_OK;
+  } catch (const Error& e) {
+    return fail(e);
+  } catch (const std::bad_alloc&) {
+    return fail(Error("InternalError", "out of host memory"));
+  } catch (const std::exception& e) {
+    return fail(Error("InternalError", e.what()));
+  }
+}
+
+void need(bool ok, const char* what) {
+  if (!ok) throw Error("ArgumentError", what);
+}
+
+void need_device(pantas_graph* g) {
+  need(g && g->g, "null graph handle");
+  if (!g->dev) throw Error("NoDevice", "graph is not on a device: call pantas_graph_to_device first");
+}
+
+constexpr uint64_t KIND_HIST = 0, KIND_NOVEL = 1;
+constexpr uint32_t COMMON_CODE = 0x7FFFFFFFu;
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) const char* pantas_last_error(void) { return g_err.c_str(); }
+__attribute__((visibility("default"))) const char* pantas_last_error_kind(void) { return g_kind.c_str(); }
+__attribute__((visibility("default"))) const char* pantas_version(void) { return "pantas-mi355x 0.1 (gfx950)"; }
+__attribute__((visibility("default"))) int pantas_device_count(void) { return device_count(); }
+
+__attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_path, pantas_graph** out) {
+  return guarded([&] {
+    need(gfa_path && out, "null argument");
+    double t0 = now_s();
+    auto h = std::make_unique<pantas_graph>();
+    h->g = load_graph(gfa_path);
+    h->load_s = now_s() - t0;
+    *out = h.release();
+  });
+}
+
+__attribute__((visibility("default"))) void pantas_graph_free(pantas_graph* g) { delete g; }
+
+__attribute__((visibility("default"))) int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out) {
+  return guarded([&] {
+    need(g && g->g && out, "null argument");
+    const Graph& G = *g->g;
+    out->segments = G.V;
+    out->link_slots = G.A;
+    out->lines = G.n_lines;
+    out->s_lines = G.n_s_lines;
+    out->l_lines = G.n_l_lines;
+    out->p_lines = G.n_p_lines;
+    out->text_bytes = G.text.size;
+    out->max_segment_len = G.max_seg_len;
+    out->dense_names = G.names.dense ? 1u : 0u;
+    out->load_seconds = g->load_s;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_graph_to_device(pantas_graph* g, int device) {
+  return guarded([&] {
+    need(g && g->g, "null graph handle");
+    if (!g->dev) g->dev = upload_graph(*g->g, device);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_reset(pantas_graph* g) {
+  return guarded([&] {
+    need_device(g);
+    reset_counters(*g->dev);
+    g->have_result = false;
+    g->res = AugmentResult();
+    g->lines = g->rejected = g->skipped = 0;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_gaf_split(const char* gaf_path, int rank, int world, uint64_t* begin, uint64_t* end,
+                     uint64_t* lines_before) {
+  return guarded([&] {
+    need(gaf_path && begin && end && world > 0 && rank >= 0 && rank < world, "bad argument");
+    MappedFile f;
+    f.open(gaf_path);
+    auto cut = [&](int r) -> size_t {
+      if (r <= 0) return 0;
+      if (r >= world) return f.size;
+      size_t p = f.size / size_t(world) * size_t(r);
+      if (p == 0) return 0;
+      const void* nl = memchr(f.data + p - 1, '\n', f.size - (p - 1));   // p is a line start iff data[p-1] == '\n'
+      return nl ? size_t(static_cast<const char*>(nl) - f.data) + 1 : f.size;
+    };
+    *begin = cut(rank);
+    *end = cut(rank + 1);
+    if (lines_before) {
+      uint64_t n = 0;
+      const char* p = f.data;
+      const char* e = f.data + *begin;
+      while (p < e) {
+        const void* nl = memchr(p, '\n', size_t(e - p));
+        if (!nl) break;
+        ++n;
+        p = static_cast<const char*>(nl) + 1;
+      }
+      *lines_before = n;
+    }
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,
+                            uint64_t first_line, pantas_batch** out, pantas_batch_stats* stats) {
+  return guarded([&] {
+    need_device(g);
+    need(gaf_path && out, "null argument");
+    MappedFile f;
+    f.open(gaf_path);
+    if (end == 0 || end > f.size) end = f.size;
+    need(begin <= end, "bad byte range");
+    GafBatch b;
+    double t0 = now_s();
+    tokenize_gaf(*g->g, f.data + begin, size_t(end - begin), thr, first_line, 0, b);
+    double t1 = now_s();
+    auto h = std::make_unique<pantas_batch>();
+    h->dev = upload_batch(*g->dev, b);
+    double t2 = now_s();
+    pantas_batch_stats& s = h->st;
+    s.lines = b.lines_total;
+    s.rejected = b.rejected;
+    s.skipped = b.skipped;
+    s.records = b.size();
+    s.path_nodes = b.nodes.size();
+    s.cs_ops = b.ops.size();
+    s.del_records = b.del_lines;
+    s.text_bytes = b.bytes;
+    s.alg_bytes = batch_alg_bytes(*h->dev);
+    s.tokenize_seconds = t1 - t0;
+    s.upload_seconds = t2 - t1;
+    g->lines += b.lines_total;
+    g->rejected += b.rejected;
+    g->skipped += b.skipped;
+    if (stats) *stats = s;
+    *out = h.release();
+  });
+}
+
+__attribute__((visibility("default"))) void pantas_batch_free(pantas_batch* b) { delete b; }
+
+__attribute__((visibility("default"))) int pantas_augment_launch(pantas_graph* g, pantas_batch* b, pantas_launch_stats* out) {
+  return guarded([&] {
+    need_device(g);
+    need(b && b->dev, "null batch");
+    float r = 0, m = 0;
+    launch_augment(*g->dev, *b->dev, &r, &m);
+    if (out) { out->rare_ms = r; out->main_ms = m; }
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words) {
+  return guarded([&] {
+    need_device(g);
+    need(dev_ptr && words, "null argument");
+    CounterPtrs p = counter_ptrs(*g->dev);
+    *dev_ptr = p.nc;
+    *words = 3 * p.V + p.A;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g) {
+  return guarded([&] {
+    need_device(g);
+    check_device_status(*g->dev, nullptr);
+    download_result(*g->dev, *g->g, g->res);
+    g->res.lines_total = g->lines;
+    g->res.rejected = g->rejected;
+    g->res.skipped = g->skipped;
+    g->have_result = true;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_sparse_count(pantas_graph* g, uint64_t* rows) {
+  return guarded([&] {
+    need(g && g->have_result && rows, "no finished run");
+    *rows = g->res.hist.size() + g->res.novel.size();
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_sparse_export(pantas_graph* g, uint64_t* out, uint64_t capacity) {
+  return guarded([&] {
+    need(g && g->have_result && out, "no finished run");
+    need(capacity >= g->res.hist.size() + g->res.novel.size(), "buffer too small");
+    uint64_t* p = out;
+    for (const HistEntry& h : g->res.hist) {
+      uint32_t code = h.is_common ? COMMON_CODE : (uint32_t(h.pos + 1) & 0x7FFFFFFFu);
+      *p++ = (uint64_t(h.node) << 32) | (uint64_t(h.side) << 31) | code;
+      *p++ = h.count;
+      *p++ = h.first;
+      *p++ = KIND_HIST;
+    }
+    for (const NovelLink& n : g->res.novel) {
+      *p++ = (uint64_t(n.u) << 32) | n.v;
+      *p++ = n.count;
+      *p++ = n.first;
+      *p++ = KIND_NOVEL;
+    }
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_sparse_import(pantas_graph* g, const uint64_t* rows, uint64_t n) {
+  return guarded([&] {
+    need(g && g->have_result && (rows || n == 0), "no finished run");
+    // merge by key: counts add, first-seen takes the minimum
+    std::vector<HistEntry>& H = g->res.hist;
+    std::vector<NovelLink>& N = g->res.novel;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t key = rows[4 * i], cnt = rows[4 * i + 1], first = rows[4 * i + 2], kind = rows[4 * i + 3];
+      if (kind == KIND_HIST) {
+        uint32_t code = uint32_t(key) & 0x7FFFFFFFu;
+        bool common = code == COMMON_CODE;
+        H.push_back(HistEntry{uint32_t(key >> 32), uint32_t(key >> 31) & 1u, common ? 0 : int32_t(code) - 1,
+                              uint32_t(cnt), first, common});
+      } else {
+        N.push_back(NovelLink{uint32_t(key >> 32), uint32_t(key), uint32_t(cnt), first});
+      }
+    }
+    auto hkey = [](const HistEntry& h) {
+      return std::make_tuple(h.node, h.side, h.is_common ? 1 : 0, h.pos);
+    };
+    std::sort(H.begin(), H.end(), [&](const HistEntry& a, const HistEntry& b) { return hkey(a) < hkey(b); });
+    size_t w = 0;
+    for (size_t i = 0; i < H.size(); ++i) {
+      if (w && hkey(H[w - 1]) == hkey(H[i])) {
+        H[w - 1].count += H[i].count;
+        H[w - 1].first = std::min(H[w - 1].first, H[i].first);
+      } else H[w++] = H[i];
+    }
+    H.resize(w);
+    std::sort(N.begin(), N.end(), [](const NovelLink& a, const NovelLink& b) {
+      return a.u != b.u ? a.u < b.u : a.v < b.v;
+    });
+    w = 0;
+    for (size_t i = 0; i < N.size(); ++i) {
+      if (w && N[w - 1].u == N[i].u && N[w - 1].v == N[i].v) {
+        N[w - 1].count += N[i].count;
+        N[w - 1].first = std::min(N[w - 1].first, N[i].first);
+      } else N[w++] = N[i];
+    }
+    N.resize(w);
+    finalize_result(g->res);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_read(pantas_graph* g, uint32_t* nc, uint32_t* il0, uint32_t* oll, uint32_t* rc) {
+  return guarded([&] {
+    need(g && g->have_result, "no finished run");
+    const AugmentResult& r = g->res;
+    if (nc) memcpy(nc, r.nc.data(), r.nc.size() * 4);
+    if (il0) memcpy(il0, r.il0.data(), r.il0.size() * 4);
+    if (oll) memcpy(oll, r.oll.data(), r.oll.size() * 4);
+    if (rc) memcpy(rc, r.rc.data(), r.rc.size() * 4);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_write_gfa(pantas_graph* g, int fd) {
+  return guarded([&] {
+    need(g && g->have_result, "no finished run");
+    write_augmented_gfa(*g->g, g->res, fd);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
+                       pantas_launch_stats* launch) {
+  int rc = pantas_augment_reset(g);
+  if (rc) return rc;
+  pantas_batch* b = nullptr;
+  rc = pantas_augment_load_gaf(g, gaf_path, thr, 0, 0, 0, &b, stats);
+  if (rc) return rc;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    rc = pantas_augment_launch(g, b, launch);
+    if (rc) break;
+    rc = pantas_augment_finish(g);
+    if (rc == PANTAS_E_INTERNAL && g_kind == "TableOverflow") {
+      // the novel-link table was sized from a guess: enlarge and redo the run
+      uint64_t lines = g->lines, rej = g->rejected, skip = g->skipped;
+      boost_novel_table(*g->dev);
+      int r2 = pantas_augment_reset(g);
+      if (r2) { rc = r2; break; }
+      g->lines = lines; g->rejected = rej; g->skipped = skip;
+      continue;
+    }
+    break;
+  }
+  pantas_batch_free(b);
+  if (rc) return rc;
+  if (fd_out >= 0) rc = pantas_augment_write_gfa(g, fd_out);
+  return rc;
+}
+
+}  // extern "C"

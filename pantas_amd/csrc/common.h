@@ -1,0 +1,118 @@
+// Shared host-side helpers for libpantas_gpu: errors, mmap, ASCII tokenising with the
+// whitespace rules of Python's str.strip()/str.split() (the reference tokenises every
+// GFA/GAF line that way: scripts/alignments_augmentation_from_gaf.py:125,142,381,420 and
+// scripts/call.py:146-172), and a minimal parallel_for.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <cstdio>
+#include <string>
+#include <string_view>
+#include <stdexcept>
+#include <thread>
+#include <vector>
+#include <functional>
+#include <algorithm>
+
+namespace pantas {
+
+// Error raised where the reference would die with a Python exception (kind = its class
+// name) or where this library refuses an input.  Converted to a status code + message at
+// the C-ABI; never crosses it.
+struct Error : std::runtime_error {
+  std::string kind;
+  Error(std::string k, const std::string& msg) : std::runtime_error(k + ": " + msg), kind(std::move(k)) {}
+};
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+
+// Python's ASCII whitespace for str.split()/strip(): \t \n \v \f \r, 0x1c-0x1f, space.
+inline bool is_ws(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+
+struct MappedFile {
+  const char* data = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  MappedFile() = default;
+  MappedFile(const MappedFile&) = delete;
+  MappedFile& operator=(const MappedFile&) = delete;
+  ~MappedFile();
+  void open(const char* path);   // throws Error("FileNotFoundError"/"OSError")
+  void close();
+};
+
+// A half-open byte range of a mapped text file.
+struct Span {
+  const char* b;
+  const char* e;
+  size_t size() const { return size_t(e - b); }
+  std::string_view sv() const { return std::string_view(b, size_t(e - b)); }
+};
+
+inline Span strip(Span s) {
+  while (s.b < s.e && is_ws((unsigned char)*s.b)) ++s.b;
+  while (s.e > s.b && is_ws((unsigned char)s.e[-1])) --s.e;
+  return s;
+}
+
+// Iterates whitespace-separated tokens of a (stripped or not) line.
+struct Tokens {
+  const char* p;
+  const char* e;
+  explicit Tokens(Span s) : p(s.b), e(s.e) {}
+  bool next(Span& t) {
+    while (p < e && is_ws((unsigned char)*p)) ++p;
+    if (p >= e) return false;
+    t.b = p;
+    while (p < e && !is_ws((unsigned char)*p)) ++p;
+    t.e = p;
+    return true;
+  }
+};
+
+// Canonical non-negative decimal (no sign, no leading zeros except "0", <= 18 digits).
+inline bool parse_canonical_u64(Span t, uint64_t& v) {
+  size_t n = t.size();
+  if (n == 0 || n > 18) return false;
+  if (n > 1 && t.b[0] == '0') return false;
+  uint64_t x = 0;
+  for (const char* c = t.b; c < t.e; ++c) {
+    if (*c < '0' || *c > '9') return false;
+    x = x * 10 + uint64_t(*c - '0');
+  }
+  v = x;
+  return true;
+}
+
+// Python int(str) for the ASCII subset: optional sign, digits with single '_' separators.
+inline bool parse_py_int(Span t, int64_t& v) {
+  const char* c = t.b;
+  if (c >= t.e) return false;
+  bool neg = false;
+  if (*c == '+' || *c == '-') { neg = (*c == '-'); ++c; }
+  if (c >= t.e || *c < '0' || *c > '9') return false;
+  uint64_t x = 0;
+  bool prev_us = false;
+  for (; c < t.e; ++c) {
+    if (*c == '_') { if (prev_us) return false; prev_us = true; continue; }
+    if (*c < '0' || *c > '9') return false;
+    prev_us = false;
+    if (x > (uint64_t(1) << 60)) return false;
+    x = x * 10 + uint64_t(*c - '0');
+  }
+  if (prev_us) return false;
+  v = neg ? -int64_t(x) : int64_t(x);
+  return true;
+}
+
+unsigned hw_threads();
+
+// Runs fn(chunk_index, begin, end) over [0, n) split into `chunks` contiguous ranges.
+void parallel_chunks(size_t n, unsigned chunks, const std::function<void(unsigned, size_t, size_t)>& fn);
+
+// Splits a text buffer into `want` byte ranges that end on '\n' boundaries.
+std::vector<std::pair<size_t, size_t>> split_at_newlines(const char* data, size_t size, unsigned want);
+
+double now_s();
+
+}  // namespace pantas

@@ -1,0 +1,267 @@
+#include "gaf.h"
+
+#include <cstdlib>
+#include <memory>
+
+namespace pantas {
+
+namespace {
+
+inline bool is_op_char(char c) { return c == '=' || c == ':' || c == '*' || c == '+' || c == '-' || c == '~'; }
+
+inline uint32_t op_code(char c) {
+  switch (c) {
+    case ':': return OP_COLON;
+    case '*': return OP_STAR;
+    case '+': return OP_PLUS;
+    case '-': return OP_MINUS;
+    case '=': return OP_EQUAL;
+    default: return OP_TILDE;
+  }
+}
+
+struct Chunk {
+  GafBatch b;
+  std::unique_ptr<Error> err;
+  uint64_t err_line = 0;
+};
+
+[[noreturn]] void fail(const char* kind, uint64_t local_line, const std::string& what) {
+  // local_line is patched to the global number by the caller through the message prefix
+  throw Error(kind, "GAF line @" + std::to_string(local_line) + "@: " + what);
+}
+
+// cs ops of `text` (already without "cs:Z:") appended to ops; returns count.  (:10-37)
+uint32_t parse_cs(const char* b, const char* e, std::vector<uint32_t>& ops, uint64_t line) {
+  uint32_t n = 0;
+  const char* p = b;
+  while (p < e && !is_op_char(*p)) ++p;   // text before the first op char opens no entry
+  while (p < e) {
+    const char op = *p++;
+    const char* r = p;
+    while (p < e && !is_op_char(*p)) ++p;
+    uint64_t val;
+    if (op == '*') {
+      val = 1;
+    } else {
+      bool digits = p > r;
+      for (const char* q = r; q < p && digits; ++q) digits = (*q >= '0' && *q <= '9');
+      if (digits) {
+        val = 0;
+        for (const char* q = r; q < p; ++q) {
+          val = val * 10 + uint64_t(*q - '0');
+          if (val > OP_MAX_LEN) fail("Unsupported", line, "cs op longer than 2^29-1");
+        }
+      } else {
+        val = uint64_t(p - r);
+        if (val > OP_MAX_LEN) fail("Unsupported", line, "cs op longer than 2^29-1");
+      }
+    }
+    ops.push_back(uint32_t(val << 3) | op_code(op));
+    ++n;
+  }
+  return n;
+}
+
+void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chunk& ck) {
+  GafBatch& out = ck.b;
+  out.node_off.push_back(0);
+  out.op_off.push_back(0);
+  std::string cs_buf;
+  std::vector<Span> tok;
+  tok.reserve(32);
+  const char* p = data;
+  const char* end = data + size;
+  uint64_t line = 0;   // local line index
+  while (p < end) {
+    const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
+    const char* le = nl ? nl : end;
+    ck.err_line = line;
+    tok.clear();
+    {
+      Tokens tk(Span{p, le});
+      Span t;
+      while (tk.next(t)) tok.push_back(t);
+    }
+    ++out.lines_total;
+    p = nl ? nl + 1 : end;
+    const uint64_t this_line = line++;
+    if (tok.size() < 12) fail("IndexError", this_line, "fewer than 12 columns");
+    int64_t mapq;
+    if (!parse_py_int(tok[11], mapq)) fail("ValueError", this_line, "mapq is not an integer");
+    if (mapq < thr) { ++out.rejected; continue; }                                  // :143-146
+    if (tok[5].size() == 1 && *tok[5].b == '*') { ++out.skipped; continue; }       // :147-148
+    int64_t path_len, start, endpos;
+    if (!parse_py_int(tok[6], path_len) || !parse_py_int(tok[7], start) || !parse_py_int(tok[8], endpos))
+      fail("ValueError", this_line, "path length / start / end is not an integer");
+    // ---- cs tag: first "cs:" in any optional field, up to the end of that field (:154-160)
+    const size_t ops_before = out.ops.size();
+    bool found_cs = false;
+    for (size_t i = 12; i < tok.size() && !found_cs; ++i) {
+      const char* b = tok[i].b;
+      const char* e = tok[i].e;
+      for (const char* q = b; q + 3 <= e; ++q) {
+        if (q[0] == 'c' && q[1] == 's' && q[2] == ':') {
+          // drop every "cs:Z:" inside the matched text
+          cs_buf.clear();
+          const char* s = q;
+          while (s < e) {
+            if (e - s >= 5 && memcmp(s, "cs:Z:", 5) == 0) { s += 5; continue; }
+            cs_buf.push_back(*s++);
+          }
+          parse_cs(cs_buf.data(), cs_buf.data() + cs_buf.size(), out.ops, this_line);
+          found_cs = true;
+          break;
+        }
+      }
+    }
+    if (!found_cs) out.ops.push_back((1u << 3) | OP_STAR);   // cigar "*" -> [('*', 1)]
+    // ---- two-op clipping (:40-50, :164-167)
+    if (out.ops.size() - ops_before == 2) {
+      uint32_t a = out.ops[ops_before], b2 = out.ops[ops_before + 1];
+      if ((a & 7u) == OP_PLUS && (b2 & 7u) == OP_COLON) {
+        start += int64_t(a >> 3);
+        out.ops[ops_before] = b2;
+        out.ops.pop_back();
+      } else if ((a & 7u) == OP_COLON && (b2 & 7u) == OP_PLUS) {
+        out.ops.pop_back();
+      }
+    }
+    // ---- dv tag: first "dv:f:" followed by a digit (:172-180)
+    bool found_dv = false;
+    double dv = 0.0;
+    for (size_t i = 12; i < tok.size() && !found_dv; ++i) {
+      const char* b = tok[i].b;
+      const char* e = tok[i].e;
+      for (const char* q = b; q + 6 <= e; ++q) {
+        if (memcmp(q, "dv:f:", 5) == 0 && q[5] >= '0' && q[5] <= '9') {
+          const char* s = q + 5;
+          const char* t = s;
+          while (t < e && *t >= '0' && *t <= '9') ++t;
+          if (t + 1 < e && *t == '.' && t[1] >= '0' && t[1] <= '9') {
+            ++t;
+            while (t < e && *t >= '0' && *t <= '9') ++t;
+          }
+          std::string num(s, t);
+          dv = strtod(num.c_str(), nullptr);
+          found_dv = true;
+          break;
+        }
+      }
+    }
+    if (!found_dv) fail("ValueError", this_line, "could not convert string to float: '*' (no dv:f: tag)");
+    if (dv > 0.1) { out.ops.resize(ops_before); ++out.skipped; continue; }
+    // ---- path (:185-197)
+    const size_t nodes_before = out.nodes.size();
+    {
+      const char* b = tok[5].b;
+      const char* e = tok[5].e;
+      const bool rev = *b != '>';
+      const char sep = rev ? '<' : '>';
+      const char* q = static_cast<const char*>(memchr(b, sep, size_t(e - b)));
+      if (!q) fail("AssertionError", this_line, "path holds no node");
+      while (q < e) {
+        const char* s = q + 1;
+        const char* t = static_cast<const char*>(memchr(s, sep, size_t(e - s)));
+        if (!t) t = e;
+        uint32_t idx = g.names.find(Span{s, t});
+        if (idx == NONE32)
+          fail("KeyError", this_line, "path node '" + std::string(s, t) + "' has no S line");
+        if (out.nodes.size() == nodes_before || out.nodes.back() != idx) out.nodes.push_back(idx);
+        q = t;
+      }
+      const int64_t tail = path_len - endpos;
+      if (start < INT32_MIN || start > INT32_MAX || tail < INT32_MIN || tail > INT32_MAX)
+        fail("Unsupported", this_line, "start / end offsets beyond 32 bits");
+      uint32_t flags = rev ? LINE_REV : 0u;
+      bool has_del = false;
+      for (size_t i = ops_before; i < out.ops.size(); ++i) has_del |= (out.ops[i] & 7u) == OP_MINUS;
+      if (has_del) {
+        flags |= LINE_HAS_DEL;
+        ++out.del_lines;
+        out.del_nodes += out.nodes.size() - nodes_before;
+      }
+      out.hdr.push_back(LineHdr{int32_t(start), int32_t(tail), uint32_t(this_line), flags});
+    }
+    if (out.nodes.size() >= NONE32 || out.ops.size() >= NONE32)
+      fail("Unsupported", this_line, "more than 2^32-2 path nodes or cs ops in one batch");
+    out.node_off.push_back(uint32_t(out.nodes.size()));
+    out.op_off.push_back(uint32_t(out.ops.size()));
+  }
+}
+
+}  // namespace
+
+void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
+                  unsigned threads, GafBatch& out) {
+  if (threads == 0) threads = hw_threads();
+  if (size < (1u << 20)) threads = 1;
+  auto ranges = split_at_newlines(data, size, threads);
+  std::vector<Chunk> cks(ranges.size());
+  parallel_chunks(ranges.size(), unsigned(ranges.size()), [&](unsigned, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      try {
+        tokenize_range(g, data + ranges[i].first, ranges[i].second - ranges[i].first, thr, cks[i]);
+      } catch (const Error& er) {
+        cks[i].err = std::make_unique<Error>(er);
+      }
+    }
+  });
+  // the reference stops at the first offending line: report the earliest one
+  uint64_t line_base = first_line_id;
+  for (auto& c : cks) {
+    if (c.err) {
+      std::string msg = c.err->what();
+      // patch "@local@" into the 1-based global line number
+      size_t a = msg.find('@'), b = msg.find('@', a + 1);
+      if (a != std::string::npos && b != std::string::npos) {
+        uint64_t local = strtoull(msg.substr(a + 1, b - a - 1).c_str(), nullptr, 10);
+        msg = msg.substr(0, a) + std::to_string(line_base + local + 1) + msg.substr(b + 1);
+      }
+      size_t colon = msg.find(": ");
+      throw Error(c.err->kind, colon == std::string::npos ? msg : msg.substr(colon + 2));
+    }
+    line_base += c.b.lines_total;
+  }
+  size_t n = 0, nn = 0, no = 0;
+  for (auto& c : cks) { n += c.b.hdr.size(); nn += c.b.nodes.size(); no += c.b.ops.size(); }
+  if (nn >= NONE32 || no >= NONE32) throw Error("Unsupported", "more than 2^32-2 path nodes or cs ops in one batch");
+  out.hdr.resize(n);
+  out.node_off.resize(n + 1);
+  out.op_off.resize(n + 1);
+  out.nodes.resize(nn);
+  out.ops.resize(no);
+  out.bytes = size;
+  std::vector<size_t> hb(cks.size() + 1, 0), nb(cks.size() + 1, 0), ob(cks.size() + 1, 0);
+  std::vector<uint64_t> lb(cks.size() + 1, first_line_id);
+  for (size_t i = 0; i < cks.size(); ++i) {
+    hb[i + 1] = hb[i] + cks[i].b.hdr.size();
+    nb[i + 1] = nb[i] + cks[i].b.nodes.size();
+    ob[i + 1] = ob[i] + cks[i].b.ops.size();
+    lb[i + 1] = lb[i] + cks[i].b.lines_total;
+    out.lines_total += cks[i].b.lines_total;
+    out.rejected += cks[i].b.rejected;
+    out.skipped += cks[i].b.skipped;
+    out.del_lines += cks[i].b.del_lines;
+    out.del_nodes += cks[i].b.del_nodes;
+  }
+  if (lb.back() > uint64_t(NONE32)) throw Error("Unsupported", "more than 2^32-1 GAF lines");
+  parallel_chunks(cks.size(), unsigned(cks.size()), [&](unsigned, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      const GafBatch& s = cks[i].b;
+      for (size_t k = 0; k < s.hdr.size(); ++k) {
+        LineHdr h = s.hdr[k];
+        h.line_id = uint32_t(lb[i] + h.line_id);
+        out.hdr[hb[i] + k] = h;
+        out.node_off[hb[i] + k] = uint32_t(nb[i] + s.node_off[k]);
+        out.op_off[hb[i] + k] = uint32_t(ob[i] + s.op_off[k]);
+      }
+      if (!s.nodes.empty()) memcpy(&out.nodes[nb[i]], s.nodes.data(), s.nodes.size() * 4);
+      if (!s.ops.empty()) memcpy(&out.ops[ob[i]], s.ops.data(), s.ops.size() * 4);
+    }
+  });
+  out.node_off[n] = uint32_t(nn);
+  out.op_off[n] = uint32_t(no);
+}
+
+}  // namespace pantas

@@ -1,0 +1,35 @@
+// GAF text -> binary alignment records (host side, multi-threaded).
+// Covers the text half of the reference's per-line work: column split, mapq / unmapped /
+// divergence filters, cs parsing, the two-op clipping rule and the path split
+// (scripts/alignments_augmentation_from_gaf.py:142-197, :10-50).  The numeric half (:209-363)
+// runs on the GPU over these records.
+//
+// Record layout (structure of arrays, what the kernels read with coalesced loads):
+//   hdr[n]        LineHdr {start, tail, line_id, flags}
+//   node_off[n+1] offsets into nodes[]   (node indices of the path, consecutive repeats removed)
+//   op_off[n+1]   offsets into ops[]     ((length << 3) | op code)
+#pragma once
+#include "common.h"
+#include "graph.h"
+#include "walk.h"
+
+namespace pantas {
+
+struct GafBatch {
+  uint64_t lines_total = 0;   // text lines seen
+  uint64_t rejected = 0;      // mapq below threshold (reference's "Rejected alignments")
+  uint64_t skipped = 0;       // unmapped ('*' path) or dv > 0.1
+  std::vector<LineHdr> hdr;
+  std::vector<uint32_t> node_off, op_off, nodes, ops;
+  uint64_t del_lines = 0;     // records with a '-' op
+  uint64_t del_nodes = 0;     // sum of path lengths over those records
+  uint64_t bytes = 0;         // text bytes tokenised
+  size_t size() const { return hdr.size(); }
+};
+
+// Tokenises the byte range [data, data+size) (whole lines).  first_line_id = index of its
+// first line in the file.  Throws Error where the reference's loop would raise.
+void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
+                  unsigned threads, GafBatch& out);
+
+}  // namespace pantas

@@ -1,0 +1,69 @@
+// GFA -> CSR node/link layout (host side).  Replaces the reference's dict-of-objects
+// graph model (scripts/gfautils.py:92-128) and the inline S/L parsers of the two hot-path
+// scripts (scripts/alignments_augmentation_from_gaf.py:121-126,377-424; scripts/call.py:145-181).
+//
+// Layout (all indices uint32):
+//   node index      = order of first appearance of the segment name in an S line
+//   seg_len[V]      = len(sequence) of the LAST S line carrying that name (dict overwrite)
+//   out CSR         = row_ptr[V+1], col[A]; one slot per L line whose two ends have S lines,
+//                     rows in L-line file order (adjacency order the caller relies on,
+//                     call.py:174-175); duplicate (u,v) lines keep separate slots
+//   slot_off[A]     = byte offset (stripped line start) of the L line behind a slot
+//   in CSR          = irow_ptr[V+1], icol[A] (source node), islot[A] (out-CSR slot)
+// The GFA text stays mmapped: the augment writer re-emits it line by line.
+#pragma once
+#include "common.h"
+#include <memory>
+#include <unordered_map>
+
+namespace pantas {
+
+struct NameIndex {
+  // dense table for canonical decimal names, else a string map
+  bool dense = false;
+  uint64_t base = 0;
+  std::vector<uint32_t> table;                           // id - base -> node, NONE32 = absent
+  std::unordered_map<std::string_view, uint32_t> map;    // keys point into the mmap
+  uint32_t find(Span name) const {
+    if (dense) {
+      uint64_t id;
+      if (!parse_canonical_u64(name, id) || id < base || id - base >= table.size()) return NONE32;
+      return table[id - base];
+    }
+    auto it = map.find(name.sv());
+    return it == map.end() ? NONE32 : it->second;
+  }
+};
+
+struct Graph {
+  MappedFile text;
+  std::string path;
+  uint32_t V = 0;          // distinct segment names
+  uint64_t A = 0;          // adjacency slots (L lines with both ends known)
+  uint64_t n_lines = 0, n_s_lines = 0, n_l_lines = 0, n_p_lines = 0;
+  NameIndex names;
+  std::vector<uint32_t> seg_len;       // [V]
+  std::vector<uint64_t> seg_line_off;  // [V] stripped-line offset of the defining (last) S line
+  std::vector<uint64_t> seg_name_off;  // [V] offset of the name token (first S line)
+  std::vector<uint16_t> seg_name_len;  // [V]
+  std::vector<uint32_t> row_ptr, col;  // out CSR
+  std::vector<uint64_t> slot_off;      // [A]
+  std::vector<uint32_t> irow_ptr, icol, islot;  // in CSR
+  // facts the two consumers validate differently
+  bool dup_names = false;              // some name has more than one S line
+  bool link_before_segment = false;    // an L line precedes the S line of one of its ends
+  uint64_t links_unknown_end = 0;      // L lines naming a segment without S line
+  uint64_t first_bad_p_off = UINT64_MAX;   // first P line without exactly 4 tokens
+  uint64_t first_short_l_off = UINT64_MAX; // first non-bare L line with fewer than 6 tokens
+  uint32_t max_seg_len = 0;
+
+  Span name_of(uint32_t node) const {
+    const char* b = text.data + seg_name_off[node];
+    return Span{b, b + seg_name_len[node]};
+  }
+};
+
+// Parses the GFA at `path`.  Throws Error on inputs the reference's first GFA pass dies on.
+std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
+
+}  // namespace pantas

@@ -1,0 +1,183 @@
+// Per-GAF-line walk: lays the line's cs ops over its path nodes and reports what the
+// line contributes to node coverage (NC), link coverage (RC) and the in/out-link position
+// histograms (IL/OL).  This is the body of the augment kernels (augment.hip instantiates it
+// with a sink that does device atomics); it is a header so that tests/hostsim can compile
+// the very same code for the CPU under ASan/UBSan.  It is NOT a CPU path of the product.
+//
+// Behaviour restated from scripts/alignments_augmentation_from_gaf.py:
+//   op distribution over nodes            :209-255
+//   lone '+'/'-' node dropped, compaction :63-107
+//   NC                                    :263-269
+//   IL/OL, forward and reverse strand     :276-353
+//   RC on consecutive kept nodes          :357-363
+//
+// Instead of materialising the per-node op lists, the walk keeps a constant-size summary of
+// the compacted list of the node in hand (first entry, last entry, how many entries are
+// neither '-' nor '*') -- everything :276-353 reads -- and holds each kept node back until
+// the next kept node (or the end of the line) is known, because the IL/OL rules ask "is this
+// the last kept node?".
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PANTAS_HD __host__ __device__ __forceinline__
+#else
+#define PANTAS_HD inline
+#endif
+
+namespace pantas {
+
+// cs op codes of the tokenised record: word = (length << 3) | code
+enum : uint32_t { OP_COLON = 0, OP_STAR = 1, OP_PLUS = 2, OP_MINUS = 3, OP_EQUAL = 4, OP_TILDE = 5 };
+constexpr uint32_t OP_MAX_LEN = (1u << 29) - 1;
+
+// node_len word: low 30 bits = segment length; the two top bits mark nodes whose IL / OL
+// histogram holds a key other than the common one (set by the first augment kernel)
+constexpr uint32_t LEN_MASK = 0x3FFFFFFFu;
+constexpr uint32_t FLAG_IL = 1u << 30;
+constexpr uint32_t FLAG_OL = 1u << 31;
+
+constexpr uint32_t LINE_REV = 1u;       // path written with '<'
+constexpr uint32_t LINE_HAS_DEL = 2u;   // cs string holds a '-' op
+
+struct LineHdr {
+  int32_t start;     // start position on the first node (after the 2-op clipping rule)
+  int32_t tail;      // path_len - end position
+  uint32_t line_id;  // 0-based index of the line in the GAF file (first-seen ordering)
+  uint32_t flags;
+};
+
+enum : int { WALK_OK = 0, WALK_OPS_EXHAUSTED = 1, WALK_TILDE = 2 };
+
+enum : uint32_t { SIDE_IL = 0, SIDE_OL = 1 };
+
+// first-seen order of an event: (line, index of the node among the line's kept nodes, phase)
+// phase 0 = first compacted entry, 1 = any entry that is neither '-' nor '*', 2 = last entry
+PANTAS_HD uint64_t event_order(uint32_t line_id, uint32_t kept_idx, uint32_t phase) {
+  return (uint64_t(line_id) << 32) | (uint64_t(kept_idx) << 2) | phase;
+}
+
+struct KeptNode {
+  uint32_t node;
+  uint32_t word;       // node_len word as loaded (length + flags)
+  uint32_t entries;    // compacted list length
+  uint32_t first_op, first_len, last_op, last_len;
+  uint32_t plain;      // entries whose op is neither '-' nor '*'
+};
+
+// Sink concept:
+//   uint32_t node_word(uint32_t node)                 gather of the node_len word
+//   void nc(uint32_t node)
+//   void common(uint32_t node, uint32_t word, uint32_t side, uint32_t times, uint64_t order)
+//        IL key 0 / OL key len(node), `times` increments
+//   void rare(uint32_t node, uint32_t side, int32_t pos, uint64_t order)   one increment
+//   void edge(uint32_t from, uint32_t to, uint64_t order)
+template <class Sink>
+PANTAS_HD void flush_kept(const KeptNode& kn, uint32_t idx, bool is_last, const LineHdr& h, Sink& sink) {
+  const bool rev = (h.flags & LINE_REV) != 0;
+  const bool is_first = idx == 0;
+  const int32_t len = int32_t(kn.word & LEN_MASK);
+  sink.nc(kn.node);
+  if (kn.entries == 0) return;
+  // which histogram faces the previous kept node / the next kept node of the read
+  const uint32_t enter = rev ? SIDE_OL : SIDE_IL;
+  const uint32_t leave = rev ? SIDE_IL : SIDE_OL;
+  if (!is_first && kn.first_op == OP_MINUS) {
+    int32_t pos = rev ? len - 1 - int32_t(kn.first_len) : int32_t(kn.first_len);
+    sink.rare(kn.node, enter, pos, event_order(h.line_id, idx, 0));
+  }
+  if (kn.plain) {
+    // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first
+    if (!is_first) sink.common(kn.node, kn.word, enter, kn.plain, event_order(h.line_id, idx, 1));
+    if (!is_last) sink.common(kn.node, kn.word, leave, kn.plain, event_order(h.line_id, idx, 1));
+  }
+  if (!is_last && kn.last_op == OP_MINUS) {
+    int32_t pos = rev ? int32_t(kn.last_len) : len - int32_t(kn.last_len) - 1;
+    sink.rare(kn.node, leave, pos, event_order(h.line_id, idx, 2));
+  }
+}
+
+template <class Sink>
+PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_nodes, const uint32_t* ops,
+                        uint32_t n_ops, Sink& sink) {
+  uint32_t oi = 0;          // index of the op in hand (or of the next one when !have)
+  uint32_t cur_op = 0, cur_rem = 0;
+  bool have = false;
+  bool pending = false;
+  KeptNode pend{};
+  uint32_t kept = 0;        // kept nodes flushed or pending so far
+  const bool rev = (h.flags & LINE_REV) != 0;
+
+  for (uint32_t i = 0; i < n_nodes; ++i) {
+    const uint32_t node = nodes[i];
+    const uint32_t word = sink.node_word(node);
+    int64_t room = int64_t(word & LEN_MASK);
+    if (i == 0) room -= h.start;
+    if (i == n_nodes - 1) room = room - h.tail + 1;
+    KeptNode kn{node, word, 0, 0, 0, 0, 0, 0};
+    uint32_t pieces = 0;
+    uint32_t piece0_op = 0;
+    while (room > 0) {
+      if (!have) {
+        if (oi >= n_ops) return WALK_OPS_EXHAUSTED;   // reference: IndexError at :227
+        const uint32_t w = ops[oi];
+        cur_op = w & 7u;
+        cur_rem = w >> 3;
+        have = true;
+      }
+      if (cur_op == OP_TILDE) return WALK_TILDE;      // reference: stale/unbound length at :228-234
+      uint32_t take;
+      const uint32_t op = cur_op;
+      if (room <= int64_t(cur_rem)) {
+        take = uint32_t(room);
+        cur_rem -= take;
+        room = 0;
+        if (cur_rem == 0) { have = false; ++oi; }
+      } else {
+        take = cur_rem;
+        room -= int64_t(cur_rem);
+        have = false;
+        ++oi;
+      }
+      // ---- compaction of this node's op list, one piece at a time (:63-94)
+      if (pieces == 0) {
+        piece0_op = op;
+        if (op != OP_STAR) {
+          kn.entries = 1;
+          kn.first_op = kn.last_op = op;
+          kn.first_len = kn.last_len = take;
+          kn.plain = (op != OP_MINUS) ? 1u : 0u;
+        }
+      } else if (kn.entries == 0) {
+        kn.entries = 1;
+        kn.first_op = kn.last_op = op;
+        kn.first_len = kn.last_len = take + 1;
+        kn.plain = (op != OP_MINUS && op != OP_STAR) ? 1u : 0u;
+      } else if (op == kn.last_op || op == OP_STAR) {
+        kn.last_len += take;
+        if (kn.entries == 1) kn.first_len = kn.last_len;
+      } else {
+        ++kn.entries;
+        kn.last_op = op;
+        kn.last_len = take;
+        if (op != OP_MINUS) ++kn.plain;   // op cannot be '*' here
+      }
+      ++pieces;
+      if (!have && oi >= n_ops) break;                // ops used up: this node is closed (:252-255)
+    }
+    if (pieces == 0) continue;                                               // no room: node not touched
+    if (pieces == 1 && (piece0_op == OP_PLUS || piece0_op == OP_MINUS)) continue;  // :101-102
+    if (pending) {
+      flush_kept(pend, kept - 1, false, h, sink);
+      if (rev) sink.edge(node, pend.node, event_order(h.line_id, kept - 1, 0));
+      else sink.edge(pend.node, node, event_order(h.line_id, kept - 1, 0));
+    }
+    pend = kn;
+    pending = true;
+    ++kept;
+  }
+  if (pending) flush_kept(pend, kept - 1, true, h, sink);
+  return WALK_OK;
+}
+
+}  // namespace pantas

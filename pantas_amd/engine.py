@@ -1,0 +1,107 @@
+"""Object wrappers over the C ABI: a loaded graph and resident GAF batches."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _lib
+from ._lib import BatchStats, GraphStats, LaunchStats, PantasError, check, lib  # noqa: F401
+
+
+class Batch:
+    def __init__(self, handle, stats: BatchStats):
+        self._h = handle
+        self.stats = stats
+
+    def free(self):
+        if self._h:
+            lib.pantas_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.free()
+
+
+class Graph:
+    """A GFA loaded into the CSR node/link layout (host) and, after ``to_device``, HBM."""
+
+    def __init__(self, gfa_path: str):
+        h = C.c_void_p()
+        check(lib.pantas_graph_load(os.fsencode(gfa_path), C.byref(h)))
+        self._h = h
+        self.path = gfa_path
+
+    def close(self):
+        if self._h:
+            lib.pantas_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def stats(self) -> GraphStats:
+        s = GraphStats()
+        check(lib.pantas_graph_get_stats(self._h, C.byref(s)))
+        return s
+
+    def to_device(self, device: int = 0) -> "Graph":
+        check(lib.pantas_graph_to_device(self._h, device))
+        return self
+
+    # ---- augment -------------------------------------------------------------------------
+    def augment_reset(self):
+        check(lib.pantas_augment_reset(self._h))
+
+    def load_gaf(self, gaf_path: str, thr: int = 20, begin: int = 0, end: int = 0, first_line: int = 0) -> Batch:
+        b = C.c_void_p()
+        st = BatchStats()
+        check(lib.pantas_augment_load_gaf(self._h, os.fsencode(gaf_path), thr, begin, end, first_line,
+                                          C.byref(b), C.byref(st)))
+        return Batch(b, st)
+
+    def launch(self, batch: Batch) -> LaunchStats:
+        st = LaunchStats()
+        check(lib.pantas_augment_launch(self._h, batch._h, C.byref(st)))
+        return st
+
+    def counters(self):
+        """(device pointer, words) of the dense counters [NC | IL0 | OLL | RC]."""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        check(lib.pantas_augment_counters(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def finish(self):
+        check(lib.pantas_augment_finish(self._h))
+
+    def read_counters(self):
+        import numpy as np
+        s = self.stats
+        nc = np.zeros(s.segments, dtype=np.uint32)
+        il0 = np.zeros(s.segments, dtype=np.uint32)
+        oll = np.zeros(s.segments, dtype=np.uint32)
+        rc = np.zeros(s.link_slots, dtype=np.uint32)
+        check(lib.pantas_augment_read(self._h, nc.ctypes.data, il0.ctypes.data, oll.ctypes.data, rc.ctypes.data))
+        return nc, il0, oll, rc
+
+    def sparse_export(self):
+        import numpy as np
+        n = C.c_uint64()
+        check(lib.pantas_augment_sparse_count(self._h, C.byref(n)))
+        rows = np.zeros((n.value, 4), dtype=np.uint64)
+        check(lib.pantas_augment_sparse_export(self._h, rows.ctypes.data_as(C.POINTER(C.c_uint64)), n.value))
+        return rows
+
+    def sparse_import(self, rows):
+        import numpy as np
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        check(lib.pantas_augment_sparse_import(self._h, rows.ctypes.data_as(C.POINTER(C.c_uint64)), rows.shape[0]))
+
+    def write_gfa(self, fd: int):
+        check(lib.pantas_augment_write_gfa(self._h, fd))
+
+    def augment(self, gaf_path: str, thr: int = 20, fd_out: int = -1):
+        bs, ls = BatchStats(), LaunchStats()
+        check(lib.pantas_augment_run(self._h, os.fsencode(gaf_path), thr, fd_out, C.byref(bs), C.byref(ls)))
+        return bs, ls

@@ -386,7 +386,7 @@ def make_gaf_lines(model: Model, seed: int = 1, n_lines: int = 500, read_len: in
             before = sum(lens[:jpos])
             lo = max(0, before - span + 5)
             hi = min(total - span, max(0, before - 5))
-            off = rng.randint(min(lo, hi), max(lo, hi))
+            off = min(max(0, total - span), rng.randint(min(lo, hi), max(lo, hi)))
         # window -> node sub-path
         acc = 0
         i0 = 0

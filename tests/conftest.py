@@ -8,6 +8,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+ROOT_GOLDEN = None
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CASES = ["micro", "quirks", "mixedwidth", "synth_a", "synth_b", "synth_c"]
 

@@ -1,0 +1,97 @@
+"""Parity of the HIP augment path (through the C ABI) with the reference goldens and the oracle."""
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+import augment_oracle
+from conftest import CASES, GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_engine(gfa, gaf, thr=20):
+    from pantas_amd.engine import Graph
+    g = Graph(gfa).to_device(0)
+    with tempfile.TemporaryFile() as f:
+        bs, ls = g.augment(gaf, thr, f.fileno())
+        f.seek(0)
+        return f.read().decode(), bs, g
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_bytes(case):
+    d = os.path.join(GOLDEN, case)
+    got, bs, _ = run_engine(f"{d}/in.gfa", f"{d}/in.gaf")
+    assert got == open(f"{d}/expected.aug.gfa").read()
+    assert bs.rejected == json.load(open(f"{d}/expected.json"))["rejected"]
+
+
+def test_cli_matches_reference_streams():
+    d = os.path.join(GOLDEN, "quirks")
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", f"{d}/in.gaf", f"{d}/in.gfa"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(f"{d}/expected.aug.gfa").read()
+    want = json.load(open(f"{d}/expected.json"))["stderr"]
+    assert r.stderr.splitlines() == want
+
+
+def test_crash_inputs_fail_with_empty_stdout():
+    from pantas_amd.engine import PantasError
+    crashes = [c for c in json.load(open(os.path.join(GOLDEN, "crashes.json"))) if c["stage"] == "augment"]
+    cd = os.path.join(GOLDEN, "crashes")
+    for c in crashes:
+        with pytest.raises(PantasError) as ei:
+            run_engine(f"{cd}/{c['name']}.gfa", f"{cd}/{c['name']}.gaf")
+        if c["name"] != "aug_tilde_first":
+            assert ei.value.kind == c["exception"], c["name"]
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", f"{cd}/{c['name']}.gaf", f"{cd}/{c['name']}.gfa"],
+                           capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 1 and r.stdout == ""
+
+
+@pytest.mark.parametrize("seed,genes,lines,kw", [
+    (11, 60, 20000, {}),
+    (12, 30, 30000, dict(p_indel=0.3, p_sub=0.5, bubble_rate=0.15, p_novel_skip=0.1, p_novel_ce=0.05)),
+    (13, 5, 20000, dict(zipf_a=3.0)),          # heavy skew: a few hot nodes take most increments
+])
+def test_oracle_parity_larger(tmp_path, seed, genes, lines, kw):
+    from pantas_amd import synth
+    pre = str(tmp_path / "s")
+    synth.write_all(pre, seed=seed, n_genes=genes, n_lines=lines, **kw)
+    got, bs, _ = run_engine(pre + ".gfa", pre + ".gaf")
+    want = io.StringIO()
+    a = augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    assert bs.rejected == a.rejected
+    assert got == want.getvalue()
+
+
+def test_threshold_argument(tmp_path):
+    d = os.path.join(GOLDEN, "synth_b")
+    for thr in (0, 5, 61):
+        got, bs, _ = run_engine(f"{d}/in.gfa", f"{d}/in.gaf", thr)
+        want = io.StringIO()
+        a = augment_oracle.augment(f"{d}/in.gaf", f"{d}/in.gfa", want, thr=thr)
+        assert got == want.getvalue() and bs.rejected == a.rejected
+
+
+def test_relaunch_is_linear():
+    """counters after two launches over the same resident batch = 2 x one launch (size-independent property)."""
+    from pantas_amd.engine import Graph
+    d = os.path.join(GOLDEN, "synth_a")
+    g = Graph(f"{d}/in.gfa").to_device(0)
+    g.augment_reset()
+    b = g.load_gaf(f"{d}/in.gaf")
+    g.launch(b)
+    g.finish()
+    one = [x.copy() for x in g.read_counters()]
+    g.launch(b)
+    g.finish()
+    two = g.read_counters()
+    for a, c in zip(one, two):
+        assert (2 * a.astype("int64") == c.astype("int64")).all()
