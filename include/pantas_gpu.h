@@ -108,6 +108,35 @@ int pantas_augment_write_gfa(pantas_graph* g, int fd);
 int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
                        pantas_launch_stats* launch);
 
+/* ---- call: scripts/call.py main() :132-1105 ------------------------------------------------ */
+typedef struct {
+  int32_t rca;            /* --rca (default -1) */
+  int32_t isw;            /* --isw (default 5) */
+  int32_t minintronsize;  /* --minintronsize (default 100) */
+  uint32_t events;        /* --events: bit 0 ES, bit 1 SS, bit 2 IR (default 7) */
+  int32_t novel;          /* --novel */
+  int32_t no_annotated;   /* --no-annotated */
+  const char* junction;   /* --junction "u-v" or NULL */
+} pantas_call_opts;
+
+typedef struct {
+  uint64_t junctions;       /* annotated junction links (JN) */
+  uint64_t novel_links;     /* links with ID:Z:N */
+  uint64_t evaluated;       /* junction evaluations launched over the three passes */
+  uint64_t events;          /* CSV rows written */
+  uint64_t ex_entries, jn_entries;
+  double parse_seconds;     /* tag + GTF parsing and interning (host) */
+  double upload_seconds;
+  double render_seconds;
+  float annotated_ms, novel_ms, around_ms;   /* kernels of each pass, HIP events */
+} pantas_call_stats;
+
+/* :145-216: parse the tags of the (augmented) GFA behind `g` and the GTF, intern them, copy the
+ * tables to the HBM of `device` */
+int pantas_call_prepare(pantas_graph* g, const char* gtf_path, int device);
+/* :218-1105: header + event rows to fd_csv, "Skipping ..." lines to fd_err (-1: drop) */
+int pantas_call_run(pantas_graph* g, const pantas_call_opts* opts, int fd_csv, int fd_err, pantas_call_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

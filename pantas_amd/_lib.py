@@ -41,6 +41,18 @@ class LaunchStats(C.Structure):
     _fields_ = [("rare_ms", C.c_float), ("main_ms", C.c_float)]
 
 
+class CallOpts(C.Structure):
+    _fields_ = [("rca", C.c_int32), ("isw", C.c_int32), ("minintronsize", C.c_int32), ("events", C.c_uint32),
+                ("novel", C.c_int32), ("no_annotated", C.c_int32), ("junction", C.c_char_p)]
+
+
+class CallStats(C.Structure):
+    _fields_ = [("junctions", C.c_uint64), ("novel_links", C.c_uint64), ("evaluated", C.c_uint64),
+                ("events", C.c_uint64), ("ex_entries", C.c_uint64), ("jn_entries", C.c_uint64),
+                ("parse_seconds", C.c_double), ("upload_seconds", C.c_double), ("render_seconds", C.c_double),
+                ("annotated_ms", C.c_float), ("novel_ms", C.c_float), ("around_ms", C.c_float)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is not built: the pantas_amd engine is a HIP library and has no "
@@ -70,6 +82,8 @@ def _load():
         "pantas_augment_read": (i32, [vp, vp, vp, vp, vp]),
         "pantas_augment_write_gfa": (i32, [vp, i32]),
         "pantas_augment_run": (i32, [vp, C.c_char_p, i32, i32, P(BatchStats), P(LaunchStats)]),
+        "pantas_call_prepare": (i32, [vp, C.c_char_p, i32]),
+        "pantas_call_run": (i32, [vp, P(CallOpts), i32, i32, P(CallStats)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

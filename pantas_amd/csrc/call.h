@@ -1,0 +1,22 @@
+// Device side of the call path (call.hip).
+#pragma once
+#include "call_host.h"
+#include <memory>
+
+namespace pantas {
+
+struct DeviceCall;
+struct DeviceCallDeleter { void operator()(DeviceCall*) const; };
+using DeviceCallPtr = std::unique_ptr<DeviceCall, DeviceCallDeleter>;
+
+struct CallTimes {
+  float annotated_ms = 0, novel_ms = 0, around_ms = 0;   // count + scan + write kernels of each pass (HIP events)
+  uint64_t junctions = 0;                                // junction evaluations launched
+};
+
+DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device);
+// Runs the three passes; fills records + payload (host).  Throws where the reference raises.
+void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, std::vector<EventRec>& recs,
+              std::vector<uint32_t>& side, CallTimes& times);
+
+}  // namespace pantas

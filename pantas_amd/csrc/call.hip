@@ -1,0 +1,227 @@
+// HIP kernels (gfx950) of the call path and their launcher.
+//
+// One thread per junction (annotated pass, novel-link pass, novel-around-annotated pass); the
+// per-junction logic is call_device.h (scripts/call.py:239-1102).  Rows are variable in number
+// and in length (IR sub-paths), so every pass runs count -> exclusive scan -> write:
+//   call_count_kernel   runs the logic with a counting emitter: records and payload words per junction
+//   scan_kernel         exclusive prefix sums of both counts (wave64 __shfl_up scan, one workgroup)
+//   call_write_kernel   runs the logic again and writes records / payload at the scanned offsets
+// The output order is therefore fixed (pass, junction in file order, emission order) without
+// any sort or atomic cursor.
+#include <hip/hip_runtime.h>
+
+#include "call_host.h"
+#include "call.h"
+
+namespace pantas {
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      throw Error("HipError", std::string(#expr) + ": " + hipGetErrorString(e__));                     \
+  } while (0)
+
+template <int PASS, class Emit>
+__device__ __forceinline__ void run_junction(const CallView& c, uint32_t slot, uint32_t jidx, Emit& e, Fault& f) {
+  if (PASS == 0) annotated_junction(c, slot, e, f);
+  else if (PASS == 1) novel_link(c, slot, e, f);
+  else novel_around(c, slot, jidx, e, f);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void call_count_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx,
+                                                         uint32_t n, uint32_t* nrec, uint32_t* nword,
+                                                         unsigned long long* status) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    CountEmit e;
+    Fault f;
+    run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
+    if (f.bad()) {
+      atomicMin(status, (static_cast<unsigned long long>(PASS) << 40) | (static_cast<unsigned long long>(i) << 8) | f.code);
+      e.recs = 0;
+      e.words = 0;
+    }
+    nrec[i] = e.recs;
+    nword[i] = e.words;
+  }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void call_write_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx,
+                                                         uint32_t n, const uint32_t* rec_off, const uint32_t* word_off,
+                                                         EventRec* recs, uint32_t* side) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    if (rec_off[i + 1] == rec_off[i]) continue;   // nothing to emit: skip the second evaluation
+    WriteEmit e{recs, side, rec_off[i], word_off[i]};
+    Fault f;
+    run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
+  }
+}
+
+// Exclusive scan of a[0..n) into out[0..n], out[n] = total.  One workgroup of 1024 threads
+// (16 waves): wave-level inclusive scan with __shfl_up, wave totals through LDS, running carry.
+__global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* a, uint32_t* out, uint32_t n) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 1024u) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < n ? a[i] : 0u;
+    uint32_t x = v;
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+      const uint32_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63u) wave_tot[wave] = x;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < n) out[i] = carry + before + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023u) carry_s = carry + before + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+// ------------------------------------------------------------------------------------------
+struct DeviceCall {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<void*> allocs;
+  CallView view{};
+  uint32_t* d_junctions = nullptr;
+  uint32_t* d_novels = nullptr;
+  uint32_t nJ = 0, nN = 0;
+  unsigned long long* status = nullptr;
+};
+
+void DeviceCallDeleter::operator()(DeviceCall* d) const {
+  if (!d) return;
+  (void)hipSetDevice(d->device);
+  for (void* p : d->allocs) (void)hipFree(p);
+  if (d->ev0) (void)hipEventDestroy(d->ev0);
+  if (d->ev1) (void)hipEventDestroy(d->ev1);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+template <class T>
+static const T* up(DeviceCall& d, const std::vector<T>& v) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
+  d.allocs.push_back(p);
+  if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, d.stream));
+  return static_cast<const T*>(p);
+}
+
+template <class T>
+static T* dalloc(DeviceCall& d, size_t n) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
+  d.allocs.push_back(p);
+  return static_cast<T*>(p);
+}
+
+DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= device)
+    throw Error("NoDevice", "no HIP device " + std::to_string(device) + " (the call kernels have no CPU path)");
+  HIP_OK(hipSetDevice(device));
+  DeviceCallPtr d(new DeviceCall());
+  d->device = device;
+  HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  HIP_OK(hipEventCreate(&d->ev0));
+  HIP_OK(hipEventCreate(&d->ev1));
+  CallView& c = d->view;
+  c.V = g.V;
+  c.row_ptr = up(*d, g.row_ptr); c.col = up(*d, g.col);
+  c.irow_ptr = up(*d, g.irow_ptr); c.icol = up(*d, g.icol); c.islot = up(*d, g.islot);
+  c.first_slot = up(*d, t.first_slot); c.src = up(*d, t.src); c.lflags = up(*d, t.lflags);
+  c.rc = up(*d, t.rc); c.nc = up(*d, t.nc); c.nflags = up(*d, t.nflags); c.ln = up(*d, g.seg_len); c.rank = up(*d, t.rank);
+  c.ex_ptr = up(*d, t.ex_ptr); c.ex_tag = up(*d, t.ex_tag); c.ex_tx = up(*d, t.ex_tx); c.ex_gene = up(*d, t.ex_gene);
+  c.jn_ptr = up(*d, t.jn_ptr); c.jn_ftx = up(*d, t.jn_ftx);
+  c.jt_ptr = up(*d, t.jt_ptr); c.jt = up(*d, t.jt);
+  c.jx_ptr = up(*d, t.jx_ptr); c.jx = up(*d, t.jx);
+  c.jg_ptr = up(*d, t.jg_ptr); c.jg = up(*d, t.jg);
+  c.tx_gene = up(*d, t.tx_gene);
+  c.probe = up(*d, t.probe); c.probe_ok = up(*d, t.probe_ok);
+  d->status = dalloc<unsigned long long>(*d, 1);
+  HIP_OK(hipStreamSynchronize(d->stream));
+  return d;
+}
+
+template <int PASS>
+static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_t>& slots, const std::vector<uint32_t>* jidx,
+                     std::vector<EventRec>& recs, std::vector<uint32_t>& side, float& ms) {
+  const uint32_t n = uint32_t(slots.size());
+  if (!n) return;
+  std::vector<void*> tmp;
+  auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 4))); tmp.push_back(p); return p; };
+  struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } guard{tmp};
+  uint32_t* d_slots = static_cast<uint32_t*>(dev(size_t(n) * 4));
+  uint32_t* d_jidx = jidx ? static_cast<uint32_t*>(dev(size_t(n) * 4)) : nullptr;
+  uint32_t* nrec = static_cast<uint32_t*>(dev(size_t(n) * 4));
+  uint32_t* nword = static_cast<uint32_t*>(dev(size_t(n) * 4));
+  uint32_t* rec_off = static_cast<uint32_t*>(dev((size_t(n) + 1) * 4));
+  uint32_t* word_off = static_cast<uint32_t*>(dev((size_t(n) + 1) * 4));
+  HIP_OK(hipMemcpyAsync(d_slots, slots.data(), size_t(n) * 4, hipMemcpyHostToDevice, d.stream));
+  if (jidx) HIP_OK(hipMemcpyAsync(d_jidx, jidx->data(), size_t(n) * 4, hipMemcpyHostToDevice, d.stream));
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(n) + 255) / 256, 1u << 16));
+  HIP_OK(hipEventRecord(d.ev0, d.stream));
+  hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, d.status);
+  HIP_OK(hipGetLastError());
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, nrec, rec_off, n);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, nword, word_off, n);
+  HIP_OK(hipGetLastError());
+  uint32_t totals[2] = {0, 0};
+  HIP_OK(hipMemcpyAsync(&totals[0], rec_off + n, 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipMemcpyAsync(&totals[1], word_off + n, 4, hipMemcpyDeviceToHost, d.stream));
+  unsigned long long st = 0;
+  HIP_OK(hipMemcpyAsync(&st, d.status, 8, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  if (st != ~0ull) {
+    const uint32_t code = uint32_t(st & 0xFF);
+    throw Error(call_error_kind(code), call_error_text(code));
+  }
+  EventRec* d_recs = static_cast<EventRec*>(dev(size_t(totals[0]) * sizeof(EventRec)));
+  uint32_t* d_side = static_cast<uint32_t*>(dev(size_t(totals[1]) * 4));
+  hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, d_recs, d_side);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(d.ev1, d.stream));
+  // append to the host arrays; payload offsets become global
+  const size_t r0 = recs.size(), w0 = side.size();
+  recs.resize(r0 + totals[0]);
+  side.resize(w0 + totals[1]);
+  if (totals[0]) HIP_OK(hipMemcpyAsync(recs.data() + r0, d_recs, size_t(totals[0]) * sizeof(EventRec), hipMemcpyDeviceToHost, d.stream));
+  if (totals[1]) HIP_OK(hipMemcpyAsync(side.data() + w0, d_side, size_t(totals[1]) * 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  float t = 0;
+  HIP_OK(hipEventElapsedTime(&t, d.ev0, d.ev1));
+  ms += t;
+  for (size_t i = r0; i < recs.size(); ++i) recs[i].side_off += uint32_t(w0);
+}
+
+void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, std::vector<EventRec>& recs,
+              std::vector<uint32_t>& side, CallTimes& times) {
+  HIP_OK(hipSetDevice(d.device));
+  CallView c = d.view;
+  c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
+  std::vector<uint32_t> ann, nov, around, around_j;
+  pass_lists(g, t, o, ann, nov, around, around_j);
+  HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));
+  recs.clear();
+  side.clear();
+  times = CallTimes();
+  run_pass<0>(d, c, ann, nullptr, recs, side, times.annotated_ms);
+  run_pass<1>(d, c, nov, nullptr, recs, side, times.novel_ms);
+  run_pass<2>(d, c, around, &around_j, recs, side, times.around_ms);
+  times.junctions = ann.size() + nov.size() + around.size();
+}
+
+}  // namespace pantas

@@ -1,0 +1,679 @@
+// Per-junction event enumeration of the call path -- the body of the call kernels
+// (call.hip instantiates these templates once with a counting emitter and once with a
+// writing emitter); a header so that tests/hostsim can compile the same source for the CPU.
+// It is NOT a CPU path of the product.
+//
+// Restated from scripts/call.py:
+//   annotated_junction   check_nonnovel  :239-524   (ES :316-375, SS :377-463, IR :465-524)
+//   novel_link           check_novel     :531-893   (ES :550-614, SS-1 :616-726, SS-2 :728-835, IR-1 :837-893)
+//   novel_around         check_novel     :895-1102  (CE :954-984, IR-2 :985-1102)
+//
+// Everything is integer set algebra over interned tags (call_host.cpp builds the tables):
+// EX tags of a node are a sorted array of tag ids with the transcript and gene of each; the
+// JN tags of a link are kept in file order (for printing) and as sorted transcript / gene /
+// tag-id sets.  Node names are compared through their lexicographic rank because the reference
+// compares node ids as strings (:477, :494, :848, :961, :1038).
+//
+// Where the reference leaves a choice to Python's set iteration order, a fixed rule is used
+// (rules R2-R4 of DESIGN.md): the exon tag / node that appears first in the GFA.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#ifndef PANTAS_HD
+#if defined(__HIPCC__)
+#define PANTAS_HD __host__ __device__ __forceinline__
+#else
+#define PANTAS_HD inline
+#endif
+#endif
+
+namespace pantas {
+
+constexpr uint32_t CNONE = 0xFFFFFFFFu;
+
+// link flags (per canonical slot)
+enum : uint32_t { L_JUNC = 1, L_NOVEL = 2, L_HAS_RC = 4, L_GENE_KEYERR = 8, L_FIRST = 16 };
+// node flags
+enum : uint32_t { N_HAS_NC = 1 };
+// event selection
+enum : uint32_t { EV_ES = 1, EV_SS = 2, EV_IR = 4 };
+
+// record types (EventRec.type)
+enum : uint32_t {
+  T_ES_ANN = 0, T_SS_ANN_A = 1, T_SS_ANN_B = 2, T_IR_ANN = 3, T_ES_NOV = 4, T_SS1_NOV_A = 5, T_SS1_NOV_B = 6,
+  T_SS2_NOV = 7, T_IR1_NOV = 8, T_CE_NOV = 9, T_IR2_NOV = 10, T_SKIP_ES = 11, T_SKIP_SS = 12, T_SKIP_IR = 13
+};
+
+// errors: where the reference raises (or this engine refuses)
+enum : uint32_t {
+  CE_OK = 0, CE_KEY_RC = 1, CE_KEY_TX = 2, CE_ASSERT_EXONS = 3, CE_ASSERT_JN = 4, CE_ASSERT_PATH = 5, CE_HANG = 6,
+  CE_KEY_NC = 7, CE_VALUE_INT = 8, CE_VALUE_MAX = 9, CE_FRONTIER = 10
+};
+
+struct EventRec {
+  uint32_t type, gene;
+  uint32_t j0, j1, j2;       // canonical link slots (meaning depends on type)
+  uint32_t side_off, side_len;  // payload words in the side buffer
+  uint32_t mean;             // ceil(mean NC) for IR records
+};
+
+struct CallView {
+  uint32_t V;
+  const uint32_t* row_ptr;  const uint32_t* col;                       // out CSR (duplicate link lines keep slots)
+  const uint32_t* irow_ptr; const uint32_t* icol; const uint32_t* islot;  // in CSR: source node, out slot
+  const uint32_t* first_slot;   // [A] first slot of the same (u, v) pair
+  const uint32_t* src;          // [A]
+  const uint32_t* lflags;       // [A] valid on canonical slots
+  const int32_t* rc;            // [A]
+  const int32_t* nc;            // [V]
+  const uint32_t* nflags;       // [V]
+  const uint32_t* ln;           // [V] len(sequence)
+  const uint32_t* rank;         // [V] lexicographic rank of the segment name
+  const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
+  const uint32_t* jn_ptr; const uint32_t* jn_ftx;     // per canonical slot, FILE order: filter-transcript of each JN entry
+  const uint32_t* jt_ptr; const uint32_t* jt;         // sorted unique JN tag ids
+  const uint32_t* jx_ptr; const uint32_t* jx;         // sorted unique transcripts
+  const uint32_t* jg_ptr; const uint32_t* jg;         // sorted unique genes
+  const uint32_t* tx_gene;      // [n_tx] gene of a transcript, CNONE when the GTF lacks it
+  const uint32_t* probe;        // [nJ*6] IR-2 probes per junction: (u,u+1..u+3) then (v-3..v-1,v); canonical slot or CNONE
+  const uint32_t* probe_ok;     // [nJ] bit 0: int(u) parses, bit 1: int(v) parses
+  int32_t rca, isw, minintron;
+  uint32_t events;
+};
+
+// ---- small set helpers ------------------------------------------------------------------------
+PANTAS_HD bool sorted_has(const uint32_t* p, uint32_t n, uint32_t x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (p[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo < n && p[lo] == x;
+}
+
+struct Ex { const uint32_t* tag; const uint32_t* tx; const uint32_t* gene; uint32_t n; };
+
+PANTAS_HD Ex ex_of(const CallView& c, uint32_t node) {
+  uint32_t b = c.ex_ptr[node];
+  return Ex{c.ex_tag + b, c.ex_tx + b, c.ex_gene + b, c.ex_ptr[node + 1] - b};
+}
+PANTAS_HD bool ex_has(const Ex& s, uint32_t tag) { return sorted_has(s.tag, s.n, tag); }
+// index of tag in s, or CNONE
+PANTAS_HD uint32_t ex_find(const Ex& s, uint32_t tag) {
+  uint32_t lo = 0, hi = s.n;
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (s.tag[mid] < tag) lo = mid + 1; else hi = mid;
+  }
+  return (lo < s.n && s.tag[lo] == tag) ? lo : CNONE;
+}
+// tag is an exon of `s` that belongs to gene g
+PANTAS_HD bool ex_has_gene(const Ex& s, uint32_t tag, uint32_t g) {
+  uint32_t i = ex_find(s, tag);
+  return i != CNONE && s.gene[i] == g;
+}
+
+struct Set { const uint32_t* p; uint32_t n; };
+PANTAS_HD Set jx_of(const CallView& c, uint32_t s) { return Set{c.jx + c.jx_ptr[s], c.jx_ptr[s + 1] - c.jx_ptr[s]}; }
+PANTAS_HD Set jg_of(const CallView& c, uint32_t s) { return Set{c.jg + c.jg_ptr[s], c.jg_ptr[s + 1] - c.jg_ptr[s]}; }
+PANTAS_HD Set jt_of(const CallView& c, uint32_t s) { return Set{c.jt + c.jt_ptr[s], c.jt_ptr[s + 1] - c.jt_ptr[s]}; }
+PANTAS_HD bool set_has(const Set& s, uint32_t x) { return sorted_has(s.p, s.n, x); }
+
+// first slot of row u that leads to v, or CNONE
+PANTAS_HD uint32_t find_slot(const CallView& c, uint32_t u, uint32_t v) {
+  for (uint32_t s = c.row_ptr[u]; s < c.row_ptr[u + 1]; ++s)
+    if (c.col[s] == v) return s;
+  return CNONE;
+}
+PANTAS_HD bool is_junction(const CallView& c, uint32_t u, uint32_t v) {
+  uint32_t s = find_slot(c, u, v);
+  return s != CNONE && (c.lflags[s] & L_JUNC);
+}
+
+PANTAS_HD uint32_t ceil_mean(uint64_t total, uint32_t n) { return uint32_t((total + n - 1) / n); }
+
+// Error latch of one junction's evaluation
+struct Fault {
+  uint32_t code = CE_OK;
+  PANTAS_HD void raise(uint32_t c) { if (code == CE_OK) code = c; }
+  PANTAS_HD bool bad() const { return code != CE_OK; }
+};
+
+// ---- walks ----------------------------------------------------------------------------------------
+// [:488-499, :843-852] follow the first out-neighbour whose name sorts <= goal's and that
+// passes ok(); otherwise the LAST out-neighbour.  pass 0 counts, pass 1 pushes into the emitter.
+template <class Emit, class Ok>
+PANTAS_HD bool walk_exon(const CallView& c, uint32_t start, uint32_t goal, Ok ok, Emit* emit, uint32_t& n_path,
+                         uint64_t& nc_sum, uint64_t& ln_sum, bool& nc_ok, Fault& f) {
+  uint32_t cur = start;
+  n_path = 0;
+  nc_sum = 0;
+  ln_sum = 0;
+  nc_ok = true;
+  uint32_t guard = c.V + 2;
+  for (;;) {
+    if (emit) emit->push(cur);
+    ++n_path;
+    if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;   // read only when a row is printed
+    ln_sum += c.ln[cur];
+    if (cur == goal) return true;
+    const uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
+    if (b == e) { f.raise(CE_ASSERT_PATH); return false; }
+    uint32_t nxt = c.col[e - 1];
+    for (uint32_t s = b; s < e; ++s) {
+      const uint32_t nn = c.col[s];
+      if (c.rank[nn] <= c.rank[goal] && ok(nn)) { nxt = nn; break; }
+    }
+    cur = nxt;
+    if (--guard == 0) { f.raise(CE_HANG); return false; }
+  }
+}
+
+// [:1035-1050] greedy walk of novel IR (2)
+template <class Emit>
+PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit, uint32_t& n_path, uint64_t& nc_sum,
+                           uint64_t& ln_inner, bool& nc_ok, Fault& f) {
+  uint32_t cur = u;
+  n_path = 0;
+  nc_sum = 0;
+  ln_inner = 0;
+  nc_ok = true;
+  uint32_t guard = c.V + 2;
+  for (;;) {
+    if (emit) emit->push(cur);
+    ++n_path;
+    if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;
+    if (cur == v) return true;
+    if (cur != u) ln_inner += c.ln[cur];
+    const uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
+    uint32_t occ = 0;
+    for (uint32_t s = b; s < e; ++s) occ += (c.col[s] == v) ? 1u : 0u;
+    if (n_path == 1) {
+      if (occ == 0) { f.raise(CE_VALUE_MAX); return false; }   // list.remove(x): x not in list
+      --occ;
+    }
+    if (occ > 0) { cur = v; continue; }
+    uint32_t best = CNONE;
+    int32_t best_nc = 0;
+    for (uint32_t s = b; s < e; ++s) {
+      const uint32_t x = c.col[s];
+      if (x == v || c.rank[x] > c.rank[v]) continue;
+      if (c.row_ptr[x + 1] == c.row_ptr[x]) continue;
+      if (!(c.nflags[x] & N_HAS_NC)) { f.raise(CE_KEY_NC); return false; }
+      if (best == CNONE || c.nc[x] > best_nc) { best = x; best_nc = c.nc[x]; }
+    }
+    if (best == CNONE) { f.raise(CE_VALUE_MAX); return false; }
+    cur = best;
+    if (--guard == 0) { f.raise(CE_HANG); return false; }
+  }
+}
+
+// [:734-750, :787-803] level-bounded frontier search; pop() takes the node that comes first in
+// the GFA (rule R3).  dir 0: follow out-links from `start`, targets = {n : (anchor, n) junction};
+// dir 1: follow in-links, targets = {p : (p, anchor) junction}.
+constexpr uint32_t FRONTIER_CAP = 96;
+PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t anchor, uint32_t dir, Fault& f) {
+  uint32_t vis[FRONTIER_CAP];
+  uint32_t n = 1;
+  vis[0] = start;
+  int32_t left = 1;
+  int32_t level = 0;
+  for (;;) {
+    uint32_t hit = CNONE;
+    for (uint32_t i = 0; i < n; ++i) {
+      const bool t = dir == 0 ? is_junction(c, anchor, vis[i]) : is_junction(c, vis[i], anchor);
+      if (t) { hit = vis[i]; break; }
+    }
+    if (hit != CNONE) return level < c.isw ? hit : CNONE;
+    if (level >= c.isw) return CNONE;
+    if (n == 0) return CNONE;
+    const uint32_t x = vis[0];
+    for (uint32_t i = 1; i < n; ++i) vis[i - 1] = vis[i];
+    --n;
+    --left;
+    const uint32_t b = dir == 0 ? c.row_ptr[x] : c.irow_ptr[x];
+    const uint32_t e = dir == 0 ? c.row_ptr[x + 1] : c.irow_ptr[x + 1];
+    for (uint32_t s = b; s < e; ++s) {
+      const uint32_t y = dir == 0 ? c.col[s] : c.icol[s];
+      uint32_t pos = 0;
+      while (pos < n && vis[pos] < y) ++pos;
+      if (pos < n && vis[pos] == y) continue;
+      if (n == FRONTIER_CAP) { f.raise(CE_FRONTIER); return CNONE; }
+      for (uint32_t i = n; i > pos; --i) vis[i] = vis[i - 1];
+      vis[pos] = y;
+      ++n;
+    }
+    if (left == 0) { ++level; left = int32_t(n); }
+  }
+}
+
+// ---- helpers shared by the three passes ---------------------------------------------------------------
+// every exon of `node` must have a transcript the GTF knows (the reference evaluates
+// transcript2gene[...] for each of them, :258-275); returns whether some exon is of gene g
+PANTAS_HD bool same_gene_exons(const CallView& c, uint32_t node, uint32_t g, Fault& f) {
+  const Ex s = ex_of(c, node);
+  bool any = false;
+  for (uint32_t i = 0; i < s.n; ++i) {
+    if (s.gene[i] == CNONE) { f.raise(CE_KEY_TX); return false; }
+    any |= s.gene[i] == g;
+  }
+  return any;
+}
+
+// JN entries of link s (file order) whose filter-transcript is in (jx(a) & jx(b)) minus jx(minus)
+template <class Emit>
+PANTAS_HD void push_filtered(const CallView& c, uint32_t s, uint32_t a, uint32_t b, uint32_t minus, Emit& emit) {
+  const Set xa = jx_of(c, a), xb = jx_of(c, b);
+  const Set xm = minus == CNONE ? Set{nullptr, 0} : jx_of(c, minus);
+  const uint32_t lo = c.jn_ptr[s], hi = c.jn_ptr[s + 1];
+  uint32_t cnt = 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t t = c.jn_ftx[i];
+    if (set_has(xa, t) && set_has(xb, t) && !set_has(xm, t)) ++cnt;
+  }
+  emit.push(cnt);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t t = c.jn_ftx[i];
+    if (set_has(xa, t) && set_has(xb, t) && !set_has(xm, t)) emit.push(i - lo);
+  }
+}
+
+// gene of a set of transcripts given by a predicate over candidates; returns CNONE-1 for "several"
+constexpr uint32_t GENE_MULTI = 0xFFFFFFFEu;
+PANTAS_HD void gene_accumulate(const CallView& c, uint32_t tx, uint32_t& gene, Fault& f) {
+  const uint32_t g = c.tx_gene[tx];
+  if (g == CNONE) { f.raise(CE_KEY_TX); return; }
+  if (gene == CNONE) gene = g;
+  else if (gene != g) gene = GENE_MULTI;
+}
+
+// ---- pass 1: annotated junctions (:239-524) ----------------------------------------------------------------
+template <class Emit>
+PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
+  const uint32_t u = c.src[s], v = c.col[s];
+  if (!(c.lflags[s] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+  if (c.rc[s] < c.rca) return;
+  if (c.lflags[s] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
+  const Set genes = jg_of(c, s);
+  if (genes.n != 1) return;
+  const uint32_t g = genes.p[0];
+  const bool has_u = same_gene_exons(c, u, g, f);
+  if (f.bad()) return;
+  const bool has_v = same_gene_exons(c, v, g, f);
+  if (f.bad()) return;
+  if (!has_u || !has_v) { f.raise(CE_ASSERT_EXONS); return; }
+  const Ex exu = ex_of(c, u), exv = ex_of(c, v);
+  const Set txs = jx_of(c, s);
+  // heads: other junctions leaving u; tails: other junctions entering v; both of gene g
+  const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
+  const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+  uint32_t n_heads = 0, n_tails = 0;
+  for (uint32_t t = ob; t < oe; ++t) {
+    if (c.first_slot[t] != t || t == s || !(c.lflags[t] & L_JUNC)) continue;
+    if (c.lflags[t] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
+    if (set_has(jg_of(c, t), g)) ++n_heads;
+  }
+  for (uint32_t q = ib; q < ie; ++q) {
+    const uint32_t t = c.islot[q];
+    if (c.first_slot[t] != t || t == s || !(c.lflags[t] & L_JUNC)) continue;
+    if (c.lflags[t] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
+    if (set_has(jg_of(c, t), g)) ++n_tails;
+  }
+  auto is_head = [&](uint32_t t) {
+    return c.first_slot[t] == t && t != s && (c.lflags[t] & L_JUNC) && set_has(jg_of(c, t), g);
+  };
+
+  if (c.events & EV_ES) {
+    for (uint32_t t1 = ob; t1 < oe; ++t1) {
+      if (!is_head(t1)) continue;
+      const Set x1 = jx_of(c, t1);
+      for (uint32_t q = ib; q < ie; ++q) {
+        const uint32_t t2 = c.islot[q];
+        if (!is_head(t2)) continue;
+        const Set x2 = jx_of(c, t2);
+        bool inc = false;
+        for (uint32_t i = 0; i < x1.n && !inc; ++i) inc = set_has(x2, x1.p[i]) && !set_has(txs, x1.p[i]);
+        if (!inc) continue;
+        // an exon on the far ends that is on neither end of the junction (for gene g)
+        bool fresh = false;
+        const Ex a = ex_of(c, c.col[t1]), b = ex_of(c, c.src[t2]);
+        for (uint32_t i = 0; i < a.n && !fresh; ++i) fresh = !ex_has_gene(exu, a.tag[i], g) && !ex_has_gene(exv, a.tag[i], g);
+        for (uint32_t i = 0; i < b.n && !fresh; ++i) fresh = !ex_has_gene(exu, b.tag[i], g) && !ex_has_gene(exv, b.tag[i], g);
+        if (!fresh) continue;
+        emit.begin(T_ES_ANN, g, s, t1, t2);
+        push_filtered(c, t1, t1, t2, s, emit);
+        push_filtered(c, t2, t1, t2, s, emit);
+        emit.end(0);
+      }
+    }
+  }
+
+  if (c.events & EV_SS) {
+    if (n_tails) {
+      for (uint32_t t = ob; t < oe; ++t) {          // every out-link line of u, duplicates included
+        const uint32_t n = c.col[t];
+        if (n == v) continue;
+        const Ex en = ex_of(c, n);
+        bool cont = false;
+        for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exu, en.tag[i], g);
+        if (!cont) continue;
+        for (uint32_t q = ib; q < ie; ++q) {
+          const uint32_t t2 = c.islot[q];
+          if (!is_head(t2)) continue;
+          const uint32_t from = c.src[t2];
+          if (from == u) continue;
+          const Ex ef = ex_of(c, from);
+          bool shared = false, changes = false;
+          for (uint32_t i = 0; i < ef.n; ++i) {
+            const uint32_t tg = ef.tag[i];
+            if (ex_has(en, tg) && ex_has_gene(exu, tg, g)) {
+              shared = true;
+              if (!set_has(txs, ef.tx[i])) changes = true;
+            }
+          }
+          if (!shared || !changes) continue;
+          const Set ta = jt_of(c, s), tb = jt_of(c, t2);
+          for (uint32_t i = 0; i < ta.n; ++i)
+            if (set_has(tb, ta.p[i])) { f.raise(CE_ASSERT_JN); return; }
+          emit.begin(T_SS_ANN_A, g, s, t2, CNONE);
+          emit.end(0);
+        }
+      }
+    }
+    if (n_heads) {
+      for (uint32_t q0 = ib; q0 < ie; ++q0) {        // every in-link line of v
+        const uint32_t n = c.icol[q0];
+        if (n == u) continue;
+        const Ex en = ex_of(c, n);
+        bool cont = false;
+        for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exv, en.tag[i], g);
+        if (!cont) continue;
+        for (uint32_t t1 = ob; t1 < oe; ++t1) {
+          if (!is_head(t1)) continue;
+          const uint32_t to = c.col[t1];
+          if (to == v) continue;
+          const Ex et = ex_of(c, to);
+          bool shared = false, changes = false;
+          for (uint32_t i = 0; i < et.n; ++i) {
+            const uint32_t tg = et.tag[i];
+            if (ex_has(en, tg) && ex_has_gene(exv, tg, g)) {
+              shared = true;
+              if (!set_has(txs, et.tx[i])) changes = true;
+            }
+          }
+          if (!shared || !changes) continue;
+          emit.begin(T_SS_ANN_B, g, s, t1, CNONE);
+          emit.end(0);
+        }
+      }
+    }
+  }
+
+  if (c.events & EV_IR) {
+    bool done = false;
+    for (uint32_t t = ob; t < oe && !done; ++t) {
+      const uint32_t n1 = c.col[t];
+      if (n1 == v) continue;
+      const Ex e1 = ex_of(c, n1);
+      for (uint32_t q = ib; q < ie && !done; ++q) {
+        const uint32_t n2 = c.icol[q];
+        if (n2 == u) continue;
+        if (c.rank[n2] < c.rank[n1]) continue;
+        const Ex e2 = ex_of(c, n2);
+        uint32_t pick = CNONE;   // smallest tag id in EX(n1) & EX(n2) & ex_u & ex_v (rule R2)
+        for (uint32_t i = 0; i < e1.n; ++i) {
+          const uint32_t tg = e1.tag[i];
+          if (ex_has(e2, tg) && ex_has_gene(exu, tg, g) && ex_has_gene(exv, tg, g)) { pick = tg; break; }
+        }
+        if (pick == CNONE) continue;
+        auto ok = [&](uint32_t nn) { return ex_has(ex_of(c, nn), pick); };
+        uint32_t np;
+        uint64_t ncs, lns;
+        bool nc_ok;
+        if (!walk_exon<Emit>(c, n1, n2, ok, nullptr, np, ncs, lns, nc_ok, f)) return;
+        if (!nc_ok) { f.raise(CE_KEY_NC); return; }
+        emit.begin(T_IR_ANN, g, s, CNONE, CNONE);
+        emit.push(np);
+        walk_exon<Emit>(c, n1, n2, ok, &emit, np, ncs, lns, nc_ok, f);
+        emit.end(ceil_mean(ncs, np));
+        done = true;
+      }
+    }
+  }
+}
+
+// ---- pass 2: links seen only in reads (:531-893) ------------------------------------------------------------
+template <class Emit>
+PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
+  const uint32_t u = c.src[s], v = c.col[s];
+  if (!(c.lflags[s] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+  if (c.rc[s] < c.rca) return;
+  const Ex ex0 = ex_of(c, u), ex1 = ex_of(c, v);
+  if (ex0.n == 0 && ex1.n == 0) return;
+  const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
+  const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+  // cap = transcripts with an exon on both ends
+  auto in_cap = [&](uint32_t tx) {
+    bool a = false, b = false;
+    for (uint32_t i = 0; i < ex0.n && !a; ++i) a = ex0.tx[i] == tx;
+    for (uint32_t i = 0; i < ex1.n && !b; ++i) b = ex1.tx[i] == tx;
+    return a && b;
+  };
+  bool cap_any = false;
+  for (uint32_t i = 0; i < ex0.n && !cap_any; ++i)
+    for (uint32_t k = 0; k < ex1.n && !cap_any; ++k) cap_any = ex0.tx[i] == ex1.tx[k];
+
+  if (c.events & EV_ES) {
+    if (ex0.n && ex1.n) {
+      uint32_t both = 0;
+      for (uint32_t i = 0; i < ex0.n; ++i) both += ex_has(ex1, ex0.tag[i]) ? 1u : 0u;
+      if (both != ex0.n) {
+        for (uint32_t t = ob; t < oe; ++t) {
+          const uint32_t j1 = c.first_slot[t];
+          if (!(c.lflags[j1] & L_JUNC)) continue;
+          for (uint32_t q = ib; q < ie; ++q) {
+            const uint32_t j2 = c.first_slot[c.islot[q]];
+            if (!(c.lflags[j2] & L_JUNC)) continue;
+            const Set x1 = jx_of(c, j1), x2 = jx_of(c, j2);
+            uint32_t gene = CNONE;
+            bool any = false;
+            for (uint32_t i = 0; i < x1.n; ++i)
+              if (set_has(x2, x1.p[i])) { any = true; gene_accumulate(c, x1.p[i], gene, f); }
+            if (!any) continue;
+            if (f.bad()) return;
+            if (gene == GENE_MULTI) { emit.begin(T_SKIP_ES, CNONE, s, CNONE, CNONE); emit.end(0); continue; }
+            emit.begin(T_ES_NOV, gene, s, j1, j2);
+            push_filtered(c, j1, j1, j2, CNONE, emit);
+            push_filtered(c, j2, j1, j2, CNONE, emit);
+            emit.end(0);
+          }
+        }
+      }
+    }
+  }
+
+  if (c.events & EV_SS) {
+    if (cap_any) {
+      // side 0: annotated junctions (u, n) into an exon that also covers v; side 1: (p, v) out of an exon covering u
+      for (uint32_t side = 0; side < 2; ++side) {
+        const Ex spl = side == 0 ? ex1 : ex0;
+        if (spl.n == 0) continue;
+        const uint32_t b = side == 0 ? ob : ib, e = side == 0 ? oe : ie;
+        for (uint32_t t = b; t < e; ++t) {
+          const uint32_t n = side == 0 ? c.col[t] : c.icol[t];
+          const uint32_t jj = c.first_slot[side == 0 ? t : c.islot[t]];
+          const Ex en = ex_of(c, n);
+          bool shared = false;
+          uint32_t gene = CNONE;
+          bool keep = false;
+          for (uint32_t i = 0; i < en.n; ++i) {
+            if (!ex_has(spl, en.tag[i])) continue;
+            shared = true;
+            if (in_cap(en.tx[i])) keep = true;
+          }
+          if (!shared || !keep || !(c.lflags[jj] & L_JUNC)) continue;
+          for (uint32_t i = 0; i < en.n; ++i)
+            if (ex_has(spl, en.tag[i]) && in_cap(en.tx[i])) gene_accumulate(c, en.tx[i], gene, f);
+          if (f.bad()) return;
+          if (gene == GENE_MULTI) { emit.begin(T_SKIP_SS, CNONE, s, CNONE, CNONE); emit.end(0); continue; }
+          emit.begin(side == 0 ? T_SS1_NOV_A : T_SS1_NOV_B, gene, s, jj, CNONE);
+          emit.end(0);
+        }
+      }
+    }
+    uint32_t j1 = CNONE;
+    if (ex0.n && !ex1.n) {
+      const uint32_t hit = frontier_search(c, v, u, 0, f);
+      if (f.bad()) return;
+      if (hit != CNONE) j1 = find_slot(c, u, hit);
+    } else if (!ex0.n && ex1.n) {
+      const uint32_t hit = frontier_search(c, u, v, 1, f);
+      if (f.bad()) return;
+      if (hit != CNONE) j1 = find_slot(c, hit, v);
+    }
+    if (j1 != CNONE) {
+      if (c.lflags[j1] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
+      const Set gs = jg_of(c, j1);
+      if (gs.n > 1) { emit.begin(T_SKIP_SS, CNONE, s, CNONE, CNONE); emit.end(0); }
+      else { emit.begin(T_SS2_NOV, gs.p[0], j1, s, CNONE); emit.end(0); }
+    }
+  }
+
+  if ((c.events & EV_IR) && cap_any) {
+    bool inside_any = false;
+    for (uint32_t i = 0; i < ex0.n && !inside_any; ++i) inside_any = ex_has(ex1, ex0.tag[i]);
+    if (inside_any) {
+      auto ok = [&](uint32_t nn) {
+        const Ex en = ex_of(c, nn);
+        for (uint32_t i = 0; i < en.n; ++i)
+          if (ex_has(ex0, en.tag[i]) && ex_has(ex1, en.tag[i])) return true;
+        return false;
+      };
+      uint32_t np;
+      uint64_t ncs, lns;
+      bool nc_ok;
+      if (!walk_exon<Emit>(c, u, v, ok, nullptr, np, ncs, lns, nc_ok, f)) return;
+      if (int64_t(lns) >= int64_t(c.minintron)) {
+        uint32_t gene = CNONE, n_in = 0;
+        for (uint32_t i = 0; i < ex0.n; ++i)
+          if (ex_has(ex1, ex0.tag[i])) { ++n_in; gene_accumulate(c, ex0.tx[i], gene, f); }
+        if (f.bad()) return;
+        if (gene == GENE_MULTI) { emit.begin(T_SKIP_IR, CNONE, s, CNONE, CNONE); emit.end(0); }
+        else {
+          if (!nc_ok) { f.raise(CE_KEY_NC); return; }
+          emit.begin(T_IR1_NOV, gene, s, CNONE, CNONE);
+          emit.push(np);
+          walk_exon<Emit>(c, u, v, ok, &emit, np, ncs, lns, nc_ok, f);
+          emit.push(n_in);
+          for (uint32_t i = 0; i < ex0.n; ++i)
+            if (ex_has(ex1, ex0.tag[i])) emit.push(ex0.tag[i]);
+          emit.end(ceil_mean(ncs, np));
+        }
+      }
+    }
+  }
+}
+
+// ---- pass 3: annotated junctions against the novel links around them (:895-1102) --------------------------
+template <class Emit>
+PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& emit, Fault& f) {
+  if (!(c.events & (EV_IR | EV_ES))) return;
+  const uint32_t u = c.src[s], v = c.col[s];
+  if (!(c.lflags[s] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+  if (c.rc[s] < c.rca) return;
+  if (c.lflags[s] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
+  const Set genes = jg_of(c, s);
+  if (genes.n != 1) return;
+  const uint32_t g = genes.p[0];
+  const bool has_u = same_gene_exons(c, u, g, f);
+  if (f.bad()) return;
+  const bool has_v = same_gene_exons(c, v, g, f);
+  if (f.bad()) return;
+  if (!has_u || !has_v) { f.raise(CE_ASSERT_EXONS); return; }
+  const Ex exu = ex_of(c, u), exv = ex_of(c, v);
+  const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
+  const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+
+  if (c.events & EV_ES) {
+    for (uint32_t t1 = ob; t1 < oe; ++t1) {
+      if (c.first_slot[t1] != t1 || t1 == s || !(c.lflags[t1] & L_NOVEL)) continue;
+      for (uint32_t q = ib; q < ie; ++q) {
+        const uint32_t t2 = c.islot[q];
+        if (c.first_slot[t2] != t2 || t2 == s || !(c.lflags[t2] & L_NOVEL)) continue;
+        if (c.rank[c.col[t1]] <= c.rank[c.src[t2]]) {
+          if (!(c.lflags[t1] & L_HAS_RC) || !(c.lflags[t2] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+          emit.begin(T_CE_NOV, g, s, t1, t2);
+          emit.end(0);
+        }
+      }
+    }
+  }
+
+  if (c.events & EV_IR) {
+    if (!(c.probe_ok[jidx] & 1u)) { f.raise(CE_VALUE_INT); return; }   // int(u) fails
+    const uint32_t* pr = c.probe + uint64_t(jidx) * 6;
+    bool left = false, right = false;
+    for (uint32_t d = 0; d < 3; ++d) {
+      const uint32_t t = pr[d];
+      if (t == CNONE || (c.lflags[t] & L_JUNC)) continue;
+      if (!(c.lflags[t] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+      left |= c.rc[t] >= c.rca;
+    }
+    if (!left) return;
+    if (!(c.probe_ok[jidx] & 2u)) { f.raise(CE_VALUE_INT); return; }   // int(v) fails
+    for (uint32_t d = 3; d < 6; ++d) {
+      const uint32_t t = pr[d];
+      if (t == CNONE || (c.lflags[t] & L_JUNC)) continue;
+      if (!(c.lflags[t] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+      right |= c.rc[t] >= c.rca;
+    }
+    if (!right) return;
+    // exons of gene g that END at u (no out-neighbour carries them) and START at v
+    auto ends_at_u = [&](uint32_t i) {
+      if (exu.gene[i] != g) return false;
+      for (uint32_t t = ob; t < oe; ++t) if (ex_has(ex_of(c, c.col[t]), exu.tag[i])) return false;
+      return true;
+    };
+    auto starts_at_v = [&](uint32_t k) {
+      if (exv.gene[k] != g) return false;
+      for (uint32_t q = ib; q < ie; ++q) if (ex_has(ex_of(c, c.icol[q]), exv.tag[k])) return false;
+      return true;
+    };
+    uint32_t n_pairs = 0;
+    uint32_t gene2 = CNONE;
+    Fault gf;
+    for (uint32_t i = 0; i < exu.n; ++i) {
+      if (!ends_at_u(i)) continue;
+      for (uint32_t k = 0; k < exv.n; ++k) {
+        if (exu.tx[i] != exv.tx[k] || !starts_at_v(k)) continue;
+        ++n_pairs;
+        gene_accumulate(c, exu.tx[i], gene2, gf);
+      }
+    }
+    if (n_pairs == 0) return;
+    uint32_t np;
+    uint64_t ncs, lin;
+    bool nc_ok;
+    if (!walk_greedy<Emit>(c, u, v, nullptr, np, ncs, lin, nc_ok, f)) return;
+    if (int64_t(lin) < int64_t(c.minintron)) return;
+    if (gf.bad()) { f.raise(gf.code); return; }
+    if (gene2 == GENE_MULTI) { emit.begin(T_SKIP_IR, CNONE, s, CNONE, CNONE); emit.end(0); return; }
+    if (!nc_ok) { f.raise(CE_KEY_NC); return; }
+    emit.begin(T_IR2_NOV, gene2, s, CNONE, CNONE);
+    emit.push(np);
+    walk_greedy<Emit>(c, u, v, &emit, np, ncs, lin, nc_ok, f);
+    emit.push(n_pairs);
+    for (uint32_t i = 0; i < exu.n; ++i) {
+      if (!ends_at_u(i)) continue;
+      for (uint32_t k = 0; k < exv.n; ++k) {
+        if (exu.tx[i] != exv.tx[k] || !starts_at_v(k)) continue;
+        emit.push(exu.tag[i]);
+        emit.push(exv.tag[k]);
+      }
+    }
+    emit.end(ceil_mean(ncs, np));
+  }
+}
+
+}  // namespace pantas

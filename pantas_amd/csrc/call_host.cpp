@@ -1,0 +1,636 @@
+#include "call_host.h"
+
+#include <map>
+#include <unordered_map>
+
+namespace pantas {
+
+const char* const CALL_CSV_HEADER =
+    "event_type,annotated/novel,chrom,gene,strand,transcripts1,transcripts2,transcripts3,"
+    "nodes1,coverage1,nodes2,coverage2,nodes3,coverage3";
+
+const char* call_error_kind(uint32_t code) {
+  switch (code) {
+    case CE_KEY_RC: case CE_KEY_TX: case CE_KEY_NC: return "KeyError";
+    case CE_ASSERT_EXONS: case CE_ASSERT_JN: case CE_ASSERT_PATH: return "AssertionError";
+    case CE_VALUE_INT: case CE_VALUE_MAX: return "ValueError";
+    default: return "Unsupported";
+  }
+}
+const char* call_error_text(uint32_t code) {
+  switch (code) {
+    case CE_KEY_RC: return "'RC' (a link the caller reads has no RC tag: GFA not augmented?)";
+    case CE_KEY_TX: return "a transcript named by an EX/JN tag is not in the GTF";
+    case CE_KEY_NC: return "'NC' (a segment on a reported path has no NC tag)";
+    case CE_ASSERT_EXONS: return "a junction end carries no exon of the junction's gene";
+    case CE_ASSERT_JN: return "two junctions compared for an alternative splice site share a JN tag";
+    case CE_ASSERT_PATH: return "Error while reconstrucing IR path";
+    case CE_VALUE_INT: return "invalid literal for int(): segment name of a junction end";
+    case CE_VALUE_MAX: return "max() arg is an empty sequence (novel IR walk ran into a dead end)";
+    case CE_HANG: return "intron walk does not terminate (the reference would loop forever)";
+    case CE_FRONTIER: return "intronic search frontier larger than the engine's bound";
+    default: return "unknown";
+  }
+}
+
+namespace {
+
+struct SegAttr { uint64_t ex_off = 0; uint32_t ex_len = 0; bool has_ex = false; };
+struct LinkAttr { uint64_t jn_off = 0; uint32_t jn_len = 0; bool has_jn = false, has_id = false, has_rc = false; int32_t rc = 0; };
+
+[[noreturn]] void bad_tag(uint64_t off, Span f) {
+  throw Error("ValueError", "GFA byte " + std::to_string(off) + ": tag '" + std::string(f.b, f.size()) +
+                                "' does not split into 3 fields on ':'");
+}
+
+// name:type:value with exactly two ':' (scripts/call.py:28)
+inline bool split_tag(Span f, Span& name, Span& value) {
+  const char* c1 = static_cast<const char*>(memchr(f.b, ':', f.size()));
+  if (!c1) return false;
+  const char* c2 = static_cast<const char*>(memchr(c1 + 1, ':', size_t(f.e - c1 - 1)));
+  if (!c2) return false;
+  if (memchr(c2 + 1, ':', size_t(f.e - c2 - 1))) return false;
+  name = Span{f.b, c1};
+  value = Span{c2 + 1, f.e};
+  return true;
+}
+
+inline bool name_is(Span n, const char* s) { return n.size() == 2 && n.b[0] == s[0] && n.b[1] == s[1]; }
+
+int32_t tag_int(Span v, uint64_t off) {
+  int64_t x;
+  if (!parse_py_int(v, x)) throw Error("ValueError", "GFA byte " + std::to_string(off) + ": invalid literal for int()");
+  if (x < 0 || x > INT32_MAX) throw Error("Unsupported", "GFA byte " + std::to_string(off) + ": count outside [0, 2^31)");
+  return int32_t(x);
+}
+
+// IL/OL values are parsed (ints around '.') by the reference although never used (:33-66)
+void check_hist_value(Span v, uint64_t off) {
+  const char* p = v.b;
+  while (p <= v.e) {
+    const char* q = static_cast<const char*>(memchr(p, ',', size_t(v.e - p)));
+    if (!q) q = v.e;
+    const char* a = p;
+    while (a <= q) {
+      const char* d = static_cast<const char*>(memchr(a, '.', size_t(q - a)));
+      if (!d) d = q;
+      int64_t x;
+      if (!parse_py_int(Span{a, d}, x)) throw Error("ValueError", "GFA byte " + std::to_string(off) + ": IL/OL value is not 'int.int'");
+      a = d + 1;
+    }
+    p = q + 1;
+  }
+}
+
+// 'T_H.k' -> 'T' (:107-121): drop the last '.'-field, then the last '_'-field
+inline Span tx_of_exon(Span tag) {
+  const char* d = tag.e;
+  while (d > tag.b && d[-1] != '.') --d;
+  if (d == tag.b) return Span{tag.b, tag.b};
+  Span ht{tag.b, d - 1};
+  const char* u = ht.e;
+  while (u > ht.b && u[-1] != '_') --u;
+  if (u == ht.b) return Span{tag.b, tag.b};
+  return Span{tag.b, u - 1};
+}
+// 'T_H.k.k2' -> 'T' (:98-104): drop the last two '.'-fields, then the last '_'-field
+inline Span tx_of_junction(Span tag) {
+  const char* d = tag.e;
+  int dots = 0;
+  while (d > tag.b) {
+    if (d[-1] == '.') { if (++dots == 2) break; }
+    --d;
+  }
+  if (dots < 2) return Span{tag.b, tag.b};
+  Span ht{tag.b, d - 1};
+  const char* u = ht.e;
+  while (u > ht.b && u[-1] != '_') --u;
+  if (u == ht.b) return Span{tag.b, tag.b};
+  return Span{tag.b, u - 1};
+}
+// "_".join(x.split("_")[:-1]) (:356, :364, :595, :603)
+inline Span tx_for_filter(Span tag) {
+  const char* u = tag.e;
+  while (u > tag.b && u[-1] != '_') --u;
+  if (u == tag.b) return Span{tag.b, tag.b};
+  return Span{tag.b, u - 1};
+}
+
+struct Gtf {
+  std::unordered_map<std::string, uint32_t> gene_id;    // gene name -> id
+  std::unordered_map<std::string, uint32_t> tx_gene;    // transcript name -> gene id
+};
+
+bool is_id_char(char c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9') || c == '_'; }
+
+// re.search('<key> "[A-Za-z0-9_]+";', s): first match
+bool find_attr(Span s, const char* key, Span& out) {
+  const size_t kl = strlen(key);
+  for (const char* p = s.b; p + kl + 4 <= s.e; ++p) {
+    if (memcmp(p, key, kl) != 0 || p[kl] != ' ' || p[kl + 1] != '"') continue;
+    const char* q = p + kl + 2;
+    const char* r = q;
+    while (r < s.e && is_id_char(*r)) ++r;
+    if (r > q && r + 1 < s.e && r[0] == '"' && r[1] == ';') { out = Span{q, r}; return true; }
+  }
+  return false;
+}
+
+void parse_gtf(const char* path, Gtf& gtf, CallTables& t) {
+  MappedFile f;
+  f.open(path);
+  const char* p = f.data;
+  const char* end = f.data + f.size;
+  uint64_t lineno = 0;
+  static const char* feats[] = {"mRNA", "transcript", "miRNA", "ncRNA", "pre_miRNA", "snoRNA", "pseudogene"};
+  while (p < end) {
+    const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
+    const char* le = nl ? nl : end;
+    ++lineno;
+    Span line{p, le};
+    p = nl ? nl + 1 : end;
+    if (line.size() && *line.b == '#') continue;
+    // split on '\t' only (:194)
+    std::vector<Span> col;
+    const char* a = line.b;
+    for (;;) {
+      const char* tb = static_cast<const char*>(memchr(a, '\t', size_t(line.e - a)));
+      if (!tb) { col.push_back(Span{a, line.e}); break; }
+      col.push_back(Span{a, tb});
+      a = tb + 1;
+    }
+    if (col.size() < 3) throw Error("IndexError", "GTF line " + std::to_string(lineno) + ": fewer than 3 columns");
+    bool want = false;
+    for (const char* ft : feats) want |= col[2].sv() == ft;
+    if (!want) continue;
+    Span gid, tid;
+    if (!find_attr(col.back(), "gene_id", gid) || !find_attr(col.back(), "transcript_id", tid))
+      throw Error("AttributeError", "GTF line " + std::to_string(lineno) +
+                                        ": 'NoneType' object has no attribute 'group' (gene_id/transcript_id \"[A-Za-z0-9_]+\";)");
+    if (col.size() < 7) throw Error("IndexError", "GTF line " + std::to_string(lineno) + ": fewer than 7 columns");
+    std::string g(gid.b, gid.size());
+    auto it = gtf.gene_id.find(g);
+    uint32_t id;
+    if (it == gtf.gene_id.end()) {
+      id = uint32_t(t.gene_name.size());
+      gtf.gene_id.emplace(g, id);
+      t.gene_name.push_back(g);
+      t.gene_strand.emplace_back();
+      t.gene_chrom.emplace_back();
+    } else id = it->second;
+    t.gene_strand[id].assign(col[6].b, col[6].size());
+    t.gene_chrom[id].assign(col[0].b, col[0].size());
+    gtf.tx_gene[std::string(tid.b, tid.size())] = id;
+  }
+}
+
+template <class T>
+void sort_unique(std::vector<T>& v) {
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+}
+
+}  // namespace
+
+void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsigned threads) {
+  const double t0 = now_s();
+  if (threads == 0) threads = hw_threads();
+  const char* base = g.text.data;
+  // inputs the reference's GFA loop dies on (call.py:145-181)
+  if (g.first_bad_p_off != UINT64_MAX)
+    throw Error("ValueError", "GFA byte " + std::to_string(g.first_bad_p_off) + ": P line does not have exactly 4 fields");
+  if (g.first_short_l_off != UINT64_MAX)
+    throw Error("ValueError", "GFA byte " + std::to_string(g.first_short_l_off) + ": L line with fewer than 6 fields");
+  if (g.links_unknown_end || g.link_before_segment)
+    throw Error("KeyError", "an L line names a segment with no S line before it");
+  if (g.dup_names) throw Error("Unsupported", "duplicate S lines for one segment name (call)");
+  const uint32_t V = g.V;
+  const size_t A = g.A;
+
+  Gtf gtf;
+  parse_gtf(gtf_path, gtf, t);
+
+  // ---- phase A (parallel): locate the tags of every S line and every link slot -----------------
+  std::vector<SegAttr> sa(V);
+  t.nc.assign(V, 0);
+  t.nflags.assign(V, 0);
+  parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+    for (size_t n = b; n < e; ++n) {
+      const uint64_t off = g.seg_line_off[n];
+      const char* le = static_cast<const char*>(memchr(base + off, '\n', g.text.size - off));
+      Span st = strip(Span{base + off, le ? le : base + g.text.size});
+      Tokens tk(st);
+      Span f;
+      tk.next(f); tk.next(f); tk.next(f);
+      while (tk.next(f)) {
+        Span name, value;
+        if (!split_tag(f, name, value)) bad_tag(off, f);
+        if (name_is(name, "NC")) { t.nc[n] = tag_int(value, off); t.nflags[n] |= N_HAS_NC; }
+        else if (name_is(name, "LN") || name_is(name, "RC")) (void)tag_int(value, off);
+        else if (name_is(name, "IL") || name_is(name, "OL")) check_hist_value(value, off);
+        else if (name_is(name, "EX")) { sa[n].ex_off = uint64_t(value.b - base); sa[n].ex_len = uint32_t(value.size()); sa[n].has_ex = true; }
+      }
+    }
+  });
+  std::vector<LinkAttr> la(A);
+  t.src.resize(A);
+  parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+    for (size_t u = b; u < e; ++u)
+      for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s) {
+        t.src[s] = uint32_t(u);
+        const uint64_t off = g.slot_off[s];
+        const char* le = static_cast<const char*>(memchr(base + off, '\n', g.text.size - off));
+        Span st = strip(Span{base + off, le ? le : base + g.text.size});
+        Tokens tk(st);
+        Span f;
+        for (int i = 0; i < 6; ++i) tk.next(f);
+        LinkAttr& a = la[s];
+        while (tk.next(f)) {
+          Span name, value;
+          if (!split_tag(f, name, value)) bad_tag(off, f);
+          if (name_is(name, "RC")) { a.rc = tag_int(value, off); a.has_rc = true; }
+          else if (name_is(name, "LN") || name_is(name, "NC")) (void)tag_int(value, off);
+          else if (name_is(name, "IL") || name_is(name, "OL")) check_hist_value(value, off);
+          else if (name_is(name, "JN")) { a.jn_off = uint64_t(value.b - base); a.jn_len = uint32_t(value.size()); a.has_jn = true; }
+          else if (name_is(name, "ID")) a.has_id = true;
+        }
+      }
+  });
+
+  // ---- canonical slots: first slot of each (u, v); attributes of the LAST duplicate (dict overwrite, :173)
+  t.first_slot.resize(A);
+  t.lflags.assign(A, 0);
+  t.rc.assign(A, 0);
+  std::vector<uint32_t> attr_slot(A);
+  for (uint32_t u = 0; u < V; ++u) {
+    const uint32_t b = g.row_ptr[u], e = g.row_ptr[u + 1];
+    for (uint32_t s = b; s < e; ++s) {
+      uint32_t first = s;
+      for (uint32_t q = b; q < s; ++q) if (g.col[q] == g.col[s]) { first = q; break; }
+      t.first_slot[s] = first;
+      attr_slot[first] = s;   // the last duplicate wins
+      if (first != s) {
+        // membership in `junctions` / `noveljunctions` is decided line by line; refuse the case where the
+        // lines of one pair disagree (the reference would then index a missing key or a stale set entry)
+        if (la[s].has_jn != la[first].has_jn || la[s].has_id != la[first].has_id)
+          throw Error("Unsupported", "duplicate L lines of one link disagree on JN/ID tags");
+      }
+    }
+  }
+  for (size_t s = 0; s < A; ++s) {
+    if (t.first_slot[s] != s) continue;
+    const LinkAttr& a = la[attr_slot[s]];
+    uint32_t fl = L_FIRST;
+    if (a.has_jn) fl |= L_JUNC;
+    if (a.has_id) fl |= L_NOVEL;
+    if (a.has_rc) { fl |= L_HAS_RC; t.rc[s] = a.rc; }
+    t.lflags[s] = fl;
+  }
+
+  // ---- phase B: intern transcripts, EX tags, JN tags (first-appearance order) -------------------------
+  std::unordered_map<std::string_view, uint32_t> tx_ids;
+  auto tx_id = [&](Span name) -> uint32_t {
+    auto it = tx_ids.find(name.sv());
+    if (it != tx_ids.end()) return it->second;
+    uint32_t id = uint32_t(t.tx_gene.size());
+    tx_ids.emplace(name.sv(), id);
+    auto gi = gtf.tx_gene.find(std::string(name.b, name.size()));
+    t.tx_gene.push_back(gi == gtf.tx_gene.end() ? CNONE : gi->second);
+    return id;
+  };
+  std::unordered_map<std::string_view, uint32_t> ex_ids;
+  std::vector<uint32_t> extag_tx;
+  t.ex_ptr.assign(size_t(V) + 1, 0);
+  std::vector<uint32_t> tmp;
+  for (uint32_t n = 0; n < V; ++n) {
+    t.ex_ptr[n] = uint32_t(t.ex_tag.size());
+    if (!sa[n].has_ex) continue;
+    tmp.clear();
+    const char* p = base + sa[n].ex_off;
+    const char* e = p + sa[n].ex_len;
+    for (;;) {
+      const char* c = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
+      Span tag{p, c ? c : e};
+      auto it = ex_ids.find(tag.sv());
+      uint32_t id;
+      if (it == ex_ids.end()) {
+        id = uint32_t(t.extag_span.size());
+        ex_ids.emplace(tag.sv(), id);
+        t.extag_span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
+        extag_tx.push_back(tx_id(tx_of_exon(tag)));
+      } else id = it->second;
+      tmp.push_back(id);
+      if (!c) break;
+      p = c + 1;
+    }
+    sort_unique(tmp);
+    for (uint32_t id : tmp) {
+      t.ex_tag.push_back(id);
+      t.ex_tx.push_back(extag_tx[id]);
+      t.ex_gene.push_back(t.tx_gene[extag_tx[id]]);
+    }
+  }
+  t.ex_ptr[V] = uint32_t(t.ex_tag.size());
+
+  std::unordered_map<std::string_view, uint32_t> jn_ids;
+  t.jn_ptr.assign(A + 1, 0);
+  t.jt_ptr.assign(A + 1, 0);
+  t.jx_ptr.assign(A + 1, 0);
+  t.jg_ptr.assign(A + 1, 0);
+  std::vector<uint32_t> tags, txs, genes;
+  for (size_t s = 0; s < A; ++s) {
+    t.jn_ptr[s] = uint32_t(t.jn_ftx.size());
+    t.jt_ptr[s] = uint32_t(t.jt.size());
+    t.jx_ptr[s] = uint32_t(t.jx.size());
+    t.jg_ptr[s] = uint32_t(t.jg.size());
+    if (t.first_slot[s] != s || !(t.lflags[s] & L_JUNC)) continue;
+    const LinkAttr& a = la[attr_slot[s]];
+    tags.clear(); txs.clear(); genes.clear();
+    const char* p = base + a.jn_off;
+    const char* e = p + a.jn_len;
+    bool keyerr = false;
+    for (;;) {
+      const char* c = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
+      Span tag{p, c ? c : e};
+      uint32_t id = jn_ids.emplace(tag.sv(), uint32_t(jn_ids.size())).first->second;
+      tags.push_back(id);
+      const uint32_t tx = tx_id(tx_of_junction(tag));
+      txs.push_back(tx);
+      if (t.tx_gene[tx] == CNONE) keyerr = true; else genes.push_back(t.tx_gene[tx]);
+      t.jn_ftx.push_back(tx_id(tx_for_filter(tag)));
+      t.jn_span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
+      if (!c) break;
+      p = c + 1;
+    }
+    sort_unique(tags); sort_unique(txs); sort_unique(genes);
+    t.jt.insert(t.jt.end(), tags.begin(), tags.end());
+    t.jx.insert(t.jx.end(), txs.begin(), txs.end());
+    t.jg.insert(t.jg.end(), genes.begin(), genes.end());
+    if (keyerr) t.lflags[s] |= L_GENE_KEYERR;
+  }
+  t.jn_ptr[A] = uint32_t(t.jn_ftx.size());
+  t.jt_ptr[A] = uint32_t(t.jt.size());
+  t.jx_ptr[A] = uint32_t(t.jx.size());
+  t.jg_ptr[A] = uint32_t(t.jg.size());
+
+  // ---- lexicographic rank of segment names ------------------------------------------------------------
+  t.rank.resize(V);
+  bool fixed_width = g.names.dense && V > 0;
+  if (fixed_width) {
+    uint16_t w = g.seg_name_len[0];
+    for (uint32_t n = 0; n < V && fixed_width; ++n) fixed_width = g.seg_name_len[n] == w;
+  }
+  if (fixed_width) {
+    // equal-length canonical decimals: string order == numeric order
+    for (uint32_t n = 0; n < V; ++n) {
+      uint64_t id = 0;
+      parse_canonical_u64(g.name_of(n), id);
+      t.rank[n] = uint32_t(id - g.names.base);
+    }
+  } else {
+    std::vector<uint32_t> order(V);
+    for (uint32_t n = 0; n < V; ++n) order[n] = n;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.name_of(a).sv() < g.name_of(b).sv(); });
+    for (uint32_t i = 0; i < V; ++i) t.rank[order[i]] = i;
+  }
+
+  // ---- junction / novel lists in file order; IR-2 probes -----------------------------------------------
+  for (size_t s = 0; s < A; ++s) {
+    if (t.first_slot[s] != s) continue;
+    if (t.lflags[s] & L_JUNC) t.junctions.push_back(uint32_t(s));
+    if (t.lflags[s] & L_NOVEL) t.novels.push_back(uint32_t(s));
+  }
+  auto by_off = [&](uint32_t a, uint32_t b) { return g.slot_off[a] < g.slot_off[b]; };
+  std::sort(t.junctions.begin(), t.junctions.end(), by_off);
+  std::sort(t.novels.begin(), t.novels.end(), by_off);
+  t.probe.assign(t.junctions.size() * 6, CNONE);
+  t.probe_ok.assign(t.junctions.size(), 0);
+  auto pair_slot = [&](uint32_t u, uint32_t v) -> uint32_t {
+    for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s) if (g.col[s] == v) return s;
+    return CNONE;
+  };
+  for (size_t j = 0; j < t.junctions.size(); ++j) {
+    const uint32_t s = t.junctions[j];
+    const uint32_t u = t.src[s], v = g.col[s];
+    int64_t iu, iv;
+    char buf[32];
+    if (parse_py_int(g.name_of(u), iu)) {
+      t.probe_ok[j] |= 1u;
+      for (int d = 1; d <= 3; ++d) {
+        int n = snprintf(buf, sizeof buf, "%lld", (long long)(iu + d));
+        uint32_t x = g.names.find(Span{buf, buf + n});
+        if (x != CNONE) t.probe[j * 6 + size_t(d - 1)] = pair_slot(u, x);
+      }
+    }
+    if (parse_py_int(g.name_of(v), iv)) {
+      t.probe_ok[j] |= 2u;
+      for (int d = 3; d >= 1; --d) {
+        int n = snprintf(buf, sizeof buf, "%lld", (long long)(iv - d));
+        uint32_t x = g.names.find(Span{buf, buf + n});
+        if (x != CNONE) t.probe[j * 6 + 3 + size_t(3 - d)] = pair_slot(x, v);
+      }
+    }
+  }
+  t.parse_s = now_s() - t0;
+}
+
+CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
+  CallView c{};
+  c.V = g.V;
+  c.row_ptr = g.row_ptr.data(); c.col = g.col.data();
+  c.irow_ptr = g.irow_ptr.data(); c.icol = g.icol.data(); c.islot = g.islot.data();
+  c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
+  c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
+  c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
+  c.jn_ptr = t.jn_ptr.data(); c.jn_ftx = t.jn_ftx.data();
+  c.jt_ptr = t.jt_ptr.data(); c.jt = t.jt.data();
+  c.jx_ptr = t.jx_ptr.data(); c.jx = t.jx.data();
+  c.jg_ptr = t.jg_ptr.data(); c.jg = t.jg.data();
+  c.tx_gene = t.tx_gene.data();
+  c.probe = t.probe.data(); c.probe_ok = t.probe_ok.data();
+  c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
+  return c;
+}
+
+void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::vector<uint32_t>& annotated,
+                std::vector<uint32_t>& novel, std::vector<uint32_t>& around, std::vector<uint32_t>& around_jidx) {
+  annotated.clear(); novel.clear(); around.clear(); around_jidx.clear();
+  auto matches = [&](uint32_t s) {
+    if (!o.has_junction) return true;
+    Span a = g.name_of(t.src[s]), b = g.name_of(g.col[s]);
+    std::string k(a.b, a.size());
+    k += '-';
+    k.append(b.b, b.size());
+    return k == o.junction;
+  };
+  if (!o.no_annotated) {
+    // :241 compares the LITERAL "f{_j[0]}-{_j[1]}" (missing f-prefix) with --junction
+    if (!o.has_junction || o.junction == "f{_j[0]}-{_j[1]}") annotated = t.junctions;
+  }
+  if (o.novel) {
+    for (uint32_t s : t.novels) if (matches(s)) novel.push_back(s);
+    for (size_t j = 0; j < t.junctions.size(); ++j)
+      if (matches(t.junctions[j])) { around.push_back(t.junctions[j]); around_jidx.push_back(uint32_t(j)); }
+  }
+}
+
+namespace {
+
+inline void put_u(std::string& s, uint64_t v) {
+  char buf[24];
+  int n = 0;
+  do { buf[n++] = char('0' + v % 10); v /= 10; } while (v);
+  while (n) s.push_back(buf[--n]);
+}
+
+struct Renderer {
+  const Graph& g;
+  const CallTables& t;
+  const char* base;
+  std::string& out;
+  void name(uint32_t node) { Span n = g.name_of(node); out.append(n.b, n.size()); }
+  void link_nodes(uint32_t s) { name(t.src[s]); out.push_back('>'); name(g.col[s]); }
+  void link_rc(uint32_t s) { put_u(out, uint64_t(t.rc[s])); }
+  void jn_all(uint32_t s) {
+    for (uint32_t i = t.jn_ptr[s]; i < t.jn_ptr[s + 1]; ++i) {
+      if (i != t.jn_ptr[s]) out.push_back('|');
+      out.append(base + t.jn_span[i].off, t.jn_span[i].len);
+    }
+  }
+  // payload: count, then indices into the link's JN list
+  const uint32_t* jn_some(uint32_t s, const uint32_t* p) {
+    uint32_t n = *p++;
+    for (uint32_t i = 0; i < n; ++i) {
+      if (i) out.push_back('|');
+      const StrRef& r = t.jn_span[t.jn_ptr[s] + p[i]];
+      out.append(base + r.off, r.len);
+    }
+    return p + n;
+  }
+  const uint32_t* path(const uint32_t* p) {
+    uint32_t n = *p++;
+    for (uint32_t i = 0; i < n; ++i) { if (i) out.push_back('>'); name(p[i]); }
+    return p + n;
+  }
+  void extag(uint32_t id) { out.append(base + t.extag_span[id].off, t.extag_span[id].len); }
+  void head(const char* type, const char* kind, uint32_t gene, const char* strand_plus, const char* strand_other) {
+    const std::string& st = t.gene_strand[gene];
+    out += type ? type : (st == "+" ? strand_plus : strand_other);
+    out.push_back(',');
+    out += kind;
+    out.push_back(',');
+    out += t.gene_chrom[gene];
+    out.push_back(',');
+    out += t.gene_name[gene];
+    out.push_back(',');
+    out += st;
+    out.push_back(',');
+  }
+};
+
+}  // namespace
+
+void render_events(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
+                   std::string& csv, std::string& err) {
+  Renderer R{g, t, g.text.data, csv};
+  for (size_t i = 0; i < n; ++i) {
+    const EventRec& r = recs[i];
+    const uint32_t* p = side + r.side_off;
+    std::string& o = csv;
+    switch (r.type) {
+      case T_ES_ANN:
+        R.head("ES", "annotated", r.gene, nullptr, nullptr);
+        R.jn_all(r.j0); o.push_back(',');
+        p = R.jn_some(r.j1, p); o.push_back(',');
+        p = R.jn_some(r.j2, p); o.push_back(',');
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.link_nodes(r.j1); o.push_back(','); R.link_rc(r.j1); o.push_back(',');
+        R.link_nodes(r.j2); o.push_back(','); R.link_rc(r.j2);
+        break;
+      case T_SS_ANN_A:
+      case T_SS_ANN_B:
+        R.head(nullptr, "annotated", r.gene, r.type == T_SS_ANN_A ? "A5" : "A3", r.type == T_SS_ANN_A ? "A3" : "A5");
+        R.jn_all(r.j0); o.push_back(',');
+        R.jn_all(r.j1); o += ",.,";
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.link_nodes(r.j1); o.push_back(','); R.link_rc(r.j1); o += ",.,.";
+        break;
+      case T_IR_ANN:
+        R.head("IR", "annotated", r.gene, nullptr, nullptr);
+        R.jn_all(r.j0); o += ",.,.,";
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        p = R.path(p); o.push_back(','); put_u(o, r.mean); o += ",.,.";
+        break;
+      case T_ES_NOV:
+        R.head("ES", "novel", r.gene, nullptr, nullptr);
+        o += "?,";
+        p = R.jn_some(r.j1, p); o.push_back(',');
+        p = R.jn_some(r.j2, p); o.push_back(',');
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.link_nodes(r.j1); o.push_back(','); R.link_rc(r.j1); o.push_back(',');
+        R.link_nodes(r.j2); o.push_back(','); R.link_rc(r.j2);
+        break;
+      case T_SS1_NOV_A:
+      case T_SS1_NOV_B:
+        R.head(nullptr, "novel", r.gene, r.type == T_SS1_NOV_A ? "A3" : "A5", r.type == T_SS1_NOV_A ? "A5" : "A3");
+        o += "?,";
+        R.jn_all(r.j1); o += ",.,";
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.link_nodes(r.j1); o.push_back(','); R.link_rc(r.j1); o += ",.,.";
+        break;
+      case T_SS2_NOV:
+        // j0 = the annotated junction, j1 = the novel link; both branches print "A3" on '+' (:767, :820)
+        R.head(nullptr, "novel", r.gene, "A3", "A5");
+        R.jn_all(r.j0); o += ",?,.,";
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.link_nodes(r.j1); o.push_back(','); R.link_rc(r.j1); o += ",.,.";
+        break;
+      case T_IR1_NOV: {
+        R.head("IR", "novel", r.gene, nullptr, nullptr);
+        o += "?,";
+        const uint32_t np = p[0];
+        const uint32_t* tags = p + 1 + np;
+        for (uint32_t k = 0; k < tags[0]; ++k) { if (k) o.push_back('|'); R.extag(tags[1 + k]); }
+        o += ",.,";
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.path(p); o.push_back(','); put_u(o, r.mean); o += ",.,.";
+        break;
+      }
+      case T_CE_NOV:
+        R.head("CE", "novel", r.gene, nullptr, nullptr);
+        R.jn_all(r.j0); o += ",?,?,";
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
+        R.link_nodes(r.j1); o.push_back(','); R.link_rc(r.j1); o.push_back(',');
+        R.link_nodes(r.j2); o.push_back(','); R.link_rc(r.j2);
+        break;
+      case T_IR2_NOV: {
+        R.head("IR", "novel", r.gene, nullptr, nullptr);
+        const uint32_t np = p[0];
+        const uint32_t* pr = p + 1 + np;
+        for (uint32_t k = 0; k < pr[0]; ++k) {
+          if (k) o.push_back('|');
+          R.extag(pr[1 + 2 * k]);
+          o.push_back('.');
+          // e1.split(".")[-1]
+          const StrRef& b = t.extag_span[pr[2 + 2 * k]];
+          const char* s = R.base + b.off;
+          const char* e = s + b.len;
+          const char* d = e;
+          while (d > s && d[-1] != '.') --d;
+          o.append(d, size_t(e - d));
+        }
+        o += ",?,.,";
+        R.path(p); o.push_back(','); put_u(o, r.mean); o.push_back(',');
+        R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o += ",.,.";
+        break;
+      }
+      case T_SKIP_ES: err += "Skipping ES due to multiple genes\n"; continue;
+      case T_SKIP_SS: err += "Skipping SS due to multiple genes\n"; continue;
+      case T_SKIP_IR: err += "Skipping novel IR due to multiple genes\n"; continue;
+      default: throw Error("InternalError", "unknown event record type");
+    }
+    o.push_back('\n');
+  }
+}
+
+}  // namespace pantas

@@ -1,0 +1,84 @@
+// Host side of the call path: tag/GTF parsing and interning (scripts/call.py:25-69,145-216),
+// the tables the kernels read, and the CSV renderer (:218-234 and every print(..., sep=",")).
+#pragma once
+#include "call_device.h"
+#include "common.h"
+#include "graph.h"
+
+namespace pantas {
+
+struct CallOptions {
+  int32_t rca = -1;            // --rca
+  int32_t isw = 5;             // --isw
+  int32_t minintron = 100;     // --minintronsize
+  uint32_t events = EV_ES | EV_SS | EV_IR;   // --events
+  bool novel = false;          // --novel
+  bool no_annotated = false;   // --no-annotated
+  bool has_junction = false;   // --junction given
+  std::string junction;        // "u-v"
+};
+
+struct StrRef { uint64_t off; uint32_t len; };
+
+struct CallTables {
+  // ---- mirrored to the device -----------------------------------------------------------
+  std::vector<uint32_t> first_slot, src, lflags;
+  std::vector<int32_t> rc, nc;
+  std::vector<uint32_t> nflags, rank;
+  std::vector<uint32_t> ex_ptr, ex_tag, ex_tx, ex_gene;
+  std::vector<uint32_t> jn_ptr, jn_ftx, jt_ptr, jt, jx_ptr, jx, jg_ptr, jg;
+  std::vector<uint32_t> tx_gene;
+  std::vector<uint32_t> junctions, novels;   // canonical slots in file order
+  std::vector<uint32_t> probe, probe_ok;
+  // ---- rendering only ----------------------------------------------------------------------
+  std::vector<StrRef> jn_span;               // per JN entry (file order, aligned with jn_ptr)
+  std::vector<StrRef> extag_span;            // per EX tag id
+  std::vector<std::string> gene_name, gene_strand, gene_chrom;
+  double parse_s = 0;
+};
+
+// Parses the tags of an (augmented) GFA already loaded as `g` plus the GTF.  Throws Error where
+// the reference's parsers raise.
+void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsigned threads = 0);
+
+// A CallView over the host arrays (used by the CPU test harness; the product builds one over
+// device copies in call.hip).
+CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o);
+
+// The slots each pass iterates, after the --junction filter (:241, :532, :897)
+void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::vector<uint32_t>& annotated,
+                std::vector<uint32_t>& novel, std::vector<uint32_t>& around, std::vector<uint32_t>& around_jidx);
+
+// CSV header + rows (stdout of the reference) and the "Skipping ..." lines (stderr)
+void render_events(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
+                   std::string& csv, std::string& err);
+extern const char* const CALL_CSV_HEADER;
+
+const char* call_error_kind(uint32_t code);
+const char* call_error_text(uint32_t code);
+
+// emitters shared by call.hip and the CPU harness
+struct CountEmit {
+  uint32_t recs = 0, words = 0;
+  PANTAS_HD void begin(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { ++recs; }
+  PANTAS_HD void push(uint32_t) { ++words; }
+  PANTAS_HD void end(uint32_t) {}
+};
+struct WriteEmit {
+  EventRec* rec;
+  uint32_t* side;
+  uint32_t rec_i, word_i;
+  PANTAS_HD void begin(uint32_t type, uint32_t gene, uint32_t j0, uint32_t j1, uint32_t j2) {
+    EventRec& r = rec[rec_i];
+    r.type = type; r.gene = gene; r.j0 = j0; r.j1 = j1; r.j2 = j2; r.side_off = word_i; r.side_len = 0; r.mean = 0;
+  }
+  PANTAS_HD void push(uint32_t w) { side[word_i++] = w; }
+  PANTAS_HD void end(uint32_t mean) {
+    EventRec& r = rec[rec_i];
+    r.side_len = word_i - r.side_off;
+    r.mean = mean;
+    ++rec_i;
+  }
+};
+
+}  // namespace pantas

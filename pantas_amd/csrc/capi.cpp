@@ -2,6 +2,9 @@
 #include "../../include/pantas_gpu.h"
 
 #include "augment.h"
+#include "call.h"
+
+#include <unistd.h>
 
 #include <string>
 
@@ -14,6 +17,10 @@ struct pantas_graph {
   bool have_result = false;
   uint64_t lines = 0, rejected = 0, skipped = 0;
   double load_s = 0;
+  // call
+  std::unique_ptr<CallTables> call_tables;
+  DeviceCallPtr call_dev;
+  double call_upload_s = 0;
 };
 
 struct pantas_batch {
@@ -336,6 +343,73 @@ __attribute__((visibility("default"))) int pantas_augment_run(pantas_graph* g, c
   if (rc) return rc;
   if (fd_out >= 0) rc = pantas_augment_write_gfa(g, fd_out);
   return rc;
+}
+
+
+static void write_fd(int fd, const std::string& s) {
+  const char* p = s.data();
+  size_t n = s.size();
+  while (n) {
+    ssize_t w = ::write(fd, p, n);
+    if (w < 0) { if (errno == EINTR) continue; throw Error("OSError", "write failed"); }
+    p += w;
+    n -= size_t(w);
+  }
+}
+
+__attribute__((visibility("default"))) int pantas_call_prepare(pantas_graph* g, const char* gtf_path, int device) {
+  return guarded([&] {
+    need(g && g->g && gtf_path, "null argument");
+    auto t = std::make_unique<CallTables>();
+    build_call_tables(*g->g, gtf_path, *t);
+    double t0 = now_s();
+    g->call_dev = upload_call(*g->g, *t, device);
+    g->call_upload_s = now_s() - t0;
+    g->call_tables = std::move(t);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, const pantas_call_opts* opts, int fd_csv, int fd_err,
+                                                            pantas_call_stats* stats) {
+  return guarded([&] {
+    need(g && g->g && opts, "null argument");
+    if (!g->call_dev || !g->call_tables) throw Error("NoDevice", "call tables are not on a device: call pantas_call_prepare first");
+    CallOptions o;
+    o.rca = opts->rca;
+    o.isw = opts->isw;
+    o.minintron = opts->minintronsize;
+    o.events = opts->events;
+    o.novel = opts->novel != 0;
+    o.no_annotated = opts->no_annotated != 0;
+    if (opts->junction) { o.has_junction = true; o.junction = opts->junction; }
+    std::vector<EventRec> recs;
+    std::vector<uint32_t> side;
+    CallTimes times;
+    run_call(*g->call_dev, *g->g, *g->call_tables, o, recs, side, times);
+    double t0 = now_s();
+    std::string csv = std::string(CALL_CSV_HEADER) + "\n", err;
+    render_events(*g->g, *g->call_tables, recs.data(), recs.size(), side.data(), csv, err);
+    double t1 = now_s();
+    if (fd_csv >= 0) write_fd(fd_csv, csv);
+    if (fd_err >= 0) write_fd(fd_err, err);
+    if (stats) {
+      const CallTables& t = *g->call_tables;
+      stats->junctions = t.junctions.size();
+      stats->novel_links = t.novels.size();
+      stats->evaluated = times.junctions;
+      uint64_t rows = 0;
+      for (const EventRec& r : recs) rows += r.type < T_SKIP_ES ? 1 : 0;
+      stats->events = rows;
+      stats->ex_entries = t.ex_tag.size();
+      stats->jn_entries = t.jn_ftx.size();
+      stats->parse_seconds = t.parse_s;
+      stats->upload_seconds = g->call_upload_s;
+      stats->render_seconds = t1 - t0;
+      stats->annotated_ms = times.annotated_ms;
+      stats->novel_ms = times.novel_ms;
+      stats->around_ms = times.around_ms;
+    }
+  });
 }
 
 }  // extern "C"

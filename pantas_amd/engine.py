@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 from . import _lib
-from ._lib import BatchStats, GraphStats, LaunchStats, PantasError, check, lib  # noqa: F401
+from ._lib import BatchStats, CallOpts, CallStats, GraphStats, LaunchStats, PantasError, check, lib  # noqa: F401
 
 
 class Batch:
@@ -105,3 +105,19 @@ class Graph:
         bs, ls = BatchStats(), LaunchStats()
         check(lib.pantas_augment_run(self._h, os.fsencode(gaf_path), thr, fd_out, C.byref(bs), C.byref(ls)))
         return bs, ls
+
+    # ---- call ----------------------------------------------------------------------------
+    def call_prepare(self, gtf_path: str, device: int = 0):
+        check(lib.pantas_call_prepare(self._h, os.fsencode(gtf_path), device))
+
+    def call(self, fd_csv: int = -1, fd_err: int = -1, rca: int = -1, novel: bool = False,
+             no_annotated: bool = False, events=("ES", "SS", "IR"), isw: int = 5, minintronsize: int = 100,
+             junction=None) -> CallStats:
+        mask = 0
+        for e in events:
+            mask |= {"ES": 1, "SS": 2, "IR": 4}.get(e, 0)
+        o = CallOpts(rca, isw, minintronsize, mask, int(bool(novel)), int(bool(no_annotated)),
+                     None if junction is None else os.fsencode(junction))
+        st = CallStats()
+        check(lib.pantas_call_run(self._h, C.byref(o), fd_csv, fd_err, C.byref(st)))
+        return st

@@ -1,0 +1,75 @@
+// TEST HARNESS ONLY -- not part of the product and never loaded by it.
+// Runs the call kernels' per-junction source (pantas_amd/csrc/call_device.h) on the CPU over
+// the product's own host tables, with the same count -> scan -> write protocol as call.hip,
+// under ASan/UBSan.  usage: hostsim_call [call.py options] GFA GTF > events.csv
+#include <cstdio>
+#include "call_host.h"
+
+using namespace pantas;
+
+template <class Fn>
+static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, std::vector<EventRec>& recs,
+                     std::vector<uint32_t>& side, Fn fn) {
+  std::vector<uint32_t> nrec(slots.size() + 1, 0), nword(slots.size() + 1, 0);
+  for (size_t i = 0; i < slots.size(); ++i) {
+    CountEmit e;
+    Fault f;
+    fn(c, slots[i], uint32_t(i), e, f);
+    if (f.bad()) throw Error(call_error_kind(f.code), call_error_text(f.code));
+    nrec[i + 1] = nrec[i] + e.recs;
+    nword[i + 1] = nword[i] + e.words;
+  }
+  const size_t r0 = recs.size(), w0 = side.size();
+  recs.resize(r0 + nrec.back());
+  side.resize(w0 + nword.back());
+  for (size_t i = 0; i < slots.size(); ++i) {
+    WriteEmit e{recs.data(), side.data(), uint32_t(r0 + nrec[i]), uint32_t(w0 + nword[i])};
+    Fault f;
+    fn(c, slots[i], uint32_t(i), e, f);
+    if (e.rec_i != r0 + nrec[i + 1] || e.word_i != w0 + nword[i + 1]) throw Error("InternalError", "count/write mismatch");
+  }
+}
+
+int main(int argc, char** argv) {
+  CallOptions o;
+  std::vector<const char*> pos;
+  try {
+    for (int i = 1; i < argc; ++i) {
+      std::string a = argv[i];
+      if (a == "--rca") o.rca = atoi(argv[++i]);
+      else if (a == "--isw") o.isw = atoi(argv[++i]);
+      else if (a == "--minintronsize") o.minintron = atoi(argv[++i]);
+      else if (a == "--novel") o.novel = true;
+      else if (a == "--no-annotated") o.no_annotated = true;
+      else if (a == "--junction") { o.has_junction = true; o.junction = argv[++i]; }
+      else if (a == "--events") {
+        o.events = 0;
+        while (i + 1 < argc && argv[i + 1][0] != '-' && (std::string(argv[i + 1]) == "ES" || std::string(argv[i + 1]) == "SS" || std::string(argv[i + 1]) == "IR")) {
+          std::string e = argv[++i];
+          o.events |= e == "ES" ? EV_ES : e == "SS" ? EV_SS : EV_IR;
+        }
+      } else pos.push_back(argv[i]);
+    }
+    if (pos.size() != 2) { fprintf(stderr, "usage: hostsim_call [options] GFA GTF\n"); return 2; }
+    auto g = load_graph(pos[0], 3);
+    CallTables t;
+    build_call_tables(*g, pos[1], t, 3);
+    CallView c = host_view(*g, t, o);
+    std::vector<uint32_t> ann, nov, around, around_j;
+    pass_lists(*g, t, o, ann, nov, around, around_j);
+    std::vector<EventRec> recs;
+    std::vector<uint32_t> side;
+    printf("%s\n", CALL_CSV_HEADER);
+    run_pass(c, ann, recs, side, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { annotated_junction(c, s, e, f); });
+    run_pass(c, nov, recs, side, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { novel_link(c, s, e, f); });
+    run_pass(c, around, recs, side, [&](const CallView& c, uint32_t s, uint32_t i, auto& e, Fault& f) { novel_around(c, s, around_j[i], e, f); });
+    std::string csv, err;
+    render_events(*g, t, recs.data(), recs.size(), side.data(), csv, err);
+    fwrite(csv.data(), 1, csv.size(), stdout);
+    fwrite(err.data(), 1, err.size(), stderr);
+    return 0;
+  } catch (const Error& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+}

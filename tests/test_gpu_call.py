@@ -1,0 +1,96 @@
+"""Parity of the HIP call path (through the C ABI) with the reference goldens and the oracle."""
+import collections
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+import augment_oracle
+import call_oracle
+from conftest import CASES, GOLDEN, ROOT
+from test_oracle_golden import _flags_to_opts, check_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_call(gfa, gtf, flags):
+    from pantas_amd.engine import Graph
+    o = _flags_to_opts(flags)
+    g = Graph(gfa)
+    g.call_prepare(gtf, 0)
+    with tempfile.TemporaryFile() as f:
+        st = g.call(f.fileno(), -1, rca=o["rca"], novel=o["novel"], no_annotated=o["no_annotated"],
+                    events=o["events"], isw=o["isw"], minintronsize=o["minintronsize"], junction=o["junction"])
+        f.seek(0)
+        rows = f.read().decode().splitlines()
+    assert rows[0] == call_oracle.HEADER
+    assert st.events == len(rows) - 1
+    return rows[1:]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_golden_rows(case):
+    d = os.path.join(GOLDEN, case)
+    for gc in json.load(open(f"{d}/expected.json"))["calls"]:
+        check_rows(engine_call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", gc["flags"]), gc)
+
+
+def test_cli_streams():
+    d = os.path.join(GOLDEN, "synth_a")
+    flags = ["--rca", "3", "--novel", "--minintronsize", "25"]
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.call", *flags, f"{d}/expected.aug.gfa", f"{d}/in.gtf"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    rows = r.stdout.splitlines()
+    assert rows[0] == call_oracle.HEADER
+    gc = [c for c in json.load(open(f"{d}/expected.json"))["calls"] if c["flags"] == flags][0]
+    check_rows(rows[1:], gc)
+    err = r.stderr.splitlines()
+    assert err[0].endswith("Parsing GFA..") and err[1].endswith("Parsing GTF..")
+
+
+def test_crash_inputs():
+    from pantas_amd.engine import PantasError
+    cd = os.path.join(GOLDEN, "crashes")
+    for c in json.load(open(os.path.join(GOLDEN, "crashes.json"))):
+        if c["stage"] != "call":
+            continue
+        with pytest.raises(PantasError) as ei:
+            engine_call(f"{cd}/{c['call_input']}", f"{cd}/{c['name']}.gtf", c["flags"])
+        assert ei.value.kind == c["exception"], c["name"]
+
+
+@pytest.mark.parametrize("seed,genes,lines,kw,flags", [
+    (31, 120, 30000, {}, ["--rca", "2", "--novel", "--minintronsize", "30"]),
+    (32, 60, 30000, dict(bubble_rate=0.15, p_novel_skip=0.1, p_novel_ce=0.06, p_intron=0.15, p_novel_ss=0.1),
+     ["--rca", "1", "--novel", "--isw", "3", "--minintronsize", "10"]),
+    (33, 80, 20000, dict(bubble_rate=0.0), ["--events", "IR", "SS", "--novel", "--rca", "0", "--minintronsize", "1"]),
+])
+def test_augment_then_call_vs_oracle(tmp_path, seed, genes, lines, kw, flags):
+    """Whole hot path on the GPU (augment, then call on its output) against the oracle's rows."""
+    from pantas_amd import synth
+    from pantas_amd.engine import Graph
+    pre = str(tmp_path / "s")
+    synth.write_all(pre, seed=seed, n_genes=genes, n_lines=lines, **kw)
+    g = Graph(pre + ".gfa").to_device(0)
+    with open(pre + ".aug.gfa", "wb") as f:
+        g.augment(pre + ".gaf", 20, f.fileno())
+    want_gfa = io.StringIO()
+    augment_oracle.augment(pre + ".gaf", pre + ".gfa", want_gfa)
+    assert open(pre + ".aug.gfa").read() == want_gfa.getvalue()
+    rows = engine_call(pre + ".aug.gfa", pre + ".gtf", flags)
+    want = call_oracle.call(pre + ".aug.gfa", pre + ".gtf", None, **_flags_to_opts(flags))
+    assert len(want) > 100
+    assert collections.Counter(map(call_oracle.normalise_row, rows)) == collections.Counter(map(call_oracle.normalise_row, want))
+
+
+def test_call_is_deterministic_and_ordered():
+    """Two runs give byte-identical CSV (fixed emission order, no atomics in the output path)."""
+    d = os.path.join(GOLDEN, "synth_b")
+    a = engine_call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", ["--rca", "2", "--novel", "--minintronsize", "40"])
+    b = engine_call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", ["--rca", "2", "--novel", "--minintronsize", "40"])
+    assert a == b
