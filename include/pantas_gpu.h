@@ -137,6 +137,48 @@ int pantas_call_prepare(pantas_graph* g, const char* gtf_path, int device);
 /* :218-1105: header + event rows to fd_csv, "Skipping ..." lines to fd_err (-1: drop) */
 int pantas_call_run(pantas_graph* g, const pantas_call_opts* opts, int fd_csv, int fd_err, pantas_call_stats* stats);
 
+/* ---- synthetic workloads (SURVEY.md 8-d recipe) for benchmarks and scale tests ------------------
+ * Generates annotated GFA + GTF + GAF TEXT in memory; the *_mem entry points run the product's
+ * real parsers over such buffers (or any caller-owned text), which must outlive the handles
+ * built from them. */
+typedef struct pantas_synth pantas_synth;
+typedef struct {
+  uint64_t seed;
+  uint32_t n_genes;
+  uint32_t n_chrom;
+  uint64_t n_lines;
+  uint64_t base_id;        /* first node id; ids must keep one decimal width */
+  double bubble_rate;
+  uint32_t max_exons;
+  uint32_t intron_long_max;
+  uint32_t intergenic_min, intergenic_max;
+  uint32_t read_len;
+  int32_t with_path;
+  double zipf_a;
+  double p_lowmapq, p_unmapped, p_sub, p_indel, p_highdv;
+  double p_novel_skip, p_novel_ce, p_intron, p_novel_ss, p_clip;
+  uint64_t line_offset;    /* lines [line_offset, line_offset + n_lines) of the read stream */
+} pantas_synth_params;
+typedef struct {
+  uint64_t nodes, links, junction_links, transcripts, gaf_lines;
+  uint64_t gfa_bytes, gtf_bytes, gaf_bytes;
+  double seconds;
+} pantas_synth_stats;
+void pantas_synth_defaults(pantas_synth_params* p);
+int pantas_synth_generate(const pantas_synth_params* p, pantas_synth** out, pantas_synth_stats* stats);
+/* which: 0 GFA, 1 GTF, 2 GAF */
+int pantas_synth_text(const pantas_synth* s, int which, const char** data, uint64_t* size);
+/* writes <prefix>.gfa/.gtf and the first max_gaf_lines lines (0 = all) of the GAF to <prefix>.gaf */
+int pantas_synth_write(const pantas_synth* s, const char* prefix, uint64_t max_gaf_lines);
+void pantas_synth_free(pantas_synth* s);
+int pantas_graph_load_mem(const char* gfa_text, uint64_t size, pantas_graph** out);
+int pantas_augment_load_gaf_mem(pantas_graph* g, const char* gaf_text, uint64_t size, int thr, uint64_t first_line,
+                                pantas_batch** out, pantas_batch_stats* stats);
+int pantas_call_prepare_mem(pantas_graph* g, const char* gtf_text, uint64_t size, int device);
+/* augment -> call without the GFA text round trip: like pantas_call_prepare on
+ * the GFA this handle's last finished augment run WOULD write -- NC / RC from its counters, its
+ * novel links appended after the GFA's own links.  gtf_text == NULL: read gtf_path instead. */
+int pantas_call_prepare_fused(pantas_graph* g, const char* gtf_path, const char* gtf_text, uint64_t size, int device);
 #ifdef __cplusplus
 }
 #endif

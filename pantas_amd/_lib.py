@@ -53,6 +53,23 @@ class CallStats(C.Structure):
                 ("annotated_ms", C.c_float), ("novel_ms", C.c_float), ("around_ms", C.c_float)]
 
 
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_genes", C.c_uint32), ("n_chrom", C.c_uint32), ("n_lines", C.c_uint64),
+                ("base_id", C.c_uint64), ("bubble_rate", C.c_double), ("max_exons", C.c_uint32),
+                ("intron_long_max", C.c_uint32), ("intergenic_min", C.c_uint32), ("intergenic_max", C.c_uint32),
+                ("read_len", C.c_uint32), ("with_path", C.c_int32), ("zipf_a", C.c_double),
+                ("p_lowmapq", C.c_double), ("p_unmapped", C.c_double), ("p_sub", C.c_double), ("p_indel", C.c_double),
+                ("p_highdv", C.c_double), ("p_novel_skip", C.c_double), ("p_novel_ce", C.c_double),
+                ("p_intron", C.c_double), ("p_novel_ss", C.c_double), ("p_clip", C.c_double),
+                ("line_offset", C.c_uint64)]
+
+
+class SynthStats(C.Structure):
+    _fields_ = [("nodes", C.c_uint64), ("links", C.c_uint64), ("junction_links", C.c_uint64),
+                ("transcripts", C.c_uint64), ("gaf_lines", C.c_uint64), ("gfa_bytes", C.c_uint64),
+                ("gtf_bytes", C.c_uint64), ("gaf_bytes", C.c_uint64), ("seconds", C.c_double)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is not built: the pantas_amd engine is a HIP library and has no "
@@ -84,6 +101,15 @@ def _load():
         "pantas_augment_run": (i32, [vp, C.c_char_p, i32, i32, P(BatchStats), P(LaunchStats)]),
         "pantas_call_prepare": (i32, [vp, C.c_char_p, i32]),
         "pantas_call_run": (i32, [vp, P(CallOpts), i32, i32, P(CallStats)]),
+        "pantas_synth_defaults": (None, [P(SynthParams)]),
+        "pantas_synth_generate": (i32, [P(SynthParams), P(vp), P(SynthStats)]),
+        "pantas_synth_text": (i32, [vp, i32, P(C.c_char_p), P(u64)]),
+        "pantas_synth_write": (i32, [vp, C.c_char_p, u64]),
+        "pantas_synth_free": (None, [vp]),
+        "pantas_graph_load_mem": (i32, [C.c_char_p, u64, P(vp)]),
+        "pantas_augment_load_gaf_mem": (i32, [vp, C.c_char_p, u64, i32, u64, P(vp), P(BatchStats)]),
+        "pantas_call_prepare_mem": (i32, [vp, C.c_char_p, u64, i32]),
+        "pantas_call_prepare_fused": (i32, [vp, C.c_char_p, C.c_char_p, u64, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

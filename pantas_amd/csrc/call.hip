@@ -121,6 +121,15 @@ static const T* up(DeviceCall& d, const std::vector<T>& v) {
 }
 
 template <class T>
+static const T* up_raw(DeviceCall& d, const T* src, size_t n) {
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
+  d.allocs.push_back(p);
+  if (n) HIP_OK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, d.stream));
+  return static_cast<const T*>(p);
+}
+
+template <class T>
 static T* dalloc(DeviceCall& d, size_t n) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
@@ -140,8 +149,8 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   HIP_OK(hipEventCreate(&d->ev1));
   CallView& c = d->view;
   c.V = g.V;
-  c.row_ptr = up(*d, g.row_ptr); c.col = up(*d, g.col);
-  c.irow_ptr = up(*d, g.irow_ptr); c.icol = up(*d, g.icol); c.islot = up(*d, g.islot);
+  c.row_ptr = up_raw(*d, t.row_ptr, size_t(g.V) + 1); c.col = up_raw(*d, t.col, t.A);
+  c.irow_ptr = up_raw(*d, t.irow_ptr, size_t(g.V) + 1); c.icol = up_raw(*d, t.icol, t.A); c.islot = up_raw(*d, t.islot, t.A);
   c.first_slot = up(*d, t.first_slot); c.src = up(*d, t.src); c.lflags = up(*d, t.lflags);
   c.rc = up(*d, t.rc); c.nc = up(*d, t.nc); c.nflags = up(*d, t.nflags); c.ln = up(*d, g.seg_len); c.rank = up(*d, t.rank);
   c.ex_ptr = up(*d, t.ex_ptr); c.ex_tag = up(*d, t.ex_tag); c.ex_tx = up(*d, t.ex_tx); c.ex_gene = up(*d, t.ex_gene);

@@ -136,9 +136,7 @@ bool find_attr(Span s, const char* key, Span& out) {
   return false;
 }
 
-void parse_gtf(const char* path, Gtf& gtf, CallTables& t) {
-  MappedFile f;
-  f.open(path);
+void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t) {
   const char* p = f.data;
   const char* end = f.data + f.size;
   uint64_t lineno = 0;
@@ -193,6 +191,13 @@ void sort_unique(std::vector<T>& v) {
 }  // namespace
 
 void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsigned threads) {
+  MappedFile f;
+  f.open(gtf_path);
+  build_call_tables_mem(g, f.data, f.size, t, threads);
+}
+
+void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size, CallTables& t, unsigned threads,
+                           const AugmentResult* aug) {
   const double t0 = now_s();
   if (threads == 0) threads = hw_threads();
   const char* base = g.text.data;
@@ -205,10 +210,72 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
     throw Error("KeyError", "an L line names a segment with no S line before it");
   if (g.dup_names) throw Error("Unsupported", "duplicate S lines for one segment name (call)");
   const uint32_t V = g.V;
-  const size_t A = g.A;
+  // ---- link layout -------------------------------------------------------------------------------
+  std::vector<uint32_t> old_slot;   // fused: slot of the graph behind each slot of the layout (NONE32 = added link)
+  if (!aug || aug->novel.empty()) {
+    t.A = g.A;
+    t.row_ptr = g.row_ptr.data(); t.col = g.col.data();
+    t.irow_ptr = g.irow_ptr.data(); t.icol = g.icol.data(); t.islot = g.islot.data();
+    t.order = g.slot_off.data();
+  } else {
+    const size_t extra = aug->novel.size();
+    const size_t An = g.A + extra;
+    if (An >= NONE32) throw Error("Unsupported", "more than 2^32-2 links");
+    t.x_row_ptr.assign(size_t(V) + 1, 0);
+    t.x_irow_ptr.assign(size_t(V) + 1, 0);
+    for (uint32_t u = 0; u < V; ++u) {
+      t.x_row_ptr[u + 1] = g.row_ptr[u + 1] - g.row_ptr[u];
+      t.x_irow_ptr[u + 1] = g.irow_ptr[u + 1] - g.irow_ptr[u];
+    }
+    for (const NovelLink& nl : aug->novel) { ++t.x_row_ptr[nl.u + 1]; ++t.x_irow_ptr[nl.v + 1]; }
+    for (uint32_t u = 0; u < V; ++u) { t.x_row_ptr[u + 1] += t.x_row_ptr[u]; t.x_irow_ptr[u + 1] += t.x_irow_ptr[u]; }
+    t.x_col.resize(An); t.x_order.resize(An); t.x_icol.resize(An); t.x_islot.resize(An);
+    old_slot.assign(An, NONE32);
+    std::vector<uint32_t> new_of_old(g.A);
+    std::vector<uint32_t> cur(V), icur(V);
+    for (uint32_t u = 0; u < V; ++u) {
+      uint32_t w = t.x_row_ptr[u];
+      for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s, ++w) {
+        t.x_col[w] = g.col[s];
+        t.x_order[w] = g.slot_off[s];
+        old_slot[w] = s;
+        new_of_old[s] = w;
+      }
+      cur[u] = w;
+    }
+    for (uint32_t v = 0; v < V; ++v) {
+      uint32_t w = t.x_irow_ptr[v];
+      for (uint32_t q = g.irow_ptr[v]; q < g.irow_ptr[v + 1]; ++q, ++w) {
+        t.x_icol[w] = g.icol[q];
+        t.x_islot[w] = new_of_old[g.islot[q]];
+      }
+      icur[v] = w;
+    }
+    for (size_t i = 0; i < extra; ++i) {          // aug->novel is in first-seen order = file order of the appended lines
+      const NovelLink& nl = aug->novel[i];
+      const uint32_t w = cur[nl.u]++;
+      t.x_col[w] = nl.v;
+      t.x_order[w] = uint64_t(g.text.size) + i;
+      const uint32_t q = icur[nl.v]++;
+      t.x_icol[q] = nl.u;
+      t.x_islot[q] = w;
+    }
+    t.A = An;
+    t.row_ptr = t.x_row_ptr.data(); t.col = t.x_col.data();
+    t.irow_ptr = t.x_irow_ptr.data(); t.icol = t.x_icol.data(); t.islot = t.x_islot.data();
+    t.order = t.x_order.data();
+  }
+  const size_t A = t.A;
+  auto graph_slot = [&](size_t s) -> uint32_t { return old_slot.empty() ? uint32_t(s) : old_slot[s]; };
+  size_t next_novel = 0;
+  (void)next_novel;
 
   Gtf gtf;
-  parse_gtf(gtf_path, gtf, t);
+  {
+    MappedFile f;
+    f.attach(gtf_data, gtf_size);
+    parse_gtf(f, gtf, t);
+  }
 
   // ---- phase A (parallel): locate the tags of every S line and every link slot -----------------
   std::vector<SegAttr> sa(V);
@@ -230,15 +297,22 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
         else if (name_is(name, "IL") || name_is(name, "OL")) check_hist_value(value, off);
         else if (name_is(name, "EX")) { sa[n].ex_off = uint64_t(value.b - base); sa[n].ex_len = uint32_t(value.size()); sa[n].has_ex = true; }
       }
+      if (aug) {     // the NC tag augment would append overrides any earlier one (dict semantics, call.py:25-32)
+        if (aug->nc[n] > uint32_t(INT32_MAX)) throw Error("Unsupported", "node coverage beyond 2^31");
+        t.nc[n] = int32_t(aug->nc[n]);
+        t.nflags[n] |= N_HAS_NC;
+      }
     }
   });
   std::vector<LinkAttr> la(A);
   t.src.resize(A);
   parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
     for (size_t u = b; u < e; ++u)
-      for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s) {
+      for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s) {
         t.src[s] = uint32_t(u);
-        const uint64_t off = g.slot_off[s];
+        const uint32_t gs = graph_slot(s);
+        if (gs == NONE32) continue;      // a link added by the reads: filled in below
+        const uint64_t off = g.slot_off[gs];
         const char* le = static_cast<const char*>(memchr(base + off, '\n', g.text.size - off));
         Span st = strip(Span{base + off, le ? le : base + g.text.size});
         Tokens tk(st);
@@ -254,8 +328,25 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
           else if (name_is(name, "JN")) { a.jn_off = uint64_t(value.b - base); a.jn_len = uint32_t(value.size()); a.has_jn = true; }
           else if (name_is(name, "ID")) a.has_id = true;
         }
+        if (aug) {
+          if (aug->rc[gs] > uint32_t(INT32_MAX)) throw Error("Unsupported", "link coverage beyond 2^31");
+          a.rc = int32_t(aug->rc[gs]);
+          a.has_rc = true;
+        }
       }
   });
+  if (aug && !old_slot.empty()) {
+    // "L u + v + * RC:i:n ID:Z:N" lines the augment writer appends
+    std::vector<uint32_t> cur(V);
+    for (uint32_t u = 0; u < V; ++u) cur[u] = t.row_ptr[u] + (g.row_ptr[u + 1] - g.row_ptr[u]);
+    for (const NovelLink& nl : aug->novel) {
+      LinkAttr& a = la[cur[nl.u]++];
+      if (nl.count > uint32_t(INT32_MAX)) throw Error("Unsupported", "link coverage beyond 2^31");
+      a.rc = int32_t(nl.count);
+      a.has_rc = true;
+      a.has_id = true;
+    }
+  }
 
   // ---- canonical slots: first slot of each (u, v); attributes of the LAST duplicate (dict overwrite, :173)
   t.first_slot.resize(A);
@@ -263,10 +354,10 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
   t.rc.assign(A, 0);
   std::vector<uint32_t> attr_slot(A);
   for (uint32_t u = 0; u < V; ++u) {
-    const uint32_t b = g.row_ptr[u], e = g.row_ptr[u + 1];
+    const uint32_t b = t.row_ptr[u], e = t.row_ptr[u + 1];
     for (uint32_t s = b; s < e; ++s) {
       uint32_t first = s;
-      for (uint32_t q = b; q < s; ++q) if (g.col[q] == g.col[s]) { first = q; break; }
+      for (uint32_t q = b; q < s; ++q) if (t.col[q] == t.col[s]) { first = q; break; }
       t.first_slot[s] = first;
       attr_slot[first] = s;   // the last duplicate wins
       if (first != s) {
@@ -400,18 +491,18 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
     if (t.lflags[s] & L_JUNC) t.junctions.push_back(uint32_t(s));
     if (t.lflags[s] & L_NOVEL) t.novels.push_back(uint32_t(s));
   }
-  auto by_off = [&](uint32_t a, uint32_t b) { return g.slot_off[a] < g.slot_off[b]; };
+  auto by_off = [&](uint32_t a, uint32_t b) { return t.order[a] < t.order[b]; };
   std::sort(t.junctions.begin(), t.junctions.end(), by_off);
   std::sort(t.novels.begin(), t.novels.end(), by_off);
   t.probe.assign(t.junctions.size() * 6, CNONE);
   t.probe_ok.assign(t.junctions.size(), 0);
   auto pair_slot = [&](uint32_t u, uint32_t v) -> uint32_t {
-    for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s) if (g.col[s] == v) return s;
+    for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s) if (t.col[s] == v) return s;
     return CNONE;
   };
   for (size_t j = 0; j < t.junctions.size(); ++j) {
     const uint32_t s = t.junctions[j];
-    const uint32_t u = t.src[s], v = g.col[s];
+    const uint32_t u = t.src[s], v = t.col[s];
     int64_t iu, iv;
     char buf[32];
     if (parse_py_int(g.name_of(u), iu)) {
@@ -437,8 +528,8 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
 CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   CallView c{};
   c.V = g.V;
-  c.row_ptr = g.row_ptr.data(); c.col = g.col.data();
-  c.irow_ptr = g.irow_ptr.data(); c.icol = g.icol.data(); c.islot = g.islot.data();
+  c.row_ptr = t.row_ptr; c.col = t.col;
+  c.irow_ptr = t.irow_ptr; c.icol = t.icol; c.islot = t.islot;
   c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
   c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
   c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
@@ -457,7 +548,7 @@ void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::
   annotated.clear(); novel.clear(); around.clear(); around_jidx.clear();
   auto matches = [&](uint32_t s) {
     if (!o.has_junction) return true;
-    Span a = g.name_of(t.src[s]), b = g.name_of(g.col[s]);
+    Span a = g.name_of(t.src[s]), b = g.name_of(t.col[s]);
     std::string k(a.b, a.size());
     k += '-';
     k.append(b.b, b.size());
@@ -489,7 +580,7 @@ struct Renderer {
   const char* base;
   std::string& out;
   void name(uint32_t node) { Span n = g.name_of(node); out.append(n.b, n.size()); }
-  void link_nodes(uint32_t s) { name(t.src[s]); out.push_back('>'); name(g.col[s]); }
+  void link_nodes(uint32_t s) { name(t.src[s]); out.push_back('>'); name(t.col[s]); }
   void link_rc(uint32_t s) { put_u(out, uint64_t(t.rc[s])); }
   void jn_all(uint32_t s) {
     for (uint32_t i = t.jn_ptr[s]; i < t.jn_ptr[s + 1]; ++i) {

@@ -4,6 +4,7 @@
 #include "call_device.h"
 #include "common.h"
 #include "graph.h"
+#include "augment.h"
 
 namespace pantas {
 
@@ -21,6 +22,18 @@ struct CallOptions {
 struct StrRef { uint64_t off; uint32_t len; };
 
 struct CallTables {
+  // ---- link layout the call path works on: the graph's CSR, or (fused augment -> call) a copy
+  //      extended by the links the reads added, which the reference appends after the GFA's
+  //      own lines (alignments_augmentation_from_gaf.py:426-427) ------------------------------
+  size_t A = 0;
+  const uint32_t* row_ptr = nullptr;
+  const uint32_t* col = nullptr;
+  const uint32_t* irow_ptr = nullptr;
+  const uint32_t* icol = nullptr;
+  const uint32_t* islot = nullptr;
+  const uint64_t* order = nullptr;           // file-order key of a slot (byte offset; novel links after the text)
+  std::vector<uint32_t> x_row_ptr, x_col, x_irow_ptr, x_icol, x_islot;
+  std::vector<uint64_t> x_order;
   // ---- mirrored to the device -----------------------------------------------------------
   std::vector<uint32_t> first_slot, src, lflags;
   std::vector<int32_t> rc, nc;
@@ -40,6 +53,11 @@ struct CallTables {
 // Parses the tags of an (augmented) GFA already loaded as `g` plus the GTF.  Throws Error where
 // the reference's parsers raise.
 void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsigned threads = 0);
+// `aug` (optional): results of an augment run on the same graph.  NC / RC then come from its
+// counters and its novel links join the layout, exactly as if the augmented GFA text had been
+// written and parsed again.
+void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size, CallTables& t, unsigned threads = 0,
+                           const AugmentResult* aug = nullptr);
 
 // A CallView over the host arrays (used by the CPU test harness; the product builds one over
 // device copies in call.hip).

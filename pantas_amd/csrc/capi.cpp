@@ -3,6 +3,9 @@
 
 #include "augment.h"
 #include "call.h"
+#include "synth.h"
+
+#include <fcntl.h>
 
 #include <unistd.h>
 
@@ -21,6 +24,10 @@ struct pantas_graph {
   std::unique_ptr<CallTables> call_tables;
   DeviceCallPtr call_dev;
   double call_upload_s = 0;
+};
+
+struct pantas_synth {
+  SynthOutput out;
 };
 
 struct pantas_batch {
@@ -71,6 +78,17 @@ constexpr uint64_t KIND_HIST = 0, KIND_NOVEL = 1;
 constexpr uint32_t COMMON_CODE = 0x7FFFFFFFu;
 
 }  // namespace
+
+static void write_fd(int fd, const std::string& s) {
+  const char* p = s.data();
+  size_t n = s.size();
+  while (n) {
+    ssize_t w = ::write(fd, p, n);
+    if (w < 0) { if (errno == EINTR) continue; throw Error("OSError", "write failed"); }
+    p += w;
+    n -= size_t(w);
+  }
+}
 
 extern "C" {
 
@@ -157,6 +175,34 @@ __attribute__((visibility("default"))) int pantas_gaf_split(const char* gaf_path
   });
 }
 
+static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int thr, uint64_t first_line,
+                            pantas_batch** out, pantas_batch_stats* stats) {
+  GafBatch b;
+  double t0 = now_s();
+  tokenize_gaf(*g->g, data, size, thr, first_line, 0, b);
+  double t1 = now_s();
+  auto h = std::make_unique<pantas_batch>();
+  h->dev = upload_batch(*g->dev, b);
+  double t2 = now_s();
+  pantas_batch_stats& s = h->st;
+  s.lines = b.lines_total;
+  s.rejected = b.rejected;
+  s.skipped = b.skipped;
+  s.records = b.size();
+  s.path_nodes = b.nodes.size();
+  s.cs_ops = b.ops.size();
+  s.del_records = b.del_lines;
+  s.text_bytes = b.bytes;
+  s.alg_bytes = batch_alg_bytes(*h->dev);
+  s.tokenize_seconds = t1 - t0;
+  s.upload_seconds = t2 - t1;
+  g->lines += b.lines_total;
+  g->rejected += b.rejected;
+  g->skipped += b.skipped;
+  if (stats) *stats = s;
+  *out = h.release();
+}
+
 __attribute__((visibility("default"))) int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,
                             uint64_t first_line, pantas_batch** out, pantas_batch_stats* stats) {
   return guarded([&] {
@@ -166,30 +212,16 @@ __attribute__((visibility("default"))) int pantas_augment_load_gaf(pantas_graph*
     f.open(gaf_path);
     if (end == 0 || end > f.size) end = f.size;
     need(begin <= end, "bad byte range");
-    GafBatch b;
-    double t0 = now_s();
-    tokenize_gaf(*g->g, f.data + begin, size_t(end - begin), thr, first_line, 0, b);
-    double t1 = now_s();
-    auto h = std::make_unique<pantas_batch>();
-    h->dev = upload_batch(*g->dev, b);
-    double t2 = now_s();
-    pantas_batch_stats& s = h->st;
-    s.lines = b.lines_total;
-    s.rejected = b.rejected;
-    s.skipped = b.skipped;
-    s.records = b.size();
-    s.path_nodes = b.nodes.size();
-    s.cs_ops = b.ops.size();
-    s.del_records = b.del_lines;
-    s.text_bytes = b.bytes;
-    s.alg_bytes = batch_alg_bytes(*h->dev);
-    s.tokenize_seconds = t1 - t0;
-    s.upload_seconds = t2 - t1;
-    g->lines += b.lines_total;
-    g->rejected += b.rejected;
-    g->skipped += b.skipped;
-    if (stats) *stats = s;
-    *out = h.release();
+    load_gaf_common(g, f.data + begin, size_t(end - begin), thr, first_line, out, stats);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_load_gaf_mem(pantas_graph* g, const char* gaf_text, uint64_t size, int thr,
+                                                                        uint64_t first_line, pantas_batch** out, pantas_batch_stats* stats) {
+  return guarded([&] {
+    need_device(g);
+    need(gaf_text && out, "null argument");
+    load_gaf_common(g, gaf_text, size_t(size), thr, first_line, out, stats);
   });
 }
 
@@ -346,17 +378,6 @@ __attribute__((visibility("default"))) int pantas_augment_run(pantas_graph* g, c
 }
 
 
-static void write_fd(int fd, const std::string& s) {
-  const char* p = s.data();
-  size_t n = s.size();
-  while (n) {
-    ssize_t w = ::write(fd, p, n);
-    if (w < 0) { if (errno == EINTR) continue; throw Error("OSError", "write failed"); }
-    p += w;
-    n -= size_t(w);
-  }
-}
-
 __attribute__((visibility("default"))) int pantas_call_prepare(pantas_graph* g, const char* gtf_path, int device) {
   return guarded([&] {
     need(g && g->g && gtf_path, "null argument");
@@ -409,6 +430,132 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
       stats->novel_ms = times.novel_ms;
       stats->around_ms = times.around_ms;
     }
+  });
+}
+
+
+__attribute__((visibility("default"))) void pantas_synth_defaults(pantas_synth_params* p) {
+  if (!p) return;
+  SynthParams d;
+  p->seed = d.seed; p->n_genes = d.n_genes; p->n_chrom = d.n_chrom; p->n_lines = d.n_lines; p->base_id = d.base_id;
+  p->bubble_rate = d.bubble_rate; p->max_exons = d.max_exons; p->intron_long_max = d.intron_long_max;
+  p->intergenic_min = d.intergenic_min; p->intergenic_max = d.intergenic_max; p->read_len = d.read_len;
+  p->with_path = d.with_path; p->zipf_a = d.zipf_a;
+  p->p_lowmapq = d.p_lowmapq; p->p_unmapped = d.p_unmapped; p->p_sub = d.p_sub; p->p_indel = d.p_indel; p->p_highdv = d.p_highdv;
+  p->p_novel_skip = d.p_novel_skip; p->p_novel_ce = d.p_novel_ce; p->p_intron = d.p_intron; p->p_novel_ss = d.p_novel_ss;
+  p->p_clip = d.p_clip;
+  p->line_offset = 0;
+}
+
+__attribute__((visibility("default"))) int pantas_synth_generate(const pantas_synth_params* p, pantas_synth** out,
+                                                                  pantas_synth_stats* stats) {
+  return guarded([&] {
+    need(p && out, "null argument");
+    SynthParams d;
+    d.seed = p->seed; d.n_genes = p->n_genes; d.n_chrom = p->n_chrom ? p->n_chrom : 1; d.n_lines = p->n_lines; d.base_id = p->base_id;
+    d.bubble_rate = p->bubble_rate; d.max_exons = p->max_exons; d.intron_long_max = p->intron_long_max;
+    d.intergenic_min = p->intergenic_min; d.intergenic_max = p->intergenic_max; d.read_len = p->read_len;
+    d.with_path = p->with_path; d.zipf_a = p->zipf_a;
+    d.p_lowmapq = p->p_lowmapq; d.p_unmapped = p->p_unmapped; d.p_sub = p->p_sub; d.p_indel = p->p_indel; d.p_highdv = p->p_highdv;
+    d.p_novel_skip = p->p_novel_skip; d.p_novel_ce = p->p_novel_ce; d.p_intron = p->p_intron; d.p_novel_ss = p->p_novel_ss;
+    d.p_clip = p->p_clip;
+    d.line_offset = p->line_offset;
+    auto h = std::make_unique<pantas_synth>();
+    double t0 = now_s();
+    synth_generate(d, h->out);
+    if (stats) {
+      stats->nodes = h->out.nodes; stats->links = h->out.links; stats->junction_links = h->out.junction_links;
+      stats->transcripts = h->out.transcripts; stats->gaf_lines = h->out.gaf_lines;
+      stats->gfa_bytes = h->out.gfa.size(); stats->gtf_bytes = h->out.gtf.size(); stats->gaf_bytes = h->out.gaf.size();
+      stats->seconds = now_s() - t0;
+    }
+    *out = h.release();
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_synth_text(const pantas_synth* s, int which, const char** data, uint64_t* size) {
+  return guarded([&] {
+    need(s && data && size && which >= 0 && which <= 2, "bad argument");
+    *data = which == 0 ? s->out.gfa.data() : which == 1 ? s->out.gtf.data() : s->out.gaf.data();
+    *size = which == 0 ? s->out.gfa.size() : which == 1 ? s->out.gtf.size() : s->out.gaf.size();
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_synth_write(const pantas_synth* s, const char* prefix, uint64_t max_gaf_lines) {
+  return guarded([&] {
+    need(s && prefix, "null argument");
+    auto dump = [&](const char* ext, const char* p, size_t n) {
+      std::string path = std::string(prefix) + ext;
+      int fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (fd < 0) throw Error("OSError", path + ": cannot create");
+      try {
+        while (n) {
+          ssize_t w = ::write(fd, p, std::min<size_t>(n, size_t(1) << 30));
+          if (w < 0) { if (errno == EINTR) continue; throw Error("OSError", path + ": write failed"); }
+          p += w;
+          n -= size_t(w);
+        }
+      } catch (...) { ::close(fd); throw; }
+      ::close(fd);
+    };
+    dump(".gfa", s->out.gfa.data(), s->out.gfa.size());
+    dump(".gtf", s->out.gtf.data(), s->out.gtf.size());
+    size_t n = s->out.gaf.size();
+    if (max_gaf_lines) {
+      const char* p = s->out.gaf.data();
+      const char* e = p + n;
+      uint64_t k = 0;
+      while (p < e && k < max_gaf_lines) {
+        const void* nl = memchr(p, '\n', size_t(e - p));
+        if (!nl) { p = e; break; }
+        p = static_cast<const char*>(nl) + 1;
+        ++k;
+      }
+      n = size_t(p - s->out.gaf.data());
+    }
+    dump(".gaf", s->out.gaf.data(), n);
+  });
+}
+
+__attribute__((visibility("default"))) void pantas_synth_free(pantas_synth* s) { delete s; }
+
+__attribute__((visibility("default"))) int pantas_graph_load_mem(const char* gfa_text, uint64_t size, pantas_graph** out) {
+  return guarded([&] {
+    need(gfa_text && out, "null argument");
+    double t0 = now_s();
+    auto h = std::make_unique<pantas_graph>();
+    h->g = load_graph_mem(gfa_text, size_t(size));
+    h->load_s = now_s() - t0;
+    *out = h.release();
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_call_prepare_mem(pantas_graph* g, const char* gtf_text, uint64_t size, int device) {
+  return guarded([&] {
+    need(g && g->g && gtf_text, "null argument");
+    auto t = std::make_unique<CallTables>();
+    build_call_tables_mem(*g->g, gtf_text, size_t(size), *t);
+    double t0 = now_s();
+    g->call_dev = upload_call(*g->g, *t, device);
+    g->call_upload_s = now_s() - t0;
+    g->call_tables = std::move(t);
+  });
+}
+
+
+__attribute__((visibility("default"))) int pantas_call_prepare_fused(pantas_graph* g, const char* gtf_path, const char* gtf_text,
+                                                                      uint64_t size, int device) {
+  return guarded([&] {
+    need(g && g->g && (gtf_path || gtf_text), "null argument");
+    need(g->have_result, "no finished augment run on this handle");
+    auto t = std::make_unique<CallTables>();
+    MappedFile f;
+    if (gtf_text) f.attach(gtf_text, size_t(size)); else f.open(gtf_path);
+    build_call_tables_mem(*g->g, f.data, f.size, *t, 0, &g->res);
+    double t0 = now_s();
+    g->call_dev = upload_call(*g->g, *t, device);
+    g->call_upload_s = now_s() - t0;
+    g->call_tables = std::move(t);
   });
 }
 

@@ -28,7 +28,8 @@ void MappedFile::open(const char* path) {
 }
 
 void MappedFile::close() {
-  if (data && size) munmap(const_cast<char*>(data), size);
+  if (data && size && !borrowed) munmap(const_cast<char*>(data), size);
+  borrowed = false;
   if (fd >= 0) ::close(fd);
   data = nullptr;
   size = 0;

@@ -33,11 +33,13 @@ struct MappedFile {
   const char* data = nullptr;
   size_t size = 0;
   int fd = -1;
+  bool borrowed = false;
   MappedFile() = default;
   MappedFile(const MappedFile&) = delete;
   MappedFile& operator=(const MappedFile&) = delete;
   ~MappedFile();
   void open(const char* path);   // throws Error("FileNotFoundError"/"OSError")
+  void attach(const char* p, size_t n) { close(); data = p; size = n; borrowed = true; }   // caller keeps p alive
   void close();
 };
 

@@ -60,10 +60,23 @@ void scan_chunk(const char* base, size_t b, size_t e, ChunkOut& out) {
 
 }  // namespace
 
+static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned threads);
+
 std::unique_ptr<Graph> load_graph(const char* path, unsigned threads) {
   auto g = std::make_unique<Graph>();
   g->path = path;
   g->text.open(path);
+  return parse_graph(std::move(g), threads);
+}
+
+std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads) {
+  auto g = std::make_unique<Graph>();
+  g->path = "<memory>";
+  g->text.attach(data, size);
+  return parse_graph(std::move(g), threads);
+}
+
+static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned threads) {
   const char* base = g->text.data;
   if (threads == 0) threads = hw_threads();
   if (g->text.size < (1u << 20)) threads = 1;

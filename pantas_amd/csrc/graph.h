@@ -65,5 +65,7 @@ struct Graph {
 
 // Parses the GFA at `path`.  Throws Error on inputs the reference's first GFA pass dies on.
 std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
+// Same over text already in memory (the buffer must outlive the graph).
+std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads = 0);
 
 }  // namespace pantas

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 from . import _lib
-from ._lib import BatchStats, CallOpts, CallStats, GraphStats, LaunchStats, PantasError, check, lib  # noqa: F401
+from ._lib import (BatchStats, CallOpts, CallStats, GraphStats, LaunchStats, PantasError, SynthParams,  # noqa: F401
+                   SynthStats, check, lib)
 
 
 class Batch:
@@ -25,9 +26,14 @@ class Batch:
 class Graph:
     """A GFA loaded into the CSR node/link layout (host) and, after ``to_device``, HBM."""
 
-    def __init__(self, gfa_path: str):
+    def __init__(self, gfa_path: str = None, *, text=None):
+        """From a GFA file, or from (address, size) of GFA text kept alive by the caller."""
         h = C.c_void_p()
-        check(lib.pantas_graph_load(os.fsencode(gfa_path), C.byref(h)))
+        if text is not None:
+            self._keep = text
+            check(lib.pantas_graph_load_mem(C.c_char_p(text[0]), text[1], C.byref(h)))
+        else:
+            check(lib.pantas_graph_load(os.fsencode(gfa_path), C.byref(h)))
         self._h = h
         self.path = gfa_path
 
@@ -58,6 +64,13 @@ class Graph:
         st = BatchStats()
         check(lib.pantas_augment_load_gaf(self._h, os.fsencode(gaf_path), thr, begin, end, first_line,
                                           C.byref(b), C.byref(st)))
+        return Batch(b, st)
+
+    def load_gaf_mem(self, text, thr: int = 20, first_line: int = 0) -> Batch:
+        b = C.c_void_p()
+        st = BatchStats()
+        check(lib.pantas_augment_load_gaf_mem(self._h, C.c_char_p(text[0]), text[1], thr, first_line,
+                                              C.byref(b), C.byref(st)))
         return Batch(b, st)
 
     def launch(self, batch: Batch) -> LaunchStats:
@@ -110,6 +123,16 @@ class Graph:
     def call_prepare(self, gtf_path: str, device: int = 0):
         check(lib.pantas_call_prepare(self._h, os.fsencode(gtf_path), device))
 
+    def call_prepare_mem(self, text, device: int = 0):
+        check(lib.pantas_call_prepare_mem(self._h, C.c_char_p(text[0]), text[1], device))
+
+    def call_prepare_fused(self, gtf_path: str = None, *, text=None, device: int = 0):
+        """Prepare call on the result of this handle's last augment run (no GFA text round trip)."""
+        if text is not None:
+            check(lib.pantas_call_prepare_fused(self._h, None, C.c_char_p(text[0]), text[1], device))
+        else:
+            check(lib.pantas_call_prepare_fused(self._h, os.fsencode(gtf_path), None, 0, device))
+
     def call(self, fd_csv: int = -1, fd_err: int = -1, rca: int = -1, novel: bool = False,
              no_annotated: bool = False, events=("ES", "SS", "IR"), isw: int = 5, minintronsize: int = 100,
              junction=None) -> CallStats:
@@ -121,3 +144,46 @@ class Graph:
         st = CallStats()
         check(lib.pantas_call_run(self._h, C.byref(o), fd_csv, fd_err, C.byref(st)))
         return st
+
+
+class Synth:
+    """In-memory synthetic GFA / GTF / GAF text (SURVEY.md 8-d recipe at BASELINE.json scales)."""
+
+    def __init__(self, **kw):
+        p = SynthParams()
+        lib.pantas_synth_defaults(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise TypeError(f"unknown synth parameter {k}")
+            setattr(p, k, v)
+        self.params = p
+        self.stats = SynthStats()
+        h = C.c_void_p()
+        check(lib.pantas_synth_generate(C.byref(p), C.byref(h), C.byref(self.stats)))
+        self._h = h
+
+    def text(self, which: int):
+        """(address, size) of the GFA (0), GTF (1) or GAF (2) text; valid while this object lives."""
+        d = C.c_char_p()
+        n = C.c_uint64()
+        pp = C.cast(C.byref(d), C.POINTER(C.c_char_p))
+        check(lib.pantas_synth_text(self._h, which, pp, C.byref(n)))
+        return (C.cast(d, C.c_void_p).value, n.value)
+
+    @property
+    def gfa(self): return self.text(0)
+    @property
+    def gtf(self): return self.text(1)
+    @property
+    def gaf(self): return self.text(2)
+
+    def write(self, prefix: str, max_gaf_lines: int = 0):
+        check(lib.pantas_synth_write(self._h, os.fsencode(prefix), max_gaf_lines))
+
+    def close(self):
+        if self._h:
+            lib.pantas_synth_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()

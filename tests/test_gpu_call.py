@@ -94,3 +94,31 @@ def test_call_is_deterministic_and_ordered():
     a = engine_call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", ["--rca", "2", "--novel", "--minintronsize", "40"])
     b = engine_call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", ["--rca", "2", "--novel", "--minintronsize", "40"])
     assert a == b
+
+
+def test_fused_equals_text_round_trip(tmp_path):
+    """augment -> call on the same handle (no GFA text) == call on the written augmented GFA, byte for byte."""
+    from pantas_amd.engine import Graph, Synth
+    syn = Synth(seed=5, n_genes=400, n_lines=60000)
+    pre = str(tmp_path / "w")
+    syn.write(pre)
+    g = Graph(pre + ".gfa").to_device(0)
+    with open(pre + ".aug.gfa", "wb") as f:
+        g.augment(pre + ".gaf", 20, f.fileno())
+    flags = dict(rca=2, novel=True, minintronsize=30)
+    g.call_prepare_fused(pre + ".gtf")
+    with tempfile.TemporaryFile() as f:
+        g.call(f.fileno(), -1, **flags)
+        f.seek(0)
+        fused = f.read()
+    g2 = Graph(pre + ".aug.gfa")
+    g2.call_prepare(pre + ".gtf", 0)
+    with tempfile.TemporaryFile() as f:
+        st = g2.call(f.fileno(), -1, **flags)
+        f.seek(0)
+        text = f.read()
+    assert st.events > 500
+    assert fused == text
+    want = call_oracle.call(pre + ".aug.gfa", pre + ".gtf", None, **flags)
+    norm = call_oracle.normalise_row
+    assert collections.Counter(map(norm, text.decode().splitlines()[1:])) == collections.Counter(map(norm, want))
