@@ -67,6 +67,7 @@ typedef struct {
   uint64_t path_nodes;     /* sum of path lengths of those */
   uint64_t cs_ops;
   uint64_t del_records;    /* records with a '-' op */
+  uint64_t del_path_nodes; /* sum of their path lengths (4x this bounds the distinct IL/OL keys they create) */
   uint64_t text_bytes;
   uint64_t alg_bytes;      /* algorithmic bytes of one launch over this batch */
   double tokenize_seconds, upload_seconds;
@@ -90,6 +91,17 @@ int pantas_gaf_split(const char* gaf_path, int rank, int world, uint64_t* begin,
 void pantas_batch_free(pantas_batch* b);
 /* :209-363 on the GPU: both kernels over a resident batch, accumulating into g's counters */
 int pantas_augment_launch(pantas_graph* g, pantas_batch* b, pantas_launch_stats* out);
+/* the two kernels separately, for runs sharded over several GPUs: after the rare-key kernel every
+ * rank exports the node flags it set ((node << 1) | side, uint32), the ranks all-gather them, import
+ * the union, and only then run the main kernel (it records the first-seen order of the common IL/OL
+ * key on flagged nodes).  pantas_augment_launch == launch_rare + launch_main. */
+/* sharded runs, after reset and before the first launch: room for `keys` distinct IL/OL keys (the sum
+ * over ranks of 4 * del_path_nodes), since every rank also records keys for nodes other ranks flagged */
+int pantas_augment_reserve(pantas_graph* g, uint64_t keys);
+int pantas_augment_launch_rare(pantas_graph* g, pantas_batch* b, float* ms);
+int pantas_augment_launch_main(pantas_graph* g, pantas_batch* b, float* ms);
+int pantas_augment_flags_export(pantas_graph* g, uint32_t* codes, uint64_t capacity, uint64_t* n);
+int pantas_augment_flags_import(pantas_graph* g, const uint32_t* codes, uint64_t n);
 /* device address of the dense counters [NC V | IL0 V | OLL V | RC A] (uint32) for a
  * caller-run all-reduce (RCCL through torch.distributed); words = 3V + A */
 int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words);

@@ -33,7 +33,7 @@ class GraphStats(C.Structure):
 class BatchStats(C.Structure):
     _fields_ = [("lines", C.c_uint64), ("rejected", C.c_uint64), ("skipped", C.c_uint64),
                 ("records", C.c_uint64), ("path_nodes", C.c_uint64), ("cs_ops", C.c_uint64),
-                ("del_records", C.c_uint64), ("text_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
+                ("del_records", C.c_uint64), ("del_path_nodes", C.c_uint64), ("text_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
                 ("tokenize_seconds", C.c_double), ("upload_seconds", C.c_double)]
 
 
@@ -91,6 +91,11 @@ def _load():
         "pantas_gaf_split": (i32, [C.c_char_p, i32, i32, P(u64), P(u64), P(u64)]),
         "pantas_batch_free": (None, [vp]),
         "pantas_augment_launch": (i32, [vp, vp, P(LaunchStats)]),
+        "pantas_augment_reserve": (i32, [vp, u64]),
+        "pantas_augment_launch_rare": (i32, [vp, vp, P(C.c_float)]),
+        "pantas_augment_launch_main": (i32, [vp, vp, P(C.c_float)]),
+        "pantas_augment_flags_export": (i32, [vp, vp, u64, P(u64)]),
+        "pantas_augment_flags_import": (i32, [vp, vp, u64]),
         "pantas_augment_counters": (i32, [vp, P(vp), P(u64)]),
         "pantas_augment_sparse_count": (i32, [vp, P(u64)]),
         "pantas_augment_sparse_export": (i32, [vp, P(u64), u64]),

@@ -59,9 +59,15 @@ DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);
 // Launches the two augment kernels over a resident batch; accumulates into dg's counters.
 // Returns the device time of the two kernels in ms (HIP events on the launch stream).
 float launch_augment(DeviceGraph& dg, DeviceBatch& db, float* ms_rare = nullptr, float* ms_main = nullptr);
+// The two stages separately (multi-GPU: node flags are exchanged between them).
+float launch_rare(DeviceGraph& dg, DeviceBatch& db);
+float launch_main(DeviceGraph& dg, DeviceBatch& db);
+void export_flags(DeviceGraph& dg, std::vector<uint32_t>& codes);          // (node << 1 | side), sorted
+void import_flags(DeviceGraph& dg, const uint32_t* codes, size_t n);
 // Raises Error if a kernel reported a line the reference would have died on.
 void check_device_status(DeviceGraph& dg, const DeviceBatch* db);
-void boost_novel_table(DeviceGraph& dg);              // next sizing of the novel-link table is 4x larger
+void boost_novel_table(DeviceGraph& dg);
+void reserve_hist(DeviceGraph& dg, uint64_t keys);   // bound on distinct IL/OL keys of the whole (sharded) run              // next sizing of the novel-link table is 4x larger
 void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 // device pointers of the dense counters, for collectives run by the caller (RCCL via torch.distributed)
 struct CounterPtrs { void* nc; void* rc; void* il0; void* oll; uint64_t V, A; };

@@ -83,7 +83,10 @@ __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, u
     }
     if (cur == key) {
       if (add) atomicAdd(&t.cnt[h], add);
-      atomicMin(reinterpret_cast<unsigned long long*>(&t.first[h]), order);
+      // first-seen is a running minimum: once the early lines have landed nearly every later
+      // candidate loses, and a (possibly stale, hence too large) read is enough to know it
+      if (order < __atomic_load_n(&t.first[h], __ATOMIC_RELAXED))
+        atomicMin(reinterpret_cast<unsigned long long*>(&t.first[h]), order);
       return;
     }
     h = (h + 1) & t.mask;
@@ -145,6 +148,79 @@ __global__ __launch_bounds__(256) void augment_main_kernel(GraphView g, BatchVie
     run_line<MainSink>(g, b, i);
 }
 
+// ---- LDS-aggregating main kernel ----------------------------------------------------------------
+// Records arrive bucketed by locus (gaf.cpp bucket_by_locus), so the CHUNK consecutive records one
+// workgroup walks keep hitting the same counters.  Increments are first summed in a workgroup-private
+// open-addressing table in LDS, keyed by the counter's index in the [NC | IL0 | OLL | RC] allocation,
+// and reach HBM as ONE global atomic per distinct counter per chunk.  An increment that finds no
+// slot within a few probes goes straight to memory, so capacity is a speed matter only.
+constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
+
+template <uint32_t LOG_CAP>
+struct LdsSink {
+  const GraphView& g;
+  uint32_t* keys;
+  uint32_t* vals;
+  uint32_t V;
+  __device__ __forceinline__ void bump(uint32_t key, uint32_t times) const {
+    constexpr uint32_t CAP = 1u << LOG_CAP;
+    uint32_t h = (key * 2654435761u) >> (32 - LOG_CAP);
+#pragma unroll 1
+    for (uint32_t probe = 0; probe < 12; ++probe) {
+      uint32_t cur = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+      if (cur == LDS_EMPTY) {
+        cur = atomicCAS(&keys[h], LDS_EMPTY, key);
+        if (cur == LDS_EMPTY) cur = key;
+      }
+      if (cur == key) { atomicAdd(&vals[h], times); return; }
+      h = (h + 1) & (CAP - 1);
+    }
+    atomicAdd(&g.nc[key], times);   // g.nc is the base of the counter allocation
+  }
+  __device__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
+  __device__ void nc(uint32_t n) const { bump(n, 1u); }
+  __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
+    bump((side == SIDE_IL ? V : 2u * V) + n, times);
+    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+  }
+  __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
+  __device__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
+    const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
+    for (uint32_t s = lo; s < hi; ++s) {
+      if (g.col[s] == b) { bump(3u * V + s, 1u); return; }
+    }
+    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
+  }
+};
+
+template <uint32_t THREADS, uint32_t LOG_CAP, uint32_t CHUNK>
+__global__ __launch_bounds__(THREADS) void augment_main_lds_kernel(GraphView g, BatchView b, uint32_t V) {
+  constexpr uint32_t CAP = 1u << LOG_CAP;
+  __shared__ uint32_t keys[CAP];
+  __shared__ uint32_t vals[CAP];
+  const uint32_t n_chunks = (b.n + CHUNK - 1) / CHUNK;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (uint32_t i = threadIdx.x; i < CAP; i += THREADS) { keys[i] = LDS_EMPTY; vals[i] = 0u; }
+    __syncthreads();
+    const uint32_t lo = c * CHUNK;
+    const uint32_t hi = min(b.n, lo + CHUNK);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+      const LineHdr h = b.hdr[i];
+      const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
+      const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
+      LdsSink<LOG_CAP> sink{g, keys, vals, V};
+      const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+      if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CAP; i += THREADS) {
+      const uint32_t k = keys[i];
+      if (k != LDS_EMPTY) atomicAdd(&g.nc[k], vals[i]);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void clear_flags_kernel(uint32_t* word, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) word[i] &= LEN_MASK;
 }
@@ -189,6 +265,8 @@ struct DeviceGraph {
   uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
   Table hist, novel;
   uint64_t novel_boost = 1;       // grown after a TableOverflow("novel") retry
+  uint64_t imported_flags = 0;    // node flags received from other ranks this run
+  uint64_t reserved_hist = 0;     // caller's bound on distinct IL/OL keys (sharded runs)
   GraphView view() const {
     GraphView g{};
     g.word = word; g.row_ptr = row_ptr; g.col = col;
@@ -294,6 +372,8 @@ void reset_counters(DeviceGraph& d) {
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
+  d.imported_flags = 0;
+  d.reserved_hist = 0;
 }
 
 template <class T>
@@ -357,12 +437,9 @@ static BatchView batch_view(const DeviceBatch& b) {
   return v;
 }
 
-void boost_novel_table(DeviceGraph& d) { d.novel_boost *= 4; }
-
-float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_main) {
-  HIP_OK(hipSetDevice(d.device));
+static void ensure_tables(DeviceGraph& d, DeviceBatch& b) {
   // capacity: every rare event and every flagged dense key is at most one key per (node, side) visit
-  const uint64_t hist_bound = 4 * b.del_nodes;
+  const uint64_t hist_bound = std::max<uint64_t>(4 * b.del_nodes, d.reserved_hist);
   const uint64_t edges = b.n_nodes > b.n ? b.n_nodes - b.n : 0;
   const uint64_t novel_guess = std::min<uint64_t>(edges, std::max<uint64_t>(1u << 16, edges / 4 * d.novel_boost));
   if (hist_bound * 2 + 1024 > d.hist.cap || novel_guess * 2 + 1024 > d.novel.cap) {
@@ -372,6 +449,14 @@ float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_m
     if (nk[0] || nk[2]) throw Error("InternalError", "device tables must be sized before the first batch of a run");
     size_tables(d, hist_bound, novel_guess);
   }
+}
+
+void boost_novel_table(DeviceGraph& d) { d.novel_boost *= 4; }
+void reserve_hist(DeviceGraph& d, uint64_t keys) { d.reserved_hist = keys; }
+
+float launch_rare(DeviceGraph& d, DeviceBatch& b) {
+  HIP_OK(hipSetDevice(d.device));
+  ensure_tables(d, b);
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[0], d.stream));
@@ -381,19 +466,104 @@ float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_m
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
+  HIP_OK(hipEventSynchronize(d.ev[1]));
+  float a = 0;
+  HIP_OK(hipEventElapsedTime(&a, d.ev[0], d.ev[1]));
+  return a;
+}
+
+float launch_main(DeviceGraph& d, DeviceBatch& b) {
+  HIP_OK(hipSetDevice(d.device));
+  ensure_tables(d, b);
+  const GraphView g = d.view();
+  const BatchView bv = batch_view(b);
+  HIP_OK(hipEventRecord(d.ev[1], d.stream));
   if (b.n) {
-    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
-    hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
+    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 3;
+    const bool keys_fit = 3ull * d.V + d.A < 0xFFFFFFFFull;
+    if (variant == 0 || !keys_fit) {
+      const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
+      hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
+    } else if (variant == 2) {
+      constexpr uint32_t CH = 1024;
+      const uint32_t blocks = (b.n + CH - 1) / CH;
+      hipLaunchKernelGGL((augment_main_lds_kernel<256, 12, CH>), dim3(blocks), dim3(256), 0, d.stream, g, bv, d.V);
+    } else if (variant == 1) {
+      constexpr uint32_t CH = 2048;
+      const uint32_t blocks = (b.n + CH - 1) / CH;
+      hipLaunchKernelGGL((augment_main_lds_kernel<512, 13, CH>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V);
+    } else {
+      constexpr uint32_t CH = 4096;
+      const uint32_t blocks = (b.n + CH - 1) / CH;
+      hipLaunchKernelGGL((augment_main_lds_kernel<1024, 14, CH>), dim3(blocks), dim3(1024), 0, d.stream, g, bv, d.V);
+    }
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(d.ev[2], d.stream));
   HIP_OK(hipEventSynchronize(d.ev[2]));
-  float a = 0, m = 0;
-  HIP_OK(hipEventElapsedTime(&a, d.ev[0], d.ev[1]));
+  float m = 0;
   HIP_OK(hipEventElapsedTime(&m, d.ev[1], d.ev[2]));
+  return m;
+}
+
+float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_main) {
+  const float a = launch_rare(d, b);
+  const float m = launch_main(d, b);
   if (ms_rare) *ms_rare = a;
   if (ms_main) *ms_main = m;
   return a + m;
+}
+
+// (node << 1 | side) of every node flag the rare kernel has set so far -- what other ranks need
+// before THEIR main kernel so that the first-seen order of the common key is recorded everywhere
+__global__ void collect_flags_kernel(const uint32_t* word, uint32_t n, uint32_t* out, uint32_t* cursor, uint32_t cap) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t w = word[i];
+    if (w & FLAG_IL) { const uint32_t o = atomicAdd(cursor, 1u); if (o < cap) out[o] = i << 1; }
+    if (w & FLAG_OL) { const uint32_t o = atomicAdd(cursor, 1u); if (o < cap) out[o] = (i << 1) | 1u; }
+  }
+}
+
+__global__ void apply_flags_kernel(uint32_t* word, const uint32_t* codes, uint32_t n, uint32_t V) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t c = codes[i];
+    if ((c >> 1) < V) atomicOr(&word[c >> 1], (c & 1u) ? FLAG_OL : FLAG_IL);
+  }
+}
+
+void export_flags(DeviceGraph& d, std::vector<uint32_t>& codes) {
+  HIP_OK(hipSetDevice(d.device));
+  codes.clear();
+  if (!d.V) return;
+  uint32_t nk = 0;
+  HIP_OK(hipMemcpy(&nk, d.small + 2, 4, hipMemcpyDeviceToHost));   // distinct rare keys bound the flag count
+  const uint32_t cap = nk + 16;
+  uint32_t* out = nullptr;
+  HIP_OK(hipMalloc(&out, size_t(cap) * 4));
+  HIP_OK(hipMemsetAsync(d.small + 6, 0, 4, d.stream));
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(d.V) + 255) / 256, 4096));
+  hipLaunchKernelGGL(collect_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.V, out, d.small + 6, cap);
+  uint32_t n = 0;
+  HIP_OK(hipMemcpyAsync(&n, d.small + 6, 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  n = std::min(n, cap);
+  codes.resize(n);
+  if (n) HIP_OK(hipMemcpy(codes.data(), out, size_t(n) * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(out);
+  std::sort(codes.begin(), codes.end());
+}
+
+void import_flags(DeviceGraph& d, const uint32_t* codes, size_t n) {
+  HIP_OK(hipSetDevice(d.device));
+  if (!n) return;
+  uint32_t* in = nullptr;
+  HIP_OK(hipMalloc(&in, n * 4));
+  HIP_OK(hipMemcpyAsync(in, codes, n * 4, hipMemcpyHostToDevice, d.stream));
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((n + 255) / 256, 4096));
+  hipLaunchKernelGGL(apply_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, in, uint32_t(n), d.V);
+  HIP_OK(hipStreamSynchronize(d.stream));
+  (void)hipFree(in);
+  d.imported_flags += n;
 }
 
 void check_device_status(DeviceGraph& d, const DeviceBatch*) {

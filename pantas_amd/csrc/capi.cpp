@@ -180,6 +180,7 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
   GafBatch b;
   double t0 = now_s();
   tokenize_gaf(*g->g, data, size, thr, first_line, 0, b);
+  if (!getenv("PANTAS_NO_BUCKET")) bucket_by_locus(b);
   double t1 = now_s();
   auto h = std::make_unique<pantas_batch>();
   h->dev = upload_batch(*g->dev, b);
@@ -192,6 +193,7 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
   s.path_nodes = b.nodes.size();
   s.cs_ops = b.ops.size();
   s.del_records = b.del_lines;
+  s.del_path_nodes = b.del_nodes;
   s.text_bytes = b.bytes;
   s.alg_bytes = batch_alg_bytes(*h->dev);
   s.tokenize_seconds = t1 - t0;
@@ -234,6 +236,53 @@ __attribute__((visibility("default"))) int pantas_augment_launch(pantas_graph* g
     float r = 0, m = 0;
     launch_augment(*g->dev, *b->dev, &r, &m);
     if (out) { out->rare_ms = r; out->main_ms = m; }
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_reserve(pantas_graph* g, uint64_t keys) {
+  return guarded([&] {
+    need_device(g);
+    reserve_hist(*g->dev, keys);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_launch_rare(pantas_graph* g, pantas_batch* b, float* ms) {
+  return guarded([&] {
+    need_device(g);
+    need(b && b->dev, "null batch");
+    float t = launch_rare(*g->dev, *b->dev);
+    if (ms) *ms = t;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_launch_main(pantas_graph* g, pantas_batch* b, float* ms) {
+  return guarded([&] {
+    need_device(g);
+    need(b && b->dev, "null batch");
+    float t = launch_main(*g->dev, *b->dev);
+    if (ms) *ms = t;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_flags_export(pantas_graph* g, uint32_t* codes, uint64_t capacity, uint64_t* n) {
+  return guarded([&] {
+    need_device(g);
+    need(n, "null argument");
+    std::vector<uint32_t> v;
+    export_flags(*g->dev, v);
+    *n = v.size();
+    if (codes) {
+      need(capacity >= v.size(), "buffer too small");
+      if (!v.empty()) memcpy(codes, v.data(), v.size() * 4);
+    }
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_flags_import(pantas_graph* g, const uint32_t* codes, uint64_t n) {
+  return guarded([&] {
+    need_device(g);
+    need(codes || n == 0, "null argument");
+    import_flags(*g->dev, codes, size_t(n));
   });
 }
 

@@ -264,4 +264,78 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
   out.op_off[n] = uint32_t(no);
 }
 
+
+namespace {
+
+// parallel LSD radix sort of (key, idx) pairs, 16-bit digits
+void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads) {
+  const size_t n = key.size();
+  std::vector<uint32_t> key2(n), idx2(n);
+  const unsigned T = n < (1u << 16) ? 1 : threads;
+  uint32_t maxk = 0;
+  for (uint32_t k : key) maxk = std::max(maxk, k);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shift = pass * 16;
+    if (pass == 1 && (maxk >> 16) == 0) break;
+    std::vector<std::vector<uint32_t>> hist(T, std::vector<uint32_t>(65536, 0));
+    parallel_chunks(n, T, [&](unsigned c, size_t b, size_t e) {
+      uint32_t* h = hist[c].data();
+      for (size_t i = b; i < e; ++i) ++h[(key[i] >> shift) & 0xFFFFu];
+    });
+    uint64_t run = 0;
+    for (uint32_t d = 0; d < 65536; ++d)
+      for (unsigned c = 0; c < T; ++c) { uint32_t x = hist[c][d]; hist[c][d] = uint32_t(run); run += x; }
+    parallel_chunks(n, T, [&](unsigned c, size_t b, size_t e) {
+      uint32_t* h = hist[c].data();
+      for (size_t i = b; i < e; ++i) {
+        const uint32_t o = h[(key[i] >> shift) & 0xFFFFu]++;
+        key2[o] = key[i];
+        idx2[o] = idx[i];
+      }
+    });
+    key.swap(key2);
+    idx.swap(idx2);
+  }
+}
+
+}  // namespace
+
+void bucket_by_locus(GafBatch& b, unsigned threads) {
+  const size_t n = b.size();
+  if (n < 2) return;
+  if (threads == 0) threads = hw_threads();
+  std::vector<uint32_t> key(n), idx(n);
+  parallel_chunks(n, n < (1u << 16) ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      key[i] = b.node_off[i + 1] > b.node_off[i] ? b.nodes[b.node_off[i]] : 0u;
+      idx[i] = uint32_t(i);
+    }
+  });
+  radix_sort_pairs(key, idx, threads);
+  std::vector<LineHdr> hdr(n);
+  std::vector<uint32_t> node_off(n + 1), op_off(n + 1), nodes(b.nodes.size()), ops(b.ops.size());
+  // sizes, then exclusive offsets (sequential scan: 2 adds per record), then a parallel gather
+  node_off[0] = 0;
+  op_off[0] = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t s = idx[i];
+    node_off[i + 1] = node_off[i] + (b.node_off[s + 1] - b.node_off[s]);
+    op_off[i + 1] = op_off[i] + (b.op_off[s + 1] - b.op_off[s]);
+  }
+  parallel_chunks(n, n < (1u << 16) ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      const uint32_t s = idx[i];
+      hdr[i] = b.hdr[s];
+      const uint32_t nn = b.node_off[s + 1] - b.node_off[s], no = b.op_off[s + 1] - b.op_off[s];
+      if (nn) memcpy(&nodes[node_off[i]], &b.nodes[b.node_off[s]], size_t(nn) * 4);
+      if (no) memcpy(&ops[op_off[i]], &b.ops[b.op_off[s]], size_t(no) * 4);
+    }
+  });
+  b.hdr.swap(hdr);
+  b.node_off.swap(node_off);
+  b.op_off.swap(op_off);
+  b.nodes.swap(nodes);
+  b.ops.swap(ops);
+}
+
 }  // namespace pantas

@@ -27,6 +27,11 @@ struct GafBatch {
   size_t size() const { return hdr.size(); }
 };
 
+// Reorders the records of a batch by the index of their first path node (stable), so that a
+// workgroup's consecutive records touch the same few hundred counters and graph rows.  The
+// result of a run does not depend on record order (line_id carries the file order).
+void bucket_by_locus(GafBatch& b, unsigned threads = 0);
+
 // Tokenises the byte range [data, data+size) (whole lines).  first_line_id = index of its
 // first line in the file.  Throws Error where the reference's loop would raise.
 void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,

@@ -1,0 +1,148 @@
+"""Sharded `pantas augment` over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  The graph is replicated; the GAF is cut into `world` contiguous byte ranges at
+line starts; global line index = lines before the shard + local index (first-seen ordering).
+
+    rank r:  tokenise shard r -> rare-key kernel
+    all:     all-gather the node flags the rare kernels set      (tiny, variable length)
+    rank r:  main kernel over shard r
+    all:     ONE all-reduce(sum) over the dense counters [NC | IL0 | OLL | RC]
+    rank 0:  gathers the sparse side results (novel links, rare IL/OL keys; counts add,
+             first-seen takes the minimum) and writes the GFA
+
+The driver is written against a small backend interface so that the CPU test-suite can run the
+identical exchange logic over gloo with the CPU harness standing in for the kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+
+class LibBackend:
+    """libpantas_gpu on one GPU."""
+
+    def __init__(self, gfa_path: str, device: int):
+        from .engine import Graph
+        self.device = device
+        self.g = Graph(gfa_path).to_device(device)
+        self.g.augment_reset()
+        self.batch = None
+
+    def split(self, gaf_path, rank, world):
+        from ._lib import check, lib
+        b, e, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.pantas_gaf_split(os.fsencode(gaf_path), rank, world, C.byref(b), C.byref(e), C.byref(n)))
+        return b.value, e.value, n.value
+
+    def load_shard(self, gaf_path, thr, begin, end, first_line):
+        if begin == end:
+            # an empty shard still needs a (zero-record) batch
+            self.batch = self.g.load_gaf_mem((C.addressof(C.create_string_buffer(1)), 0), thr, first_line)
+        else:
+            self.batch = self.g.load_gaf(gaf_path, thr, begin, end, first_line)
+        s = self.batch.stats
+        return dict(lines=s.lines, rejected=s.rejected, del_path_nodes=s.del_path_nodes)
+
+    def reserve(self, keys): self.g.reserve(keys)
+    def launch_rare(self): return self.g.launch_rare(self.batch)
+    def launch_main(self): return self.g.launch_main(self.batch)
+    def flags_export(self): return self.g.flags_export()
+    def flags_import(self, codes): self.g.flags_import(codes)
+
+    def counters_tensor(self):
+        import torch
+        ptr, words = self.g.counters()
+
+        class _Dev:  # zero-copy view of the library's counter allocation
+            __cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(_Dev(), device=torch.device("cuda", self.device))
+
+    def finish(self): self.g.finish()
+    def sparse_export(self): return self.g.sparse_export()
+    def sparse_import(self, rows): self.g.sparse_import(rows)
+    def write_gfa(self, fd): self.g.write_gfa(fd)
+
+
+def _gather_var(dist, arr: np.ndarray, device):
+    """all-gather of 1-D/2-D integer arrays of different lengths; returns the list per rank."""
+    import torch
+    world = dist.get_world_size()
+    flat = np.ascontiguousarray(arr).reshape(-1)
+    as_i64 = flat.view(np.int64) if flat.dtype == np.uint64 else flat.astype(np.int64)
+    n = torch.tensor([as_i64.shape[0]], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(max(sizes), 1)
+    buf = torch.zeros(m, dtype=torch.int64, device=device)
+    if as_i64.shape[0]:
+        buf[:as_i64.shape[0]] = torch.from_numpy(as_i64.copy()).to(device)
+    outs = [torch.zeros(m, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
+
+
+def augment_sharded(backend, gaf_path: str, thr: int, out_fd: int, dist, device=None) -> dict:
+    """Runs one sharded augment; rank 0 writes the augmented GFA to out_fd.  Returns totals."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = device if device is not None else torch.device("cpu")
+    begin, end, lines_before = backend.split(gaf_path, rank, world)
+    st = backend.load_shard(gaf_path, thr, begin, end, lines_before)
+    tot = torch.tensor([st["lines"], st["rejected"], 4 * st["del_path_nodes"]], dtype=torch.int64, device=device)
+    dist.all_reduce(tot)
+    lines, rejected, hist_keys = (int(x) for x in tot.tolist())
+    backend.reserve(hist_keys + 1024)
+    backend.launch_rare()
+    codes = _gather_var(dist, backend.flags_export().astype(np.int64), device)
+    union = np.unique(np.concatenate(codes)).astype(np.uint32) if codes else np.zeros(0, np.uint32)
+    backend.flags_import(union)
+    backend.launch_main()
+    ct = backend.counters_tensor()
+    dist.all_reduce(ct)                      # THE data-path collective: uint32 sums as int32 bit patterns
+    if ct.is_cuda:
+        torch.cuda.synchronize()
+    backend.finish()
+    rows = _gather_var(dist, backend.sparse_export(), device)
+    if rank == 0:
+        others = [r.view(np.uint64).reshape(-1, 4) for i, r in enumerate(rows) if i != 0 and r.shape[0]]
+        if others:
+            backend.sparse_import(np.concatenate(others))
+        if out_fd is not None and out_fd >= 0:
+            backend.write_gfa(out_fd)
+    dist.barrier()
+    return dict(lines=lines, rejected=rejected)
+
+
+def main(argv=None) -> int:
+    """torchrun entry:  python -m torch.distributed.run --nproc-per-node N -m pantas_amd.distributed GAF GFA [thr]"""
+    import sys
+    import torch
+    import torch.distributed as dist
+    argv = sys.argv[1:] if argv is None else argv
+    gaf, gfa = argv[0], argv[1]
+    thr = int(argv[2]) if len(argv) > 2 else 20
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if dist.get_rank() == 0:
+        print("Read GFA", file=sys.stderr)
+    be = LibBackend(gfa, local)
+    if dist.get_rank() == 0:
+        print("Augmentation by GAF alignments", file=sys.stderr)
+    sys.stdout.flush()
+    tot = augment_sharded(be, gaf, thr, sys.stdout.fileno() if dist.get_rank() == 0 else -1, dist,
+                          torch.device("cuda", local))
+    if dist.get_rank() == 0:
+        print(f"Rejected alignments: {tot['rejected']}", file=sys.stderr)
+        print("Annotating GFA", file=sys.stderr)
+    dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -78,6 +78,33 @@ class Graph:
         check(lib.pantas_augment_launch(self._h, batch._h, C.byref(st)))
         return st
 
+    def reserve(self, keys: int):
+        check(lib.pantas_augment_reserve(self._h, keys))
+
+    def launch_rare(self, batch: Batch) -> float:
+        ms = C.c_float()
+        check(lib.pantas_augment_launch_rare(self._h, batch._h, C.byref(ms)))
+        return ms.value
+
+    def launch_main(self, batch: Batch) -> float:
+        ms = C.c_float()
+        check(lib.pantas_augment_launch_main(self._h, batch._h, C.byref(ms)))
+        return ms.value
+
+    def flags_export(self):
+        import numpy as np
+        n = C.c_uint64()
+        check(lib.pantas_augment_flags_export(self._h, None, 0, C.byref(n)))
+        codes = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            check(lib.pantas_augment_flags_export(self._h, codes.ctypes.data, n.value, C.byref(n)))
+        return codes
+
+    def flags_import(self, codes):
+        import numpy as np
+        codes = np.ascontiguousarray(codes, dtype=np.uint32)
+        check(lib.pantas_augment_flags_import(self._h, codes.ctypes.data, codes.shape[0]))
+
     def counters(self):
         """(device pointer, words) of the dense counters [NC | IL0 | OLL | RC]."""
         p = C.c_void_p()

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
     gaf.open(argv[1]);
     GafBatch b;
     tokenize_gaf(*g, gaf.data, gaf.size, thr, 0, threads, b);
+    if (getenv("HOSTSIM_BUCKET")) bucket_by_locus(b, threads);
     Tables t;
     t.word = g->seg_len;
     t.nc.assign(g->V, 0);

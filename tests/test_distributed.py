@@ -1,0 +1,130 @@
+"""The N>1 path (pantas_amd/distributed.py) over gloo, world_size 2 and 3, on CPU.
+
+The exchange logic under test is the product's (shard split, node-flag all-gather, the dense
+all-reduce, sparse merge, rank-0 writer); the kernels are replaced by the CPU harness
+(tests/hostsim/hostsim_lib.cpp: the device walk compiled for the host), because there is no GPU
+here.  The result must be byte-identical to the reference golden, like a single-GPU run."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+BUILD = os.path.join(ROOT, "build", "hostsim")
+CSRC = os.path.join(ROOT, "pantas_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def hostsim_lib():
+    os.makedirs(BUILD, exist_ok=True)
+    out = os.path.join(BUILD, "libhostsim.so")
+    srcs = [os.path.join(ROOT, "tests/hostsim/hostsim_lib.cpp")] + [os.path.join(CSRC, f) for f in
+            ("graph.cpp", "common.cpp", "gaf.cpp", "augment_host.cpp")]
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-I", CSRC, "-o", out, *srcs, "-lpthread"])
+    return out
+
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pantas_amd.distributed import augment_sharded
+from pantas_amd._lib import lib, check
+
+class HostsimBackend:
+    """CPU stand-in with the interface of pantas_amd.distributed.LibBackend"""
+    def __init__(self, so, gfa):
+        self.L = C.CDLL(so)
+        self.L.hs_open.restype = C.c_void_p
+        self.L.hs_counters.restype = C.POINTER(C.c_uint32)
+        self.L.hs_flags_export.restype = C.c_uint64
+        self.L.hs_sparse_count.restype = C.c_uint64
+        self.h = C.c_void_p(self.L.hs_open(gfa.encode()))
+        assert self.h
+    def split(self, gaf, rank, world):
+        b, e, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.pantas_gaf_split(gaf.encode(), rank, world, C.byref(b), C.byref(e), C.byref(n)))
+        return b.value, e.value, n.value
+    def load_shard(self, gaf, thr, begin, end, first_line):
+        st = (C.c_uint64 * 3)()
+        if begin == end:
+            return dict(lines=0, rejected=0, del_path_nodes=0)
+        assert self.L.hs_load_shard(self.h, gaf.encode(), thr, C.c_uint64(begin), C.c_uint64(end), C.c_uint64(first_line), st) == 0
+        return dict(lines=st[0], rejected=st[1], del_path_nodes=st[2])
+    def reserve(self, keys): pass
+    def launch_rare(self): assert self.L.hs_rare(self.h) == 0
+    def launch_main(self): assert self.L.hs_main(self.h) == 0
+    def flags_export(self):
+        n = self.L.hs_flags_export(self.h, None, C.c_uint64(0))
+        a = np.zeros(n, dtype=np.uint32)
+        self.L.hs_flags_export(self.h, a.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(n))
+        return a
+    def flags_import(self, codes):
+        codes = np.ascontiguousarray(codes, dtype=np.uint32)
+        self.L.hs_flags_import(self.h, codes.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint64(codes.shape[0]))
+    def counters_tensor(self):
+        w = C.c_uint64()
+        p = self.L.hs_counters(self.h, C.byref(w))
+        a = np.ctypeslib.as_array(p, shape=(w.value,)).view(np.int32)
+        return torch.from_numpy(a)          # shares memory: the all-reduce lands in the harness' array
+    def finish(self): assert self.L.hs_finish(self.h) == 0
+    def sparse_export(self):
+        n = self.L.hs_sparse_count(self.h)
+        a = np.zeros((n, 4), dtype=np.uint64)
+        self.L.hs_sparse_export(self.h, a.ctypes.data_as(C.POINTER(C.c_uint64)))
+        return a
+    def sparse_import(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        assert self.L.hs_sparse_import(self.h, rows.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint64(rows.shape[0])) == 0
+    def write_gfa(self, fd): assert self.L.hs_write(self.h, fd) == 0
+
+so, gfa, gaf, out = sys.argv[2:6]
+dist.init_process_group(backend="gloo")
+be = HostsimBackend(so, gfa)
+fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644) if dist.get_rank() == 0 else -1
+tot = augment_sharded(be, gaf, 20, fd, dist)
+if dist.get_rank() == 0:
+    os.close(fd)
+    open(out + ".rej", "w").write(str(tot["rejected"]))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("case,world", [("synth_a", 2), ("quirks", 2), ("synth_b", 3), ("micro", 2)])
+def test_sharded_augment_gloo(hostsim_lib, tmp_path, case, world):
+    import json
+    d = os.path.join(GOLDEN, case)
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER)
+    out = str(tmp_path / "out.gfa")
+    port = 29500 + (os.getpid() + world * 7 + len(case)) % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker), ROOT, hostsim_lib,
+                        f"{d}/in.gfa", f"{d}/in.gaf", out], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out).read() == open(f"{d}/expected.aug.gfa").read()
+    assert int(open(out + ".rej").read()) == json.load(open(f"{d}/expected.json"))["rejected"]
+
+
+def test_gaf_split_covers_file_once():
+    from pantas_amd._lib import check, lib
+    gaf = os.path.join(GOLDEN, "synth_a", "in.gaf")
+    size = os.path.getsize(gaf)
+    text = open(gaf, "rb").read()
+    for world in (1, 2, 3, 7, 64):
+        pos, lines = 0, 0
+        for r in range(world):
+            b, e, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            check(lib.pantas_gaf_split(gaf.encode(), r, world, C.byref(b), C.byref(e), C.byref(n)))
+            assert b.value == pos and e.value >= b.value
+            assert b.value == 0 or text[b.value - 1:b.value] == b"\n"
+            assert n.value == lines
+            lines += text[b.value:e.value].count(b"\n")
+            pos = e.value
+        assert pos == size

@@ -95,3 +95,19 @@ def test_relaunch_is_linear():
     two = g.read_counters()
     for a, c in zip(one, two):
         assert (2 * a.astype("int64") == c.astype("int64")).all()
+
+
+def test_sharded_driver_nccl_single_rank(tmp_path):
+    """pantas_amd.distributed with the real library and the RCCL backend (one rank: the only GPU here).
+    Exercises the zero-copy tensor view of the counters, the collectives and the rank-0 writer."""
+    d = os.path.join(GOLDEN, "synth_b")
+    out = tmp_path / "out.gfa"
+    port = 29600 + os.getpid() % 1000
+    with open(out, "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pantas_amd.distributed",
+                            f"{d}/in.gaf", f"{d}/in.gfa"], stdout=f, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                           timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out).read() == open(f"{d}/expected.aug.gfa").read()
+    assert f"Rejected alignments: {json.load(open(f'{d}/expected.json'))['rejected']}" in r.stderr

@@ -1,0 +1,17 @@
+#!/bin/bash
+# PMC passes over the bench (run on the GPU box): tools/pmc.sh <tag> <scale> [env assignments...]
+tag=$1; scale=$2; shift 2
+export TMPDIR=/tmp
+for e in "$@"; do export "$e"; done
+run() { # name counters...
+  name=$1; shift
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}/$name -- python3 bench.py --scale $scale --steps 4 --warmup 1 --no-cpu --no-call > gpurun_out/pmc_${tag}/$name.log 2>&1
+}
+mkdir -p gpurun_out/pmc_${tag}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+run fetch FETCH_SIZE GRBM_GUI_ACTIVE
+run write WRITE_SIZE TCC_EA0_ATOMIC_sum
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+python3 tools/pmc_summary.py gpurun_out/pmc_${tag} > gpurun_out/pmc_${tag}/summary.txt
+cat gpurun_out/pmc_${tag}/summary.txt
