@@ -127,6 +127,11 @@ def main(argv=None) -> int:
     gaf, gfa = argv[0], argv[1]
     thr = int(argv[2]) if len(argv) > 2 else 20
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout is the data channel (the augmented GFA): keep a private handle on it and point fd 1 at
+    # stderr, because RCCL prints a version banner to stdout when the communicator comes up
+    sys.stdout.flush()
+    data_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local)
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if dist.get_rank() == 0:
@@ -135,8 +140,9 @@ def main(argv=None) -> int:
     if dist.get_rank() == 0:
         print("Augmentation by GAF alignments", file=sys.stderr)
     sys.stdout.flush()
-    tot = augment_sharded(be, gaf, thr, sys.stdout.fileno() if dist.get_rank() == 0 else -1, dist,
+    tot = augment_sharded(be, gaf, thr, data_fd if dist.get_rank() == 0 else -1, dist,
                           torch.device("cuda", local))
+    os.close(data_fd)
     if dist.get_rank() == 0:
         print(f"Rejected alignments: {tot['rejected']}", file=sys.stderr)
         print("Annotating GFA", file=sys.stderr)
