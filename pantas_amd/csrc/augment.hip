@@ -60,7 +60,9 @@ struct BatchView {
   const uint32_t* nodes;
   const uint32_t* ops;
   const uint32_t* del_idx;    // records holding a '-' op
-  uint32_t n, n_del;
+  const uint32_t* chunk_lo;   // [n_chunks + 1] locus chunks of the bucketed records
+  const uint32_t* chunk_base; // [n_chunks]
+  uint32_t n, n_del, n_chunks;
 };
 
 __device__ __forceinline__ uint32_t mix64(uint64_t k) {
@@ -221,6 +223,182 @@ __global__ __launch_bounds__(THREADS) void augment_main_lds_kernel(GraphView g, 
   }
 }
 
+// ---- group-walk main kernel -------------------------------------------------------------------------
+// Eight lanes walk one record: lane l of a group owns path node 8t + l of tile t, so the node_len
+// gathers, the CSR row scans and the counter updates of a record are issued side by side instead of
+// one after the other.  Node budgets are laid over the cs ops with a prefix sum (width-8 __shfl_up):
+// node j covers [P_j, P_j + room_j) of "op space", its pieces are the intersections with the op
+// intervals -- the same pieces the sequential loop (:209-255) produces.  Which nodes are kept, their
+// rank among the kept nodes and their predecessor come from a ballot over the group.  The last kept
+// node of a tile is held back (it may be the last kept node of the read, which the IL/OL rules ask
+// about) until the next tile shows a kept node or the record ends.
+//
+// One workgroup takes one locus chunk (gaf.cpp): the counters of the W nodes from the chunk's base and
+// of their out-links live in LDS as plain arrays (one ds_add_u32 per increment, no return value, so
+// nothing waits on it); anything outside goes to memory with a no-return global atomic.  The arrays
+// are flushed with one global atomic per touched counter.
+template <uint32_t W, uint32_t SMAX>
+struct WindowSink {
+  const GraphView& g;
+  uint32_t* cnt;        // LDS: [NC W | IL0 W | OLL W | RC SMAX]
+  uint32_t base, slot_base;
+  __device__ __forceinline__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
+  __device__ __forceinline__ void nc(uint32_t n) const {
+    const uint32_t d = n - base;
+    if (d < W) atomicAdd(&cnt[d], 1u); else atomicAdd(&g.nc[n], 1u);
+  }
+  __device__ __forceinline__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
+    const uint32_t d = n - base;
+    if (d < W) atomicAdd(&cnt[(side == SIDE_IL ? W : 2u * W) + d], times);
+    else atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
+    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+  }
+  __device__ __forceinline__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
+  __device__ __forceinline__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
+    const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
+    for (uint32_t s = lo; s < hi; ++s) {
+      if (g.col[s] == b) {
+        const uint32_t d = s - slot_base;
+        if (d < SMAX) atomicAdd(&cnt[3u * W + d], 1u); else atomicAdd(&g.rc[s], 1u);
+        return;
+      }
+    }
+    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
+  }
+};
+
+template <uint32_t THREADS, uint32_t W, uint32_t SMAX>
+__global__ __launch_bounds__(THREADS) void augment_main_grp_kernel(GraphView g, BatchView b, uint32_t V, uint64_t A) {
+  constexpr uint32_t G = 8;                        // lanes per record
+  constexpr uint32_t GROUPS = THREADS / G;
+  constexpr uint32_t NCNT = 3u * W + SMAX;
+  __shared__ uint32_t cnt[NCNT];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t gl = lane & (G - 1);              // lane within the group
+  const uint32_t gbase = lane & ~(G - 1);          // first lane of the group within the wave
+  const uint32_t my_group = threadIdx.x / G;
+  for (uint32_t c = blockIdx.x; c < b.n_chunks; c += gridDim.x) {
+    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) cnt[i] = 0u;
+    const uint32_t base = b.chunk_base[c];
+    const uint32_t slot_base = g.row_ptr[base];
+    const uint32_t rec_lo = b.chunk_lo[c], rec_hi = b.chunk_lo[c + 1];
+    __syncthreads();
+    WindowSink<W, SMAX> sink{g, cnt, base, slot_base};
+    for (uint32_t r0 = rec_lo; r0 < rec_hi; r0 += GROUPS) {
+      const uint32_t rec = r0 + my_group;
+      const bool valid = rec < rec_hi;
+      LineHdr h{0, 0, 0, 0};
+      uint32_t n0 = 0, k = 0, o0 = 0, nops = 0;
+      if (valid) {
+        h = b.hdr[rec];
+        n0 = b.node_off[rec];
+        k = b.node_off[rec + 1] - n0;
+        o0 = b.op_off[rec];
+        nops = b.op_off[rec + 1] - o0;
+      }
+      const bool slow = (h.flags & LINE_SLOW) != 0;
+      const bool fast = valid && !slow;
+      const bool rev = (h.flags & LINE_REV) != 0;
+      // total op length of the record (every lane: the ops are a few words of one cache line)
+      uint64_t T = 0;
+      if (fast) for (uint32_t j = 0; j < nops; ++j) T += b.ops[o0 + j] >> 3;
+      uint64_t carry = 0;          // op-space position where the next tile starts
+      uint32_t kept_before = 0;    // kept nodes of earlier tiles (the held-back one included)
+      bool pend_valid = false;
+      KeptNode pend{};
+      const uint32_t my_tiles = fast ? (k + G - 1) / G : 0u;
+      for (uint32_t t = 0; __any(t < my_tiles); ++t) {
+        const uint32_t i = t * G + gl;
+        const bool has = fast && i < k;
+        const uint32_t node = has ? b.nodes[n0 + i] : 0u;
+        const uint32_t word = has ? g.word[node] : 0u;
+        int64_t room = int64_t(word & LEN_MASK);
+        if (i == 0) room -= h.start;
+        if (i == k - 1) room = room - h.tail + 1;
+        const uint32_t rp = (has && room > 0) ? uint32_t(room) : 0u;
+        // exclusive prefix of the budgets within the group
+        uint32_t x = rp;
+#pragma unroll
+        for (uint32_t d = 1; d < G; d <<= 1) {
+          const uint32_t y = __shfl_up(x, d, G);
+          if (gl >= d) x += y;
+        }
+        const uint64_t P = carry + (x - rp);
+        carry += __shfl(x, int(gbase + G - 1), 64);
+        PieceAcc acc;
+        acc.begin(node, word);
+        if (rp) {
+          if (P >= T) {
+            atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(WALK_OPS_EXHAUSTED));
+          } else {
+            const uint64_t end = min(P + rp, T);
+            uint64_t O = 0;
+            for (uint32_t j = 0; j < nops; ++j) {
+              const uint32_t w = b.ops[o0 + j];
+              const uint64_t e2 = min(O + (w >> 3), end);
+              const uint64_t a2 = max(O, P);
+              if (e2 > a2) acc.add(w & 7u, uint32_t(e2 - a2));
+              O += w >> 3;
+              if (O >= end) break;
+            }
+          }
+        }
+        const bool kept = acc.kept();
+        const uint32_t gmask = uint32_t(__ballot(kept) >> gbase) & 0xFFu;
+        const uint32_t below = gmask & ((1u << gl) - 1u);
+        const uint32_t above = gmask >> (gl + 1u);
+        const uint32_t my_kidx = kept_before + __popc(below);
+        const uint32_t prev_lane = below ? (31u - uint32_t(__clz(int(below)))) : 0u;
+        const uint32_t prev_in_tile = uint32_t(__shfl(int(node), int(gbase + prev_lane), 64));
+        if (kept) {
+          // predecessor among the kept nodes: in this tile, or the one held back from earlier tiles
+          const bool has_prev = below != 0u || pend_valid;
+          const uint32_t prev = below ? prev_in_tile : pend.node;
+          if (below == 0u && pend_valid) flush_kept(pend, kept_before - 1u, false, h, sink);   // the held-back node is not the last
+          if (above != 0u) flush_kept(acc.kn, my_kidx, false, h, sink);                       // not the last of its tile
+          if (has_prev) {
+            const uint64_t ord = event_order(h.line_id, my_kidx - 1u, 0);
+            if (rev) sink.edge(node, prev, ord); else sink.edge(prev, node, ord);
+          }
+        }
+        if (gmask) {
+          // the last kept node of this tile becomes the held-back one (every lane of the group keeps a copy)
+          const int src = int(gbase + 31u - uint32_t(__clz(int(gmask))));
+          pend.node = uint32_t(__shfl(int(acc.kn.node), src, 64));
+          pend.word = uint32_t(__shfl(int(acc.kn.word), src, 64));
+          pend.entries = uint32_t(__shfl(int(acc.kn.entries), src, 64));
+          pend.first_op = uint32_t(__shfl(int(acc.kn.first_op), src, 64));
+          pend.first_len = uint32_t(__shfl(int(acc.kn.first_len), src, 64));
+          pend.last_op = uint32_t(__shfl(int(acc.kn.last_op), src, 64));
+          pend.last_len = uint32_t(__shfl(int(acc.kn.last_len), src, 64));
+          pend.plain = uint32_t(__shfl(int(acc.kn.plain), src, 64));
+          pend_valid = true;
+          kept_before += __popc(gmask);
+        }
+      }
+      if (pend_valid && gl == 0u) flush_kept(pend, kept_before - 1u, true, h, sink);
+      if (valid && slow && gl == 0u) {
+        // zero-length or '~' ops: the scalar walk keeps the reference's corner cases in one place
+        const int st = walk_line(h, b.nodes + n0, k, b.ops + o0, nops, sink);
+        if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+      }
+    }
+    __syncthreads();
+    // flush: one global atomic per touched counter
+    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) {
+      const uint32_t v = cnt[i];
+      if (!v) continue;
+      if (i < 3u * W) {
+        const uint32_t which = i / W, d = i - which * W;
+        atomicAdd(&g.nc[size_t(which) * V + base + d], v);     // NC, IL0, OLL are V apart in one allocation
+      } else {
+        atomicAdd(&g.rc[slot_base + (i - 3u * W)], v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void clear_flags_kernel(uint32_t* word, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) word[i] &= LEN_MASK;
 }
@@ -280,7 +458,8 @@ struct DeviceGraph {
 struct DeviceBatch {
   LineHdr* hdr = nullptr;
   uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
-  uint32_t n = 0, n_del = 0;
+  uint32_t *chunk_lo = nullptr, *chunk_base = nullptr;
+  uint32_t n = 0, n_del = 0, n_chunks = 0;
   uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
   std::vector<uint32_t> first_line_ids;   // unused placeholder for error reports
 };
@@ -299,7 +478,8 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
 
 void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   if (!b) return;
-  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx})
+  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx,
+                  (void*)b->chunk_lo, (void*)b->chunk_base})
     if (p) (void)hipFree(p);
   delete b;
 }
@@ -418,6 +598,12 @@ DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
   p->nodes = to_device(b.nodes, d.stream);
   p->ops = to_device(b.ops, d.stream);
   p->del_idx = to_device(del, d.stream);
+  if (b.chunk_lo.size() == b.chunk_base.size() + 1 && !b.chunk_base.empty()) {
+    if (b.chunk_lo.back() != b.size()) throw Error("InternalError", "chunk table does not cover the batch");
+    p->n_chunks = uint32_t(b.chunk_base.size());
+    p->chunk_lo = to_device(b.chunk_lo, d.stream);
+    p->chunk_base = to_device(b.chunk_base, d.stream);
+  }
   HIP_OK(hipStreamSynchronize(d.stream));
   return p;
 }
@@ -433,7 +619,8 @@ uint64_t batch_alg_bytes(const DeviceBatch& db) {
 static BatchView batch_view(const DeviceBatch& b) {
   BatchView v{};
   v.hdr = b.hdr; v.node_off = b.node_off; v.op_off = b.op_off; v.nodes = b.nodes; v.ops = b.ops; v.del_idx = b.del_idx;
-  v.n = b.n; v.n_del = b.n_del;
+  v.chunk_lo = b.chunk_lo; v.chunk_base = b.chunk_base;
+  v.n = b.n; v.n_del = b.n_del; v.n_chunks = b.n_chunks;
   return v;
 }
 
@@ -479,9 +666,15 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   if (b.n) {
-    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 3;
+    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 4;
     const bool keys_fit = 3ull * d.V + d.A < 0xFFFFFFFFull;
-    if (variant == 0 || !keys_fit) {
+    if (variant >= 4 && b.n_chunks) {
+      const uint32_t blocks = std::min<uint32_t>(b.n_chunks, 1u << 20);
+      if (variant == 5)
+        hipLaunchKernelGGL((augment_main_grp_kernel<256, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(256), 0, d.stream, g, bv, d.V, d.A);
+      else
+        hipLaunchKernelGGL((augment_main_grp_kernel<512, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V, d.A);
+    } else if (variant == 0 || !keys_fit) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else if (variant == 2) {

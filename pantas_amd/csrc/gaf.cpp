@@ -175,7 +175,10 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
         fail("Unsupported", this_line, "start / end offsets beyond 32 bits");
       uint32_t flags = rev ? LINE_REV : 0u;
       bool has_del = false;
-      for (size_t i = ops_before; i < out.ops.size(); ++i) has_del |= (out.ops[i] & 7u) == OP_MINUS;
+      for (size_t i = ops_before; i < out.ops.size(); ++i) {
+        has_del |= (out.ops[i] & 7u) == OP_MINUS;
+        if ((out.ops[i] >> 3) == 0 || (out.ops[i] & 7u) == OP_TILDE) flags |= LINE_SLOW;
+      }
       if (has_del) {
         flags |= LINE_HAS_DEL;
         ++out.del_lines;
@@ -302,12 +305,21 @@ void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, un
 
 void bucket_by_locus(GafBatch& b, unsigned threads) {
   const size_t n = b.size();
-  if (n < 2) return;
+  if (n < 2) {
+    b.chunk_lo.assign(1, 0u);
+    b.chunk_base.clear();
+    if (n == 1) {
+      b.chunk_lo.push_back(1u);
+      b.chunk_base.push_back(b.node_off[1] > b.node_off[0] ? std::min(b.nodes[b.node_off[0]], b.nodes[b.node_off[1] - 1]) : 0u);
+    }
+    return;
+  }
   if (threads == 0) threads = hw_threads();
   std::vector<uint32_t> key(n), idx(n);
   parallel_chunks(n, n < (1u << 16) ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) {
-      key[i] = b.node_off[i + 1] > b.node_off[i] ? b.nodes[b.node_off[i]] : 0u;
+      // lowest end of the path (reverse-strand reads list their nodes downwards)
+      key[i] = b.node_off[i + 1] > b.node_off[i] ? std::min(b.nodes[b.node_off[i]], b.nodes[b.node_off[i + 1] - 1]) : 0u;
       idx[i] = uint32_t(i);
     }
   });
@@ -331,6 +343,19 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
       if (no) memcpy(&ops[op_off[i]], &b.ops[b.op_off[s]], size_t(no) * 4);
     }
   });
+  // chunk table over the sorted keys
+  b.chunk_lo.clear();
+  b.chunk_base.clear();
+  size_t i = 0;
+  while (i < n) {
+    const uint32_t base = key[i];
+    size_t j = i + 1;
+    while (j < n && j - i < CHUNK_MAX_RECORDS && key[j] - base < CHUNK_KEY_SPAN) ++j;
+    b.chunk_lo.push_back(uint32_t(i));
+    b.chunk_base.push_back(base);
+    i = j;
+  }
+  b.chunk_lo.push_back(uint32_t(n));
   b.hdr.swap(hdr);
   b.node_off.swap(node_off);
   b.op_off.swap(op_off);

@@ -39,6 +39,7 @@ constexpr uint32_t FLAG_OL = 1u << 31;
 
 constexpr uint32_t LINE_REV = 1u;       // path written with '<'
 constexpr uint32_t LINE_HAS_DEL = 2u;   // cs string holds a '-' op
+constexpr uint32_t LINE_SLOW = 4u;      // cs holds a zero-length or '~' op: walked by the scalar code only
 
 struct LineHdr {
   int32_t start;     // start position on the first node (after the 2-op clipping rule)
@@ -63,6 +64,45 @@ struct KeptNode {
   uint32_t entries;    // compacted list length
   uint32_t first_op, first_len, last_op, last_len;
   uint32_t plain;      // entries whose op is neither '-' nor '*'
+};
+
+// Compaction of one node's op list, one piece at a time (:63-94), and the lone '+'/'-' rule (:101-102).
+struct PieceAcc {
+  KeptNode kn;
+  uint32_t pieces;
+  uint32_t piece0_op;
+  PANTAS_HD void begin(uint32_t node, uint32_t word) {
+    kn = KeptNode{node, word, 0, 0, 0, 0, 0, 0};
+    pieces = 0;
+    piece0_op = 0;
+  }
+  PANTAS_HD void add(uint32_t op, uint32_t take) {
+    if (pieces == 0) {
+      piece0_op = op;
+      if (op != OP_STAR) {
+        kn.entries = 1;
+        kn.first_op = kn.last_op = op;
+        kn.first_len = kn.last_len = take;
+        kn.plain = (op != OP_MINUS) ? 1u : 0u;
+      }
+    } else if (kn.entries == 0) {
+      kn.entries = 1;
+      kn.first_op = kn.last_op = op;
+      kn.first_len = kn.last_len = take + 1;
+      kn.plain = (op != OP_MINUS && op != OP_STAR) ? 1u : 0u;
+    } else if (op == kn.last_op || op == OP_STAR) {
+      kn.last_len += take;
+      if (kn.entries == 1) kn.first_len = kn.last_len;
+    } else {
+      ++kn.entries;
+      kn.last_op = op;
+      kn.last_len = take;
+      if (op != OP_MINUS) ++kn.plain;   // op cannot be '*' here
+    }
+    ++pieces;
+  }
+  // touched by the read and not a lone insertion / deletion
+  PANTAS_HD bool kept() const { return pieces != 0 && !(pieces == 1 && (piece0_op == OP_PLUS || piece0_op == OP_MINUS)); }
 };
 
 // Sink concept:
@@ -114,9 +154,8 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
     int64_t room = int64_t(word & LEN_MASK);
     if (i == 0) room -= h.start;
     if (i == n_nodes - 1) room = room - h.tail + 1;
-    KeptNode kn{node, word, 0, 0, 0, 0, 0, 0};
-    uint32_t pieces = 0;
-    uint32_t piece0_op = 0;
+    PieceAcc acc;
+    acc.begin(node, word);
     while (room > 0) {
       if (!have) {
         if (oi >= n_ops) return WALK_OPS_EXHAUSTED;   // reference: IndexError at :227
@@ -139,34 +178,11 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
         have = false;
         ++oi;
       }
-      // ---- compaction of this node's op list, one piece at a time (:63-94)
-      if (pieces == 0) {
-        piece0_op = op;
-        if (op != OP_STAR) {
-          kn.entries = 1;
-          kn.first_op = kn.last_op = op;
-          kn.first_len = kn.last_len = take;
-          kn.plain = (op != OP_MINUS) ? 1u : 0u;
-        }
-      } else if (kn.entries == 0) {
-        kn.entries = 1;
-        kn.first_op = kn.last_op = op;
-        kn.first_len = kn.last_len = take + 1;
-        kn.plain = (op != OP_MINUS && op != OP_STAR) ? 1u : 0u;
-      } else if (op == kn.last_op || op == OP_STAR) {
-        kn.last_len += take;
-        if (kn.entries == 1) kn.first_len = kn.last_len;
-      } else {
-        ++kn.entries;
-        kn.last_op = op;
-        kn.last_len = take;
-        if (op != OP_MINUS) ++kn.plain;   // op cannot be '*' here
-      }
-      ++pieces;
+      acc.add(op, take);
       if (!have && oi >= n_ops) break;                // ops used up: this node is closed (:252-255)
     }
-    if (pieces == 0) continue;                                               // no room: node not touched
-    if (pieces == 1 && (piece0_op == OP_PLUS || piece0_op == OP_MINUS)) continue;  // :101-102
+    if (!acc.kept()) continue;                        // no room, or a lone '+'/'-' (:101-102)
+    const KeptNode& kn = acc.kn;
     if (pending) {
       flush_kept(pend, kept - 1, false, h, sink);
       if (rev) sink.edge(node, pend.node, event_order(h.line_id, kept - 1, 0));
