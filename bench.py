@@ -204,7 +204,9 @@ def main():
                                    f"({bs.records} walked, {bs.path_nodes / max(1, bs.records):.2f} nodes/line, "
                                    f"{bs.cs_ops / max(1, bs.records):.2f} cs ops/line), gene expression Zipf a={kw.get('zipf_a', 1.2)}",
                        "parallelism": f"read shards x{world}, graph replicated, one all-reduce per replicate"},
-            "kernel_ms": {"augment_main": avg_main, "augment_rare": sum(rare_ms) / len(rare_ms)},
+            "kernel_ms": {"augment_main": avg_main, "augment_rare": sum(rare_ms) / len(rare_ms),
+                          "augment_main_min": min(main_ms), "augment_main_max": max(main_ms),
+                          "augment_main_all": [round(x, 3) for x in main_ms]},
             "allreduce_ms": allreduce_ms,
             "records_per_s_kernel_only": bs.records / (avg_main * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

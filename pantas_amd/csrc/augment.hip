@@ -51,6 +51,7 @@ struct GraphView {
   uint32_t* rc;               // [A]
   TableView hist, novel;
   unsigned long long* status; // min over failing lines of (line_id << 8 | code)
+  uint32_t ablate;            // timing experiments only (PANTAS_ABLATE): 1 no flagged-key order, 2 no novel insert, 4 no link lookup, 8 no counter updates
 };
 
 struct BatchView {
@@ -165,6 +166,7 @@ struct LdsSink {
   uint32_t* vals;
   uint32_t V;
   __device__ __forceinline__ void bump(uint32_t key, uint32_t times) const {
+    if (g.ablate & 8u) return;
     constexpr uint32_t CAP = 1u << LOG_CAP;
     uint32_t h = (key * 2654435761u) >> (32 - LOG_CAP);
 #pragma unroll 1
@@ -183,14 +185,16 @@ struct LdsSink {
   __device__ void nc(uint32_t n) const { bump(n, 1u); }
   __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
     bump((side == SIDE_IL ? V : 2u * V) + n, times);
-    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+    if (!(g.ablate & 1u) && (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL))) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
   }
   __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
   __device__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
+    if (g.ablate & 4u) return;
     const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
     for (uint32_t s = lo; s < hi; ++s) {
       if (g.col[s] == b) { bump(3u * V + s, 1u); return; }
     }
+    if (g.ablate & 2u) return;
     table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
   }
 };
@@ -244,25 +248,31 @@ struct WindowSink {
   uint32_t base, slot_base;
   __device__ __forceinline__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
   __device__ __forceinline__ void nc(uint32_t n) const {
+    if (g.ablate & 8u) return;
     const uint32_t d = n - base;
     if (d < W) atomicAdd(&cnt[d], 1u); else atomicAdd(&g.nc[n], 1u);
   }
   __device__ __forceinline__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
     const uint32_t d = n - base;
-    if (d < W) atomicAdd(&cnt[(side == SIDE_IL ? W : 2u * W) + d], times);
-    else atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
-    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+    if (!(g.ablate & 8u)) {
+      if (d < W) atomicAdd(&cnt[(side == SIDE_IL ? W : 2u * W) + d], times);
+      else atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
+    }
+    if (!(g.ablate & 1u) && (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL))) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
   }
   __device__ __forceinline__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
   __device__ __forceinline__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
+    if (g.ablate & 4u) return;
     const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
     for (uint32_t s = lo; s < hi; ++s) {
       if (g.col[s] == b) {
+        if (g.ablate & 8u) return;
         const uint32_t d = s - slot_base;
         if (d < SMAX) atomicAdd(&cnt[3u * W + d], 1u); else atomicAdd(&g.rc[s], 1u);
         return;
       }
     }
+    if (g.ablate & 2u) return;
     table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
   }
 };
@@ -399,6 +409,238 @@ __global__ __launch_bounds__(THREADS) void augment_main_grp_kernel(GraphView g, 
   }
 }
 
+// ---- main kernel, third form ------------------------------------------------------------------------
+// Thread per record over fixed blocks of CHUNK bucketed records, workgroup-private aggregation in LDS:
+//   node table   key = node            -> {NC, IL[0], OL[len]} increments (ONE probe per kept node)
+//   link table   key = adjacency slot  -> RC increments
+//   order table  key = node<<1 | side  -> min first-seen order of the common key on flagged nodes
+// flushed as one global atomic per touched counter (one table update per flagged key) per chunk.
+// Records whose cs holds only ':' and a few '*' ops (LINE_SIMPLE; the tokeniser puts them first in every
+// block of 2048) take a short walk: such a node has either exactly one compacted ':' entry or, when every
+// base it covers is a mismatch, none -- so no op list has to be built.  Both walks fetch the node's
+// length word and its CSR row bounds together when the node is first touched; only the col[] scan of the
+// link lookup depends on an earlier load.
+template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F>
+struct AggSink {
+  static constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CF = 1u << LOG_F;
+  const GraphView& g;
+  uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN]
+  uint32_t* skey; uint32_t* scnt;
+  uint32_t* fkey; unsigned long long* fmin;
+
+  template <uint32_t LOG>
+  static __device__ __forceinline__ uint32_t probe(uint32_t* keys, uint32_t key) {
+    constexpr uint32_t CAP = 1u << LOG;
+    uint32_t h = (key * 2654435761u) >> (32 - LOG);
+#pragma unroll 1
+    for (uint32_t p = 0; p < 10; ++p) {
+      uint32_t cur = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
+      if (cur == LDS_EMPTY) {
+        cur = atomicCAS(&keys[h], LDS_EMPTY, key);
+        if (cur == LDS_EMPTY) cur = key;
+      }
+      if (cur == key) return h;
+      h = (h + 1) & (CAP - 1);
+    }
+    return LDS_EMPTY;
+  }
+  __device__ __forceinline__ void bump_node(uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol) const {
+    if (g.ablate & 8u) return;
+    const uint32_t h = probe<LOG_N>(nkey, n);
+    if (h != LDS_EMPTY) {
+      if (a_nc) atomicAdd(&ncnt[h], a_nc);
+      if (a_il) atomicAdd(&ncnt[CN + h], a_il);
+      if (a_ol) atomicAdd(&ncnt[2u * CN + h], a_ol);
+    } else {
+      if (a_nc) atomicAdd(&g.nc[n], a_nc);
+      if (a_il) atomicAdd(&g.il0[n], a_il);
+      if (a_ol) atomicAdd(&g.oll[n], a_ol);
+    }
+  }
+  __device__ __forceinline__ void bump_slot(uint32_t s) const {
+    if (g.ablate & 8u) return;
+    const uint32_t h = probe<LOG_S>(skey, s);
+    if (h != LDS_EMPTY) atomicAdd(&scnt[h], 1u); else atomicAdd(&g.rc[s], 1u);
+  }
+  __device__ __forceinline__ void order_min(uint32_t n, uint32_t side, uint64_t order) const {
+    if (g.ablate & 1u) return;
+    const uint32_t h = probe<LOG_F>(fkey, (n << 1) | side);
+    if (h != LDS_EMPTY) {
+      if (order < __atomic_load_n(&fmin[h], __ATOMIC_RELAXED)) atomicMin(&fmin[h], static_cast<unsigned long long>(order));
+    } else {
+      table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+    }
+  }
+  // link (a -> b) given a's CSR row bounds
+  __device__ __forceinline__ void link(uint32_t a, uint32_t lo, uint32_t hi, uint32_t b, uint64_t order) const {
+    if (g.ablate & 4u) return;
+    for (uint32_t s = lo; s < hi; ++s) {
+      if (g.col[s] == b) { bump_slot(s); return; }
+    }
+    if (g.ablate & 2u) return;
+    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
+  }
+  // ---- sink interface of walk_line / flush_kept (records that need the general walk)
+  __device__ __forceinline__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
+  __device__ __forceinline__ void nc(uint32_t n) const { bump_node(n, 1u, 0u, 0u); }
+  __device__ __forceinline__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
+    bump_node(n, 0u, side == SIDE_IL ? times : 0u, side == SIDE_OL ? times : 0u);
+    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) order_min(n, side, order);
+  }
+  __device__ __forceinline__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
+  __device__ __forceinline__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
+    link(a, g.row_ptr[a], g.row_ptr[a + 1], b, order);
+  }
+};
+
+// A kept node of the short walk waiting to learn whether it is the read's last kept node.
+struct SimplePend {
+  uint32_t node, word, row_lo, row_hi;
+  bool has_colon;
+};
+
+template <class Sink>
+__device__ __forceinline__ void flush_simple(const SimplePend& p, uint32_t idx, bool is_last, const LineHdr& h, const Sink& sink) {
+  const bool rev = (h.flags & LINE_REV) != 0;
+  const bool is_first = idx == 0;
+  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351)
+  const bool enter = p.has_colon && !is_first, leave = p.has_colon && !is_last;
+  const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
+  const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
+  sink.bump_node(p.node, 1u, a_il, a_ol);
+  if (a_il && (p.word & FLAG_IL)) sink.order_min(p.node, SIDE_IL, event_order(h.line_id, idx, 1));
+  if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
+}
+
+// Short walk for LINE_SIMPLE records.  Equivalent to walk_line on them: a node with room r > 0 at op-space
+// position P < T gets pieces that are all ':' or '*'; they compact to one ':' entry (plain = 1) unless all of
+// them are '*', in which case the node is kept (NC) but has no IL/OL entry.
+template <class Sink>
+__device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
+                                           const uint32_t* ops, uint32_t nops, const Sink& sink) {
+  uint32_t T = 0, ns = 0;
+  uint32_t star[SIMPLE_MAX_STARS];
+#pragma unroll 1
+  for (uint32_t j = 0; j < nops; ++j) {
+    const uint32_t w = ops[j];
+    if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
+    T += w >> 3;
+  }
+  const bool rev = (h.flags & LINE_REV) != 0;
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  SimplePend pend{};
+#pragma unroll 1
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = nodes[i];
+    const uint32_t word = g.word[node];
+    const uint32_t row_lo = g.row_ptr[node], row_hi = g.row_ptr[node + 1];
+    int64_t room = int64_t(word & LEN_MASK);
+    if (i == 0) room -= h.start;
+    if (i == k - 1) room = room - h.tail + 1;
+    if (room <= 0) continue;
+    if (P >= T) return WALK_OPS_EXHAUSTED;
+    const uint32_t le = uint32_t(min(room, int64_t(T - P)));
+    uint32_t stars_in = 0;
+    for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
+    if (pending) {
+      flush_simple(pend, kept - 1u, false, h, sink);
+      const uint64_t ord = event_order(h.line_id, kept - 1u, 0);
+      if (rev) sink.link(node, row_lo, row_hi, pend.node, ord);
+      else sink.link(pend.node, pend.row_lo, pend.row_hi, node, ord);
+    }
+    pend = SimplePend{node, word, row_lo, row_hi, stars_in < le};
+    pending = true;
+    ++kept;
+    P = (room >= int64_t(T - P)) ? T : P + uint32_t(room);
+  }
+  if (pending) flush_simple(pend, kept - 1u, true, h, sink);
+  return WALK_OK;
+}
+
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F>
+__global__ __launch_bounds__(THREADS) void augment_main_agg_kernel(GraphView g, BatchView b) {
+  using Sink = AggSink<LOG_N, LOG_S, LOG_F>;
+  constexpr uint32_t CN = Sink::CN, CS = Sink::CS, CF = Sink::CF;
+  __shared__ unsigned long long fmin[CF];
+  __shared__ uint32_t nkey[CN];
+  __shared__ uint32_t ncnt[3 * CN];
+  __shared__ uint32_t skey[CS];
+  __shared__ uint32_t scnt[CS];
+  __shared__ uint32_t fkey[CF];
+  const uint32_t n_chunks = (b.n + CHUNK - 1) / CHUNK;
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) { nkey[i] = LDS_EMPTY; ncnt[i] = 0u; ncnt[CN + i] = 0u; ncnt[2 * CN + i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; }
+    __syncthreads();
+    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin};
+    const uint32_t lo = c * CHUNK;
+    const uint32_t hi = min(b.n, lo + CHUNK);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+      const LineHdr h = b.hdr[i];
+      const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
+      const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
+      int st;
+      if ((h.flags & LINE_SIMPLE) && !(g.ablate & 16u)) st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+      else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+      if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
+      const uint32_t n = nkey[i];
+      if (n == LDS_EMPTY) continue;
+      const uint32_t a = ncnt[i], il = ncnt[CN + i], ol = ncnt[2 * CN + i];
+      if (a) atomicAdd(&g.nc[n], a);
+      if (il) atomicAdd(&g.il0[n], il);
+      if (ol) atomicAdd(&g.oll[n], ol);
+    }
+    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
+      const uint32_t s = skey[i];
+      if (s != LDS_EMPTY && scnt[i]) atomicAdd(&g.rc[s], scnt[i]);
+    }
+    for (uint32_t i = threadIdx.x; i < CF; i += THREADS) {
+      const uint32_t k = fkey[i];
+      if (k != LDS_EMPTY && fmin[i] != ~0ull) table_update(g.hist, hist_key(k >> 1, k & 1u, COMMON_POS), 0u, fmin[i]);
+    }
+    __syncthreads();
+  }
+}
+
+// thread-per-record walk over a locus chunk with the direct LDS counter windows
+template <uint32_t THREADS, uint32_t W, uint32_t SMAX>
+__global__ __launch_bounds__(THREADS) void augment_main_win_kernel(GraphView g, BatchView b, uint32_t V) {
+  constexpr uint32_t NCNT = 3u * W + SMAX;
+  __shared__ uint32_t cnt[NCNT];
+  for (uint32_t c = blockIdx.x; c < b.n_chunks; c += gridDim.x) {
+    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) cnt[i] = 0u;
+    const uint32_t base = b.chunk_base[c];
+    const uint32_t slot_base = g.row_ptr[base];
+    const uint32_t rec_lo = b.chunk_lo[c], rec_hi = b.chunk_lo[c + 1];
+    __syncthreads();
+    WindowSink<W, SMAX> sink{g, cnt, base, slot_base};
+    for (uint32_t i = rec_lo + threadIdx.x; i < rec_hi; i += THREADS) {
+      const LineHdr h = b.hdr[i];
+      const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
+      const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
+      const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+      if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) {
+      const uint32_t v = cnt[i];
+      if (!v) continue;
+      if (i < 3u * W) {
+        const uint32_t which = i / W, d = i - which * W;
+        atomicAdd(&g.nc[size_t(which) * V + base + d], v);
+      } else {
+        atomicAdd(&g.rc[slot_base + (i - 3u * W)], v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void clear_flags_kernel(uint32_t* word, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) word[i] &= LEN_MASK;
 }
@@ -451,6 +693,7 @@ struct DeviceGraph {
     g.nc = counters; g.il0 = counters + V; g.oll = counters + 2 * size_t(V); g.rc = counters + 3 * size_t(V);
     g.hist = hist.v; g.novel = novel.v;
     g.status = reinterpret_cast<unsigned long long*>(small);
+    g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;
     return g;
   }
 };
@@ -666,11 +909,32 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   if (b.n) {
-    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 4;
+    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 9;
     const bool keys_fit = 3ull * d.V + d.A < 0xFFFFFFFFull;
-    if (variant >= 4 && b.n_chunks) {
+    if (variant >= 8 && variant < 40) {
+#define PANTAS_AGG(ID, T, CH, LN, LS, LF) \
+      case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
+      switch (variant) {
+        PANTAS_AGG(8, 1024, 4096, 12, 12, 9)
+        PANTAS_AGG(10, 512, 4096, 11, 11, 8)
+        PANTAS_AGG(11, 256, 1024, 10, 10, 7)
+        PANTAS_AGG(12, 256, 2048, 10, 10, 7)
+        PANTAS_AGG(13, 512, 1024, 11, 11, 8)
+        PANTAS_AGG(14, 512, 2048, 10, 10, 7)
+        PANTAS_AGG(15, 256, 512, 9, 9, 7)
+        PANTAS_AGG(16, 256, 1024, 11, 11, 8)
+        PANTAS_AGG(17, 1024, 4096, 11, 11, 8)
+        default:
+        PANTAS_AGG(9, 512, 2048, 11, 11, 8)
+      }
+#undef PANTAS_AGG
+    } else if (variant >= 4 && b.n_chunks) {
       const uint32_t blocks = std::min<uint32_t>(b.n_chunks, 1u << 20);
-      if (variant == 5)
+      if (variant == 6)
+        hipLaunchKernelGGL((augment_main_win_kernel<512, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V);
+      else if (variant == 7)
+        hipLaunchKernelGGL((augment_main_win_kernel<1024, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(1024), 0, d.stream, g, bv, d.V);
+      else if (variant == 5)
         hipLaunchKernelGGL((augment_main_grp_kernel<256, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(256), 0, d.stream, g, bv, d.V, d.A);
       else
         hipLaunchKernelGGL((augment_main_grp_kernel<512, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V, d.A);
@@ -678,9 +942,9 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else if (variant == 2) {
-      constexpr uint32_t CH = 1024;
+      constexpr uint32_t CH = 8192;
       const uint32_t blocks = (b.n + CH - 1) / CH;
-      hipLaunchKernelGGL((augment_main_lds_kernel<256, 12, CH>), dim3(blocks), dim3(256), 0, d.stream, g, bv, d.V);
+      hipLaunchKernelGGL((augment_main_lds_kernel<1024, 14, CH>), dim3(blocks), dim3(1024), 0, d.stream, g, bv, d.V);
     } else if (variant == 1) {
       constexpr uint32_t CH = 2048;
       const uint32_t blocks = (b.n + CH - 1) / CH;

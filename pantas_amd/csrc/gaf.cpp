@@ -175,10 +175,17 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
         fail("Unsupported", this_line, "start / end offsets beyond 32 bits");
       uint32_t flags = rev ? LINE_REV : 0u;
       bool has_del = false;
+      bool simple = out.ops.size() > ops_before;
+      uint32_t stars = 0;
+      uint64_t total = 0;
       for (size_t i = ops_before; i < out.ops.size(); ++i) {
-        has_del |= (out.ops[i] & 7u) == OP_MINUS;
-        if ((out.ops[i] >> 3) == 0 || (out.ops[i] & 7u) == OP_TILDE) flags |= LINE_SLOW;
+        const uint32_t code = out.ops[i] & 7u;
+        has_del |= code == OP_MINUS;
+        if ((out.ops[i] >> 3) == 0 || code == OP_TILDE) flags |= LINE_SLOW;
+        if (code == OP_STAR) ++stars; else if (code != OP_COLON) simple = false;
+        total += out.ops[i] >> 3;
       }
+      if (simple && !(flags & LINE_SLOW) && stars <= SIMPLE_MAX_STARS && total < (1ull << 31)) flags |= LINE_SIMPLE;
       if (has_del) {
         flags |= LINE_HAS_DEL;
         ++out.del_lines;
@@ -324,6 +331,29 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
     }
   });
   radix_sort_pairs(key, idx, threads);
+  // inside every block of PARTITION_BLOCK sorted records, the records eligible for the short walk
+  // come first, so that a wave seldom holds both kinds
+  {
+    constexpr size_t PARTITION_BLOCK = 2048;
+    const size_t nb = (n + PARTITION_BLOCK - 1) / PARTITION_BLOCK;
+    parallel_chunks(nb, nb < 64 ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
+      std::vector<uint32_t> tmp;
+      for (size_t blk = lo; blk < hi; ++blk) {
+        const size_t a = blk * PARTITION_BLOCK, e = std::min(n, a + PARTITION_BLOCK);
+        tmp.clear();
+        size_t w = a;
+        for (size_t i = a; i < e; ++i) {
+          if (b.hdr[idx[i]].flags & LINE_SIMPLE) idx[w++] = idx[i]; else tmp.push_back(idx[i]);
+        }
+        for (uint32_t v : tmp) idx[w++] = v;
+      }
+    });
+    // keys no longer match idx order inside a block; the chunk table below only needs block-level order
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t s = idx[i];
+      key[i] = b.node_off[s + 1] > b.node_off[s] ? std::min(b.nodes[b.node_off[s]], b.nodes[b.node_off[s + 1] - 1]) : 0u;
+    }
+  }
   std::vector<LineHdr> hdr(n);
   std::vector<uint32_t> node_off(n + 1), op_off(n + 1), nodes(b.nodes.size()), ops(b.ops.size());
   // sizes, then exclusive offsets (sequential scan: 2 adds per record), then a parallel gather
@@ -348,11 +378,17 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
   b.chunk_base.clear();
   size_t i = 0;
   while (i < n) {
-    const uint32_t base = key[i];
+    uint32_t lo = key[i], hi = key[i];
     size_t j = i + 1;
-    while (j < n && j - i < CHUNK_MAX_RECORDS && key[j] - base < CHUNK_KEY_SPAN) ++j;
+    while (j < n && j - i < CHUNK_MAX_RECORDS) {
+      const uint32_t lo2 = std::min(lo, key[j]), hi2 = std::max(hi, key[j]);
+      if (hi2 - lo2 >= CHUNK_KEY_SPAN) break;
+      lo = lo2;
+      hi = hi2;
+      ++j;
+    }
     b.chunk_lo.push_back(uint32_t(i));
-    b.chunk_base.push_back(base);
+    b.chunk_base.push_back(lo);
     i = j;
   }
   b.chunk_lo.push_back(uint32_t(n));

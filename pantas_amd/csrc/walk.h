@@ -40,6 +40,8 @@ constexpr uint32_t FLAG_OL = 1u << 31;
 constexpr uint32_t LINE_REV = 1u;       // path written with '<'
 constexpr uint32_t LINE_HAS_DEL = 2u;   // cs string holds a '-' op
 constexpr uint32_t LINE_SLOW = 4u;      // cs holds a zero-length or '~' op: walked by the scalar code only
+constexpr uint32_t LINE_SIMPLE = 8u;    // cs holds only ':' and at most 4 '*' ops (no zero lengths): eligible for the short walk
+constexpr uint32_t SIMPLE_MAX_STARS = 4;
 
 struct LineHdr {
   int32_t start;     // start position on the first node (after the 2-op clipping rule)
