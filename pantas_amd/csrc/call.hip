@@ -89,6 +89,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* a, uint32_t*
 }
 
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t ARENA_SLOTS = 4096, ARENA_CAP = 16384;   // 256 MB of overflow frontiers per kernel
+
 struct DeviceCall {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -99,6 +101,8 @@ struct DeviceCall {
   uint32_t* d_novels = nullptr;
   uint32_t nJ = 0, nN = 0;
   unsigned long long* status = nullptr;
+  uint32_t* arena = nullptr;
+  uint32_t* arena_next = nullptr;
 };
 
 void DeviceCallDeleter::operator()(DeviceCall* d) const {
@@ -161,6 +165,8 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.tx_gene = up(*d, t.tx_gene);
   c.probe = up(*d, t.probe); c.probe_ok = up(*d, t.probe_ok);
   d->status = dalloc<unsigned long long>(*d, 1);
+  d->arena = dalloc<uint32_t>(*d, size_t(ARENA_SLOTS) * ARENA_CAP);
+  d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
   return d;
 }
@@ -182,6 +188,7 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
   HIP_OK(hipMemcpyAsync(d_slots, slots.data(), size_t(n) * 4, hipMemcpyHostToDevice, d.stream));
   if (jidx) HIP_OK(hipMemcpyAsync(d_jidx, jidx->data(), size_t(n) * 4, hipMemcpyHostToDevice, d.stream));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(n) + 255) / 256, 1u << 16));
+  HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
   HIP_OK(hipEventRecord(d.ev0, d.stream));
   hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, d.status);
   HIP_OK(hipGetLastError());
@@ -198,6 +205,7 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
     const uint32_t code = uint32_t(st & 0xFF);
     throw Error(call_error_kind(code), call_error_text(code));
   }
+  HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
   EventRec* d_recs = static_cast<EventRec*>(dev(size_t(totals[0]) * sizeof(EventRec)));
   uint32_t* d_side = static_cast<uint32_t*>(dev(size_t(totals[1]) * 4));
   hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, d_recs, d_side);
@@ -221,6 +229,7 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   HIP_OK(hipSetDevice(d.device));
   CallView c = d.view;
   c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
+  c.arena = d.arena; c.arena_next = d.arena_next; c.arena_slots = ARENA_SLOTS; c.arena_cap = ARENA_CAP;
   std::vector<uint32_t> ann, nov, around, around_j;
   pass_lists(g, t, o, ann, nov, around, around_j);
   HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));

@@ -80,7 +80,19 @@ struct CallView {
   const uint32_t* probe_ok;     // [nJ] bit 0: int(u) parses, bit 1: int(v) parses
   int32_t rca, isw, minintron;
   uint32_t events;
+  // overflow space of the intronic search: slices of arena_cap words claimed with a counter
+  uint32_t* arena;
+  uint32_t* arena_next;
+  uint32_t arena_slots, arena_cap;
 };
+
+PANTAS_HD uint32_t claim_slice(uint32_t* counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(counter, 1u);
+#else
+  return (*counter)++;
+#endif
+}
 
 // ---- small set helpers ------------------------------------------------------------------------
 PANTAS_HD bool sorted_has(const uint32_t* p, uint32_t n, uint32_t x) {
@@ -212,9 +224,11 @@ PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit
 // [:734-750, :787-803] level-bounded frontier search; pop() takes the node that comes first in
 // the GFA (rule R3).  dir 0: follow out-links from `start`, targets = {n : (anchor, n) junction};
 // dir 1: follow in-links, targets = {p : (p, anchor) junction}.
-constexpr uint32_t FRONTIER_CAP = 96;
+constexpr uint32_t FRONTIER_LOCAL = 24;
 PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t anchor, uint32_t dir, Fault& f) {
-  uint32_t vis[FRONTIER_CAP];
+  uint32_t local[FRONTIER_LOCAL];
+  uint32_t* vis = local;      // sorted set of node indices; moves to an arena slice when it outgrows `local`
+  uint32_t cap = FRONTIER_LOCAL;
   uint32_t n = 1;
   vis[0] = start;
   int32_t left = 1;
@@ -236,12 +250,24 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
     const uint32_t e = dir == 0 ? c.row_ptr[x + 1] : c.irow_ptr[x + 1];
     for (uint32_t s = b; s < e; ++s) {
       const uint32_t y = dir == 0 ? c.col[s] : c.icol[s];
-      uint32_t pos = 0;
-      while (pos < n && vis[pos] < y) ++pos;
-      if (pos < n && vis[pos] == y) continue;
-      if (n == FRONTIER_CAP) { f.raise(CE_FRONTIER); return CNONE; }
-      for (uint32_t i = n; i > pos; --i) vis[i] = vis[i - 1];
-      vis[pos] = y;
+      // binary search for the insertion point
+      uint32_t lo = 0, hi = n;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (vis[mid] < y) lo = mid + 1; else hi = mid;
+      }
+      if (lo < n && vis[lo] == y) continue;
+      if (n == cap) {
+        if (vis != local || c.arena == nullptr) { f.raise(CE_FRONTIER); return CNONE; }
+        const uint32_t slice = claim_slice(c.arena_next);
+        if (slice >= c.arena_slots) { f.raise(CE_FRONTIER); return CNONE; }
+        uint32_t* big = c.arena + size_t(slice) * c.arena_cap;
+        for (uint32_t i = 0; i < n; ++i) big[i] = vis[i];
+        vis = big;
+        cap = c.arena_cap;
+      }
+      for (uint32_t i = n; i > lo; --i) vis[i] = vis[i - 1];
+      vis[lo] = y;
       ++n;
     }
     if (left == 0) { ++level; left = int32_t(n); }

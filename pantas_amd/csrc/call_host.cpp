@@ -28,7 +28,7 @@ const char* call_error_text(uint32_t code) {
     case CE_VALUE_INT: return "invalid literal for int(): segment name of a junction end";
     case CE_VALUE_MAX: return "max() arg is an empty sequence (novel IR walk ran into a dead end)";
     case CE_HANG: return "intron walk does not terminate (the reference would loop forever)";
-    case CE_FRONTIER: return "intronic search frontier larger than the engine's bound";
+    case CE_FRONTIER: return "intronic search frontier beyond the engine's overflow arena (a node with tens of thousands of links near a novel junction)";
     default: return "unknown";
   }
 }
@@ -540,6 +540,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.tx_gene = t.tx_gene.data();
   c.probe = t.probe.data(); c.probe_ok = t.probe_ok.data();
   c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
+  c.arena = nullptr; c.arena_next = nullptr; c.arena_slots = 0; c.arena_cap = 0;
   return c;
 }
 

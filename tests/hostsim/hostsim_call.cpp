@@ -55,6 +55,9 @@ int main(int argc, char** argv) {
     CallTables t;
     build_call_tables(*g, pos[1], t, 3);
     CallView c = host_view(*g, t, o);
+    std::vector<uint32_t> arena(size_t(64) * 4096);
+    uint32_t arena_next = 0;
+    c.arena = arena.data(); c.arena_next = &arena_next; c.arena_slots = 64; c.arena_cap = 4096;
     std::vector<uint32_t> ann, nov, around, around_j;
     pass_lists(*g, t, o, ann, nov, around, around_j);
     std::vector<EventRec> recs;

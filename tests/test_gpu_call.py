@@ -122,3 +122,13 @@ def test_fused_equals_text_round_trip(tmp_path):
     want = call_oracle.call(pre + ".aug.gfa", pre + ".gtf", None, **flags)
     norm = call_oracle.normalise_row
     assert collections.Counter(map(norm, text.decode().splitlines()[1:])) == collections.Counter(map(norm, want))
+
+
+@pytest.mark.parametrize("fan", [10, 40, 300, 5000])
+def test_intronic_search_beyond_local_frontier(tmp_path, fan):
+    from hub_case import write_hub_case
+    pre = str(tmp_path / "hub")
+    write_hub_case(pre, fan)
+    flags = ["--novel", "--rca", "0"]
+    want = call_oracle.call(pre + ".gfa", pre + ".gtf", None, **_flags_to_opts(flags))
+    assert sorted(engine_call(pre + ".gfa", pre + ".gtf", flags)) == sorted(want)

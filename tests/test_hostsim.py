@@ -95,3 +95,17 @@ def test_sources_vs_oracle_exact(hostsim, tmp_path, seed, genes, lines, kw, flag
     ref = collections.Counter(call_oracle.normalise_row(x) for x in rows)
     assert len(rows) > 50
     assert mine == ref
+
+
+@pytest.mark.parametrize("fan,isw", [(10, 5), (40, 5), (300, 5), (40, 2)])
+def test_intronic_search_beyond_local_frontier(hostsim, tmp_path, fan, isw):
+    from hub_case import write_hub_case
+    pre = str(tmp_path / "hub")
+    write_hub_case(pre, fan)
+    flags = ["--novel", "--rca", "0", "--isw", str(isw)]
+    want = call_oracle.call(pre + ".gfa", pre + ".gtf", None, **_flags_to_opts(flags))
+    r = run([hostsim["call"], *flags, pre + ".gfa", pre + ".gtf"])
+    assert r.returncode == 0, r.stderr
+    assert sorted(r.stdout.splitlines()[1:]) == sorted(want)
+    if isw >= 3:
+        assert any(x.startswith("A3,novel") for x in want)      # the search reaches the acceptor through the fan
