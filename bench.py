@@ -174,16 +174,19 @@ def main():
         g.call_prepare_fused(text=syn.gtf, device=local_rank)
         t_prep = time.perf_counter() - t1
         fd = os.open(os.devnull, os.O_WRONLY)
+        # coverage has accumulated over every launch of the same batch: scale the read-count threshold with it,
+        # so that the events are those of `--rca 3` on one pass over the batch
+        rca = 3 * (args.steps + args.warmup)
         runs = []
         for _ in range(3):
             t1 = time.perf_counter()
-            cs = g.call(fd, -1, rca=3, novel=True)
+            cs = g.call(fd, -1, rca=rca, novel=True)
             runs.append((time.perf_counter() - t1, cs))
         os.close(fd)
         wall, cs = min(runs, key=lambda x: x[0])
         k_ms = cs.annotated_ms + cs.novel_ms + cs.around_ms
         call = {"events": cs.events, "junctions": cs.junctions, "novel_links": cs.novel_links,
-                "evaluated": cs.evaluated, "flags": "--rca 3 --novel",
+                "evaluated": cs.evaluated, "flags": f"--rca {rca} --novel (= --rca 3 per pass over the batch)",
                 "events_per_s": cs.events / wall, "wall_s": wall, "kernel_ms": k_ms,
                 "junction_evals_per_s_kernel": cs.evaluated / (k_ms * 1e-3) if k_ms else None,
                 "prepare_s": t_prep, "tag_parse_s": cs.parse_seconds, "render_s": cs.render_seconds}

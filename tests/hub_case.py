@@ -4,7 +4,7 @@ fans out over `fan` parallel alleles before the annotated acceptor."""
 
 
 def write_hub_case(prefix: str, fan: int = 40):
-    ids = iter(range(5000, 9000))
+    ids = iter(range(10000, 99999))
     e1a, e1b = next(ids), next(ids)          # exon 1
     w = next(ids)                            # intron node the novel link lands on
     alleles = [next(ids) for _ in range(fan)]
