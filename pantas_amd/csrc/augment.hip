@@ -424,9 +424,48 @@ template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F>
 struct AggSink {
   static constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CF = 1u << LOG_F;
   const GraphView& g;
-  uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN]
+  uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN | RC of the node's first out-slot CN]
   uint32_t* skey; uint32_t* scnt;
   uint32_t* fkey; unsigned long long* fmin;
+  unsigned long long* vkey; uint32_t* vcnt; unsigned long long* vmin;   // links absent from the graph (CF entries)
+
+  // link (a, b) that is not in the graph: aggregate in LDS, else straight to the global table
+  __device__ __forceinline__ void novel(uint32_t a, uint32_t b, uint64_t order) const {
+    if (g.ablate & 2u) return;
+    const unsigned long long key = (static_cast<unsigned long long>(a) << 32) | b;
+    uint32_t h = mix64(key) & (CF - 1);
+#pragma unroll 1
+    for (uint32_t p = 0; p < 8; ++p) {
+      unsigned long long cur = __atomic_load_n(&vkey[h], __ATOMIC_RELAXED);
+      if (cur == EMPTY_KEY) {
+        cur = atomicCAS(&vkey[h], EMPTY_KEY, key);
+        if (cur == EMPTY_KEY) cur = key;
+      }
+      if (cur == key) {
+        atomicAdd(&vcnt[h], 1u);
+        if (order < __atomic_load_n(&vmin[h], __ATOMIC_RELAXED)) atomicMin(&vmin[h], static_cast<unsigned long long>(order));
+        return;
+      }
+      h = (h + 1) & (CF - 1);
+    }
+    table_update(g.novel, key, 1u, order);
+  }
+  // link (a -> b): the target of a's first slot was fetched when a was first touched; ha = a's node-table
+  // slot if known.  A hit on the first slot (the usual n -> n+1 step) is counted in a's own entry.
+  __device__ __forceinline__ void link_pf(uint32_t a, uint32_t ha, uint32_t lo, uint32_t hi, uint32_t col0, uint32_t b, uint64_t order) const {
+    if (g.ablate & 4u) return;
+    if (lo < hi) {
+      if (col0 == b) {
+        if (g.ablate & 8u) return;
+        if (ha != LDS_EMPTY) atomicAdd(&ncnt[3u * CN + ha], 1u); else bump_slot(lo);
+        return;
+      }
+      for (uint32_t s = lo + 1; s < hi; ++s) {
+        if (g.col[s] == b) { bump_slot(s); return; }
+      }
+    }
+    novel(a, b, order);
+  }
 
   template <uint32_t LOG>
   static __device__ __forceinline__ uint32_t probe(uint32_t* keys, uint32_t key) {
@@ -444,8 +483,9 @@ struct AggSink {
     }
     return LDS_EMPTY;
   }
-  __device__ __forceinline__ void bump_node(uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol) const {
-    if (g.ablate & 8u) return;
+  // returns the node's table slot (LDS_EMPTY when the increments went to memory)
+  __device__ __forceinline__ uint32_t bump_node(uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol) const {
+    if (g.ablate & 8u) return LDS_EMPTY;
     const uint32_t h = probe<LOG_N>(nkey, n);
     if (h != LDS_EMPTY) {
       if (a_nc) atomicAdd(&ncnt[h], a_nc);
@@ -456,6 +496,7 @@ struct AggSink {
       if (a_il) atomicAdd(&g.il0[n], a_il);
       if (a_ol) atomicAdd(&g.oll[n], a_ol);
     }
+    return h;
   }
   __device__ __forceinline__ void bump_slot(uint32_t s) const {
     if (g.ablate & 8u) return;
@@ -477,8 +518,7 @@ struct AggSink {
     for (uint32_t s = lo; s < hi; ++s) {
       if (g.col[s] == b) { bump_slot(s); return; }
     }
-    if (g.ablate & 2u) return;
-    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
+    novel(a, b, order);
   }
   // ---- sink interface of walk_line / flush_kept (records that need the general walk)
   __device__ __forceinline__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
@@ -495,26 +535,30 @@ struct AggSink {
 
 // A kept node of the short walk waiting to learn whether it is the read's last kept node.
 struct SimplePend {
-  uint32_t node, word, row_lo, row_hi;
+  uint32_t node, word, row_lo, row_hi, col0;
   bool has_colon;
 };
 
 template <class Sink>
-__device__ __forceinline__ void flush_simple(const SimplePend& p, uint32_t idx, bool is_last, const LineHdr& h, const Sink& sink) {
+__device__ __forceinline__ uint32_t flush_simple(const SimplePend& p, uint32_t idx, bool is_last, const LineHdr& h, const Sink& sink) {
   const bool rev = (h.flags & LINE_REV) != 0;
   const bool is_first = idx == 0;
   // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351)
   const bool enter = p.has_colon && !is_first, leave = p.has_colon && !is_last;
   const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
   const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
-  sink.bump_node(p.node, 1u, a_il, a_ol);
+  const uint32_t slot = sink.bump_node(p.node, 1u, a_il, a_ol);
   if (a_il && (p.word & FLAG_IL)) sink.order_min(p.node, SIDE_IL, event_order(h.line_id, idx, 1));
   if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
+  return slot;
 }
 
 // Short walk for LINE_SIMPLE records.  Equivalent to walk_line on them: a node with room r > 0 at op-space
 // position P < T gets pieces that are all ':' or '*'; they compact to one ':' entry (plain = 1) unless all of
 // them are '*', in which case the node is kept (NC) but has no IL/OL entry.
+// The loads are software-pipelined: while node i is processed, the length word and CSR row bounds of node
+// i+1 and the first link target of node i are already in flight (the chain nodes[] -> word/row_ptr -> col[]
+// is what the kernel waits on).
 template <class Sink>
 __device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
                                            const uint32_t* ops, uint32_t nops, const Sink& sink) {
@@ -530,11 +574,21 @@ __device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h,
   uint32_t P = 0, kept = 0;
   bool pending = false;
   SimplePend pend{};
+  // stage 0 of the pipeline: node 0
+  uint32_t nx_node = nodes[0];
+  uint32_t nx_word = g.word[nx_node];
+  uint32_t nx_lo = g.row_ptr[nx_node], nx_hi = g.row_ptr[nx_node + 1];
 #pragma unroll 1
   for (uint32_t i = 0; i < k; ++i) {
-    const uint32_t node = nodes[i];
-    const uint32_t word = g.word[node];
-    const uint32_t row_lo = g.row_ptr[node], row_hi = g.row_ptr[node + 1];
+    const uint32_t node = nx_node, word = nx_word, row_lo = nx_lo, row_hi = nx_hi;
+    // first link target of this node (needed one iteration later on forward reads, now on reverse reads)
+    const uint32_t col0 = row_lo < row_hi ? g.col[row_lo] : 0u;
+    if (i + 1 < k) {
+      nx_node = nodes[i + 1];
+      nx_word = g.word[nx_node];
+      nx_lo = g.row_ptr[nx_node];
+      nx_hi = g.row_ptr[nx_node + 1];
+    }
     int64_t room = int64_t(word & LEN_MASK);
     if (i == 0) room -= h.start;
     if (i == k - 1) room = room - h.tail + 1;
@@ -544,12 +598,12 @@ __device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h,
     uint32_t stars_in = 0;
     for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
     if (pending) {
-      flush_simple(pend, kept - 1u, false, h, sink);
+      const uint32_t hp = flush_simple(pend, kept - 1u, false, h, sink);
       const uint64_t ord = event_order(h.line_id, kept - 1u, 0);
-      if (rev) sink.link(node, row_lo, row_hi, pend.node, ord);
-      else sink.link(pend.node, pend.row_lo, pend.row_hi, node, ord);
+      if (rev) sink.link_pf(node, LDS_EMPTY, row_lo, row_hi, col0, pend.node, ord);
+      else sink.link_pf(pend.node, hp, pend.row_lo, pend.row_hi, pend.col0, node, ord);
     }
-    pend = SimplePend{node, word, row_lo, row_hi, stars_in < le};
+    pend = SimplePend{node, word, row_lo, row_hi, col0, stars_in < le};
     pending = true;
     ++kept;
     P = (room >= int64_t(T - P)) ? T : P + uint32_t(room);
@@ -558,23 +612,26 @@ __device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h,
   return WALK_OK;
 }
 
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F>
-__global__ __launch_bounds__(THREADS) void augment_main_agg_kernel(GraphView g, BatchView b) {
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1>
+__global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g, BatchView b) {
   using Sink = AggSink<LOG_N, LOG_S, LOG_F>;
   constexpr uint32_t CN = Sink::CN, CS = Sink::CS, CF = Sink::CF;
   __shared__ unsigned long long fmin[CF];
+  __shared__ unsigned long long vkey[CF];
+  __shared__ unsigned long long vmin[CF];
+  __shared__ uint32_t vcnt[CF];
   __shared__ uint32_t nkey[CN];
-  __shared__ uint32_t ncnt[3 * CN];
+  __shared__ uint32_t ncnt[4 * CN];
   __shared__ uint32_t skey[CS];
   __shared__ uint32_t scnt[CS];
   __shared__ uint32_t fkey[CF];
   const uint32_t n_chunks = (b.n + CHUNK - 1) / CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) { nkey[i] = LDS_EMPTY; ncnt[i] = 0u; ncnt[CN + i] = 0u; ncnt[2 * CN + i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) { nkey[i] = LDS_EMPTY; ncnt[i] = 0u; ncnt[CN + i] = 0u; ncnt[2 * CN + i] = 0u; ncnt[3 * CN + i] = 0u; }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
-    for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; }
+    for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
     __syncthreads();
-    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin};
+    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin};
     const uint32_t lo = c * CHUNK;
     const uint32_t hi = min(b.n, lo + CHUNK);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
@@ -590,10 +647,11 @@ __global__ __launch_bounds__(THREADS) void augment_main_agg_kernel(GraphView g, 
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       const uint32_t n = nkey[i];
       if (n == LDS_EMPTY) continue;
-      const uint32_t a = ncnt[i], il = ncnt[CN + i], ol = ncnt[2 * CN + i];
+      const uint32_t a = ncnt[i], il = ncnt[CN + i], ol = ncnt[2 * CN + i], r0 = ncnt[3 * CN + i];
       if (a) atomicAdd(&g.nc[n], a);
       if (il) atomicAdd(&g.il0[n], il);
       if (ol) atomicAdd(&g.oll[n], ol);
+      if (r0) atomicAdd(&g.rc[g.row_ptr[n]], r0);
     }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
       const uint32_t s = skey[i];
@@ -602,6 +660,7 @@ __global__ __launch_bounds__(THREADS) void augment_main_agg_kernel(GraphView g, 
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) {
       const uint32_t k = fkey[i];
       if (k != LDS_EMPTY && fmin[i] != ~0ull) table_update(g.hist, hist_key(k >> 1, k & 1u, COMMON_POS), 0u, fmin[i]);
+      if (vkey[i] != EMPTY_KEY) table_update(g.novel, vkey[i], vcnt[i], vmin[i]);
     }
     __syncthreads();
   }
@@ -909,23 +968,28 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   if (b.n) {
-    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 9;
+    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 18;
     const bool keys_fit = 3ull * d.V + d.A < 0xFFFFFFFFull;
     if (variant >= 8 && variant < 40) {
-#define PANTAS_AGG(ID, T, CH, LN, LS, LF) \
-      case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
+#define PANTAS_AGG(ID, T, CH, LN, LS, LF, MW) \
+      case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
       switch (variant) {
-        PANTAS_AGG(8, 1024, 4096, 12, 12, 9)
-        PANTAS_AGG(10, 512, 4096, 11, 11, 8)
-        PANTAS_AGG(11, 256, 1024, 10, 10, 7)
-        PANTAS_AGG(12, 256, 2048, 10, 10, 7)
-        PANTAS_AGG(13, 512, 1024, 11, 11, 8)
-        PANTAS_AGG(14, 512, 2048, 10, 10, 7)
-        PANTAS_AGG(15, 256, 512, 9, 9, 7)
-        PANTAS_AGG(16, 256, 1024, 11, 11, 8)
-        PANTAS_AGG(17, 1024, 4096, 11, 11, 8)
+        PANTAS_AGG(8, 1024, 4096, 12, 12, 9, 1)
+        PANTAS_AGG(11, 256, 1024, 10, 10, 7, 1)
+        PANTAS_AGG(12, 256, 2048, 10, 10, 7, 1)
+        PANTAS_AGG(14, 512, 2048, 10, 10, 7, 1)
+        PANTAS_AGG(19, 256, 1024, 10, 10, 7, 8)
+        PANTAS_AGG(20, 256, 1024, 9, 9, 7, 8)
+        PANTAS_AGG(21, 512, 2048, 11, 11, 7, 6)
+        PANTAS_AGG(22, 512, 2048, 10, 9, 7, 8)
+        PANTAS_AGG(23, 512, 4096, 10, 9, 7, 8)
+        PANTAS_AGG(24, 512, 1024, 10, 9, 7, 8)
+        PANTAS_AGG(25, 1024, 4096, 11, 9, 7, 8)
+        PANTAS_AGG(26, 256, 1024, 10, 9, 7, 8)
+        PANTAS_AGG(27, 512, 2048, 9, 9, 7, 8)
+        PANTAS_AGG(9, 512, 2048, 11, 11, 7, 1)
         default:
-        PANTAS_AGG(9, 512, 2048, 11, 11, 8)
+        PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
       }
 #undef PANTAS_AGG
     } else if (variant >= 4 && b.n_chunks) {

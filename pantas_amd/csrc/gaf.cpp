@@ -337,15 +337,18 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
     constexpr size_t PARTITION_BLOCK = 2048;
     const size_t nb = (n + PARTITION_BLOCK - 1) / PARTITION_BLOCK;
     parallel_chunks(nb, nb < 64 ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
-      std::vector<uint32_t> tmp;
+      std::vector<std::pair<uint32_t, uint32_t>> tmp;   // (class/length rank, record)
       for (size_t blk = lo; blk < hi; ++blk) {
         const size_t a = blk * PARTITION_BLOCK, e = std::min(n, a + PARTITION_BLOCK);
         tmp.clear();
-        size_t w = a;
         for (size_t i = a; i < e; ++i) {
-          if (b.hdr[idx[i]].flags & LINE_SIMPLE) idx[w++] = idx[i]; else tmp.push_back(idx[i]);
+          const uint32_t s = idx[i];
+          const uint32_t k = std::min<uint32_t>(b.node_off[s + 1] - b.node_off[s], 0xFFFFu);
+          // short-walk records first, each kind by path length: the lanes of a wave then loop alike
+          tmp.emplace_back(((b.hdr[s].flags & LINE_SIMPLE) ? 0u : 0x10000u) | k, s);
         }
-        for (uint32_t v : tmp) idx[w++] = v;
+        std::stable_sort(tmp.begin(), tmp.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+        for (size_t i = a; i < e; ++i) idx[i] = tmp[i - a].second;
       }
     });
     // keys no longer match idx order inside a block; the chunk table below only needs block-level order
