@@ -14,9 +14,15 @@ struct CallTimes {
   uint64_t junctions = 0;                                // junction evaluations launched
 };
 
+struct CallOutput {
+  std::vector<EventRec> recs;
+  std::vector<uint32_t> side;    // record payloads
+  std::vector<TaskOut> tasks;    // outcome of the deferred intron walks (indexed by EventRec.j1 of IR records)
+  std::vector<uint32_t> paths;   // walked paths
+};
+
 DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device);
 // Runs the three passes; fills records + payload (host).  Throws where the reference raises.
-void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, std::vector<EventRec>& recs,
-              std::vector<uint32_t>& side, CallTimes& times);
+void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, CallOutput& out, CallTimes& times);
 
 }  // namespace pantas

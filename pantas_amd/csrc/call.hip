@@ -31,7 +31,7 @@ __device__ __forceinline__ void run_junction(const CallView& c, uint32_t slot, u
 
 template <int PASS>
 __global__ __launch_bounds__(256) void call_count_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx,
-                                                         uint32_t n, uint32_t* nrec, uint32_t* nword,
+                                                         uint32_t n, uint32_t* nrec, uint32_t* nword, uint32_t* ntask,
                                                          unsigned long long* status) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     CountEmit e;
@@ -41,21 +41,58 @@ __global__ __launch_bounds__(256) void call_count_kernel(CallView c, const uint3
       atomicMin(status, (static_cast<unsigned long long>(PASS) << 40) | (static_cast<unsigned long long>(i) << 8) | f.code);
       e.recs = 0;
       e.words = 0;
+      e.tasks = 0;
     }
     nrec[i] = e.recs;
     nword[i] = e.words;
+    ntask[i] = e.tasks;
   }
 }
 
 template <int PASS>
 __global__ __launch_bounds__(256) void call_write_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx,
                                                          uint32_t n, const uint32_t* rec_off, const uint32_t* word_off,
-                                                         EventRec* recs, uint32_t* side) {
+                                                         const uint32_t* task_off, EventRec* recs, uint32_t* side,
+                                                         uint32_t* task_list) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     if (rec_off[i + 1] == rec_off[i]) continue;   // nothing to emit: skip the second evaluation
-    WriteEmit e{recs, side, rec_off[i], word_off[i]};
+    WriteEmit e{recs, side, rec_off[i], word_off[i], task_list, task_off[i]};
     Fault f;
     run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
+  }
+}
+
+// Deferred intron walks: one thread per task, so the lanes of a wave walk 64 different introns (inside
+// the junction kernels a walking lane would leave the other 63 idle).  First launch decides and measures,
+// the paths are written by a second launch at the scanned offsets.
+__global__ __launch_bounds__(256) void walk_count_kernel(CallView c, const EventRec* recs, const uint32_t* side,
+                                                         const uint32_t* task_list, uint32_t n, TaskOut* out, uint32_t* np,
+                                                         unsigned long long* status) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    Fault f;
+    TaskOut o;
+    run_walk_task(c, recs[task_list[i]], side, nullptr, o, f);
+    if (f.bad()) {
+      atomicMin(status, (3ull << 40) | (static_cast<unsigned long long>(i) << 8) | f.code);
+      o.status = 0;
+      o.np = 0;
+    }
+    o.path_off = 0;
+    out[i] = o;
+    np[i] = o.status == 1 ? o.np : 0u;
+  }
+}
+
+__global__ __launch_bounds__(256) void walk_write_kernel(CallView c, const EventRec* recs, const uint32_t* side,
+                                                         const uint32_t* task_list, uint32_t n, TaskOut* out,
+                                                         const uint32_t* path_off, uint32_t* paths) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    out[i].path_off = path_off[i];
+    if (out[i].status != 1) continue;
+    Fault f;
+    TaskOut o;
+    PathEmit pe{paths, path_off[i]};
+    run_walk_task(c, recs[task_list[i]], side, &pe, o, f);
   }
 }
 
@@ -173,59 +210,91 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
 
 template <int PASS>
 static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_t>& slots, const std::vector<uint32_t>* jidx,
-                     std::vector<EventRec>& recs, std::vector<uint32_t>& side, float& ms) {
+                     CallOutput& out, float& ms) {
   const uint32_t n = uint32_t(slots.size());
   if (!n) return;
   std::vector<void*> tmp;
   auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 4))); tmp.push_back(p); return p; };
   struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } guard{tmp};
-  uint32_t* d_slots = static_cast<uint32_t*>(dev(size_t(n) * 4));
-  uint32_t* d_jidx = jidx ? static_cast<uint32_t*>(dev(size_t(n) * 4)) : nullptr;
-  uint32_t* nrec = static_cast<uint32_t*>(dev(size_t(n) * 4));
-  uint32_t* nword = static_cast<uint32_t*>(dev(size_t(n) * 4));
-  uint32_t* rec_off = static_cast<uint32_t*>(dev((size_t(n) + 1) * 4));
-  uint32_t* word_off = static_cast<uint32_t*>(dev((size_t(n) + 1) * 4));
+  auto u32 = [&](size_t count) { return static_cast<uint32_t*>(dev(count * 4)); };
+  uint32_t* d_slots = u32(n);
+  uint32_t* d_jidx = jidx ? u32(n) : nullptr;
+  uint32_t *nrec = u32(n), *nword = u32(n), *ntask = u32(n);
+  uint32_t *rec_off = u32(size_t(n) + 1), *word_off = u32(size_t(n) + 1), *task_off = u32(size_t(n) + 1);
   HIP_OK(hipMemcpyAsync(d_slots, slots.data(), size_t(n) * 4, hipMemcpyHostToDevice, d.stream));
   if (jidx) HIP_OK(hipMemcpyAsync(d_jidx, jidx->data(), size_t(n) * 4, hipMemcpyHostToDevice, d.stream));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(n) + 255) / 256, 1u << 16));
+  auto check_status = [&] {
+    unsigned long long st = 0;
+    HIP_OK(hipMemcpyAsync(&st, d.status, 8, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    if (st != ~0ull) {
+      const uint32_t code = uint32_t(st & 0xFF);
+      throw Error(call_error_kind(code), call_error_text(code));
+    }
+  };
   HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
   HIP_OK(hipEventRecord(d.ev0, d.stream));
-  hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, d.status);
+  hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d.status);
   HIP_OK(hipGetLastError());
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, nrec, rec_off, n);
   hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, nword, word_off, n);
+  hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, ntask, task_off, n);
   HIP_OK(hipGetLastError());
-  uint32_t totals[2] = {0, 0};
+  uint32_t totals[3] = {0, 0, 0};
   HIP_OK(hipMemcpyAsync(&totals[0], rec_off + n, 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipMemcpyAsync(&totals[1], word_off + n, 4, hipMemcpyDeviceToHost, d.stream));
-  unsigned long long st = 0;
-  HIP_OK(hipMemcpyAsync(&st, d.status, 8, hipMemcpyDeviceToHost, d.stream));
-  HIP_OK(hipStreamSynchronize(d.stream));
-  if (st != ~0ull) {
-    const uint32_t code = uint32_t(st & 0xFF);
-    throw Error(call_error_kind(code), call_error_text(code));
-  }
+  HIP_OK(hipMemcpyAsync(&totals[2], task_off + n, 4, hipMemcpyDeviceToHost, d.stream));
+  check_status();
   HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
   EventRec* d_recs = static_cast<EventRec*>(dev(size_t(totals[0]) * sizeof(EventRec)));
-  uint32_t* d_side = static_cast<uint32_t*>(dev(size_t(totals[1]) * 4));
-  hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, d_recs, d_side);
+  uint32_t* d_side = u32(totals[1]);
+  uint32_t* d_tasks = u32(totals[2]);
+  hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, task_off,
+                     d_recs, d_side, d_tasks);
   HIP_OK(hipGetLastError());
+  // ---- deferred walks over the compacted task list
+  const uint32_t nt = totals[2];
+  TaskOut* d_tout = static_cast<TaskOut*>(dev(size_t(nt) * sizeof(TaskOut)));
+  uint32_t path_total = 0;
+  uint32_t* d_paths = nullptr;
+  if (nt) {
+    uint32_t* np = u32(nt);
+    uint32_t* path_off = u32(size_t(nt) + 1);
+    const uint32_t tb = uint32_t(std::min<uint64_t>((uint64_t(nt) + 255) / 256, 1u << 16));
+    hipLaunchKernelGGL(walk_count_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, d_tout, np, d.status);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, np, path_off, nt);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(&path_total, path_off + nt, 4, hipMemcpyDeviceToHost, d.stream));
+    check_status();
+    d_paths = u32(path_total);
+    hipLaunchKernelGGL(walk_write_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, d_tout, path_off, d_paths);
+    HIP_OK(hipGetLastError());
+  }
   HIP_OK(hipEventRecord(d.ev1, d.stream));
-  // append to the host arrays; payload offsets become global
-  const size_t r0 = recs.size(), w0 = side.size();
-  recs.resize(r0 + totals[0]);
-  side.resize(w0 + totals[1]);
-  if (totals[0]) HIP_OK(hipMemcpyAsync(recs.data() + r0, d_recs, size_t(totals[0]) * sizeof(EventRec), hipMemcpyDeviceToHost, d.stream));
-  if (totals[1]) HIP_OK(hipMemcpyAsync(side.data() + w0, d_side, size_t(totals[1]) * 4, hipMemcpyDeviceToHost, d.stream));
+  // append to the host arrays; payload / task / path offsets become global
+  const size_t r0 = out.recs.size(), w0 = out.side.size(), t0 = out.tasks.size(), p0 = out.paths.size();
+  out.recs.resize(r0 + totals[0]);
+  out.side.resize(w0 + totals[1]);
+  out.tasks.resize(t0 + nt);
+  out.paths.resize(p0 + path_total);
+  if (totals[0]) HIP_OK(hipMemcpyAsync(out.recs.data() + r0, d_recs, size_t(totals[0]) * sizeof(EventRec), hipMemcpyDeviceToHost, d.stream));
+  if (totals[1]) HIP_OK(hipMemcpyAsync(out.side.data() + w0, d_side, size_t(totals[1]) * 4, hipMemcpyDeviceToHost, d.stream));
+  if (nt) HIP_OK(hipMemcpyAsync(out.tasks.data() + t0, d_tout, size_t(nt) * sizeof(TaskOut), hipMemcpyDeviceToHost, d.stream));
+  if (path_total) HIP_OK(hipMemcpyAsync(out.paths.data() + p0, d_paths, size_t(path_total) * 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
   float t = 0;
   HIP_OK(hipEventElapsedTime(&t, d.ev0, d.ev1));
   ms += t;
-  for (size_t i = r0; i < recs.size(); ++i) recs[i].side_off += uint32_t(w0);
+  for (size_t i = r0; i < out.recs.size(); ++i) {
+    EventRec& r = out.recs[i];
+    r.side_off += uint32_t(w0);
+    if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) r.j1 += uint32_t(t0);
+  }
+  for (size_t i = t0; i < out.tasks.size(); ++i) out.tasks[i].path_off += uint32_t(p0);
 }
 
-void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, std::vector<EventRec>& recs,
-              std::vector<uint32_t>& side, CallTimes& times) {
+void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, CallOutput& out, CallTimes& times) {
   HIP_OK(hipSetDevice(d.device));
   CallView c = d.view;
   c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
@@ -233,12 +302,11 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   std::vector<uint32_t> ann, nov, around, around_j;
   pass_lists(g, t, o, ann, nov, around, around_j);
   HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));
-  recs.clear();
-  side.clear();
+  out = CallOutput();
   times = CallTimes();
-  run_pass<0>(d, c, ann, nullptr, recs, side, times.annotated_ms);
-  run_pass<1>(d, c, nov, nullptr, recs, side, times.novel_ms);
-  run_pass<2>(d, c, around, &around_j, recs, side, times.around_ms);
+  run_pass<0>(d, c, ann, nullptr, out, times.annotated_ms);
+  run_pass<1>(d, c, nov, nullptr, out, times.novel_ms);
+  run_pass<2>(d, c, around, &around_j, out, times.around_ms);
   times.junctions = ann.size() + nov.size() + around.size();
 }
 

@@ -453,16 +453,13 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
           if (ex_has(e2, tg) && ex_has_gene(exu, tg, g) && ex_has_gene(exv, tg, g)) { pick = tg; break; }
         }
         if (pick == CNONE) continue;
-        auto ok = [&](uint32_t nn) { return ex_has(ex_of(c, nn), pick); };
-        uint32_t np;
-        uint64_t ncs, lns;
-        bool nc_ok;
-        if (!walk_exon<Emit>(c, n1, n2, ok, nullptr, np, ncs, lns, nc_ok, f)) return;
-        if (!nc_ok) { f.raise(CE_KEY_NC); return; }
+        // the intron walk itself is deferred: tasks are compacted and walked by their own kernels
         emit.begin(T_IR_ANN, g, s, CNONE, CNONE);
-        emit.push(np);
-        walk_exon<Emit>(c, n1, n2, ok, &emit, np, ncs, lns, nc_ok, f);
-        emit.end(ceil_mean(ncs, np));
+        emit.task();
+        emit.push(n1);
+        emit.push(n2);
+        emit.push(pick);
+        emit.end(0);
         done = true;
       }
     }
@@ -570,33 +567,18 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
     bool inside_any = false;
     for (uint32_t i = 0; i < ex0.n && !inside_any; ++i) inside_any = ex_has(ex1, ex0.tag[i]);
     if (inside_any) {
-      auto ok = [&](uint32_t nn) {
-        const Ex en = ex_of(c, nn);
-        for (uint32_t i = 0; i < en.n; ++i)
-          if (ex_has(ex0, en.tag[i]) && ex_has(ex1, en.tag[i])) return true;
-        return false;
-      };
-      uint32_t np;
-      uint64_t ncs, lns;
-      bool nc_ok;
-      if (!walk_exon<Emit>(c, u, v, ok, nullptr, np, ncs, lns, nc_ok, f)) return;
-      if (int64_t(lns) >= int64_t(c.minintron)) {
-        uint32_t gene = CNONE, n_in = 0;
-        for (uint32_t i = 0; i < ex0.n; ++i)
-          if (ex_has(ex1, ex0.tag[i])) { ++n_in; gene_accumulate(c, ex0.tx[i], gene, f); }
-        if (f.bad()) return;
-        if (gene == GENE_MULTI) { emit.begin(T_SKIP_IR, CNONE, s, CNONE, CNONE); emit.end(0); }
-        else {
-          if (!nc_ok) { f.raise(CE_KEY_NC); return; }
-          emit.begin(T_IR1_NOV, gene, s, CNONE, CNONE);
-          emit.push(np);
-          walk_exon<Emit>(c, u, v, ok, &emit, np, ncs, lns, nc_ok, f);
-          emit.push(n_in);
-          for (uint32_t i = 0; i < ex0.n; ++i)
-            if (ex_has(ex1, ex0.tag[i])) emit.push(ex0.tag[i]);
-          emit.end(ceil_mean(ncs, np));
-        }
-      }
+      // gene of the retained exons now, the walk later (run_walk_task); a transcript the GTF lacks only
+      // matters if the intron turns out long enough (:853-858), so it travels as a status
+      uint32_t gene = CNONE, n_in = 0;
+      Fault gf;
+      for (uint32_t i = 0; i < ex0.n; ++i)
+        if (ex_has(ex1, ex0.tag[i])) { ++n_in; gene_accumulate(c, ex0.tx[i], gene, gf); }
+      emit.begin(T_IR1_NOV, gf.bad() ? CNONE : gene, s, CNONE, CNONE);
+      emit.task();
+      emit.push(n_in);
+      for (uint32_t i = 0; i < ex0.n; ++i)
+        if (ex_has(ex1, ex0.tag[i])) emit.push(ex0.tag[i]);
+      emit.end(0);
     }
   }
 }
@@ -678,17 +660,8 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
       }
     }
     if (n_pairs == 0) return;
-    uint32_t np;
-    uint64_t ncs, lin;
-    bool nc_ok;
-    if (!walk_greedy<Emit>(c, u, v, nullptr, np, ncs, lin, nc_ok, f)) return;
-    if (int64_t(lin) < int64_t(c.minintron)) return;
-    if (gf.bad()) { f.raise(gf.code); return; }
-    if (gene2 == GENE_MULTI) { emit.begin(T_SKIP_IR, CNONE, s, CNONE, CNONE); emit.end(0); return; }
-    if (!nc_ok) { f.raise(CE_KEY_NC); return; }
-    emit.begin(T_IR2_NOV, gene2, s, CNONE, CNONE);
-    emit.push(np);
-    walk_greedy<Emit>(c, u, v, &emit, np, ncs, lin, nc_ok, f);
+    emit.begin(T_IR2_NOV, gf.bad() ? CNONE : gene2, s, CNONE, CNONE);
+    emit.task();
     emit.push(n_pairs);
     for (uint32_t i = 0; i < exu.n; ++i) {
       if (!ends_at_u(i)) continue;
@@ -698,8 +671,60 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
         emit.push(exv.tag[k]);
       }
     }
-    emit.end(ceil_mean(ncs, np));
+    emit.end(0);
   }
+}
+
+// ---- deferred intron walks ---------------------------------------------------------------------------------
+// Outcome of one walk task (an IR record whose row depends on a walk through the intron).
+struct TaskOut {
+  uint32_t np;        // nodes on the path
+  uint32_t mean;      // ceil(mean NC) over the path
+  uint32_t status;    // 0: no row, 1: row, 2: "Skipping novel IR due to multiple genes"
+  uint32_t path_off;  // filled by the scan
+};
+
+struct PathEmit {
+  uint32_t* out;
+  uint32_t i;
+  PANTAS_HD void push(uint32_t w) { out[i++] = w; }
+};
+
+// Walks the intron of an IR record.  path == nullptr: decide (status, np, mean); else: write the path.
+PANTAS_HD void run_walk_task(const CallView& c, const EventRec& r, const uint32_t* side, PathEmit* path, TaskOut& out, Fault& f) {
+  out.np = 0;
+  out.mean = 0;
+  out.status = 0;
+  uint32_t np = 0;
+  uint64_t ncs = 0, ln = 0;
+  bool nc_ok = true;
+  const uint32_t u = c.src[r.j0], v = c.col[r.j0];
+  if (r.type == T_IR_ANN) {
+    const uint32_t n1 = side[r.side_off], n2 = side[r.side_off + 1], pick = side[r.side_off + 2];
+    auto ok = [&](uint32_t nn) { return ex_has(ex_of(c, nn), pick); };
+    if (!walk_exon<PathEmit>(c, n1, n2, ok, path, np, ncs, ln, nc_ok, f)) return;
+  } else if (r.type == T_IR1_NOV) {
+    const Ex ex0 = ex_of(c, u), ex1 = ex_of(c, v);
+    auto ok = [&](uint32_t nn) {
+      const Ex en = ex_of(c, nn);
+      for (uint32_t i = 0; i < en.n; ++i)
+        if (ex_has(ex0, en.tag[i]) && ex_has(ex1, en.tag[i])) return true;
+      return false;
+    };
+    if (!walk_exon<PathEmit>(c, u, v, ok, path, np, ncs, ln, nc_ok, f)) return;
+    if (int64_t(ln) < int64_t(c.minintron)) return;          // sum of LN over the whole path (:853)
+  } else {
+    if (!walk_greedy<PathEmit>(c, u, v, path, np, ncs, ln, nc_ok, f)) return;
+    if (int64_t(ln) < int64_t(c.minintron)) return;          // inner nodes only (:1052)
+  }
+  if (r.type != T_IR_ANN) {
+    if (r.gene == CNONE) { f.raise(CE_KEY_TX); return; }
+    if (r.gene == GENE_MULTI) { out.status = 2; return; }
+  }
+  if (!nc_ok) { f.raise(CE_KEY_NC); return; }
+  out.np = np;
+  out.mean = ceil_mean(ncs, np);
+  out.status = 1;
 }
 
 }  // namespace pantas

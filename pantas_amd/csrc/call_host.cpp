@@ -599,10 +599,8 @@ struct Renderer {
     }
     return p + n;
   }
-  const uint32_t* path(const uint32_t* p) {
-    uint32_t n = *p++;
+  void path(const uint32_t* p, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) { if (i) out.push_back('>'); name(p[i]); }
-    return p + n;
   }
   void extag(uint32_t id) { out.append(base + t.extag_span[id].off, t.extag_span[id].len); }
   void head(const char* type, const char* kind, uint32_t gene, const char* strand_plus, const char* strand_other) {
@@ -623,12 +621,18 @@ struct Renderer {
 }  // namespace
 
 void render_events(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
-                   std::string& csv, std::string& err) {
+                   const TaskOut* tasks, const uint32_t* paths, std::string& csv, std::string& err) {
   Renderer R{g, t, g.text.data, csv};
   for (size_t i = 0; i < n; ++i) {
     const EventRec& r = recs[i];
     const uint32_t* p = side + r.side_off;
     std::string& o = csv;
+    const TaskOut* tk = nullptr;
+    if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) {
+      tk = &tasks[r.j1];
+      if (tk->status == 2) { err += "Skipping novel IR due to multiple genes\n"; continue; }
+      if (tk->status != 1) continue;
+    }
     switch (r.type) {
       case T_ES_ANN:
         R.head("ES", "annotated", r.gene, nullptr, nullptr);
@@ -651,7 +655,7 @@ void render_events(const Graph& g, const CallTables& t, const EventRec* recs, si
         R.head("IR", "annotated", r.gene, nullptr, nullptr);
         R.jn_all(r.j0); o += ",.,.,";
         R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
-        p = R.path(p); o.push_back(','); put_u(o, r.mean); o += ",.,.";
+        R.path(paths + tk->path_off, tk->np); o.push_back(','); put_u(o, tk->mean); o += ",.,.";
         break;
       case T_ES_NOV:
         R.head("ES", "novel", r.gene, nullptr, nullptr);
@@ -680,12 +684,11 @@ void render_events(const Graph& g, const CallTables& t, const EventRec* recs, si
       case T_IR1_NOV: {
         R.head("IR", "novel", r.gene, nullptr, nullptr);
         o += "?,";
-        const uint32_t np = p[0];
-        const uint32_t* tags = p + 1 + np;
+        const uint32_t* tags = p;
         for (uint32_t k = 0; k < tags[0]; ++k) { if (k) o.push_back('|'); R.extag(tags[1 + k]); }
         o += ",.,";
         R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o.push_back(',');
-        R.path(p); o.push_back(','); put_u(o, r.mean); o += ",.,.";
+        R.path(paths + tk->path_off, tk->np); o.push_back(','); put_u(o, tk->mean); o += ",.,.";
         break;
       }
       case T_CE_NOV:
@@ -697,8 +700,7 @@ void render_events(const Graph& g, const CallTables& t, const EventRec* recs, si
         break;
       case T_IR2_NOV: {
         R.head("IR", "novel", r.gene, nullptr, nullptr);
-        const uint32_t np = p[0];
-        const uint32_t* pr = p + 1 + np;
+        const uint32_t* pr = p;
         for (uint32_t k = 0; k < pr[0]; ++k) {
           if (k) o.push_back('|');
           R.extag(pr[1 + 2 * k]);
@@ -712,7 +714,7 @@ void render_events(const Graph& g, const CallTables& t, const EventRec* recs, si
           o.append(d, size_t(e - d));
         }
         o += ",?,.,";
-        R.path(p); o.push_back(','); put_u(o, r.mean); o.push_back(',');
+        R.path(paths + tk->path_off, tk->np); o.push_back(','); put_u(o, tk->mean); o.push_back(',');
         R.link_nodes(r.j0); o.push_back(','); R.link_rc(r.j0); o += ",.,.";
         break;
       }

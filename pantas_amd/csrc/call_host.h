@@ -68,8 +68,9 @@ void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::
                 std::vector<uint32_t>& novel, std::vector<uint32_t>& around, std::vector<uint32_t>& around_jidx);
 
 // CSV header + rows (stdout of the reference) and the "Skipping ..." lines (stderr)
+// tasks[recs[i].j1] / paths hold the outcome of the deferred intron walks of IR records
 void render_events(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
-                   std::string& csv, std::string& err);
+                   const TaskOut* tasks, const uint32_t* paths, std::string& csv, std::string& err);
 extern const char* const CALL_CSV_HEADER;
 
 const char* call_error_kind(uint32_t code);
@@ -77,8 +78,9 @@ const char* call_error_text(uint32_t code);
 
 // emitters shared by call.hip and the CPU harness
 struct CountEmit {
-  uint32_t recs = 0, words = 0;
+  uint32_t recs = 0, words = 0, tasks = 0;
   PANTAS_HD void begin(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { ++recs; }
+  PANTAS_HD void task() { ++tasks; }
   PANTAS_HD void push(uint32_t) { ++words; }
   PANTAS_HD void end(uint32_t) {}
 };
@@ -86,6 +88,13 @@ struct WriteEmit {
   EventRec* rec;
   uint32_t* side;
   uint32_t rec_i, word_i;
+  uint32_t* task_list;   // record index of every walk task
+  uint32_t task_i;
+  PANTAS_HD void task() {
+    task_list[task_i] = rec_i;
+    rec[rec_i].j1 = task_i;
+    ++task_i;
+  }
   PANTAS_HD void begin(uint32_t type, uint32_t gene, uint32_t j0, uint32_t j1, uint32_t j2) {
     EventRec& r = rec[rec_i];
     r.type = type; r.gene = gene; r.j0 = j0; r.j1 = j1; r.j2 = j2; r.side_off = word_i; r.side_len = 0; r.mean = 0;

@@ -452,13 +452,13 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     o.novel = opts->novel != 0;
     o.no_annotated = opts->no_annotated != 0;
     if (opts->junction) { o.has_junction = true; o.junction = opts->junction; }
-    std::vector<EventRec> recs;
-    std::vector<uint32_t> side;
+    CallOutput co;
     CallTimes times;
-    run_call(*g->call_dev, *g->g, *g->call_tables, o, recs, side, times);
+    run_call(*g->call_dev, *g->g, *g->call_tables, o, co, times);
+    const std::vector<EventRec>& recs = co.recs;
     double t0 = now_s();
     std::string csv = std::string(CALL_CSV_HEADER) + "\n", err;
-    render_events(*g->g, *g->call_tables, recs.data(), recs.size(), side.data(), csv, err);
+    render_events(*g->g, *g->call_tables, recs.data(), recs.size(), co.side.data(), co.tasks.data(), co.paths.data(), csv, err);
     double t1 = now_s();
     if (fd_csv >= 0) write_fd(fd_csv, csv);
     if (fd_err >= 0) write_fd(fd_err, err);
@@ -468,7 +468,10 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
       stats->novel_links = t.novels.size();
       stats->evaluated = times.junctions;
       uint64_t rows = 0;
-      for (const EventRec& r : recs) rows += r.type < T_SKIP_ES ? 1 : 0;
+      for (const EventRec& r : recs) {
+        if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) rows += co.tasks[r.j1].status == 1 ? 1 : 0;
+        else rows += r.type < T_SKIP_ES ? 1 : 0;
+      }
       stats->events = rows;
       stats->ex_entries = t.ex_tag.size();
       stats->jn_entries = t.jn_ftx.size();

@@ -7,10 +7,16 @@
 
 using namespace pantas;
 
+struct Out {
+  std::vector<EventRec> recs;
+  std::vector<uint32_t> side;
+  std::vector<TaskOut> tasks;
+  std::vector<uint32_t> paths;
+};
+
 template <class Fn>
-static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, std::vector<EventRec>& recs,
-                     std::vector<uint32_t>& side, Fn fn) {
-  std::vector<uint32_t> nrec(slots.size() + 1, 0), nword(slots.size() + 1, 0);
+static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, Out& o, Fn fn) {
+  std::vector<uint32_t> nrec(slots.size() + 1, 0), nword(slots.size() + 1, 0), ntask(slots.size() + 1, 0);
   for (size_t i = 0; i < slots.size(); ++i) {
     CountEmit e;
     Fault f;
@@ -18,15 +24,46 @@ static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, std:
     if (f.bad()) throw Error(call_error_kind(f.code), call_error_text(f.code));
     nrec[i + 1] = nrec[i] + e.recs;
     nword[i + 1] = nword[i] + e.words;
+    ntask[i + 1] = ntask[i] + e.tasks;
   }
-  const size_t r0 = recs.size(), w0 = side.size();
-  recs.resize(r0 + nrec.back());
-  side.resize(w0 + nword.back());
+  const size_t r0 = o.recs.size(), w0 = o.side.size(), t0 = o.tasks.size();
+  o.recs.resize(r0 + nrec.back());
+  o.side.resize(w0 + nword.back());
+  std::vector<uint32_t> task_list(ntask.back());
   for (size_t i = 0; i < slots.size(); ++i) {
-    WriteEmit e{recs.data(), side.data(), uint32_t(r0 + nrec[i]), uint32_t(w0 + nword[i])};
+    // same protocol as call.hip: offsets are pass-local while the kernels run
+    WriteEmit e{o.recs.data() + r0, o.side.data() + w0, nrec[i], nword[i], task_list.data(), ntask[i]};
     Fault f;
     fn(c, slots[i], uint32_t(i), e, f);
-    if (e.rec_i != r0 + nrec[i + 1] || e.word_i != w0 + nword[i + 1]) throw Error("InternalError", "count/write mismatch");
+    if (e.rec_i != nrec[i + 1] || e.word_i != nword[i + 1] || e.task_i != ntask[i + 1]) throw Error("InternalError", "count/write mismatch");
+  }
+  // deferred walks: decide + measure, then write at the scanned offsets
+  o.tasks.resize(t0 + task_list.size());
+  std::vector<uint32_t> poff(task_list.size() + 1, 0);
+  for (size_t k = 0; k < task_list.size(); ++k) {
+    Fault f;
+    TaskOut to;
+    run_walk_task(c, o.recs[r0 + task_list[k]], o.side.data() + w0, nullptr, to, f);
+    if (f.bad()) throw Error(call_error_kind(f.code), call_error_text(f.code));
+    poff[k + 1] = poff[k] + (to.status == 1 ? to.np : 0);
+    o.tasks[t0 + k] = to;
+  }
+  const size_t p0 = o.paths.size();
+  o.paths.resize(p0 + poff.back());
+  for (size_t k = 0; k < task_list.size(); ++k) {
+    TaskOut& to = o.tasks[t0 + k];
+    to.path_off = uint32_t(p0 + poff[k]);
+    if (to.status != 1) continue;
+    Fault f;
+    TaskOut again;
+    PathEmit pe{o.paths.data() + p0, poff[k]};
+    run_walk_task(c, o.recs[r0 + task_list[k]], o.side.data() + w0, &pe, again, f);
+    if (pe.i != poff[k + 1]) throw Error("InternalError", "walk count/write mismatch");
+  }
+  for (size_t i = r0; i < o.recs.size(); ++i) {
+    EventRec& r = o.recs[i];
+    r.side_off += uint32_t(w0);
+    if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) r.j1 += uint32_t(t0);
   }
 }
 
@@ -60,14 +97,13 @@ int main(int argc, char** argv) {
     c.arena = arena.data(); c.arena_next = &arena_next; c.arena_slots = 64; c.arena_cap = 4096;
     std::vector<uint32_t> ann, nov, around, around_j;
     pass_lists(*g, t, o, ann, nov, around, around_j);
-    std::vector<EventRec> recs;
-    std::vector<uint32_t> side;
+    Out out;
     printf("%s\n", CALL_CSV_HEADER);
-    run_pass(c, ann, recs, side, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { annotated_junction(c, s, e, f); });
-    run_pass(c, nov, recs, side, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { novel_link(c, s, e, f); });
-    run_pass(c, around, recs, side, [&](const CallView& c, uint32_t s, uint32_t i, auto& e, Fault& f) { novel_around(c, s, around_j[i], e, f); });
+    run_pass(c, ann, out, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { annotated_junction(c, s, e, f); });
+    run_pass(c, nov, out, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { novel_link(c, s, e, f); });
+    run_pass(c, around, out, [&](const CallView& c, uint32_t s, uint32_t i, auto& e, Fault& f) { novel_around(c, s, around_j[i], e, f); });
     std::string csv, err;
-    render_events(*g, t, recs.data(), recs.size(), side.data(), csv, err);
+    render_events(*g, t, out.recs.data(), out.recs.size(), out.side.data(), out.tasks.data(), out.paths.data(), csv, err);
     fwrite(csv.data(), 1, csv.size(), stdout);
     fwrite(err.data(), 1, err.size(), stderr);
     return 0;
