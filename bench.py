@@ -188,6 +188,7 @@ def main():
         call = {"events": cs.events, "junctions": cs.junctions, "novel_links": cs.novel_links,
                 "evaluated": cs.evaluated, "flags": f"--rca {rca} --novel (= --rca 3 per pass over the batch)",
                 "events_per_s": cs.events / wall, "wall_s": wall, "kernel_ms": k_ms,
+                "kernel_ms_by_pass": {"annotated": cs.annotated_ms, "novel_links": cs.novel_ms, "novel_around": cs.around_ms},
                 "junction_evals_per_s_kernel": cs.evaluated / (k_ms * 1e-3) if k_ms else None,
                 "prepare_s": t_prep, "tag_parse_s": cs.parse_seconds, "render_s": cs.render_seconds}
 

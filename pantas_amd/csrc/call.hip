@@ -26,7 +26,8 @@ template <int PASS, class Emit>
 __device__ __forceinline__ void run_junction(const CallView& c, uint32_t slot, uint32_t jidx, Emit& e, Fault& f) {
   if (PASS == 0) annotated_junction(c, slot, e, f);
   else if (PASS == 1) novel_link(c, slot, e, f);
-  else novel_around(c, slot, jidx, e, f);
+  else if (PASS == 2) novel_around(c, slot, jidx, e, f);
+  else cassette_item(c, slot, jidx, e, f);     // jidx carries the novel head link
 }
 
 template <int PASS>
@@ -304,10 +305,17 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));
   out = CallOutput();
   times = CallTimes();
+  size_t extra_items = 0;
   run_pass<0>(d, c, ann, nullptr, out, times.annotated_ms);
   run_pass<1>(d, c, nov, nullptr, out, times.novel_ms);
   run_pass<2>(d, c, around, &around_j, out, times.around_ms);
-  times.junctions = ann.size() + nov.size() + around.size();
+  if (o.novel && (o.events & EV_ES)) {
+    std::vector<uint32_t> cj, ch;
+    cassette_items(t, around, cj, ch);
+    run_pass<3>(d, c, cj, &ch, out, times.around_ms);
+    extra_items = cj.size();
+  }
+  times.junctions = ann.size() + nov.size() + around.size() + extra_items;
 }
 
 }  // namespace pantas

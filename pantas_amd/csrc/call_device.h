@@ -437,11 +437,18 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   }
 
   if (c.events & EV_IR) {
-    bool done = false;
+    // exons (of gene g) that lie on both ends of the junction: only they can retain the intron.  Testing
+    // this first, and per out-neighbour, keeps the out x in neighbour product of :473 off hub nodes.
+    bool both_any = false;
+    for (uint32_t i = 0; i < exu.n && !both_any; ++i) both_any = exu.gene[i] == g && ex_has_gene(exv, exu.tag[i], g);
+    bool done = !both_any;
     for (uint32_t t = ob; t < oe && !done; ++t) {
       const uint32_t n1 = c.col[t];
       if (n1 == v) continue;
       const Ex e1 = ex_of(c, n1);
+      bool n1_any = false;
+      for (uint32_t i = 0; i < e1.n && !n1_any; ++i) n1_any = ex_has_gene(exu, e1.tag[i], g) && ex_has_gene(exv, e1.tag[i], g);
+      if (!n1_any) continue;
       for (uint32_t q = ib; q < ie && !done; ++q) {
         const uint32_t n2 = c.icol[q];
         if (n2 == u) continue;
@@ -603,20 +610,7 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
   const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
 
-  if (c.events & EV_ES) {
-    for (uint32_t t1 = ob; t1 < oe; ++t1) {
-      if (c.first_slot[t1] != t1 || t1 == s || !(c.lflags[t1] & L_NOVEL)) continue;
-      for (uint32_t q = ib; q < ie; ++q) {
-        const uint32_t t2 = c.islot[q];
-        if (c.first_slot[t2] != t2 || t2 == s || !(c.lflags[t2] & L_NOVEL)) continue;
-        if (c.rank[c.col[t1]] <= c.rank[c.src[t2]]) {
-          if (!(c.lflags[t1] & L_HAS_RC) || !(c.lflags[t2] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
-          emit.begin(T_CE_NOV, g, s, t1, t2);
-          emit.end(0);
-        }
-      }
-    }
-  }
+  // cassette exons (:954-984) are enumerated by cassette_item, one (junction, novel head link) per thread
 
   if (c.events & EV_IR) {
     if (!(c.probe_ok[jidx] & 1u)) { f.raise(CE_VALUE_INT); return; }   // int(u) fails
@@ -672,6 +666,35 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
       }
     }
     emit.end(0);
+  }
+}
+
+// ---- pass 4: cassette exons (:954-984), one work item per (annotated junction, novel link leaving its head) ----
+// The rows of one junction are the product (novel links from its head) x (novel links into its tail); on
+// expressed genes that is thousands of rows, so the product is spread over threads by head link.
+template <class Emit>
+PANTAS_HD void cassette_item(const CallView& c, uint32_t s, uint32_t t1, Emit& emit, Fault& f) {
+  if (!(c.events & EV_ES)) return;
+  const uint32_t u = c.src[s], v = c.col[s];
+  // same gate as novel_around (which also reports the errors)
+  if (!(c.lflags[s] & L_HAS_RC) || c.rc[s] < c.rca || (c.lflags[s] & L_GENE_KEYERR)) return;
+  const Set genes = jg_of(c, s);
+  if (genes.n != 1) return;
+  const uint32_t g = genes.p[0];
+  Fault gate;
+  const bool has_u = same_gene_exons(c, u, g, gate);
+  const bool has_v = same_gene_exons(c, v, g, gate);
+  if (gate.bad() || !has_u || !has_v) return;
+  const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+  const uint32_t es_rank = c.rank[c.col[t1]];
+  for (uint32_t q = ib; q < ie; ++q) {
+    const uint32_t t2 = c.islot[q];
+    if (c.first_slot[t2] != t2 || t2 == s || !(c.lflags[t2] & L_NOVEL)) continue;
+    if (es_rank <= c.rank[c.src[t2]]) {
+      if (!(c.lflags[t1] & L_HAS_RC) || !(c.lflags[t2] & L_HAS_RC)) { f.raise(CE_KEY_RC); return; }
+      emit.begin(T_CE_NOV, g, s, t1, t2);
+      emit.end(0);
+    }
   }
 }
 

@@ -566,6 +566,20 @@ void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::
   }
 }
 
+void cassette_items(const CallTables& t, const std::vector<uint32_t>& around, std::vector<uint32_t>& junction,
+                    std::vector<uint32_t>& head_link) {
+  junction.clear();
+  head_link.clear();
+  for (uint32_t s : around) {
+    const uint32_t u = t.src[s];
+    for (uint32_t t1 = t.row_ptr[u]; t1 < t.row_ptr[u + 1]; ++t1) {
+      if (t.first_slot[t1] != t1 || t1 == s || !(t.lflags[t1] & L_NOVEL)) continue;
+      junction.push_back(s);
+      head_link.push_back(t1);
+    }
+  }
+}
+
 namespace {
 
 inline void put_u(std::string& s, uint64_t v) {

@@ -66,6 +66,9 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o);
 // The slots each pass iterates, after the --junction filter (:241, :532, :897)
 void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::vector<uint32_t>& annotated,
                 std::vector<uint32_t>& novel, std::vector<uint32_t>& around, std::vector<uint32_t>& around_jidx);
+// work items of the cassette-exon pass: (junction slot, canonical novel link leaving its head), junction-major
+void cassette_items(const CallTables& t, const std::vector<uint32_t>& around, std::vector<uint32_t>& junction,
+                    std::vector<uint32_t>& head_link);
 
 // CSV header + rows (stdout of the reference) and the "Skipping ..." lines (stderr)
 // tasks[recs[i].j1] / paths hold the outcome of the deferred intron walks of IR records

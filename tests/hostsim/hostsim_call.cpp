@@ -102,6 +102,11 @@ int main(int argc, char** argv) {
     run_pass(c, ann, out, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { annotated_junction(c, s, e, f); });
     run_pass(c, nov, out, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { novel_link(c, s, e, f); });
     run_pass(c, around, out, [&](const CallView& c, uint32_t s, uint32_t i, auto& e, Fault& f) { novel_around(c, s, around_j[i], e, f); });
+    if (o.novel && (o.events & EV_ES)) {
+      std::vector<uint32_t> cj, ch;
+      cassette_items(t, around, cj, ch);
+      run_pass(c, cj, out, [&](const CallView& c, uint32_t s, uint32_t i, auto& e, Fault& f) { cassette_item(c, s, ch[i], e, f); });
+    }
     std::string csv, err;
     render_events(*g, t, out.recs.data(), out.recs.size(), out.side.data(), out.tasks.data(), out.paths.data(), csv, err);
     fwrite(csv.data(), 1, csv.size(), stdout);
