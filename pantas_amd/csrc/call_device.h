@@ -334,29 +334,45 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   // heads: other junctions leaving u; tails: other junctions entering v; both of gene g
   const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+  // The rows of u and v also hold every link the reads added (thousands on expressed genes); the
+  // junctions among them are few, so they are listed once and the pair loops below run over the lists.
+  constexpr uint32_t HT_MAX = 16;
+  uint32_t heads[HT_MAX], tails[HT_MAX];
   uint32_t n_heads = 0, n_tails = 0;
   for (uint32_t t = ob; t < oe; ++t) {
     if (c.first_slot[t] != t || t == s || !(c.lflags[t] & L_JUNC)) continue;
     if (c.lflags[t] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
-    if (set_has(jg_of(c, t), g)) ++n_heads;
+    if (set_has(jg_of(c, t), g)) { if (n_heads < HT_MAX) heads[n_heads] = t; ++n_heads; }
   }
   for (uint32_t q = ib; q < ie; ++q) {
     const uint32_t t = c.islot[q];
     if (c.first_slot[t] != t || t == s || !(c.lflags[t] & L_JUNC)) continue;
     if (c.lflags[t] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
-    if (set_has(jg_of(c, t), g)) ++n_tails;
+    if (set_has(jg_of(c, t), g)) { if (n_tails < HT_MAX) tails[n_tails] = t; ++n_tails; }
   }
   auto is_head = [&](uint32_t t) {
     return c.first_slot[t] == t && t != s && (c.lflags[t] & L_JUNC) && set_has(jg_of(c, t), g);
   };
+  // i-th head / tail; beyond the local list (rare) it is found by scanning the row again
+  auto head_at = [&](uint32_t i) -> uint32_t {
+    if (i < HT_MAX) return heads[i];
+    uint32_t k = 0;
+    for (uint32_t t = ob; t < oe; ++t) if (is_head(t)) { if (k == i) return t; ++k; }
+    return CNONE;
+  };
+  auto tail_at = [&](uint32_t i) -> uint32_t {
+    if (i < HT_MAX) return tails[i];
+    uint32_t k = 0;
+    for (uint32_t q = ib; q < ie; ++q) { const uint32_t t = c.islot[q]; if (is_head(t)) { if (k == i) return t; ++k; } }
+    return CNONE;
+  };
 
   if (c.events & EV_ES) {
-    for (uint32_t t1 = ob; t1 < oe; ++t1) {
-      if (!is_head(t1)) continue;
+    for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
+      const uint32_t t1 = head_at(hi_);
       const Set x1 = jx_of(c, t1);
-      for (uint32_t q = ib; q < ie; ++q) {
-        const uint32_t t2 = c.islot[q];
-        if (!is_head(t2)) continue;
+      for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
+        const uint32_t t2 = tail_at(ti_);
         const Set x2 = jx_of(c, t2);
         bool inc = false;
         for (uint32_t i = 0; i < x1.n && !inc; ++i) inc = set_has(x2, x1.p[i]) && !set_has(txs, x1.p[i]);
@@ -384,9 +400,8 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
         bool cont = false;
         for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exu, en.tag[i], g);
         if (!cont) continue;
-        for (uint32_t q = ib; q < ie; ++q) {
-          const uint32_t t2 = c.islot[q];
-          if (!is_head(t2)) continue;
+        for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
+          const uint32_t t2 = tail_at(ti_);
           const uint32_t from = c.src[t2];
           if (from == u) continue;
           const Ex ef = ex_of(c, from);
@@ -415,8 +430,8 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
         bool cont = false;
         for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exv, en.tag[i], g);
         if (!cont) continue;
-        for (uint32_t t1 = ob; t1 < oe; ++t1) {
-          if (!is_head(t1)) continue;
+        for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
+          const uint32_t t1 = head_at(hi_);
           const uint32_t to = c.col[t1];
           if (to == v) continue;
           const Ex et = ex_of(c, to);
