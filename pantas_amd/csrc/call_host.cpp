@@ -199,6 +199,7 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
 void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size, CallTables& t, unsigned threads,
                            const AugmentResult* aug) {
   const double t0 = now_s();
+  PhaseTimer pt("call_tables");
   if (threads == 0) threads = hw_threads();
   const char* base = g.text.data;
   // inputs the reference's GFA loop dies on (call.py:145-181)
@@ -277,6 +278,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     parse_gtf(f, gtf, t);
   }
 
+  pt.lap("gtf + link layout");
   // ---- phase A (parallel): locate the tags of every S line and every link slot -----------------
   std::vector<SegAttr> sa(V);
   t.nc.assign(V, 0);
@@ -348,6 +350,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     }
   }
 
+  pt.lap("tag scan (parallel)");
   // ---- canonical slots: first slot of each (u, v); attributes of the LAST duplicate (dict overwrite, :173)
   t.first_slot.resize(A);
   t.lflags.assign(A, 0);
@@ -378,6 +381,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     t.lflags[s] = fl;
   }
 
+  pt.lap("canonical slots (sequential)");
   // ---- phase B: intern transcripts, EX tags, JN tags (first-appearance order) -------------------------
   std::unordered_map<std::string_view, uint32_t> tx_ids;
   auto tx_id = [&](Span name) -> uint32_t {
@@ -423,6 +427,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   }
   t.ex_ptr[V] = uint32_t(t.ex_tag.size());
 
+  pt.lap("intern EX (sequential)");
   std::unordered_map<std::string_view, uint32_t> jn_ids;
   t.jn_ptr.assign(A + 1, 0);
   t.jt_ptr.assign(A + 1, 0);
@@ -464,6 +469,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   t.jx_ptr[A] = uint32_t(t.jx.size());
   t.jg_ptr[A] = uint32_t(t.jg.size());
 
+  pt.lap("intern JN (sequential)");
   // ---- lexicographic rank of segment names ------------------------------------------------------------
   t.rank.resize(V);
   bool fixed_width = g.names.dense && V > 0;
@@ -485,6 +491,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     for (uint32_t i = 0; i < V; ++i) t.rank[order[i]] = i;
   }
 
+  pt.lap("name ranks");
   // ---- junction / novel lists in file order; IR-2 probes -----------------------------------------------
   for (size_t s = 0; s < A; ++s) {
     if (t.first_slot[s] != s) continue;
@@ -522,6 +529,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       }
     }
   }
+  pt.lap("lists + probes");
   t.parse_s = now_s() - t0;
 }
 

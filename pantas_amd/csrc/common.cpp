@@ -80,6 +80,14 @@ std::vector<std::pair<size_t, size_t>> split_at_newlines(const char* data, size_
   return out;
 }
 
+PhaseTimer::PhaseTimer(const char* w) : what(w), t0(now_s()), last(t0), on(getenv("PANTAS_TIMING") != nullptr) {}
+void PhaseTimer::lap(const char* phase) {
+  if (!on) return;
+  double t = now_s();
+  fprintf(stderr, "[timing] %s: %-28s %8.3f s (total %8.3f)\n", what, phase, t - last, t - t0);
+  last = t;
+}
+
 double now_s() {
   using namespace std::chrono;
   return duration<double>(steady_clock::now().time_since_epoch()).count();

@@ -117,4 +117,13 @@ std::vector<std::pair<size_t, size_t>> split_at_newlines(const char* data, size_
 
 double now_s();
 
+// phase timing to stderr when PANTAS_TIMING is set
+struct PhaseTimer {
+  const char* what;
+  double t0, last;
+  bool on;
+  explicit PhaseTimer(const char* w);
+  void lap(const char* phase);
+};
+
 }  // namespace pantas

@@ -204,6 +204,7 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
 
 void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
                   unsigned threads, GafBatch& out) {
+  PhaseTimer pt("tokenize_gaf");
   if (threads == 0) threads = hw_threads();
   if (size < (1u << 20)) threads = 1;
   auto ranges = split_at_newlines(data, size, threads);
@@ -217,6 +218,7 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
       }
     }
   });
+  pt.lap("parse lines (parallel)");
   // the reference stops at the first offending line: report the earliest one
   uint64_t line_base = first_line_id;
   for (auto& c : cks) {
@@ -272,6 +274,7 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
   });
   out.node_off[n] = uint32_t(nn);
   out.op_off[n] = uint32_t(no);
+  pt.lap("merge chunks");
 }
 
 
@@ -311,6 +314,7 @@ void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, un
 }  // namespace
 
 void bucket_by_locus(GafBatch& b, unsigned threads) {
+  PhaseTimer pt("bucket_by_locus");
   const size_t n = b.size();
   if (n < 2) {
     b.chunk_lo.assign(1, 0u);
@@ -330,7 +334,9 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
       idx[i] = uint32_t(i);
     }
   });
+  pt.lap("keys");
   radix_sort_pairs(key, idx, threads);
+  pt.lap("radix sort");
   // inside every block of PARTITION_BLOCK sorted records, the records eligible for the short walk
   // come first, so that a wave seldom holds both kinds
   {
@@ -357,6 +363,7 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
       key[i] = b.node_off[s + 1] > b.node_off[s] ? std::min(b.nodes[b.node_off[s]], b.nodes[b.node_off[s + 1] - 1]) : 0u;
     }
   }
+  pt.lap("partition blocks + rekey");
   std::vector<LineHdr> hdr(n);
   std::vector<uint32_t> node_off(n + 1), op_off(n + 1), nodes(b.nodes.size()), ops(b.ops.size());
   // sizes, then exclusive offsets (sequential scan: 2 adds per record), then a parallel gather
@@ -376,6 +383,7 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
       if (no) memcpy(&ops[op_off[i]], &b.ops[b.op_off[s]], size_t(no) * 4);
     }
   });
+  pt.lap("offsets + gather");
   // chunk table over the sorted keys
   b.chunk_lo.clear();
   b.chunk_base.clear();

@@ -78,6 +78,7 @@ std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned th
 
 static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned threads) {
   const char* base = g->text.data;
+  PhaseTimer pt("load_graph");
   if (threads == 0) threads = hw_threads();
   if (g->text.size < (1u << 20)) threads = 1;
   auto ranges = split_at_newlines(base, g->text.size, threads);
@@ -86,6 +87,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
     for (size_t i = b; i < e; ++i) scan_chunk(base, ranges[i].first, ranges[i].second, outs[i]);
   });
 
+  pt.lap("scan lines (parallel)");
   size_t ns = 0, nl = 0;
   for (auto& o : outs) {
     ns += o.s.size();
@@ -151,6 +153,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
     }
   }
+  pt.lap("name index (sequential)");
   g->V = uint32_t(g->seg_len.size());
   for (uint32_t v : g->seg_len) g->max_seg_len = std::max(g->max_seg_len, v);
 
@@ -168,6 +171,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
     }
   });
+  pt.lap("resolve link ends (parallel)");
   g->row_ptr.assign(size_t(g->V) + 1, 0);
   g->irow_ptr.assign(size_t(g->V) + 1, 0);
   uint64_t A = 0;
@@ -212,6 +216,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
         ++k;
       }
   }
+  pt.lap("CSR fill (sequential)");
   return g;
 }
 
