@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--scale", default=os.environ.get("PANTAS_BENCH_SCALE", "auto"))
     ap.add_argument("--lines", type=int, default=0, help="override the scale's GAF lines per GPU")
     ap.add_argument("--seed", type=int, default=7)
-    ap.add_argument("--cpu-sample", type=int, default=300_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-call", action="store_true")
     args = ap.parse_args()
@@ -197,6 +197,13 @@ def main():
         value = bs.lines * world / (elapsed / args.steps)
         avg_main = sum(main_ms) / len(main_ms)
         achieved = bs.alg_bytes / (avg_main * 1e-3) / 1e9
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if scale in tj and not args.lines:
+                traffic = tj[scale]["traffic_bytes"]     # measured in a separate --pmc run of this workload
+        except (OSError, ValueError):
+            pass
         out = collections.OrderedDict()
         out.update({
             "metric": "augment GAF reads/s (+ call events/s) on synthetic spliced pangenome",
@@ -214,8 +221,10 @@ def main():
             "allreduce_ms": allreduce_ms,
             "records_per_s_kernel_only": bs.records / (avg_main * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "augment_main_kernel", "alg_bytes_per_launch": bs.alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "augment_main_agg_kernel<512,2048,10,10,7,8>", "alg_bytes_per_launch": bs.alg_bytes,
+                         "traffic_note": "HBM bytes per launch from profiles/r1_traffic.json (separate rocprofv3 --pmc passes "
+                                         "of this workload), null when no profile of this scale is committed"},
             "call": call,
             "host": {"generate_s": t_gen, "gfa_load_s": gs.load_seconds, "gaf_tokenize_s": bs.tokenize_seconds,
                      "gaf_upload_s": bs.upload_seconds, "finish_download_s": t_fin,

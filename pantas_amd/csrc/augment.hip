@@ -1,19 +1,18 @@
 // HIP kernels (gfx950) of the augment path and their host-side launchers.
 //
-// Two kernels per batch of tokenised GAF lines, one thread per line, both built on
-// walk_line() of walk.h (reference scripts/alignments_augmentation_from_gaf.py:209-363):
+// Two kernels per batch of tokenised GAF records (reference scripts/alignments_augmentation_from_gaf.py:209-363):
 //
-//   augment_rare_kernel   only lines whose cs holds a '-' op.  Records the IL/OL keys that
-//                         come from deletions (key, count, first-seen order) in a device hash
-//                         table and flags the node (two top bits of its node_len word).
-//   augment_main_kernel   every line.  NC[node]++, IL[0]/OL[len] dense counters, RC[slot]++ by
-//                         scanning the node's CSR row, links missing from the graph into a
-//                         second hash table (count + first-seen order); on flagged nodes also
-//                         the first-seen order of the dense key, which the writer needs to
-//                         interleave it with the rare keys of that node.
+//   augment_rare_kernel      only records whose cs holds a '-' op (a few %).  Records the IL/OL keys that come
+//                            from deletions (key, count, first-seen order) in a device hash table and flags the
+//                            node (two top bits of its node_len word).
+//   augment_main_agg_kernel  every record, one thread each, records bucketed by locus (gaf.cpp).  NC, IL[0], OL[len]
+//                            and RC increments are summed in workgroup-private LDS tables and reach HBM as one
+//                            no-return global atomic per touched counter per chunk of 2048 records; links missing
+//                            from the graph and the first-seen order of the common IL/OL key on flagged nodes are
+//                            aggregated in LDS the same way before they go to the global tables.
+//   augment_main_kernel      the same walk with direct global atomics (A/B reference, PANTAS_MAIN_KERNEL=0).
 //
-// All counters are uint32 device-scope atomics (no-return global_atomic_add).  The dense
-// counters sit in ONE allocation [NC | IL0 | OLL | RC] so a multi-GPU run needs a single
+// The dense counters sit in ONE allocation [NC | IL0 | OLL | RC] so a multi-GPU run needs a single
 // all-reduce.
 #include <hip/hip_runtime.h>
 
@@ -61,9 +60,7 @@ struct BatchView {
   const uint32_t* nodes;
   const uint32_t* ops;
   const uint32_t* del_idx;    // records holding a '-' op
-  const uint32_t* chunk_lo;   // [n_chunks + 1] locus chunks of the bucketed records
-  const uint32_t* chunk_base; // [n_chunks]
-  uint32_t n, n_del, n_chunks;
+  uint32_t n, n_del;
 };
 
 __device__ __forceinline__ uint32_t mix64(uint64_t k) {
@@ -151,265 +148,9 @@ __global__ __launch_bounds__(256) void augment_main_kernel(GraphView g, BatchVie
     run_line<MainSink>(g, b, i);
 }
 
-// ---- LDS-aggregating main kernel ----------------------------------------------------------------
-// Records arrive bucketed by locus (gaf.cpp bucket_by_locus), so the CHUNK consecutive records one
-// workgroup walks keep hitting the same counters.  Increments are first summed in a workgroup-private
-// open-addressing table in LDS, keyed by the counter's index in the [NC | IL0 | OLL | RC] allocation,
-// and reach HBM as ONE global atomic per distinct counter per chunk.  An increment that finds no
-// slot within a few probes goes straight to memory, so capacity is a speed matter only.
 constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
 
-template <uint32_t LOG_CAP>
-struct LdsSink {
-  const GraphView& g;
-  uint32_t* keys;
-  uint32_t* vals;
-  uint32_t V;
-  __device__ __forceinline__ void bump(uint32_t key, uint32_t times) const {
-    if (g.ablate & 8u) return;
-    constexpr uint32_t CAP = 1u << LOG_CAP;
-    uint32_t h = (key * 2654435761u) >> (32 - LOG_CAP);
-#pragma unroll 1
-    for (uint32_t probe = 0; probe < 12; ++probe) {
-      uint32_t cur = __atomic_load_n(&keys[h], __ATOMIC_RELAXED);
-      if (cur == LDS_EMPTY) {
-        cur = atomicCAS(&keys[h], LDS_EMPTY, key);
-        if (cur == LDS_EMPTY) cur = key;
-      }
-      if (cur == key) { atomicAdd(&vals[h], times); return; }
-      h = (h + 1) & (CAP - 1);
-    }
-    atomicAdd(&g.nc[key], times);   // g.nc is the base of the counter allocation
-  }
-  __device__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
-  __device__ void nc(uint32_t n) const { bump(n, 1u); }
-  __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
-    bump((side == SIDE_IL ? V : 2u * V) + n, times);
-    if (!(g.ablate & 1u) && (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL))) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
-  }
-  __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
-  __device__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
-    if (g.ablate & 4u) return;
-    const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
-    for (uint32_t s = lo; s < hi; ++s) {
-      if (g.col[s] == b) { bump(3u * V + s, 1u); return; }
-    }
-    if (g.ablate & 2u) return;
-    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
-  }
-};
-
-template <uint32_t THREADS, uint32_t LOG_CAP, uint32_t CHUNK>
-__global__ __launch_bounds__(THREADS) void augment_main_lds_kernel(GraphView g, BatchView b, uint32_t V) {
-  constexpr uint32_t CAP = 1u << LOG_CAP;
-  __shared__ uint32_t keys[CAP];
-  __shared__ uint32_t vals[CAP];
-  const uint32_t n_chunks = (b.n + CHUNK - 1) / CHUNK;
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < CAP; i += THREADS) { keys[i] = LDS_EMPTY; vals[i] = 0u; }
-    __syncthreads();
-    const uint32_t lo = c * CHUNK;
-    const uint32_t hi = min(b.n, lo + CHUNK);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
-      const LineHdr h = b.hdr[i];
-      const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
-      const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
-      LdsSink<LOG_CAP> sink{g, keys, vals, V};
-      const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-      if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < CAP; i += THREADS) {
-      const uint32_t k = keys[i];
-      if (k != LDS_EMPTY) atomicAdd(&g.nc[k], vals[i]);
-    }
-    __syncthreads();
-  }
-}
-
-// ---- group-walk main kernel -------------------------------------------------------------------------
-// Eight lanes walk one record: lane l of a group owns path node 8t + l of tile t, so the node_len
-// gathers, the CSR row scans and the counter updates of a record are issued side by side instead of
-// one after the other.  Node budgets are laid over the cs ops with a prefix sum (width-8 __shfl_up):
-// node j covers [P_j, P_j + room_j) of "op space", its pieces are the intersections with the op
-// intervals -- the same pieces the sequential loop (:209-255) produces.  Which nodes are kept, their
-// rank among the kept nodes and their predecessor come from a ballot over the group.  The last kept
-// node of a tile is held back (it may be the last kept node of the read, which the IL/OL rules ask
-// about) until the next tile shows a kept node or the record ends.
-//
-// One workgroup takes one locus chunk (gaf.cpp): the counters of the W nodes from the chunk's base and
-// of their out-links live in LDS as plain arrays (one ds_add_u32 per increment, no return value, so
-// nothing waits on it); anything outside goes to memory with a no-return global atomic.  The arrays
-// are flushed with one global atomic per touched counter.
-template <uint32_t W, uint32_t SMAX>
-struct WindowSink {
-  const GraphView& g;
-  uint32_t* cnt;        // LDS: [NC W | IL0 W | OLL W | RC SMAX]
-  uint32_t base, slot_base;
-  __device__ __forceinline__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
-  __device__ __forceinline__ void nc(uint32_t n) const {
-    if (g.ablate & 8u) return;
-    const uint32_t d = n - base;
-    if (d < W) atomicAdd(&cnt[d], 1u); else atomicAdd(&g.nc[n], 1u);
-  }
-  __device__ __forceinline__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
-    const uint32_t d = n - base;
-    if (!(g.ablate & 8u)) {
-      if (d < W) atomicAdd(&cnt[(side == SIDE_IL ? W : 2u * W) + d], times);
-      else atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
-    }
-    if (!(g.ablate & 1u) && (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL))) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
-  }
-  __device__ __forceinline__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
-  __device__ __forceinline__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
-    if (g.ablate & 4u) return;
-    const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
-    for (uint32_t s = lo; s < hi; ++s) {
-      if (g.col[s] == b) {
-        if (g.ablate & 8u) return;
-        const uint32_t d = s - slot_base;
-        if (d < SMAX) atomicAdd(&cnt[3u * W + d], 1u); else atomicAdd(&g.rc[s], 1u);
-        return;
-      }
-    }
-    if (g.ablate & 2u) return;
-    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
-  }
-};
-
-template <uint32_t THREADS, uint32_t W, uint32_t SMAX>
-__global__ __launch_bounds__(THREADS) void augment_main_grp_kernel(GraphView g, BatchView b, uint32_t V, uint64_t A) {
-  constexpr uint32_t G = 8;                        // lanes per record
-  constexpr uint32_t GROUPS = THREADS / G;
-  constexpr uint32_t NCNT = 3u * W + SMAX;
-  __shared__ uint32_t cnt[NCNT];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t gl = lane & (G - 1);              // lane within the group
-  const uint32_t gbase = lane & ~(G - 1);          // first lane of the group within the wave
-  const uint32_t my_group = threadIdx.x / G;
-  for (uint32_t c = blockIdx.x; c < b.n_chunks; c += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) cnt[i] = 0u;
-    const uint32_t base = b.chunk_base[c];
-    const uint32_t slot_base = g.row_ptr[base];
-    const uint32_t rec_lo = b.chunk_lo[c], rec_hi = b.chunk_lo[c + 1];
-    __syncthreads();
-    WindowSink<W, SMAX> sink{g, cnt, base, slot_base};
-    for (uint32_t r0 = rec_lo; r0 < rec_hi; r0 += GROUPS) {
-      const uint32_t rec = r0 + my_group;
-      const bool valid = rec < rec_hi;
-      LineHdr h{0, 0, 0, 0};
-      uint32_t n0 = 0, k = 0, o0 = 0, nops = 0;
-      if (valid) {
-        h = b.hdr[rec];
-        n0 = b.node_off[rec];
-        k = b.node_off[rec + 1] - n0;
-        o0 = b.op_off[rec];
-        nops = b.op_off[rec + 1] - o0;
-      }
-      const bool slow = (h.flags & LINE_SLOW) != 0;
-      const bool fast = valid && !slow;
-      const bool rev = (h.flags & LINE_REV) != 0;
-      // total op length of the record (every lane: the ops are a few words of one cache line)
-      uint64_t T = 0;
-      if (fast) for (uint32_t j = 0; j < nops; ++j) T += b.ops[o0 + j] >> 3;
-      uint64_t carry = 0;          // op-space position where the next tile starts
-      uint32_t kept_before = 0;    // kept nodes of earlier tiles (the held-back one included)
-      bool pend_valid = false;
-      KeptNode pend{};
-      const uint32_t my_tiles = fast ? (k + G - 1) / G : 0u;
-      for (uint32_t t = 0; __any(t < my_tiles); ++t) {
-        const uint32_t i = t * G + gl;
-        const bool has = fast && i < k;
-        const uint32_t node = has ? b.nodes[n0 + i] : 0u;
-        const uint32_t word = has ? g.word[node] : 0u;
-        int64_t room = int64_t(word & LEN_MASK);
-        if (i == 0) room -= h.start;
-        if (i == k - 1) room = room - h.tail + 1;
-        const uint32_t rp = (has && room > 0) ? uint32_t(room) : 0u;
-        // exclusive prefix of the budgets within the group
-        uint32_t x = rp;
-#pragma unroll
-        for (uint32_t d = 1; d < G; d <<= 1) {
-          const uint32_t y = __shfl_up(x, d, G);
-          if (gl >= d) x += y;
-        }
-        const uint64_t P = carry + (x - rp);
-        carry += __shfl(x, int(gbase + G - 1), 64);
-        PieceAcc acc;
-        acc.begin(node, word);
-        if (rp) {
-          if (P >= T) {
-            atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(WALK_OPS_EXHAUSTED));
-          } else {
-            const uint64_t end = min(P + rp, T);
-            uint64_t O = 0;
-            for (uint32_t j = 0; j < nops; ++j) {
-              const uint32_t w = b.ops[o0 + j];
-              const uint64_t e2 = min(O + (w >> 3), end);
-              const uint64_t a2 = max(O, P);
-              if (e2 > a2) acc.add(w & 7u, uint32_t(e2 - a2));
-              O += w >> 3;
-              if (O >= end) break;
-            }
-          }
-        }
-        const bool kept = acc.kept();
-        const uint32_t gmask = uint32_t(__ballot(kept) >> gbase) & 0xFFu;
-        const uint32_t below = gmask & ((1u << gl) - 1u);
-        const uint32_t above = gmask >> (gl + 1u);
-        const uint32_t my_kidx = kept_before + __popc(below);
-        const uint32_t prev_lane = below ? (31u - uint32_t(__clz(int(below)))) : 0u;
-        const uint32_t prev_in_tile = uint32_t(__shfl(int(node), int(gbase + prev_lane), 64));
-        if (kept) {
-          // predecessor among the kept nodes: in this tile, or the one held back from earlier tiles
-          const bool has_prev = below != 0u || pend_valid;
-          const uint32_t prev = below ? prev_in_tile : pend.node;
-          if (below == 0u && pend_valid) flush_kept(pend, kept_before - 1u, false, h, sink);   // the held-back node is not the last
-          if (above != 0u) flush_kept(acc.kn, my_kidx, false, h, sink);                       // not the last of its tile
-          if (has_prev) {
-            const uint64_t ord = event_order(h.line_id, my_kidx - 1u, 0);
-            if (rev) sink.edge(node, prev, ord); else sink.edge(prev, node, ord);
-          }
-        }
-        if (gmask) {
-          // the last kept node of this tile becomes the held-back one (every lane of the group keeps a copy)
-          const int src = int(gbase + 31u - uint32_t(__clz(int(gmask))));
-          pend.node = uint32_t(__shfl(int(acc.kn.node), src, 64));
-          pend.word = uint32_t(__shfl(int(acc.kn.word), src, 64));
-          pend.entries = uint32_t(__shfl(int(acc.kn.entries), src, 64));
-          pend.first_op = uint32_t(__shfl(int(acc.kn.first_op), src, 64));
-          pend.first_len = uint32_t(__shfl(int(acc.kn.first_len), src, 64));
-          pend.last_op = uint32_t(__shfl(int(acc.kn.last_op), src, 64));
-          pend.last_len = uint32_t(__shfl(int(acc.kn.last_len), src, 64));
-          pend.plain = uint32_t(__shfl(int(acc.kn.plain), src, 64));
-          pend_valid = true;
-          kept_before += __popc(gmask);
-        }
-      }
-      if (pend_valid && gl == 0u) flush_kept(pend, kept_before - 1u, true, h, sink);
-      if (valid && slow && gl == 0u) {
-        // zero-length or '~' ops: the scalar walk keeps the reference's corner cases in one place
-        const int st = walk_line(h, b.nodes + n0, k, b.ops + o0, nops, sink);
-        if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
-      }
-    }
-    __syncthreads();
-    // flush: one global atomic per touched counter
-    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) {
-      const uint32_t v = cnt[i];
-      if (!v) continue;
-      if (i < 3u * W) {
-        const uint32_t which = i / W, d = i - which * W;
-        atomicAdd(&g.nc[size_t(which) * V + base + d], v);     // NC, IL0, OLL are V apart in one allocation
-      } else {
-        atomicAdd(&g.rc[slot_base + (i - 3u * W)], v);
-      }
-    }
-    __syncthreads();
-  }
-}
-
-// ---- main kernel, third form ------------------------------------------------------------------------
+// ---- aggregating main kernel ------------------------------------------------------------------------
 // Thread per record over fixed blocks of CHUNK bucketed records, workgroup-private aggregation in LDS:
 //   node table   key = node            -> {NC, IL[0], OL[len]} increments (ONE probe per kept node)
 //   link table   key = adjacency slot  -> RC increments
@@ -666,40 +407,6 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   }
 }
 
-// thread-per-record walk over a locus chunk with the direct LDS counter windows
-template <uint32_t THREADS, uint32_t W, uint32_t SMAX>
-__global__ __launch_bounds__(THREADS) void augment_main_win_kernel(GraphView g, BatchView b, uint32_t V) {
-  constexpr uint32_t NCNT = 3u * W + SMAX;
-  __shared__ uint32_t cnt[NCNT];
-  for (uint32_t c = blockIdx.x; c < b.n_chunks; c += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) cnt[i] = 0u;
-    const uint32_t base = b.chunk_base[c];
-    const uint32_t slot_base = g.row_ptr[base];
-    const uint32_t rec_lo = b.chunk_lo[c], rec_hi = b.chunk_lo[c + 1];
-    __syncthreads();
-    WindowSink<W, SMAX> sink{g, cnt, base, slot_base};
-    for (uint32_t i = rec_lo + threadIdx.x; i < rec_hi; i += THREADS) {
-      const LineHdr h = b.hdr[i];
-      const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
-      const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
-      const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-      if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < NCNT; i += THREADS) {
-      const uint32_t v = cnt[i];
-      if (!v) continue;
-      if (i < 3u * W) {
-        const uint32_t which = i / W, d = i - which * W;
-        atomicAdd(&g.nc[size_t(which) * V + base + d], v);
-      } else {
-        atomicAdd(&g.rc[slot_base + (i - 3u * W)], v);
-      }
-    }
-    __syncthreads();
-  }
-}
-
 __global__ void clear_flags_kernel(uint32_t* word, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) word[i] &= LEN_MASK;
 }
@@ -760,8 +467,7 @@ struct DeviceGraph {
 struct DeviceBatch {
   LineHdr* hdr = nullptr;
   uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
-  uint32_t *chunk_lo = nullptr, *chunk_base = nullptr;
-  uint32_t n = 0, n_del = 0, n_chunks = 0;
+  uint32_t n = 0, n_del = 0;
   uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
   std::vector<uint32_t> first_line_ids;   // unused placeholder for error reports
 };
@@ -780,8 +486,7 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
 
 void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   if (!b) return;
-  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx,
-                  (void*)b->chunk_lo, (void*)b->chunk_base})
+  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx})
     if (p) (void)hipFree(p);
   delete b;
 }
@@ -900,12 +605,6 @@ DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
   p->nodes = to_device(b.nodes, d.stream);
   p->ops = to_device(b.ops, d.stream);
   p->del_idx = to_device(del, d.stream);
-  if (b.chunk_lo.size() == b.chunk_base.size() + 1 && !b.chunk_base.empty()) {
-    if (b.chunk_lo.back() != b.size()) throw Error("InternalError", "chunk table does not cover the batch");
-    p->n_chunks = uint32_t(b.chunk_base.size());
-    p->chunk_lo = to_device(b.chunk_lo, d.stream);
-    p->chunk_base = to_device(b.chunk_base, d.stream);
-  }
   HIP_OK(hipStreamSynchronize(d.stream));
   return p;
 }
@@ -921,8 +620,7 @@ uint64_t batch_alg_bytes(const DeviceBatch& db) {
 static BatchView batch_view(const DeviceBatch& b) {
   BatchView v{};
   v.hdr = b.hdr; v.node_off = b.node_off; v.op_off = b.op_off; v.nodes = b.nodes; v.ops = b.ops; v.del_idx = b.del_idx;
-  v.chunk_lo = b.chunk_lo; v.chunk_base = b.chunk_base;
-  v.n = b.n; v.n_del = b.n_del; v.n_chunks = b.n_chunks;
+  v.n = b.n; v.n_del = b.n_del;
   return v;
 }
 
@@ -968,55 +666,24 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   if (b.n) {
+    // PANTAS_MAIN_KERNEL: 0 = direct global atomics (reference point for A/B), otherwise the aggregating kernel
+    // in one of a few occupancy / table-size configurations (default 18; profiles/README.md has the A/B)
     static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 18;
-    const bool keys_fit = 3ull * d.V + d.A < 0xFFFFFFFFull;
-    if (variant >= 8 && variant < 40) {
+    if (variant == 0) {
+      const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
+      hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
+    } else {
 #define PANTAS_AGG(ID, T, CH, LN, LS, LF, MW) \
       case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
       switch (variant) {
         PANTAS_AGG(8, 1024, 4096, 12, 12, 9, 1)
-        PANTAS_AGG(11, 256, 1024, 10, 10, 7, 1)
-        PANTAS_AGG(12, 256, 2048, 10, 10, 7, 1)
-        PANTAS_AGG(14, 512, 2048, 10, 10, 7, 1)
-        PANTAS_AGG(19, 256, 1024, 10, 10, 7, 8)
-        PANTAS_AGG(20, 256, 1024, 9, 9, 7, 8)
-        PANTAS_AGG(21, 512, 2048, 11, 11, 7, 6)
-        PANTAS_AGG(22, 512, 2048, 10, 9, 7, 8)
-        PANTAS_AGG(23, 512, 4096, 10, 9, 7, 8)
-        PANTAS_AGG(24, 512, 1024, 10, 9, 7, 8)
-        PANTAS_AGG(25, 1024, 4096, 11, 9, 7, 8)
-        PANTAS_AGG(26, 256, 1024, 10, 9, 7, 8)
-        PANTAS_AGG(27, 512, 2048, 9, 9, 7, 8)
         PANTAS_AGG(9, 512, 2048, 11, 11, 7, 1)
+        PANTAS_AGG(20, 256, 1024, 9, 9, 7, 8)
+        PANTAS_AGG(22, 512, 2048, 10, 9, 7, 8)
         default:
         PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
       }
 #undef PANTAS_AGG
-    } else if (variant >= 4 && b.n_chunks) {
-      const uint32_t blocks = std::min<uint32_t>(b.n_chunks, 1u << 20);
-      if (variant == 6)
-        hipLaunchKernelGGL((augment_main_win_kernel<512, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V);
-      else if (variant == 7)
-        hipLaunchKernelGGL((augment_main_win_kernel<1024, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(1024), 0, d.stream, g, bv, d.V);
-      else if (variant == 5)
-        hipLaunchKernelGGL((augment_main_grp_kernel<256, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(256), 0, d.stream, g, bv, d.V, d.A);
-      else
-        hipLaunchKernelGGL((augment_main_grp_kernel<512, CHUNK_WINDOW, CHUNK_WINDOW + CHUNK_WINDOW / 4>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V, d.A);
-    } else if (variant == 0 || !keys_fit) {
-      const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
-      hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
-    } else if (variant == 2) {
-      constexpr uint32_t CH = 8192;
-      const uint32_t blocks = (b.n + CH - 1) / CH;
-      hipLaunchKernelGGL((augment_main_lds_kernel<1024, 14, CH>), dim3(blocks), dim3(1024), 0, d.stream, g, bv, d.V);
-    } else if (variant == 1) {
-      constexpr uint32_t CH = 2048;
-      const uint32_t blocks = (b.n + CH - 1) / CH;
-      hipLaunchKernelGGL((augment_main_lds_kernel<512, 13, CH>), dim3(blocks), dim3(512), 0, d.stream, g, bv, d.V);
-    } else {
-      constexpr uint32_t CH = 4096;
-      const uint32_t blocks = (b.n + CH - 1) / CH;
-      hipLaunchKernelGGL((augment_main_lds_kernel<1024, 14, CH>), dim3(blocks), dim3(1024), 0, d.stream, g, bv, d.V);
     }
     HIP_OK(hipGetLastError());
   }

@@ -642,10 +642,25 @@ struct Renderer {
 
 }  // namespace
 
+static void render_range(const Graph& g, const CallTables& t, const EventRec* recs, size_t lo, size_t hi, const uint32_t* side,
+                         const TaskOut* tasks, const uint32_t* paths, std::string& csv, std::string& err);
+
 void render_events(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
                    const TaskOut* tasks, const uint32_t* paths, std::string& csv, std::string& err) {
+  const unsigned T = n < 100000 ? 1 : hw_threads();
+  if (T == 1) { render_range(g, t, recs, 0, n, side, tasks, paths, csv, err); return; }
+  std::vector<std::string> parts(T), errs(T);
+  parallel_chunks(n, T, [&](unsigned c, size_t lo, size_t hi) { render_range(g, t, recs, lo, hi, side, tasks, paths, parts[c], errs[c]); });
+  size_t total = csv.size();
+  for (auto& s2 : parts) total += s2.size();
+  csv.reserve(total);
+  for (unsigned c = 0; c < T; ++c) { csv += parts[c]; std::string().swap(parts[c]); err += errs[c]; }
+}
+
+static void render_range(const Graph& g, const CallTables& t, const EventRec* recs, size_t lo, size_t hi, const uint32_t* side,
+                         const TaskOut* tasks, const uint32_t* paths, std::string& csv, std::string& err) {
   Renderer R{g, t, g.text.data, csv};
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = lo; i < hi; ++i) {
     const EventRec& r = recs[i];
     const uint32_t* p = side + r.side_off;
     std::string& o = csv;

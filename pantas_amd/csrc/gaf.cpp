@@ -316,15 +316,7 @@ void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, un
 void bucket_by_locus(GafBatch& b, unsigned threads) {
   PhaseTimer pt("bucket_by_locus");
   const size_t n = b.size();
-  if (n < 2) {
-    b.chunk_lo.assign(1, 0u);
-    b.chunk_base.clear();
-    if (n == 1) {
-      b.chunk_lo.push_back(1u);
-      b.chunk_base.push_back(b.node_off[1] > b.node_off[0] ? std::min(b.nodes[b.node_off[0]], b.nodes[b.node_off[1] - 1]) : 0u);
-    }
-    return;
-  }
+  if (n < 2) return;
   if (threads == 0) threads = hw_threads();
   std::vector<uint32_t> key(n), idx(n);
   parallel_chunks(n, n < (1u << 16) ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
@@ -357,13 +349,8 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
         for (size_t i = a; i < e; ++i) idx[i] = tmp[i - a].second;
       }
     });
-    // keys no longer match idx order inside a block; the chunk table below only needs block-level order
-    for (size_t i = 0; i < n; ++i) {
-      const uint32_t s = idx[i];
-      key[i] = b.node_off[s + 1] > b.node_off[s] ? std::min(b.nodes[b.node_off[s]], b.nodes[b.node_off[s + 1] - 1]) : 0u;
-    }
   }
-  pt.lap("partition blocks + rekey");
+  pt.lap("order blocks");
   std::vector<LineHdr> hdr(n);
   std::vector<uint32_t> node_off(n + 1), op_off(n + 1), nodes(b.nodes.size()), ops(b.ops.size());
   // sizes, then exclusive offsets (sequential scan: 2 adds per record), then a parallel gather
@@ -384,25 +371,6 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
     }
   });
   pt.lap("offsets + gather");
-  // chunk table over the sorted keys
-  b.chunk_lo.clear();
-  b.chunk_base.clear();
-  size_t i = 0;
-  while (i < n) {
-    uint32_t lo = key[i], hi = key[i];
-    size_t j = i + 1;
-    while (j < n && j - i < CHUNK_MAX_RECORDS) {
-      const uint32_t lo2 = std::min(lo, key[j]), hi2 = std::max(hi, key[j]);
-      if (hi2 - lo2 >= CHUNK_KEY_SPAN) break;
-      lo = lo2;
-      hi = hi2;
-      ++j;
-    }
-    b.chunk_lo.push_back(uint32_t(i));
-    b.chunk_base.push_back(lo);
-    i = j;
-  }
-  b.chunk_lo.push_back(uint32_t(n));
   b.hdr.swap(hdr);
   b.node_off.swap(node_off);
   b.op_off.swap(op_off);

@@ -15,20 +15,12 @@
 
 namespace pantas {
 
-// Locus chunks (one workgroup each in the main augment kernel): consecutive bucketed records whose
-// sort keys (lowest end node of the path) lie within CHUNK_KEY_SPAN nodes; the kernel keeps the
-// counters of the CHUNK_WINDOW nodes from the chunk's base in LDS.
-constexpr uint32_t CHUNK_WINDOW = 4096;
-constexpr uint32_t CHUNK_KEY_SPAN = 2048;
-constexpr uint32_t CHUNK_MAX_RECORDS = 4096;
-
 struct GafBatch {
   uint64_t lines_total = 0;   // text lines seen
   uint64_t rejected = 0;      // mapq below threshold (reference's "Rejected alignments")
   uint64_t skipped = 0;       // unmapped ('*' path) or dv > 0.1
   std::vector<LineHdr> hdr;
   std::vector<uint32_t> node_off, op_off, nodes, ops;
-  std::vector<uint32_t> chunk_lo, chunk_base;   // after bucket_by_locus: chunk c = records [chunk_lo[c], chunk_lo[c+1]), window base node
   uint64_t del_lines = 0;     // records with a '-' op
   uint64_t del_nodes = 0;     // sum of path lengths over those records
   uint64_t bytes = 0;         // text bytes tokenised
