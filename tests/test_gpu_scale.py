@@ -1,0 +1,127 @@
+"""Parity at BASELINE.json sizes through size-independent properties (the oracle is a Python port and would
+take minutes here).  Synthetic S2-scale workload (Drosophila whole genome: ~6 M segments, 2 M GAF lines)
+through the real parsers and kernels."""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+S2 = dict(seed=7, n_genes=18000, n_lines=2_000_000, base_id=10**7, intron_long_max=320, n_chrom=6, zipf_a=1.0)
+
+
+@pytest.fixture(scope="module")
+def workload():
+    from pantas_amd.engine import Graph, Synth
+    syn = Synth(**S2)
+    g = Graph(text=syn.gfa).to_device(0)
+    return syn, g
+
+
+def counters_after(g, batches, launches=1):
+    g.augment_reset()
+    for b in batches:
+        for _ in range(launches):
+            g.launch(b)
+    g.finish()
+    return [x.astype(np.int64) for x in g.read_counters()], g.sparse_export()
+
+
+def test_linearity_and_shard_additivity(workload):
+    """counts(A u B) == counts(A) + counts(B); k launches == k x one launch; sparse keys merge the same way."""
+    syn, g = workload
+    addr, size = syn.gaf
+    raw = (np.ctypeslib.as_array((__import__("ctypes").c_char * size).from_address(addr))).view(np.uint8)
+    half = int(np.flatnonzero(raw[size // 2:] == 10)[0]) + size // 2 + 1
+    lines_a = int((raw[:half] == 10).sum())
+    g.augment_reset()
+    whole = g.load_gaf_mem((addr, size))
+    a = g.load_gaf_mem((addr, half))
+    b = g.load_gaf_mem((addr + half, size - half), first_line=lines_a)
+    assert whole.stats.lines == a.stats.lines + b.stats.lines == S2["n_lines"]
+    cw, sw = counters_after(g, [whole])
+    ca, _ = counters_after(g, [a])
+    cb, _ = counters_after(g, [b])
+    cab, sab = counters_after(g, [a, b])
+    for w, x, y, z in zip(cw, ca, cb, cab):
+        assert (w == x + y).all() and (w == z).all()
+    assert (sw[np.lexsort(sw.T[::-1])] == sab[np.lexsort(sab.T[::-1])]).all()      # same keys, counts, first-seen
+    c3, _ = counters_after(g, [whole], launches=3)
+    for w, t in zip(cw, c3):
+        assert (3 * w == t).all()
+    # every walked record adds exactly one NC per kept node: total NC >= records, <= path nodes
+    assert whole.stats.records <= cw[0].sum() <= whole.stats.path_nodes
+    # IL[0] and OL[len] only arise between two kept nodes of a read
+    assert cw[1].sum() <= cw[0].sum() and cw[2].sum() <= cw[0].sum()
+    # every link increment has a node increment on each side
+    assert cw[3].sum() + int(sw[sw[:, 3] == 1][:, 1].sum()) <= cw[0].sum()
+
+
+def _augmented_sha(env):
+    code = (
+        "import sys, hashlib, os\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from pantas_amd.engine import Graph, Synth\n"
+        f"syn = Synth(**{S2!r})\n"
+        "g = Graph(text=syn.gfa).to_device(0)\n"
+        "g.augment_reset(); b = g.load_gaf_mem(syn.gaf); g.launch(b); g.finish()\n"
+        "r, w = os.pipe()\n"
+        "import threading\n"
+        "h = hashlib.sha256(); n = [0]\n"
+        "def rd():\n"
+        "    with os.fdopen(r, 'rb') as f:\n"
+        "        while True:\n"
+        "            c = f.read(1 << 22)\n"
+        "            if not c: break\n"
+        "            h.update(c); n[0] += len(c)\n"
+        "t = threading.Thread(target=rd); t.start()\n"
+        "g.write_gfa(w); os.close(w); t.join()\n"
+        "print(h.hexdigest(), n[0])\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, **env})
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.split()
+
+
+def test_kernel_variants_and_record_order_give_identical_gfa():
+    """The augmented GFA (sha256 of ~600 MB) must not depend on which main kernel ran (direct global atomics vs
+    LDS aggregation) nor on whether the records were bucketed by locus."""
+    base = _augmented_sha({})
+    assert int(base[1]) > 5e8
+    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0"}) == base
+    assert _augmented_sha({"PANTAS_NO_BUCKET": "1"}) == base
+    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0", "PANTAS_NO_BUCKET": "1", "PANTAS_THREADS": "3"}) == base
+
+
+def test_call_at_scale_is_order_independent(workload):
+    """call on the fused result: two runs byte-identical; every row well-formed; row counts by type add up."""
+    syn, g = workload
+    g.augment_reset()
+    b = g.load_gaf_mem(syn.gaf)
+    g.launch(b)
+    g.finish()
+    g.call_prepare_fused(text=syn.gtf)
+    outs = []
+    for _ in range(2):
+        with tempfile.TemporaryFile() as f:
+            st = g.call(f.fileno(), -1, rca=3, novel=True)
+            f.seek(0)
+            outs.append(f.read())
+    assert outs[0] == outs[1]
+    rows = outs[0].decode().splitlines()
+    assert st.events == len(rows) - 1 and st.events > 10000
+    kinds = {}
+    for r in rows[1:]:
+        c = r.split(",")
+        assert len(c) == 14
+        kinds[(c[0], c[1])] = kinds.get((c[0], c[1]), 0) + 1
+        assert c[1] in ("annotated", "novel") and c[4] in "+-"
+    for k in [("ES", "annotated"), ("IR", "annotated"), ("A3", "annotated"), ("A5", "annotated"), ("ES", "novel"),
+              ("CE", "novel"), ("IR", "novel")]:
+        assert kinds.get(k, 0) > 0, k
