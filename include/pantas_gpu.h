@@ -89,7 +89,10 @@ int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint
 int pantas_gaf_split(const char* gaf_path, int rank, int world, uint64_t* begin, uint64_t* end,
                      uint64_t* lines_before);
 void pantas_batch_free(pantas_batch* b);
-/* :209-363 on the GPU: both kernels over a resident batch, accumulating into g's counters */
+/* :209-363 on the GPU: both kernels over a resident batch, accumulating into g's counters.
+ * A run over SEVERAL batches must use the staged form below: launch_rare for every batch, then launch_main
+ * for every batch (a late rare-key kernel cannot flag nodes for batches already walked; PANTAS_E_ARG).
+ * Relaunching a batch that was already launched in this run is allowed (benchmarks). */
 int pantas_augment_launch(pantas_graph* g, pantas_batch* b, pantas_launch_stats* out);
 /* the two kernels separately, for runs sharded over several GPUs: after the rare-key kernel every
  * rank exports the node flags it set ((node << 1) | side, uint32), the ranks all-gather them, import

@@ -450,6 +450,9 @@ struct DeviceGraph {
   uint32_t* counters = nullptr;   // [NC V | IL0 V | OLL V | RC A]
   uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
   Table hist, novel;
+  // multi-batch protocol: every batch's rare-key kernel must run before the first main kernel of the run
+  std::vector<const void*> rare_done;
+  bool main_started = false;
   uint64_t novel_boost = 1;       // grown after a TableOverflow("novel") retry
   uint64_t imported_flags = 0;    // node flags received from other ranks this run
   uint64_t reserved_hist = 0;     // caller's bound on distinct IL/OL keys (sharded runs)
@@ -561,6 +564,8 @@ void reset_counters(DeviceGraph& d) {
   HIP_OK(hipStreamSynchronize(d.stream));
   d.imported_flags = 0;
   d.reserved_hist = 0;
+  d.rare_done.clear();
+  d.main_started = false;
 }
 
 template <class T>
@@ -643,6 +648,11 @@ void reserve_hist(DeviceGraph& d, uint64_t keys) { d.reserved_hist = keys; }
 
 float launch_rare(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
+  const bool seen = std::find(d.rare_done.begin(), d.rare_done.end(), static_cast<const void*>(&b)) != d.rare_done.end();
+  if (d.main_started && !seen)
+    throw Error("ProtocolError", "rare-key kernel of a new batch after a main kernel of the same run: the node flags it sets "
+                                 "come too late for the batches already walked (launch_rare for every batch first)");
+  if (!seen) d.rare_done.push_back(&b);
   ensure_tables(d, b);
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
@@ -661,6 +671,9 @@ float launch_rare(DeviceGraph& d, DeviceBatch& b) {
 
 float launch_main(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
+  if (std::find(d.rare_done.begin(), d.rare_done.end(), static_cast<const void*>(&b)) == d.rare_done.end())
+    throw Error("ProtocolError", "main kernel of a batch whose rare-key kernel has not run");
+  d.main_started = true;
   ensure_tables(d, b);
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);

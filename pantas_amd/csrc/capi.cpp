@@ -47,6 +47,7 @@ int fail(const Error& e) {
   if (e.kind == "HipError") return PANTAS_E_HIP;
   if (e.kind == "OSError" || e.kind == "FileNotFoundError") return PANTAS_E_IO;
   if (e.kind == "InternalError" || e.kind == "TableOverflow") return PANTAS_E_INTERNAL;
+  if (e.kind == "ProtocolError") return PANTAS_E_ARG;
   if (e.kind == "ArgumentError") return PANTAS_E_ARG;
   return PANTAS_E_REFERENCE;
 }

@@ -27,9 +27,11 @@ def workload():
 
 def counters_after(g, batches, launches=1):
     g.augment_reset()
+    for b in batches:              # staged protocol: every rare-key kernel before the first main kernel
+        g.launch_rare(b)
     for b in batches:
         for _ in range(launches):
-            g.launch(b)
+            g.launch_main(b)
     g.finish()
     return [x.astype(np.int64) for x in g.read_counters()], g.sparse_export()
 
@@ -53,6 +55,11 @@ def test_linearity_and_shard_additivity(workload):
     for w, x, y, z in zip(cw, ca, cb, cab):
         assert (w == x + y).all() and (w == z).all()
     assert (sw[np.lexsort(sw.T[::-1])] == sab[np.lexsort(sab.T[::-1])]).all()      # same keys, counts, first-seen
+    from pantas_amd.engine import PantasError
+    g.augment_reset()
+    g.launch(a)
+    with pytest.raises(PantasError):      # a new batch's rare-key kernel after a main kernel is refused
+        g.launch(b)
     c3, _ = counters_after(g, [whole], launches=3)
     for w, t in zip(cw, c3):
         assert (3 * w == t).all()
