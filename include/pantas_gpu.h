@@ -132,6 +132,8 @@ typedef struct {
   int32_t novel;          /* --novel */
   int32_t no_annotated;   /* --no-annotated */
   const char* junction;   /* --junction "u-v" or NULL */
+  uint32_t shard_rank;    /* multi-GPU: evaluate every shard_world-th junction / novel link, starting at */
+  uint32_t shard_world;   /* shard_rank (0 or 1 = everything); rows of all shards together = the full CSV */
 } pantas_call_opts;
 
 typedef struct {

@@ -43,7 +43,8 @@ class LaunchStats(C.Structure):
 
 class CallOpts(C.Structure):
     _fields_ = [("rca", C.c_int32), ("isw", C.c_int32), ("minintronsize", C.c_int32), ("events", C.c_uint32),
-                ("novel", C.c_int32), ("no_annotated", C.c_int32), ("junction", C.c_char_p)]
+                ("novel", C.c_int32), ("no_annotated", C.c_int32), ("junction", C.c_char_p),
+                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32)]
 
 
 class CallStats(C.Structure):

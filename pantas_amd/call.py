@@ -14,6 +14,9 @@ import sys
 
 from .engine import Graph, PantasError
 
+CSV_HEADER = ("event_type,annotated/novel,chrom,gene,strand,transcripts1,transcripts2,transcripts3,"
+              "nodes1,coverage1,nodes2,coverage2,nodes3,coverage3")      # scripts/call.py:218-234
+
 
 def build_parser() -> argparse.ArgumentParser:
     # same options, defaults and help as the reference parser (scripts/call.py:1111-1174)

@@ -572,6 +572,19 @@ void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::
     for (size_t j = 0; j < t.junctions.size(); ++j)
       if (matches(t.junctions[j])) { around.push_back(t.junctions[j]); around_jidx.push_back(uint32_t(j)); }
   }
+  if (o.shard_world > 1) {
+    // junctions and novel links are evaluated independently of each other: deal them round-robin
+    auto keep = [&](std::vector<uint32_t>& v, std::vector<uint32_t>* w) {
+      size_t k = 0;
+      for (size_t i = 0; i < v.size(); ++i)
+        if (i % o.shard_world == o.shard_rank) { v[k] = v[i]; if (w) (*w)[k] = (*w)[i]; ++k; }
+      v.resize(k);
+      if (w) w->resize(k);
+    };
+    keep(annotated, nullptr);
+    keep(novel, nullptr);
+    keep(around, &around_jidx);
+  }
 }
 
 void cassette_items(const CallTables& t, const std::vector<uint32_t>& around, std::vector<uint32_t>& junction,

@@ -17,6 +17,7 @@ struct CallOptions {
   bool no_annotated = false;   // --no-annotated
   bool has_junction = false;   // --junction given
   std::string junction;        // "u-v"
+  uint32_t shard_rank = 0, shard_world = 1;   // multi-GPU: this process evaluates every world-th junction / novel link
 };
 
 struct StrRef { uint64_t off; uint32_t len; };

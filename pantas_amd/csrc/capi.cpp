@@ -453,6 +453,11 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     o.novel = opts->novel != 0;
     o.no_annotated = opts->no_annotated != 0;
     if (opts->junction) { o.has_junction = true; o.junction = opts->junction; }
+    if (opts->shard_world > 1) {
+      need(opts->shard_rank < opts->shard_world, "shard_rank out of range");
+      o.shard_rank = opts->shard_rank;
+      o.shard_world = opts->shard_world;
+    }
     CallOutput co;
     CallTimes times;
     run_call(*g->call_dev, *g->g, *g->call_tables, o, co, times);

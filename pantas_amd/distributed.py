@@ -118,12 +118,66 @@ def augment_sharded(backend, gaf_path: str, thr: int, out_fd: int, dist, device=
     return dict(lines=lines, rejected=rejected)
 
 
+def call_sharded(run_shard, out, dist) -> int:
+    """Sharded `pantas call`: junctions and novel links are independent given the graph and
+    the coverage, so rank r evaluates every world-th one -- ``run_shard(rank, world)`` returns that shard's
+    CSV text WITHOUT the header -- and rank 0 concatenates the shards behind one header.  No data-path
+    collective; the row multiset equals a single-process run."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    body = run_shard(rank, world)
+    parts = [None] * world
+    dist.all_gather_object(parts, body)
+    n = 0
+    if rank == 0:
+        from .call import CSV_HEADER
+        out.write(CSV_HEADER + "\n")
+        for p in parts:
+            out.write(p)
+            n += p.count("\n")
+        out.flush()
+    return n
+
+
+def call_main(argv=None) -> int:
+    """torchrun entry:  python -m torch.distributed.run --nproc-per-node N -m pantas_amd.distributed call [call options] GFA GTF"""
+    import sys
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from .call import build_parser
+    from .engine import Graph
+    args = build_parser().parse_args(argv)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    sys.stdout.flush()
+    data_fd = os.dup(1)
+    os.dup2(2, 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    g = Graph(args.GFA)
+    g.call_prepare(args.GTF, local)
+
+    def run_shard(rank, world):
+        with tempfile.TemporaryFile() as f:
+            g.call(f.fileno(), 2, rca=args.rca, novel=args.novel, no_annotated=args.annotated, events=args.events,
+                   isw=args.isw, minintronsize=args.minintronsize, junction=args.junction, shard=(rank, world))
+            f.seek(0)
+            text = f.read().decode()
+        return text.split("\n", 1)[1] if "\n" in text else ""
+
+    with os.fdopen(data_fd, "w") as out:
+        call_sharded(run_shard, out, dist)
+    dist.destroy_process_group()
+    return 0
+
+
 def main(argv=None) -> int:
     """torchrun entry:  python -m torch.distributed.run --nproc-per-node N -m pantas_amd.distributed GAF GFA [thr]"""
     import sys
     import torch
     import torch.distributed as dist
     argv = sys.argv[1:] if argv is None else argv
+    if argv and argv[0] == "call":
+        return call_main(argv[1:])
     gaf, gfa = argv[0], argv[1]
     thr = int(argv[2]) if len(argv) > 2 else 20
     local = int(os.environ.get("LOCAL_RANK", "0"))

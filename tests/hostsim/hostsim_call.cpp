@@ -69,6 +69,7 @@ static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, Out&
 
 int main(int argc, char** argv) {
   CallOptions o;
+  bool no_header = false;
   std::vector<const char*> pos;
   try {
     for (int i = 1; i < argc; ++i) {
@@ -79,6 +80,8 @@ int main(int argc, char** argv) {
       else if (a == "--novel") o.novel = true;
       else if (a == "--no-annotated") o.no_annotated = true;
       else if (a == "--junction") { o.has_junction = true; o.junction = argv[++i]; }
+      else if (a == "--shard") { o.shard_rank = uint32_t(atoi(argv[++i])); o.shard_world = uint32_t(atoi(argv[++i])); }
+      else if (a == "--no-header") no_header = true;
       else if (a == "--events") {
         o.events = 0;
         while (i + 1 < argc && argv[i + 1][0] != '-' && (std::string(argv[i + 1]) == "ES" || std::string(argv[i + 1]) == "SS" || std::string(argv[i + 1]) == "IR")) {
@@ -98,7 +101,7 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> ann, nov, around, around_j;
     pass_lists(*g, t, o, ann, nov, around, around_j);
     Out out;
-    printf("%s\n", CALL_CSV_HEADER);
+    if (!no_header) printf("%s\n", CALL_CSV_HEADER);
     run_pass(c, ann, out, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { annotated_junction(c, s, e, f); });
     run_pass(c, nov, out, [](const CallView& c, uint32_t s, uint32_t, auto& e, Fault& f) { novel_link(c, s, e, f); });
     run_pass(c, around, out, [&](const CallView& c, uint32_t s, uint32_t i, auto& e, Fault& f) { novel_around(c, s, around_j[i], e, f); });

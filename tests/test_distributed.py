@@ -14,6 +14,13 @@ import pytest
 
 from conftest import GOLDEN, ROOT
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 BUILD = os.path.join(ROOT, "build", "hostsim")
 CSRC = os.path.join(ROOT, "pantas_amd", "csrc")
 
@@ -102,7 +109,7 @@ def test_sharded_augment_gloo(hostsim_lib, tmp_path, case, world):
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER)
     out = str(tmp_path / "out.gfa")
-    port = 29500 + (os.getpid() + world * 7 + len(case)) % 2000
+    port = free_port()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker), ROOT, hostsim_lib,
                         f"{d}/in.gfa", f"{d}/in.gaf", out], capture_output=True, text=True, timeout=300,
@@ -128,3 +135,50 @@ def test_gaf_split_covers_file_once():
             lines += text[b.value:e.value].count(b"\n")
             pos = e.value
         assert pos == size
+
+
+CALL_WORKER = r'''
+import io, os, subprocess, sys
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pantas_amd.distributed import call_sharded
+exe, gfa, gtf, out = sys.argv[2:6]
+flags = sys.argv[6:]
+dist.init_process_group(backend="gloo")
+
+def run_shard(rank, world):      # the CPU harness stands in for the call kernels
+    r = subprocess.run([exe, *flags, "--shard", str(rank), str(world), "--no-header", gfa, gtf], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+buf = io.StringIO()
+call_sharded(run_shard, buf, dist)
+if dist.get_rank() == 0:
+    open(out, "w").write(buf.getvalue())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("case,world", [("synth_a", 2), ("synth_b", 3)])
+def test_sharded_call_gloo(tmp_path, case, world):
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_golden import check_rows
+    import call_oracle
+    exe = os.path.join(BUILD, "hostsim_call")
+    if True:      # always rebuild: the binary may predate the --shard option
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-I", CSRC, "-o", exe, os.path.join(ROOT, "tests/hostsim/hostsim_call.cpp"),
+                               os.path.join(CSRC, "graph.cpp"), os.path.join(CSRC, "common.cpp"), os.path.join(CSRC, "call_host.cpp"), "-lpthread"])
+    d = os.path.join(GOLDEN, case)
+    worker = tmp_path / "worker.py"
+    worker.write_text(CALL_WORKER)
+    gc = [c for c in json.load(open(f"{d}/expected.json"))["calls"] if "--novel" in c["flags"]][0]
+    out = str(tmp_path / "events.csv")
+    port = free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker), ROOT, exe,
+                        f"{d}/expected.aug.gfa", f"{d}/in.gtf", out, *gc["flags"]], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = open(out).read().splitlines()
+    assert rows[0] == call_oracle.HEADER
+    check_rows(rows[1:], gc)

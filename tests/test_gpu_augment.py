@@ -102,7 +102,10 @@ def test_sharded_driver_nccl_single_rank(tmp_path):
     Exercises the zero-copy tensor view of the counters, the collectives and the rank-0 writer."""
     d = os.path.join(GOLDEN, "synth_b")
     out = tmp_path / "out.gfa"
-    port = 29600 + os.getpid() % 1000
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     with open(out, "wb") as f:
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
                             "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pantas_amd.distributed",
