@@ -132,3 +132,24 @@ def test_intronic_search_beyond_local_frontier(tmp_path, fan):
     flags = ["--novel", "--rca", "0"]
     want = call_oracle.call(pre + ".gfa", pre + ".gtf", None, **_flags_to_opts(flags))
     assert sorted(engine_call(pre + ".gfa", pre + ".gtf", flags)) == sorted(want)
+
+
+def test_sharded_call_driver_nccl_single_rank(tmp_path):
+    """`python -m pantas_amd.distributed call ...` with the real library over the RCCL backend (one rank here)."""
+    import socket
+    d = os.path.join(GOLDEN, "synth_a")
+    flags = ["--rca", "3", "--novel", "--minintronsize", "25"]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    out = tmp_path / "events.csv"
+    with open(out, "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pantas_amd.distributed",
+                            "call", *flags, f"{d}/expected.aug.gfa", f"{d}/in.gtf"], stdout=f, stderr=subprocess.PIPE,
+                           text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = open(out).read().splitlines()
+    assert rows[0] == call_oracle.HEADER
+    gc = [c for c in json.load(open(f"{d}/expected.json"))["calls"] if c["flags"] == flags][0]
+    check_rows(rows[1:], gc)
