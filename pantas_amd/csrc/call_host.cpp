@@ -356,32 +356,36 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   t.lflags.assign(A, 0);
   t.rc.assign(A, 0);
   std::vector<uint32_t> attr_slot(A);
-  for (uint32_t u = 0; u < V; ++u) {
-    const uint32_t b = t.row_ptr[u], e = t.row_ptr[u + 1];
-    for (uint32_t s = b; s < e; ++s) {
-      uint32_t first = s;
-      for (uint32_t q = b; q < s; ++q) if (t.col[q] == t.col[s]) { first = q; break; }
-      t.first_slot[s] = first;
-      attr_slot[first] = s;   // the last duplicate wins
-      if (first != s) {
-        // membership in `junctions` / `noveljunctions` is decided line by line; refuse the case where the
-        // lines of one pair disagree (the reference would then index a missing key or a stale set entry)
-        if (la[s].has_jn != la[first].has_jn || la[s].has_id != la[first].has_id)
-          throw Error("Unsupported", "duplicate L lines of one link disagree on JN/ID tags");
+  parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t ub, size_t ue) {
+    for (size_t u = ub; u < ue; ++u) {
+      const uint32_t b = t.row_ptr[u], e = t.row_ptr[u + 1];
+      for (uint32_t s = b; s < e; ++s) {
+        uint32_t first = s;
+        for (uint32_t q = b; q < s; ++q) if (t.col[q] == t.col[s]) { first = q; break; }
+        t.first_slot[s] = first;
+        attr_slot[first] = s;   // the last duplicate wins
+        if (first != s) {
+          // membership in `junctions` / `noveljunctions` is decided line by line; refuse the case where the
+          // lines of one pair disagree (the reference would then index a missing key or a stale set entry)
+          if (la[s].has_jn != la[first].has_jn || la[s].has_id != la[first].has_id)
+            throw Error("Unsupported", "duplicate L lines of one link disagree on JN/ID tags");
+        }
       }
     }
-  }
-  for (size_t s = 0; s < A; ++s) {
-    if (t.first_slot[s] != s) continue;
-    const LinkAttr& a = la[attr_slot[s]];
-    uint32_t fl = L_FIRST;
-    if (a.has_jn) fl |= L_JUNC;
-    if (a.has_id) fl |= L_NOVEL;
-    if (a.has_rc) { fl |= L_HAS_RC; t.rc[s] = a.rc; }
-    t.lflags[s] = fl;
-  }
+  });
+  parallel_chunks(A, A < 4096 ? 1 : threads, [&](unsigned, size_t sb, size_t se) {
+    for (size_t s = sb; s < se; ++s) {
+      if (t.first_slot[s] != s) continue;
+      const LinkAttr& a = la[attr_slot[s]];
+      uint32_t fl = L_FIRST;
+      if (a.has_jn) fl |= L_JUNC;
+      if (a.has_id) fl |= L_NOVEL;
+      if (a.has_rc) { fl |= L_HAS_RC; t.rc[s] = a.rc; }
+      t.lflags[s] = fl;
+    }
+  });
 
-  pt.lap("canonical slots (sequential)");
+  pt.lap("canonical slots (parallel)");
   // ---- phase B: intern transcripts, EX tags, JN tags (first-appearance order) -------------------------
   std::unordered_map<std::string_view, uint32_t> tx_ids;
   auto tx_id = [&](Span name) -> uint32_t {
@@ -479,11 +483,13 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   }
   if (fixed_width) {
     // equal-length canonical decimals: string order == numeric order
-    for (uint32_t n = 0; n < V; ++n) {
-      uint64_t id = 0;
-      parse_canonical_u64(g.name_of(n), id);
-      t.rank[n] = uint32_t(id - g.names.base);
-    }
+    parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t nb, size_t ne) {
+      for (size_t n = nb; n < ne; ++n) {
+        uint64_t id = 0;
+        parse_canonical_u64(g.name_of(uint32_t(n)), id);
+        t.rank[n] = uint32_t(id - g.names.base);
+      }
+    });
   } else {
     std::vector<uint32_t> order(V);
     for (uint32_t n = 0; n < V; ++n) order[n] = n;

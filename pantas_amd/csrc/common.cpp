@@ -88,6 +88,38 @@ void PhaseTimer::lap(const char* phase) {
   last = t;
 }
 
+// parallel LSD radix sort of (key, idx) pairs, 16-bit digits
+void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads) {
+  const size_t n = key.size();
+  std::vector<uint32_t> key2(n), idx2(n);
+  const unsigned T = n < (1u << 16) ? 1 : threads;
+  uint32_t maxk = 0;
+  for (uint32_t k : key) maxk = std::max(maxk, k);
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shift = pass * 16;
+    if (pass == 1 && (maxk >> 16) == 0) break;
+    std::vector<std::vector<uint32_t>> hist(T, std::vector<uint32_t>(65536, 0));
+    parallel_chunks(n, T, [&](unsigned c, size_t b, size_t e) {
+      uint32_t* h = hist[c].data();
+      for (size_t i = b; i < e; ++i) ++h[(key[i] >> shift) & 0xFFFFu];
+    });
+    uint64_t run = 0;
+    for (uint32_t d = 0; d < 65536; ++d)
+      for (unsigned c = 0; c < T; ++c) { uint32_t x = hist[c][d]; hist[c][d] = uint32_t(run); run += x; }
+    parallel_chunks(n, T, [&](unsigned c, size_t b, size_t e) {
+      uint32_t* h = hist[c].data();
+      for (size_t i = b; i < e; ++i) {
+        const uint32_t o = h[(key[i] >> shift) & 0xFFFFu]++;
+        key2[o] = key[i];
+        idx2[o] = idx[i];
+      }
+    });
+    key.swap(key2);
+    idx.swap(idx2);
+  }
+}
+
+
 double now_s() {
   using namespace std::chrono;
   return duration<double>(steady_clock::now().time_since_epoch()).count();

@@ -115,6 +115,9 @@ void parallel_chunks(size_t n, unsigned chunks, const std::function<void(unsigne
 // Splits a text buffer into `want` byte ranges that end on '\n' boundaries.
 std::vector<std::pair<size_t, size_t>> split_at_newlines(const char* data, size_t size, unsigned want);
 
+// stable parallel LSD radix sort of (key, idx) pairs by key (16-bit digits)
+void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads);
+
 double now_s();
 
 // phase timing to stderr when PANTAS_TIMING is set

@@ -1,5 +1,7 @@
 #include "graph.h"
 
+#include <atomic>
+
 namespace pantas {
 
 namespace {
@@ -120,6 +122,45 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   } else {
     ix.map.reserve(ns * 2);
   }
+  // S-record ordinals: chunk bases
+  std::vector<size_t> sbase(outs.size() + 1, 0);
+  for (size_t i = 0; i < outs.size(); ++i) sbase[i + 1] = sbase[i] + outs[i].s.size();
+  bool fast_names = false;
+  const bool force_seq = getenv("PANTAS_LOADER_SEQUENTIAL") != nullptr;   // tests compare both paths
+  if (ix.dense && ns > (1u << 16) && !force_seq) {
+    // optimistic parallel fill: with no duplicate names the node index is the S-line ordinal
+    g->seg_len.resize(ns);
+    g->seg_line_off.resize(ns);
+    g->seg_name_off.resize(ns);
+    g->seg_name_len.resize(ns);
+    std::atomic<bool> dup{false}, undefined{false};
+    parallel_chunks(outs.size(), unsigned(outs.size()), [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        size_t k = sbase[i];
+        for (auto& s : outs[i].s) {
+          uint64_t id = 0;
+          parse_canonical_u64(Span{base + s.name_off, base + s.name_off + s.name_len}, id);
+          uint32_t expect = NONE32;
+          if (!__atomic_compare_exchange_n(&ix.table[size_t(id - lo)], &expect, uint32_t(k), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
+            dup.store(true, std::memory_order_relaxed);
+          if (!s.defines) undefined.store(true, std::memory_order_relaxed);
+          g->seg_len[k] = s.seq_len;
+          g->seg_line_off[k] = s.line_off;
+          g->seg_name_off[k] = s.name_off;
+          g->seg_name_len[k] = uint16_t(s.name_len);
+          ++k;
+        }
+      }
+    });
+    if (!dup.load() && !undefined.load()) {
+      fast_names = true;
+    } else {
+      // duplicates (or S lines behind leading whitespace): redo in file order
+      std::fill(ix.table.begin(), ix.table.end(), NONE32);
+      g->seg_len.clear(); g->seg_line_off.clear(); g->seg_name_off.clear(); g->seg_name_len.clear();
+    }
+  }
+  if (!fast_names) {
   g->seg_len.reserve(ns);
   g->seg_line_off.reserve(ns);
   g->seg_name_off.reserve(ns);
@@ -153,9 +194,18 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
     }
   }
-  pt.lap("name index (sequential)");
+  }
+  pt.lap(fast_names ? "name index (parallel)" : "name index (sequential)");
   g->V = uint32_t(g->seg_len.size());
-  for (uint32_t v : g->seg_len) g->max_seg_len = std::max(g->max_seg_len, v);
+  {
+    std::vector<uint32_t> mx(std::max<size_t>(1, outs.size()), 0);
+    parallel_chunks(g->V, g->V < (1u << 16) ? 1 : unsigned(mx.size()), [&](unsigned c, size_t b, size_t e) {
+      uint32_t m = 0;
+      for (size_t i = b; i < e; ++i) m = std::max(m, g->seg_len[i]);
+      mx[c] = m;
+    });
+    for (uint32_t m : mx) g->max_seg_len = std::max(g->max_seg_len, m);
+  }
 
   // ---- resolve link ends (parallel) and build the out CSR in file order --------------------
   std::vector<size_t> lbase(outs.size() + 1, 0);
@@ -172,33 +222,132 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
     }
   });
   pt.lap("resolve link ends (parallel)");
-  g->row_ptr.assign(size_t(g->V) + 1, 0);
-  g->irow_ptr.assign(size_t(g->V) + 1, 0);
-  uint64_t A = 0;
-  {
-    size_t k = 0;
-    for (auto& o : outs)
-      for (auto& r : o.l) {
-        if (r.ntok < 6 && g->first_short_l_off == UINT64_MAX) g->first_short_l_off = r.line_off;
+  // per-record facts (parallel): validity, sortedness by source, the flags the callers look at
+  const unsigned T = unsigned(outs.size());
+  std::vector<uint64_t> c_valid(T + 1, 0), c_unknown(T, 0), c_short(T, UINT64_MAX);
+  std::vector<uint8_t> c_unsorted(T, 0), c_before(T, 0);
+  parallel_chunks(T, T, [&](unsigned, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) {
+      size_t k = lbase[i];
+      uint32_t prev = 0;
+      bool have_prev = false;
+      for (auto& r : outs[i].l) {
+        if (r.ntok < 6 && c_short[i] == UINT64_MAX) c_short[i] = r.line_off;
         if (lu[k] == NONE32 || lv[k] == NONE32) {
-          ++g->links_unknown_end;
+          ++c_unknown[i];
         } else {
-          ++g->row_ptr[lu[k] + 1];
-          ++g->irow_ptr[lv[k] + 1];
-          ++A;
-          if (g->seg_line_off[lu[k]] > r.line_off || g->seg_line_off[lv[k]] > r.line_off) g->link_before_segment = true;
+          ++c_valid[i + 1];
+          if (g->seg_line_off[lu[k]] > r.line_off || g->seg_line_off[lv[k]] > r.line_off) c_before[i] = 1;
+          if (have_prev && lu[k] < prev) c_unsorted[i] = 1;
+          prev = lu[k];
+          have_prev = true;
         }
         ++k;
       }
+    }
+  });
+  bool sorted_by_source = true;
+  {
+    // also across chunk borders
+    uint32_t prev = 0;
+    bool have_prev = false;
+    for (unsigned i = 0; i < T; ++i) {
+      if (c_unsorted[i]) sorted_by_source = false;
+      size_t k = lbase[i];
+      for (size_t j = 0; j < outs[i].l.size(); ++j, ++k) {
+        if (lu[k] == NONE32 || lv[k] == NONE32) continue;
+        if (have_prev && lu[k] < prev) sorted_by_source = false;
+        break;
+      }
+      // last valid source of the chunk
+      for (size_t j = outs[i].l.size(), k2 = lbase[i + 1]; j-- > 0;) {
+        --k2;
+        if (lu[k2] == NONE32 || lv[k2] == NONE32) continue;
+        prev = lu[k2];
+        have_prev = true;
+        break;
+      }
+      g->links_unknown_end += c_unknown[i];
+      if (c_short[i] != UINT64_MAX && g->first_short_l_off == UINT64_MAX) g->first_short_l_off = c_short[i];
+      if (c_before[i]) g->link_before_segment = true;
+      c_valid[i + 1] += c_valid[i];
+    }
   }
+  uint64_t A = c_valid[T];
   if (A >= NONE32) throw Error("Unsupported", "more than 2^32-2 links");
   g->A = A;
-  for (uint32_t i = 0; i < g->V; ++i) g->row_ptr[i + 1] += g->row_ptr[i];
-  for (uint32_t i = 0; i < g->V; ++i) g->irow_ptr[i + 1] += g->irow_ptr[i];
+  g->row_ptr.assign(size_t(g->V) + 1, 0);
+  g->irow_ptr.assign(size_t(g->V) + 1, 0);
   g->col.resize(A);
   g->slot_off.resize(A);
   g->icol.resize(A);
   g->islot.resize(A);
+  const bool fast_csr = sorted_by_source && A > (1u << 16) && !force_seq;
+  if (fast_csr) {
+    // links already grouped by source in node order (what vg / the annotator write): slot = rank among valid links
+    std::vector<uint32_t> ikey(A), iidx(A);
+    parallel_chunks(T, T, [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        size_t k = lbase[i];
+        uint64_t p = c_valid[i];
+        for (auto& r : outs[i].l) {
+          if (lu[k] != NONE32 && lv[k] != NONE32) {
+            g->col[p] = lv[k];
+            g->slot_off[p] = r.line_off;
+            ikey[p] = lv[k];
+            iidx[p] = uint32_t(p);
+            ++p;
+          }
+          ++k;
+        }
+      }
+    });
+    // row_ptr[u] = first slot whose source is >= u.  Sources of slots: recover from the records again.
+    std::vector<uint32_t> src(A);
+    parallel_chunks(T, T, [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        size_t k = lbase[i];
+        uint64_t p = c_valid[i];
+        for (size_t j = 0; j < outs[i].l.size(); ++j, ++k)
+          if (lu[k] != NONE32 && lv[k] != NONE32) src[p++] = lu[k];
+      }
+    });
+    auto fill_ptr = [&](const std::vector<uint32_t>& keys, std::vector<uint32_t>& ptr) {
+      // keys are sorted: ptr[u] = lower_bound(keys, u)
+      parallel_chunks(A, threads, [&](unsigned, size_t b, size_t e) {
+        for (size_t p = b; p < e; ++p) {
+          const uint32_t cur = keys[p];
+          const uint32_t from = p == 0 ? 0u : keys[p - 1] + 1u;
+          if (p == 0 || keys[p - 1] != cur)
+            for (uint32_t u = from; u <= cur; ++u) ptr[u] = uint32_t(p);
+        }
+      });
+      const uint32_t last = A ? keys[A - 1] : 0u;
+      for (size_t u = size_t(A ? last + 1 : 0); u <= g->V; ++u) ptr[u] = uint32_t(A);
+    };
+    fill_ptr(src, g->row_ptr);
+    // in-lists: stable sort of the slots by target keeps L-line file order inside a list (call.py:175)
+    radix_sort_pairs(ikey, iidx, threads);
+    parallel_chunks(A, threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t q = b; q < e; ++q) {
+        g->islot[q] = iidx[q];
+        g->icol[q] = src[iidx[q]];
+      }
+    });
+    fill_ptr(ikey, g->irow_ptr);
+  } else {
+  {
+    size_t k = 0;
+    for (auto& o : outs)
+      for (size_t j = 0; j < o.l.size(); ++j, ++k) {
+        if (lu[k] != NONE32 && lv[k] != NONE32) {
+          ++g->row_ptr[lu[k] + 1];
+          ++g->irow_ptr[lv[k] + 1];
+        }
+      }
+  }
+  for (uint32_t i = 0; i < g->V; ++i) g->row_ptr[i + 1] += g->row_ptr[i];
+  for (uint32_t i = 0; i < g->V; ++i) g->irow_ptr[i + 1] += g->irow_ptr[i];
   {
     std::vector<uint32_t> cur(g->row_ptr.begin(), g->row_ptr.end() - 1);
     std::vector<uint32_t> icur(g->irow_ptr.begin(), g->irow_ptr.end() - 1);
@@ -216,7 +365,8 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
         ++k;
       }
   }
-  pt.lap("CSR fill (sequential)");
+  }
+  pt.lap(fast_csr ? "CSR build (parallel)" : "CSR fill (sequential)");
   return g;
 }
 

@@ -109,3 +109,22 @@ def test_intronic_search_beyond_local_frontier(hostsim, tmp_path, fan, isw):
     assert sorted(r.stdout.splitlines()[1:]) == sorted(want)
     if isw >= 3:
         assert any(x.startswith("A3,novel") for x in want)      # the search reaches the acceptor through the fan
+
+
+def test_parallel_loader_equals_sequential(hostsim, tmp_path):
+    """Above ~65 k segments the loader builds the name index and both CSRs in parallel; the sequential path
+    (also the fallback for duplicate names / unsorted links) must give the same augment and call results."""
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "w")
+    Synth(seed=31, n_genes=700, n_lines=40000, base_id=10**7, intron_long_max=200).write(pre)
+    outs = []
+    for env in ({}, {"PANTAS_LOADER_SEQUENTIAL": "1"}):
+        e = {**os.environ, **env, "HOSTSIM_THREADS": "4"}
+        a = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=e)
+        assert a.returncode == 0, a.stderr
+        open(pre + ".aug.gfa", "w").write(a.stdout)
+        c = subprocess.run([hostsim["call"], "--rca", "1", "--novel", pre + ".aug.gfa", pre + ".gtf"], capture_output=True, text=True, env=e)
+        assert c.returncode == 0, c.stderr
+        outs.append((a.stdout, c.stdout))
+    assert outs[0][0].count("\n") > 150000
+    assert outs[0] == outs[1]
