@@ -82,7 +82,10 @@ typedef struct {
 int pantas_augment_reset(pantas_graph* g);
 /* :142-197 + :10-50: tokenise GAF bytes [begin,end) of the file (end = 0: to EOF; ranges must
  * fall on line starts, see pantas_gaf_split) into binary records and upload them.
- * first_line = index of the range's first line in the whole file (first-seen ordering). */
+ * first_line = index of the range's first line in the whole file (first-seen ordering).
+ * A line the reference raises on while splitting it ends the batch; the error is reported by
+ * pantas_augment_finish AFTER the lines before it have been walked, because the reference handles the file
+ * line by line and an earlier line that only fails in the walk is the one it dies on. */
 int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,
                             uint64_t first_line, pantas_batch** out, pantas_batch_stats* stats);
 /* byte range of shard `rank` of `world` (cut at line starts) and the number of lines before it */

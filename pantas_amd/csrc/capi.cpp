@@ -19,6 +19,7 @@ struct pantas_graph {
   AugmentResult res;
   bool have_result = false;
   uint64_t lines = 0, rejected = 0, skipped = 0;
+  std::shared_ptr<Error> deferred;   // tokeniser error of a loaded batch, reported by finish (see gaf.h)
   double load_s = 0;
   // call
   std::unique_ptr<CallTables> call_tables;
@@ -142,6 +143,7 @@ __attribute__((visibility("default"))) int pantas_augment_reset(pantas_graph* g)
     g->have_result = false;
     g->res = AugmentResult();
     g->lines = g->rejected = g->skipped = 0;
+    g->deferred.reset();
   });
 }
 
@@ -202,6 +204,7 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
   g->lines += b.lines_total;
   g->rejected += b.rejected;
   g->skipped += b.skipped;
+  if (b.deferred && !g->deferred) g->deferred = b.deferred;
   if (stats) *stats = s;
   *out = h.release();
 }
@@ -300,7 +303,12 @@ __attribute__((visibility("default"))) int pantas_augment_counters(pantas_graph*
 __attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g) {
   return guarded([&] {
     need_device(g);
-    check_device_status(*g->dev, nullptr);
+    check_device_status(*g->dev, nullptr);      // a line that fails in the walk, before ...
+    if (g->deferred) {                          // ... the line the tokeniser stopped at
+      Error e = *g->deferred;
+      g->deferred.reset();
+      throw e;
+    }
     download_result(*g->dev, *g->g, g->res);
     g->res.lines_total = g->lines;
     g->res.rejected = g->rejected;

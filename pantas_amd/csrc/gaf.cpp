@@ -24,6 +24,18 @@ struct Chunk {
   GafBatch b;
   std::unique_ptr<Error> err;
   uint64_t err_line = 0;
+  size_t keep_hdr = 0, keep_nodes = 0, keep_ops = 0;
+  uint64_t keep_del_lines = 0, keep_del_nodes = 0;
+  // drop whatever the raising line had appended
+  void rollback() {
+    b.hdr.resize(keep_hdr);
+    b.nodes.resize(keep_nodes);
+    b.ops.resize(keep_ops);
+    b.node_off.resize(keep_hdr + 1);
+    b.op_off.resize(keep_hdr + 1);
+    b.del_lines = keep_del_lines;
+    b.del_nodes = keep_del_nodes;
+  }
 };
 
 [[noreturn]] void fail(const char* kind, uint64_t local_line, const std::string& what) {
@@ -86,6 +98,9 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
     ++out.lines_total;
     p = nl ? nl + 1 : end;
     const uint64_t this_line = line++;
+    // state to fall back to if this line raises
+    ck.keep_hdr = out.hdr.size(); ck.keep_nodes = out.nodes.size(); ck.keep_ops = out.ops.size();
+    ck.keep_del_lines = out.del_lines; ck.keep_del_nodes = out.del_nodes;
     if (tok.size() < 12) fail("IndexError", this_line, "fewer than 12 columns");
     int64_t mapq;
     if (!parse_py_int(tok[11], mapq)) fail("ValueError", this_line, "mapq is not an integer");
@@ -215,13 +230,16 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
         tokenize_range(g, data + ranges[i].first, ranges[i].second - ranges[i].first, thr, cks[i]);
       } catch (const Error& er) {
         cks[i].err = std::make_unique<Error>(er);
+        cks[i].rollback();
       }
     }
   });
   pt.lap("parse lines (parallel)");
-  // the reference stops at the first offending line: report the earliest one
+  // the reference stops at the first offending line: keep the records before it, remember the error
   uint64_t line_base = first_line_id;
-  for (auto& c : cks) {
+  size_t used = cks.size();
+  for (size_t ci = 0; ci < cks.size(); ++ci) {
+    Chunk& c = cks[ci];
     if (c.err) {
       std::string msg = c.err->what();
       // patch "@local@" into the 1-based global line number
@@ -231,10 +249,13 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
         msg = msg.substr(0, a) + std::to_string(line_base + local + 1) + msg.substr(b + 1);
       }
       size_t colon = msg.find(": ");
-      throw Error(c.err->kind, colon == std::string::npos ? msg : msg.substr(colon + 2));
+      out.deferred = std::make_shared<Error>(c.err->kind, colon == std::string::npos ? msg : msg.substr(colon + 2));
+      used = ci + 1;
+      break;
     }
     line_base += c.b.lines_total;
   }
+  cks.resize(used);
   size_t n = 0, nn = 0, no = 0;
   for (auto& c : cks) { n += c.b.hdr.size(); nn += c.b.nodes.size(); no += c.b.ops.size(); }
   if (nn >= NONE32 || no >= NONE32) throw Error("Unsupported", "more than 2^32-2 path nodes or cs ops in one batch");

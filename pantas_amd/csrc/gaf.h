@@ -12,6 +12,7 @@
 #include "common.h"
 #include "graph.h"
 #include "walk.h"
+#include <memory>
 
 namespace pantas {
 
@@ -24,6 +25,10 @@ struct GafBatch {
   uint64_t del_lines = 0;     // records with a '-' op
   uint64_t del_nodes = 0;     // sum of path lengths over those records
   uint64_t bytes = 0;         // text bytes tokenised
+  // A line the reference raises on while splitting / filtering it.  The batch then holds the records of the
+  // lines BEFORE it: they still have to be walked, because an earlier line that only fails in the walk is what
+  // the reference would report (it handles the file line by line).
+  std::shared_ptr<Error> deferred;
   size_t size() const { return hdr.size(); }
 };
 
@@ -33,7 +38,7 @@ struct GafBatch {
 void bucket_by_locus(GafBatch& b, unsigned threads = 0);
 
 // Tokenises the byte range [data, data+size) (whole lines).  first_line_id = index of its
-// first line in the file.  Throws Error where the reference's loop would raise.
+// first line in the file.  A line the reference raises on ends the batch and is reported in out.deferred.
 void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
                   unsigned threads, GafBatch& out);
 

@@ -97,6 +97,7 @@ int main(int argc, char** argv) {
     for (auto& kv : t.common_first)
       r.hist.push_back(HistEntry{kv.first.first, kv.first.second, 0, 0, kv.second, true});
     for (auto& kv : t.novel) r.novel.push_back(NovelLink{kv.first.first, kv.first.second, kv.second.first, kv.second.second});
+    if (b.deferred) throw *b.deferred;      // no earlier line failed in the walk: the tokeniser's error stands
     finalize_result(r);
     fprintf(stderr, "Rejected alignments: %llu\n", (unsigned long long)b.rejected);
     fprintf(stderr, "Annotating GFA\n");

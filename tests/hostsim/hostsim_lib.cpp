@@ -93,6 +93,7 @@ int hs_load_shard(HS* h, const char* gaf, int thr, uint64_t begin, uint64_t end,
     if (end == 0 || end > f.size) end = f.size;
     h->b = GafBatch();
     tokenize_gaf(*h->g, f.data + begin, size_t(end - begin), thr, first_line, 2, h->b);
+    if (h->b.deferred) throw *h->b.deferred;
     bucket_by_locus(h->b, 2);
     stats3[0] = h->b.lines_total; stats3[1] = h->b.rejected; stats3[2] = h->b.del_nodes;
   });
