@@ -128,3 +128,35 @@ def test_parallel_loader_equals_sequential(hostsim, tmp_path):
         outs.append((a.stdout, c.stdout))
     assert outs[0][0].count("\n") > 150000
     assert outs[0] == outs[1]
+
+
+def test_call_source_parameter_sweep(hostsim, tmp_path):
+    """Many small synthetic graphs with varied structure / read mixes / flags: call rows of the device source
+    equal the oracle's exactly (same fixed choice rules)."""
+    import random
+    from pantas_amd.engine import Synth
+    rng = random.Random(5)
+    total = 0
+    for i in range(14):
+        pre = str(tmp_path / f"p{i}")
+        kw = dict(seed=100 + i, n_genes=rng.choice([3, 8, 20]), n_lines=rng.choice([300, 1500, 4000]),
+                  bubble_rate=rng.choice([0.0, 0.05, 0.2]), max_exons=rng.choice([4, 9]),
+                  intron_long_max=rng.choice([12, 40, 120]), p_novel_skip=rng.choice([0.0, 0.05, 0.2]),
+                  p_novel_ce=rng.choice([0.0, 0.03, 0.1]), p_intron=rng.choice([0.0, 0.1, 0.3]),
+                  p_novel_ss=rng.choice([0.0, 0.05, 0.2]), p_indel=rng.choice([0.0, 0.1, 0.4]), zipf_a=rng.choice([0.5, 1.2, 2.5]))
+        Synth(**kw).write(pre)
+        a = run([hostsim["augment"], pre + ".gaf", pre + ".gfa"])
+        assert a.returncode == 0, a.stderr
+        open(pre + ".aug.gfa", "w").write(a.stdout)
+        flags = rng.choice([["--novel", "--rca", "0"], ["--novel", "--rca", "2", "--minintronsize", "20"],
+                            ["--events", "IR", "--novel", "--minintronsize", "1", "--rca", "1"],
+                            ["--events", "SS", "ES", "--novel", "--isw", str(rng.choice([0, 1, 3, 9]))],
+                            ["--rca", "1"], ["--no-annotated", "--novel"]])
+        want = call_oracle.call(pre + ".aug.gfa", pre + ".gtf", None, **_flags_to_opts(flags))
+        c = run([hostsim["call"], *flags, pre + ".aug.gfa", pre + ".gtf"])
+        assert c.returncode == 0, (c.stderr, kw, flags)
+        mine = collections.Counter(call_oracle.normalise_row(x) for x in c.stdout.splitlines()[1:])
+        ref = collections.Counter(call_oracle.normalise_row(x) for x in want)
+        assert mine == ref, (kw, flags)
+        total += len(want)
+    assert total > 500
