@@ -71,6 +71,10 @@ typedef struct {
   uint64_t text_bytes;
   uint64_t alg_bytes;      /* algorithmic bytes of one launch over this batch */
   double tokenize_seconds, upload_seconds;
+  /* which tokeniser made the batch (PANTAS_TOKENIZER_HOST / _DEVICE) and, for the device one, its phases:
+   * upload_seconds = text -> HBM, then line index, measure pass + scans, write pass, locus bucketing */
+  int32_t tokenizer, reserved_;
+  double tok_index_seconds, tok_measure_seconds, tok_write_seconds, tok_bucket_seconds;
 } pantas_batch_stats;
 
 typedef struct {
@@ -78,6 +82,13 @@ typedef struct {
   float main_ms;           /* augment_main_kernel */
 } pantas_launch_stats;
 
+/* Where the GAF text is turned into records (:142-197, :10-50).  AUTO = on the GPU when the graph's segment names are
+ * canonical decimals (what vg writes), else on the host; the environment variable PANTAS_TOKENIZER=host|device
+ * overrides AUTO.  DEVICE on a graph with other names is PANTAS_E_UNSUPPORTED at load time. */
+#define PANTAS_TOKENIZER_AUTO 0
+#define PANTAS_TOKENIZER_HOST 1
+#define PANTAS_TOKENIZER_DEVICE 2
+int pantas_augment_tokenizer(pantas_graph* g, int mode);
 /* zero NC/RC/IL/OL and the sparse tables (start of a run) */
 int pantas_augment_reset(pantas_graph* g);
 /* :142-197 + :10-50: tokenise GAF bytes [begin,end) of the file (end = 0: to EOF; ranges must
@@ -92,6 +103,10 @@ int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint
 int pantas_gaf_split(const char* gaf_path, int rank, int world, uint64_t* begin, uint64_t* end,
                      uint64_t* lines_before);
 void pantas_batch_free(pantas_batch* b);
+/* copies a resident batch back to the host (inspection / tests).  Sizes from its stats: hdr 4 int32 per record
+ * {start, tail, line_id, flags}, node_off and op_off records + 1, nodes path_nodes, ops cs_ops words. */
+int pantas_batch_download(pantas_graph* g, pantas_batch* b, int32_t* hdr, uint32_t* node_off, uint32_t* op_off,
+                          uint32_t* nodes, uint32_t* ops);
 /* :209-363 on the GPU: both kernels over a resident batch, accumulating into g's counters.
  * A run over SEVERAL batches must use the staged form below: launch_rare for every batch, then launch_main
  * for every batch (a late rare-key kernel cannot flag nodes for batches already walked; PANTAS_E_ARG).

@@ -34,7 +34,9 @@ class BatchStats(C.Structure):
     _fields_ = [("lines", C.c_uint64), ("rejected", C.c_uint64), ("skipped", C.c_uint64),
                 ("records", C.c_uint64), ("path_nodes", C.c_uint64), ("cs_ops", C.c_uint64),
                 ("del_records", C.c_uint64), ("del_path_nodes", C.c_uint64), ("text_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
-                ("tokenize_seconds", C.c_double), ("upload_seconds", C.c_double)]
+                ("tokenize_seconds", C.c_double), ("upload_seconds", C.c_double),
+                ("tokenizer", C.c_int32), ("reserved_", C.c_int32), ("tok_index_seconds", C.c_double),
+                ("tok_measure_seconds", C.c_double), ("tok_write_seconds", C.c_double), ("tok_bucket_seconds", C.c_double)]
 
 
 class LaunchStats(C.Structure):
@@ -116,6 +118,8 @@ def _load():
         "pantas_augment_load_gaf_mem": (i32, [vp, C.c_char_p, u64, i32, u64, P(vp), P(BatchStats)]),
         "pantas_call_prepare_mem": (i32, [vp, C.c_char_p, u64, i32]),
         "pantas_call_prepare_fused": (i32, [vp, C.c_char_p, C.c_char_p, u64, i32]),
+        "pantas_augment_tokenizer": (i32, [vp, i32]),
+        "pantas_batch_download": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -56,6 +56,13 @@ int device_count();                                   // 0 when no HIP device is
 DeviceGraphPtr upload_graph(const Graph& g, int device);
 void reset_counters(DeviceGraph& dg);                 // zero NC/RC/IL/OL, clear flags and tables
 DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);
+// GPU tokeniser (tokenize.hip): text of whole lines -> bucketed records resident on dg's device.  `counts` receives the
+// batch counters and a deferred tokeniser error, its arrays stay empty.  Needs a graph with dense (decimal) names.
+struct DeviceTokenizeTimes { double h2d_s = 0, index_s = 0, measure_s = 0, write_s = 0, bucket_s = 0, total_s = 0; };
+DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
+                                   GafBatch& counts, DeviceTokenizeTimes* times = nullptr);
+// copies a resident batch back (tests: the two tokenisers must produce the same arrays)
+void download_batch(const DeviceGraph& dg, const DeviceBatch& db, GafBatch& out);
 // Launches the two augment kernels over a resident batch; accumulates into dg's counters.
 // Returns the device time of the two kernels in ms (HIP events on the launch stream).
 float launch_augment(DeviceGraph& dg, DeviceBatch& db, float* ms_rare = nullptr, float* ms_main = nullptr);
@@ -73,6 +80,7 @@ void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 struct CounterPtrs { void* nc; void* rc; void* il0; void* oll; uint64_t V, A; };
 CounterPtrs counter_ptrs(DeviceGraph& dg);
 uint64_t batch_lines(const DeviceBatch& db);
+void batch_sizes(const DeviceBatch& db, uint64_t* path_nodes, uint64_t* cs_ops);
 uint64_t batch_alg_bytes(const DeviceBatch& db);      // algorithmic bytes of the main kernel
 
 }  // namespace pantas

@@ -17,16 +17,10 @@
 #include <hip/hip_runtime.h>
 
 #include "augment.h"
+#include "device_batch.h"
 #include "walk.h"
 
 namespace pantas {
-
-#define HIP_OK(expr)                                                                                   \
-  do {                                                                                                 \
-    hipError_t e__ = (expr);                                                                           \
-    if (e__ != hipSuccess)                                                                             \
-      throw Error("HipError", std::string(#expr) + ": " + hipGetErrorString(e__));                     \
-  } while (0)
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr uint32_t COMMON_POS = 0x7FFFFFFFu;
@@ -448,6 +442,8 @@ struct DeviceGraph {
   uint32_t* row_ptr = nullptr;
   uint32_t* col = nullptr;
   uint32_t* counters = nullptr;   // [NC V | IL0 V | OLL V | RC A]
+  std::unique_ptr<ScratchPool> scratch;   // tokenize.hip temporaries
+  uint32_t* name_table = nullptr; // dense segment-name table for the GPU tokeniser (tokenize.hip), uploaded on first use
   uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
   Table hist, novel;
   // multi-batch protocol: every batch's rare-key kernel must run before the first main kernel of the run
@@ -467,19 +463,29 @@ struct DeviceGraph {
   }
 };
 
-struct DeviceBatch {
-  LineHdr* hdr = nullptr;
-  uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
-  uint32_t n = 0, n_del = 0;
-  uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
-  std::vector<uint32_t> first_line_ids;   // unused placeholder for error reports
-};
+DeviceGraphInfo graph_info(DeviceGraph& dg) { return DeviceGraphInfo{dg.device, dg.stream, dg.V}; }
+
+ScratchPool& scratch_pool(DeviceGraph& dg) {
+  if (!dg.scratch) dg.scratch = std::make_unique<ScratchPool>();
+  return *dg.scratch;
+}
+
+uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
+  if (!dg.name_table) {
+    HIP_OK(hipSetDevice(dg.device));
+    HIP_OK(hipMalloc(&dg.name_table, std::max<size_t>(1, g.names.table.size()) * 4));
+    HIP_OK(hipMemcpyAsync(dg.name_table, g.names.table.data(), g.names.table.size() * 4, hipMemcpyHostToDevice, dg.stream));
+    HIP_OK(hipStreamSynchronize(dg.stream));
+  }
+  return dg.name_table;
+}
 
 void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->word, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small})
+  for (void* p : {(void*)d->word, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table})
     if (p) (void)hipFree(p);
+  d->scratch.reset();
   d->hist.free_all();
   d->novel.free_all();
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
@@ -614,7 +620,25 @@ DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
   return p;
 }
 
+void download_batch(const DeviceGraph& d, const DeviceBatch& b, GafBatch& out) {
+  HIP_OK(hipSetDevice(d.device));
+  out = GafBatch{};
+  out.hdr.resize(b.n);
+  out.node_off.resize(size_t(b.n) + 1);
+  out.op_off.resize(size_t(b.n) + 1);
+  out.nodes.resize(b.n_nodes);
+  out.ops.resize(b.n_ops);
+  if (b.n) HIP_OK(hipMemcpy(out.hdr.data(), b.hdr, size_t(b.n) * sizeof(LineHdr), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out.node_off.data(), b.node_off, (size_t(b.n) + 1) * 4, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out.op_off.data(), b.op_off, (size_t(b.n) + 1) * 4, hipMemcpyDeviceToHost));
+  if (b.n_nodes) HIP_OK(hipMemcpy(out.nodes.data(), b.nodes, b.n_nodes * 4, hipMemcpyDeviceToHost));
+  if (b.n_ops) HIP_OK(hipMemcpy(out.ops.data(), b.ops, b.n_ops * 4, hipMemcpyDeviceToHost));
+  out.del_lines = b.n_del;
+  out.del_nodes = b.del_nodes;
+}
+
 uint64_t batch_lines(const DeviceBatch& db) { return db.n; }
+void batch_sizes(const DeviceBatch& db, uint64_t* path_nodes, uint64_t* cs_ops) { *path_nodes = db.n_nodes; *cs_ops = db.n_ops; }
 
 uint64_t batch_alg_bytes(const DeviceBatch& db) {
   // B_line = 16 + 16 k + 4 c + 21 (k - 1)

@@ -20,6 +20,7 @@ struct pantas_graph {
   bool have_result = false;
   uint64_t lines = 0, rejected = 0, skipped = 0;
   std::shared_ptr<Error> deferred;   // tokeniser error of a loaded batch, reported by finish (see gaf.h)
+  int tokenizer = PANTAS_TOKENIZER_AUTO;
   double load_s = 0;
   // call
   std::unique_ptr<CallTables> call_tables;
@@ -178,35 +179,89 @@ __attribute__((visibility("default"))) int pantas_gaf_split(const char* gaf_path
   });
 }
 
+static int effective_tokenizer(const pantas_graph* g) {
+  int mode = g->tokenizer;
+  if (mode == PANTAS_TOKENIZER_AUTO) {
+    const char* e = getenv("PANTAS_TOKENIZER");
+    if (e && !strcmp(e, "host")) mode = PANTAS_TOKENIZER_HOST;
+    else if (e && !strcmp(e, "device")) mode = PANTAS_TOKENIZER_DEVICE;
+    else if (e && *e && strcmp(e, "auto")) throw Error("ValueError", "PANTAS_TOKENIZER must be host, device or auto");
+  }
+  if (mode == PANTAS_TOKENIZER_AUTO) mode = g->g->names.dense ? PANTAS_TOKENIZER_DEVICE : PANTAS_TOKENIZER_HOST;
+  return mode;
+}
+
 static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int thr, uint64_t first_line,
                             pantas_batch** out, pantas_batch_stats* stats) {
   GafBatch b;
-  double t0 = now_s();
-  tokenize_gaf(*g->g, data, size, thr, first_line, 0, b);
-  if (!getenv("PANTAS_NO_BUCKET")) bucket_by_locus(b);
-  double t1 = now_s();
   auto h = std::make_unique<pantas_batch>();
-  h->dev = upload_batch(*g->dev, b);
-  double t2 = now_s();
   pantas_batch_stats& s = h->st;
+  const int mode = effective_tokenizer(g);
+  s.tokenizer = mode;
+  if (mode == PANTAS_TOKENIZER_DEVICE) {
+    DeviceTokenizeTimes tm;
+    h->dev = tokenize_gaf_device(*g->dev, *g->g, data, size, thr, first_line, b, &tm);
+    s.records = batch_lines(*h->dev);
+    s.tokenize_seconds = tm.total_s - tm.h2d_s;
+    s.upload_seconds = tm.h2d_s;
+    s.tok_index_seconds = tm.index_s;
+    s.tok_measure_seconds = tm.measure_s;
+    s.tok_write_seconds = tm.write_s;
+    s.tok_bucket_seconds = tm.bucket_s;
+    uint64_t pn = 0, ops = 0;
+    batch_sizes(*h->dev, &pn, &ops);
+    s.path_nodes = pn;
+    s.cs_ops = ops;
+  } else {
+    double t0 = now_s();
+    tokenize_gaf(*g->g, data, size, thr, first_line, 0, b);
+    if (!getenv("PANTAS_NO_BUCKET")) bucket_by_locus(b);
+    double t1 = now_s();
+    h->dev = upload_batch(*g->dev, b);
+    double t2 = now_s();
+    s.records = b.size();
+    s.path_nodes = b.nodes.size();
+    s.cs_ops = b.ops.size();
+    s.tokenize_seconds = t1 - t0;
+    s.upload_seconds = t2 - t1;
+  }
   s.lines = b.lines_total;
   s.rejected = b.rejected;
   s.skipped = b.skipped;
-  s.records = b.size();
-  s.path_nodes = b.nodes.size();
-  s.cs_ops = b.ops.size();
   s.del_records = b.del_lines;
   s.del_path_nodes = b.del_nodes;
   s.text_bytes = b.bytes;
   s.alg_bytes = batch_alg_bytes(*h->dev);
-  s.tokenize_seconds = t1 - t0;
-  s.upload_seconds = t2 - t1;
   g->lines += b.lines_total;
   g->rejected += b.rejected;
   g->skipped += b.skipped;
   if (b.deferred && !g->deferred) g->deferred = b.deferred;
   if (stats) *stats = s;
   *out = h.release();
+}
+
+__attribute__((visibility("default"))) int pantas_augment_tokenizer(pantas_graph* g, int mode) {
+  return guarded([&] {
+    need(g && g->g, "null graph");
+    need(mode == PANTAS_TOKENIZER_AUTO || mode == PANTAS_TOKENIZER_HOST || mode == PANTAS_TOKENIZER_DEVICE, "bad tokenizer mode");
+    g->tokenizer = mode;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_batch_download(pantas_graph* g, pantas_batch* b, int32_t* hdr, uint32_t* node_off, uint32_t* op_off,
+                                                                  uint32_t* nodes, uint32_t* ops) {
+  return guarded([&] {
+    need_device(g);
+    need(b && b->dev && hdr && node_off && op_off && nodes && ops, "null argument");
+    GafBatch h;
+    download_batch(*g->dev, *b->dev, h);
+    static_assert(sizeof(LineHdr) == 16, "LineHdr is 4 words");
+    if (!h.hdr.empty()) memcpy(hdr, h.hdr.data(), h.hdr.size() * sizeof(LineHdr));
+    memcpy(node_off, h.node_off.data(), h.node_off.size() * 4);
+    memcpy(op_off, h.op_off.data(), h.op_off.size() * 4);
+    if (!h.nodes.empty()) memcpy(nodes, h.nodes.data(), h.nodes.size() * 4);
+    if (!h.ops.empty()) memcpy(ops, h.ops.data(), h.ops.size() * 4);
+  });
 }
 
 __attribute__((visibility("default"))) int pantas_augment_load_gaf(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,

@@ -86,23 +86,25 @@ inline bool parse_canonical_u64(Span t, uint64_t& v) {
   return true;
 }
 
-// Python int(str) for the ASCII subset: optional sign, digits with single '_' separators.
-inline bool parse_py_int(Span t, int64_t& v) {
+// Python int(str) for the ASCII subset: optional sign, digits with single '_' separators.  Values beyond 2^60 are
+// refused, or with `saturate` become +-2^61 (for fields that are only compared or range-checked afterwards).
+inline bool parse_py_int(Span t, int64_t& v, bool saturate = false) {
   const char* c = t.b;
   if (c >= t.e) return false;
   bool neg = false;
   if (*c == '+' || *c == '-') { neg = (*c == '-'); ++c; }
   if (c >= t.e || *c < '0' || *c > '9') return false;
   uint64_t x = 0;
-  bool prev_us = false;
+  bool prev_us = false, big = false;
   for (; c < t.e; ++c) {
     if (*c == '_') { if (prev_us) return false; prev_us = true; continue; }
     if (*c < '0' || *c > '9') return false;
     prev_us = false;
-    if (x > (uint64_t(1) << 60)) return false;
-    x = x * 10 + uint64_t(*c - '0');
+    if (x > (uint64_t(1) << 60)) { if (!saturate) return false; big = true; }
+    if (!big) x = x * 10 + uint64_t(*c - '0');
   }
   if (prev_us) return false;
+  if (big) x = uint64_t(1) << 61;
   v = neg ? -int64_t(x) : int64_t(x);
   return true;
 }

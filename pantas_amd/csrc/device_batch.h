@@ -1,0 +1,87 @@
+// Device-resident alignment records shared by augment.hip (consumer) and tokenize.hip (producer).
+// HIP translation units only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "walk.h"
+
+namespace pantas {
+
+#define HIP_OK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      throw Error("HipError", std::string(#expr) + ": " + hipGetErrorString(e__));                     \
+  } while (0)
+
+struct DeviceBatch {
+  LineHdr* hdr = nullptr;
+  uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
+  uint32_t n = 0, n_del = 0;
+  uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
+};
+
+// Scratch memory of the GPU tokeniser, kept with the DeviceGraph between batches: hipMalloc / hipFree / hipHostMalloc
+// cost milliseconds each, a batch needs about twenty temporaries.  take() hands out the smallest free block that
+// fits (or allocates), give() returns it; everything is released with the graph.
+struct ScratchPool {
+  struct Block { void* p; size_t bytes; bool busy; };
+  std::vector<Block> blocks;
+  void* pinned[2] = {nullptr, nullptr};
+  size_t pinned_bytes = 0;
+  hipEvent_t pinned_done[2] = {nullptr, nullptr};
+  void* take(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    Block* best = nullptr;
+    for (Block& b : blocks)
+      if (!b.busy && b.bytes >= bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best && best->bytes <= 2 * bytes + (size_t(1) << 20)) { best->busy = true; return best->p; }
+    void* p = nullptr;
+    const size_t rounded = (bytes + 4095) / 4096 * 4096;
+    if (hipMalloc(&p, rounded) != hipSuccess) {
+      trim();   // give cached blocks back and try once more
+      hipError_t e = hipMalloc(&p, rounded);
+      if (e != hipSuccess) throw Error("HipError", std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    blocks.push_back(Block{p, rounded, true});
+    return p;
+  }
+  void give(void* p) {
+    for (Block& b : blocks) if (b.p == p) { b.busy = false; return; }
+  }
+  // ownership of a block leaves the pool (it becomes part of a DeviceBatch, freed with hipFree)
+  void disown(void* p) {
+    for (size_t i = 0; i < blocks.size(); ++i) if (blocks[i].p == p) { blocks.erase(blocks.begin() + long(i)); return; }
+  }
+  void trim() {
+    for (size_t i = 0; i < blocks.size();) {
+      if (!blocks[i].busy) { (void)hipFree(blocks[i].p); blocks.erase(blocks.begin() + long(i)); } else ++i;
+    }
+  }
+  ~ScratchPool() {
+    for (Block& b : blocks) (void)hipFree(b.p);
+    for (int k = 0; k < 2; ++k) {
+      if (pinned[k]) (void)hipHostFree(pinned[k]);
+      if (pinned_done[k]) (void)hipEventDestroy(pinned_done[k]);
+    }
+  }
+};
+
+// what tokenize.hip needs from a DeviceGraph without seeing its tables
+struct DeviceGraphInfo {
+  int device;
+  hipStream_t stream;
+  uint32_t V;
+};
+struct DeviceGraph;
+DeviceGraphInfo graph_info(DeviceGraph& dg);
+struct Graph;
+// dense name table (id - base -> node) in HBM, uploaded on first use and owned by the DeviceGraph
+uint32_t* device_name_table(DeviceGraph& dg, const Graph& g);
+ScratchPool& scratch_pool(DeviceGraph& dg);
+
+}  // namespace pantas

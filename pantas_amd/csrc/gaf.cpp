@@ -103,11 +103,11 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
     ck.keep_del_lines = out.del_lines; ck.keep_del_nodes = out.del_nodes;
     if (tok.size() < 12) fail("IndexError", this_line, "fewer than 12 columns");
     int64_t mapq;
-    if (!parse_py_int(tok[11], mapq)) fail("ValueError", this_line, "mapq is not an integer");
+    if (!parse_py_int(tok[11], mapq, true)) fail("ValueError", this_line, "mapq is not an integer");
     if (mapq < thr) { ++out.rejected; continue; }                                  // :143-146
     if (tok[5].size() == 1 && *tok[5].b == '*') { ++out.skipped; continue; }       // :147-148
     int64_t path_len, start, endpos;
-    if (!parse_py_int(tok[6], path_len) || !parse_py_int(tok[7], start) || !parse_py_int(tok[8], endpos))
+    if (!parse_py_int(tok[6], path_len, true) || !parse_py_int(tok[7], start, true) || !parse_py_int(tok[8], endpos, true))
       fail("ValueError", this_line, "path length / start / end is not an integer");
     // ---- cs tag: first "cs:" in any optional field, up to the end of that field (:154-160)
     const size_t ops_before = out.ops.size();

@@ -47,23 +47,24 @@ PANTAS_HD uint32_t tk_opcode(uint32_t c) {
 }
 PANTAS_HD bool tk_digit(uint32_t c) { return c >= '0' && c <= '9'; }
 
-// Python int(str), ASCII subset: optional sign, digits with single '_' separators; beyond 2^60 refused.
+// Python int(str), ASCII subset: optional sign, digits with single '_' separators; beyond 2^60 saturates at +-2^61.
 PANTAS_HD bool tk_py_int(const uint8_t* c, const uint8_t* e, int64_t& v) {
   if (c >= e) return false;
   bool neg = false;
   if (*c == '+' || *c == '-') { neg = (*c == '-'); ++c; }
   if (c >= e || !tk_digit(*c)) return false;
   uint64_t x = 0;
-  bool prev_us = false;
+  bool prev_us = false, big = false;
   for (; c < e; ++c) {
     const uint32_t ch = *c;
     if (ch == '_') { if (prev_us) return false; prev_us = true; continue; }
     if (!tk_digit(ch)) return false;
     prev_us = false;
-    if (x > (uint64_t(1) << 60)) return false;
-    x = x * 10 + uint64_t(ch - '0');
+    if (x > (uint64_t(1) << 60)) big = true;
+    if (!big) x = x * 10 + uint64_t(ch - '0');
   }
   if (prev_us) return false;
+  if (big) x = uint64_t(1) << 61;
   v = neg ? -int64_t(x) : int64_t(x);
   return true;
 }

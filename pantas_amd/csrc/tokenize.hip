@@ -1,0 +1,546 @@
+// GAF text -> alignment records ON THE GPU: the step in front of the augment kernels.
+// The text of one byte range goes to HBM once (pinned double-buffered copies); everything after that --
+// line index, column split, mapq / unmapped / divergence filters, cs parsing, clipping, path split with the
+// name -> node lookup, locus bucketing -- runs as kernels, and the resulting DeviceBatch is what
+// augment.hip consumes.  Restates scripts/alignments_augmentation_from_gaf.py:142-197, :10-50 through
+// gaf_device.h; gaf.cpp is the host form of the same lines and the two are checked against each other
+// (tests/hostsim/hostsim_tokenize.cpp on the CPU, tests/test_gpu_tokenize.py on the GPU).
+//
+// Passes (all HBM-bound byte / integer work; T = text bytes, N = lines, n = kept records):
+//   newline count per 16 KB tile -> exclusive scan -> line starts            reads T twice, writes 8 N
+//   measure : thread per line, parse_gaf_line<CountOnly>                      reads T (through L2), writes 13 N
+//   limit + totals, three exclusive scans (record index, node offset, op offset)
+//   write   : thread per kept line, parse again, emit at the scanned offsets  reads T, writes the batch
+//   bucket  : key = lowest end node, radix sort (rocPRIM), short-walk records first inside every 2048-block,
+//             sizes -> scans -> gather                                        a few passes over the batch
+// A line the reference raises on is found by the measure pass (atomicMin over (line, code)); the records of
+// the lines before it are still produced, and the host re-reads that one line to word the error.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "augment.h"
+#include "device_batch.h"
+#include "gaf_device.h"
+
+namespace pantas {
+
+namespace {
+
+constexpr uint32_t TILE = 16384;   // text bytes per workgroup of the line-index kernels
+constexpr uint32_t TPB = 256;
+constexpr uint32_t SORT_BLOCK = 2048;
+
+struct DevBuf {
+  ScratchPool* pool = nullptr;
+  void* p = nullptr;
+  DevBuf() = default;
+  explicit DevBuf(ScratchPool& sp) : pool(&sp) {}
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void alloc(size_t bytes) {
+    release();
+    p = pool->take(bytes);
+  }
+  void release() { if (p) { pool->give(p); p = nullptr; } }
+  // the block becomes part of the batch handed to the caller (freed with hipFree by its deleter)
+  template <class T> T* hand_over() { T* q = static_cast<T*>(p); pool->disown(p); p = nullptr; return q; }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// 0x80 in every byte of w that equals '\n' (exact, no borrow artefacts)
+__device__ __forceinline__ uint32_t newline_bits(uint32_t w) {
+  const uint32_t x = w ^ 0x0A0A0A0Au;
+  const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// exclusive prefix of v over the 256 threads of the block; *total = block sum
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total) {
+  __shared__ uint32_t wave_sum[TPB / 64];
+  const uint32_t inc = wave_inclusive_scan(v);
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  if (lane == 63) wave_sum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < TPB / 64; ++w) {
+    const uint32_t s = wave_sum[w];
+    if (w < wave) base += s;
+    all += s;
+  }
+  *total = all;
+  return base + inc - v;
+}
+
+// text is padded with zero bytes to a multiple of TILE, so the loads need no bound
+__global__ void __launch_bounds__(TPB) count_newlines_kernel(const uint4* text, uint32_t* tile_cnt) {
+  const uint4* p = text + (size_t(blockIdx.x) * TILE + threadIdx.x * 64u) / 16u;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint4 v = p[j];
+    c += __popc(newline_bits(v.x)) + __popc(newline_bits(v.y)) + __popc(newline_bits(v.z)) + __popc(newline_bits(v.w));
+  }
+  uint32_t total;
+  (void)block_exclusive_scan(c, &total);
+  if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+// line i = [ls[i], ls[i+1] - 1)
+__global__ void __launch_bounds__(TPB) line_starts_kernel(const uint4* text, const uint32_t* tile_off, uint64_t* ls) {
+  const size_t byte0 = size_t(blockIdx.x) * TILE + threadIdx.x * 64u;
+  const uint4* p = text + byte0 / 16u;
+  uint32_t w[16];
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint4 v = p[j];
+    w[4 * j] = newline_bits(v.x); w[4 * j + 1] = newline_bits(v.y); w[4 * j + 2] = newline_bits(v.z); w[4 * j + 3] = newline_bits(v.w);
+    c += __popc(w[4 * j]) + __popc(w[4 * j + 1]) + __popc(w[4 * j + 2]) + __popc(w[4 * j + 3]);
+  }
+  uint32_t total;
+  uint32_t rank = tile_off[blockIdx.x] + block_exclusive_scan(c, &total);
+  if (c == 0) return;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    uint32_t m = w[j];
+    while (m) {
+      const uint32_t bit = uint32_t(__ffs(int(m))) - 1u;
+      ls[size_t(rank) + 1] = byte0 + uint32_t(j) * 4u + (bit >> 3) + 1u;
+      ++rank;
+      m &= m - 1u;
+    }
+  }
+}
+
+// One wave per workgroup, one line per lane.  The wave first copies the contiguous text of its 64 lines into LDS with
+// 16-byte coalesced loads; the byte-at-a-time scans of parse_gaf_line then run at LDS latency instead of L2 latency
+// (the parse is a chain of dependent byte loads).  A group whose text exceeds the staging buffer (very long lines)
+// parses straight from HBM.
+constexpr uint32_t LPB = 64;
+
+template <class Body>
+__device__ __forceinline__ void staged_lines(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, Body body) {
+  extern __shared__ uint4 stage4[];
+  const uint32_t first = blockIdx.x * LPB;
+  const uint32_t last = min(first + LPB, n_lines);
+  const uint64_t sb = ls[first], se = ls[last];   // se may be size + 1: the text is zero-padded
+  const uint64_t a0 = sb & ~uint64_t(15);
+  const uint64_t a1 = (se + 15) & ~uint64_t(15);
+  const uint32_t i = first + threadIdx.x;
+  if (a1 - a0 <= uint64_t(stage_bytes)) {
+    const uint4* src = reinterpret_cast<const uint4*>(text + a0);
+    const uint32_t n16 = uint32_t((a1 - a0) >> 4);
+    for (uint32_t k = threadIdx.x; k < n16; k += LPB) stage4[k] = src[k];
+    __syncthreads();
+    const uint8_t* stage = reinterpret_cast<const uint8_t*>(stage4);
+    if (i < last) body(i, stage + (ls[i] - a0), stage + (ls[i + 1] - 1 - a0));
+  } else if (i < last) {
+    body(i, text + ls[i], text + ls[i + 1] - 1);
+  }
+}
+
+__global__ void __launch_bounds__(LPB) measure_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr,
+                                                      DenseNames names, uint32_t* kept, uint32_t* cnt_nodes, uint32_t* cnt_ops, uint8_t* meta,
+                                                      unsigned long long* err) {
+  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
+    CountOnly co;
+    LineSummary r;
+    parse_gaf_line(b, e, thr, names, co, r);
+    kept[i] = r.status == TOK_KEEP ? 1u : 0u;
+    cnt_nodes[i] = r.n_nodes;
+    cnt_ops[i] = r.n_ops;
+    meta[i] = uint8_t(r.status | ((r.flags & LINE_HAS_DEL) ? 4u : 0u));
+    if (r.status == TOK_ERROR) atomicMin(err, (static_cast<unsigned long long>(i) << 8) | r.err);
+  });
+}
+
+// totals[0..6] = kept, nodes, ops, rejected, skipped, del lines, del nodes over the lines before the first raising one;
+// the counts of that line and of the lines after it are zeroed so that the scans ignore them
+__global__ void __launch_bounds__(TPB) limit_and_totals_kernel(uint32_t n_lines, const unsigned long long* err, uint32_t* kept, uint32_t* cnt_nodes,
+                                                               uint32_t* cnt_ops, const uint8_t* meta, unsigned long long* totals) {
+  const unsigned long long e = *err;
+  const uint64_t lim = e == ~0ull ? uint64_t(n_lines) : uint64_t(e >> 8);
+  unsigned long long t[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (uint64_t i = uint64_t(blockIdx.x) * TPB + threadIdx.x; i < n_lines; i += uint64_t(gridDim.x) * TPB) {
+    if (i >= lim) { kept[i] = 0; cnt_nodes[i] = 0; cnt_ops[i] = 0; continue; }
+    const uint32_t m = meta[i];
+    t[0] += kept[i]; t[1] += cnt_nodes[i]; t[2] += cnt_ops[i];
+    t[3] += (m & 3u) == TOK_REJECT; t[4] += (m & 3u) == TOK_SKIP;
+    if (m & 4u) { t[5] += 1; t[6] += cnt_nodes[i]; }
+  }
+  __shared__ unsigned long long red[7];
+  if (threadIdx.x < 7) red[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    unsigned long long v = t[k];
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&red[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 7 && red[threadIdx.x]) atomicAdd(&totals[threadIdx.x], red[threadIdx.x]);
+}
+
+struct WriteOut {
+  uint32_t* nodes;
+  uint32_t* ops;
+  __device__ __forceinline__ void node(uint32_t i, uint32_t idx) { nodes[i] = idx; }
+  __device__ __forceinline__ void op(uint32_t i, uint32_t w) { ops[i] = w; }
+};
+
+__global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr,
+                                                    DenseNames names, const uint32_t* kept, const uint32_t* rec_of, const uint32_t* node_scan,
+                                                    const uint32_t* op_scan, uint32_t first_line, LineHdr* hdr, uint32_t* node_off,
+                                                    uint32_t* op_off, uint32_t* nodes, uint32_t* ops) {
+  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
+    if (!kept[i]) return;
+    const uint32_t rec = rec_of[i], no = node_scan[i], oo = op_scan[i];
+    WriteOut wo{nodes + no, ops + oo};
+    LineSummary r;
+    parse_gaf_line(b, e, thr, names, wo, r);
+    hdr[rec] = LineHdr{r.start, r.tail, first_line + i, r.flags};
+    node_off[rec] = no;
+    op_off[rec] = oo;
+  });
+}
+
+// ---- locus bucketing (device form of gaf.cpp bucket_by_locus) ---------------------------------
+__global__ void __launch_bounds__(TPB) bucket_keys_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* nodes, uint32_t* key, uint32_t* idx) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = node_off[i], b = node_off[i + 1];
+  key[i] = b > a ? min(nodes[a], nodes[b - 1]) : 0u;
+  idx[i] = i;
+}
+
+// inside every block of 2048 sorted records: short-walk records first, each kind by path length, stable
+__global__ void __launch_bounds__(TPB) order_blocks_kernel(uint32_t n, const uint32_t* idx_in, const LineHdr* hdr, const uint32_t* node_off, uint32_t* idx_out) {
+  __shared__ uint32_t sh[SORT_BLOCK];
+  const uint32_t a = blockIdx.x * SORT_BLOCK;
+  for (uint32_t j = threadIdx.x; j < SORT_BLOCK; j += TPB) {
+    uint32_t v = 0xFFFFFFFFu;
+    if (a + j < n) {
+      const uint32_t s = idx_in[a + j];
+      const uint32_t k = min(node_off[s + 1] - node_off[s], 0xFFFFu);
+      v = ((((hdr[s].flags & LINE_SIMPLE) ? 0u : 0x10000u) | k) << 11) | j;
+    }
+    sh[j] = v;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= SORT_BLOCK; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < SORT_BLOCK; i += TPB) {
+        const uint32_t o = i ^ j;
+        if (o > i) {
+          const uint32_t x = sh[i], y = sh[o];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { sh[i] = y; sh[o] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t j = threadIdx.x; j < SORT_BLOCK; j += TPB)
+    if (a + j < n) idx_out[a + j] = idx_in[a + (sh[j] & (SORT_BLOCK - 1u))];
+}
+
+__global__ void __launch_bounds__(TPB) sorted_sizes_kernel(uint32_t n, const uint32_t* idx, const LineHdr* hdr, const uint32_t* node_off, const uint32_t* op_off,
+                                                           uint32_t* nn, uint32_t* no, uint32_t* del) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = idx[i];
+  nn[i] = node_off[s + 1] - node_off[s];
+  no[i] = op_off[s + 1] - op_off[s];
+  del[i] = (hdr[s].flags & LINE_HAS_DEL) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(TPB) gather_kernel(uint32_t n, const uint32_t* idx, const LineHdr* hdr0, const uint32_t* node_off0, const uint32_t* op_off0,
+                                                     const uint32_t* nodes0, const uint32_t* ops0, const uint32_t* node_off, const uint32_t* op_off,
+                                                     const uint32_t* del_scan, LineHdr* hdr, uint32_t* nodes, uint32_t* ops, uint32_t* del_idx) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = idx[i];
+  const LineHdr h = hdr0[s];
+  hdr[i] = h;
+  const uint32_t na = node_off0[s], nb = node_off0[s + 1], oa = op_off0[s], ob = op_off0[s + 1];
+  uint32_t* dn = nodes + node_off[i];
+  for (uint32_t k = na; k < nb; ++k) dn[k - na] = nodes0[k];
+  uint32_t* dp = ops + op_off[i];
+  for (uint32_t k = oa; k < ob; ++k) dp[k - oa] = ops0[k];
+  if (h.flags & LINE_HAS_DEL) del_idx[del_scan[i]] = i;
+}
+
+struct Scanner {
+  DevBuf tmp;
+  size_t tmp_bytes = 0;
+  explicit Scanner(ScratchPool& sp) : tmp(sp) {}
+  // out[0..n] = exclusive prefix sums of in[0..n-1] (in must have n + 1 readable words, in[n] is ignored by value)
+  void run(const uint32_t* in, uint32_t* out, size_t n_plus_1, hipStream_t s) {
+    size_t need = 0;
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, int(n_plus_1), s));
+    if (need > tmp_bytes) { tmp.alloc(need); tmp_bytes = need; }
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, in, out, int(n_plus_1), s));
+  }
+};
+
+double now() { return now_s(); }
+
+// host text -> HBM through two pinned staging buffers (kept with the graph); several host threads fill one buffer while
+// the other is in flight
+void upload_text(ScratchPool& sp, const char* data, size_t size, uint8_t* dst, hipStream_t stream) {
+  constexpr size_t STAGE = size_t(32) << 20;
+  if (size == 0) return;
+  if (!sp.pinned[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIP_OK(hipHostMalloc(&sp.pinned[k], STAGE, hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&sp.pinned_done[k], hipEventDisableTiming));
+    }
+    sp.pinned_bytes = STAGE;
+  }
+  size_t off = 0;
+  int k = 0;
+  bool used[2] = {false, false};
+  const unsigned threads = std::min<unsigned>(hw_threads(), 16);
+  while (off < size) {
+    const size_t len = std::min(STAGE, size - off);
+    if (used[k]) HIP_OK(hipEventSynchronize(sp.pinned_done[k]));
+    char* dstp = static_cast<char*>(sp.pinned[k]);
+    const char* src = data + off;
+    parallel_chunks(len, len < (size_t(4) << 20) ? 1u : threads, [&](unsigned, size_t b, size_t e) { memcpy(dstp + b, src + b, e - b); });
+    HIP_OK(hipMemcpyAsync(dst + off, sp.pinned[k], len, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipEventRecord(sp.pinned_done[k], stream));
+    used[k] = true;
+    off += len;
+    k ^= 1;
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+}
+
+inline uint32_t blocks_for(uint64_t n) { return uint32_t((n + TPB - 1) / TPB); }
+
+}  // namespace
+
+DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
+                                   GafBatch& st, DeviceTokenizeTimes* times) {
+  if (!g.names.dense)
+    throw Error("Unsupported", "the GPU tokeniser needs segment names that are canonical decimals (this graph's are not): use the host tokeniser");
+  const DeviceGraphInfo gi = graph_info(dg);
+  HIP_OK(hipSetDevice(gi.device));
+  hipStream_t s = gi.stream;
+  ScratchPool& pool = scratch_pool(dg);
+  PhaseTimer pt("tokenize_gaf_device");
+  DeviceTokenizeTimes tm{};
+  const double t_begin = now();
+
+  // ---- name table (kept with the graph between calls)
+  uint32_t* d_table = device_name_table(dg, g);
+  const DenseNames names{d_table, g.names.base, uint64_t(g.names.table.size())};
+
+  // ---- text
+  const size_t padded = (size + TILE - 1) / TILE * TILE + TILE;
+  DevBuf text(pool);
+  text.alloc(padded);
+  HIP_OK(hipMemsetAsync(text.as<uint8_t>() + size, 0, padded - size, s));
+  double t0 = now();
+  upload_text(pool, data, size, text.as<uint8_t>(), s);
+  tm.h2d_s = now() - t0;
+  pt.lap("text -> HBM");
+
+  // ---- line index
+  const uint32_t tiles = uint32_t((size + TILE - 1) / TILE);
+  if (uint64_t(tiles) * TILE / 2 >= 0xFFFFFFFFull) throw Error("Unsupported", "GAF range too large for one batch");
+  Scanner scan(pool);
+  DevBuf tile_cnt(pool), tile_off(pool);
+  tile_cnt.alloc((size_t(tiles) + 1) * 4);
+  tile_off.alloc((size_t(tiles) + 1) * 4);
+  HIP_OK(hipMemsetAsync(tile_cnt.p, 0, (size_t(tiles) + 1) * 4, s));
+  t0 = now();
+  if (tiles) {
+    hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, text.as<uint4>(), tile_cnt.as<uint32_t>());
+    HIP_OK(hipGetLastError());
+  }
+  scan.run(tile_cnt.as<uint32_t>(), tile_off.as<uint32_t>(), size_t(tiles) + 1, s);
+  uint32_t newlines = 0;
+  HIP_OK(hipMemcpyAsync(&newlines, tile_off.as<uint32_t>() + tiles, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  const bool open_tail = size > 0 && data[size - 1] != '\n';
+  const uint64_t n_lines64 = uint64_t(newlines) + (open_tail ? 1 : 0);
+  if (first_line_id + n_lines64 > uint64_t(0xFFFFFFFFu)) throw Error("Unsupported", "more than 2^32-1 GAF lines");
+  if (n_lines64 >= 0x7FFFFFFFull) throw Error("Unsupported", "more than 2^31-2 GAF lines in one batch");
+  const uint32_t n_lines = uint32_t(n_lines64);
+  DevBuf ls(pool);
+  ls.alloc((size_t(n_lines) + 2) * 8);
+  HIP_OK(hipMemsetAsync(ls.p, 0, 8, s));
+  if (tiles) {
+    hipLaunchKernelGGL(line_starts_kernel, dim3(tiles), dim3(TPB), 0, s, text.as<uint4>(), tile_off.as<uint32_t>(), ls.as<uint64_t>());
+    HIP_OK(hipGetLastError());
+  }
+  if (open_tail) {
+    const uint64_t end1 = uint64_t(size) + 1;
+    HIP_OK(hipMemcpyAsync(ls.as<uint64_t>() + n_lines, &end1, 8, hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+  }
+  tile_cnt.release();
+  if (times) { HIP_OK(hipStreamSynchronize(s)); tm.index_s = now() - t0; }
+  pt.lap("line index");
+
+  // ---- measure
+  // LDS per wave: the text of 64 average lines plus a quarter, between 4 and 64 KB
+  const uint32_t stage_bytes = uint32_t(std::min<uint64_t>(64 * 1024, std::max<uint64_t>(4096, ((n_lines ? size / n_lines : 0) * 80 + 1279) / 1024 * 1024)));
+  DevBuf kept(pool), cnt_nodes(pool), cnt_ops(pool), meta(pool), small(pool);
+  const size_t np1 = size_t(n_lines) + 1;
+  kept.alloc(np1 * 4); cnt_nodes.alloc(np1 * 4); cnt_ops.alloc(np1 * 4); meta.alloc(np1);
+  small.alloc(64);   // [0] err word, [1..7] totals
+  HIP_OK(hipMemsetAsync(kept.as<uint32_t>() + n_lines, 0, 4, s));
+  HIP_OK(hipMemsetAsync(cnt_nodes.as<uint32_t>() + n_lines, 0, 4, s));
+  HIP_OK(hipMemsetAsync(cnt_ops.as<uint32_t>() + n_lines, 0, 4, s));
+  HIP_OK(hipMemsetAsync(small.p, 0xFF, 8, s));
+  HIP_OK(hipMemsetAsync(small.as<uint8_t>() + 8, 0, 56, s));
+  t0 = now();
+  if (n_lines) {
+    hipLaunchKernelGGL(measure_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, text.as<uint8_t>(), ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
+                       kept.as<uint32_t>(), cnt_nodes.as<uint32_t>(), cnt_ops.as<uint32_t>(), meta.as<uint8_t>(), small.as<unsigned long long>());
+    HIP_OK(hipGetLastError());
+    hipLaunchKernelGGL(limit_and_totals_kernel, dim3(std::min<uint32_t>(blocks_for(n_lines), 2048)), dim3(TPB), 0, s, n_lines,
+                       small.as<unsigned long long>(), kept.as<uint32_t>(), cnt_nodes.as<uint32_t>(), cnt_ops.as<uint32_t>(), meta.as<uint8_t>(),
+                       small.as<unsigned long long>() + 1);
+    HIP_OK(hipGetLastError());
+  }
+  DevBuf rec_of(pool), node_scan(pool), op_scan(pool);
+  rec_of.alloc(np1 * 4); node_scan.alloc(np1 * 4); op_scan.alloc(np1 * 4);
+  scan.run(kept.as<uint32_t>(), rec_of.as<uint32_t>(), np1, s);
+  scan.run(cnt_nodes.as<uint32_t>(), node_scan.as<uint32_t>(), np1, s);
+  scan.run(cnt_ops.as<uint32_t>(), op_scan.as<uint32_t>(), np1, s);
+  unsigned long long host_small[8];
+  HIP_OK(hipMemcpyAsync(host_small, small.p, 64, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  tm.measure_s = now() - t0;
+  pt.lap("measure + scans");
+  cnt_nodes.release(); cnt_ops.release(); meta.release();
+
+  const unsigned long long err = host_small[0];
+  const uint64_t n_rec = host_small[1], n_nodes = host_small[2], n_ops = host_small[3];
+  if (n_nodes >= NONE32 || n_ops >= NONE32 || n_rec >= NONE32) throw Error("Unsupported", "more than 2^32-2 path nodes or cs ops in one batch");
+  st = GafBatch{};
+  st.bytes = size;
+  st.rejected = host_small[4];
+  st.skipped = host_small[5];
+  st.del_lines = host_small[6];
+  st.del_nodes = host_small[7];
+  st.lines_total = err == ~0ull ? uint64_t(n_lines) : uint64_t(err >> 8) + 1;
+  if (err != ~0ull) {
+    // word the error the way the host tokeniser does, from the one offending line
+    const uint64_t line = err >> 8;
+    uint64_t span[2];
+    HIP_OK(hipMemcpy(span, ls.as<uint64_t>() + line, 16, hipMemcpyDeviceToHost));
+    GafBatch one;
+    const size_t lb = size_t(span[0]), le = std::min<size_t>(size_t(span[1]), size);
+    tokenize_gaf(g, data + lb, le - lb, thr, first_line_id + line, 1, one);
+    if (!one.deferred) throw Error("InternalError", "GPU tokeniser refused GAF line " + std::to_string(first_line_id + line + 1) + " (code " +
+                                                      std::to_string(unsigned(err & 0xFF)) + ") but the host tokeniser accepts it");
+    st.deferred = one.deferred;
+  }
+
+  // ---- write (file order)
+  DevBuf hdr0(pool), node_off0(pool), op_off0(pool), nodes0(pool), ops0(pool);
+  hdr0.alloc((n_rec + 1) * sizeof(LineHdr));
+  node_off0.alloc((n_rec + 1) * 4); op_off0.alloc((n_rec + 1) * 4);
+  nodes0.alloc((n_nodes + 1) * 4); ops0.alloc((n_ops + 1) * 4);
+  t0 = now();
+  if (n_lines) {
+    hipLaunchKernelGGL(write_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, text.as<uint8_t>(), ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
+                       kept.as<uint32_t>(), rec_of.as<uint32_t>(), node_scan.as<uint32_t>(), op_scan.as<uint32_t>(), uint32_t(first_line_id),
+                       hdr0.as<LineHdr>(), node_off0.as<uint32_t>(), op_off0.as<uint32_t>(), nodes0.as<uint32_t>(), ops0.as<uint32_t>());
+    HIP_OK(hipGetLastError());
+  }
+  const uint32_t tot_nodes = uint32_t(n_nodes), tot_ops = uint32_t(n_ops);
+  HIP_OK(hipMemcpyAsync(node_off0.as<uint32_t>() + n_rec, &tot_nodes, 4, hipMemcpyHostToDevice, s));
+  HIP_OK(hipMemcpyAsync(op_off0.as<uint32_t>() + n_rec, &tot_ops, 4, hipMemcpyHostToDevice, s));
+  HIP_OK(hipStreamSynchronize(s));
+  tm.write_s = now() - t0;
+  pt.lap("write records");
+  text.release(); ls.release(); kept.release(); rec_of.release(); node_scan.release(); op_scan.release();
+
+  // ---- bucket by locus
+  DeviceBatchPtr out(new DeviceBatch());
+  out->n = uint32_t(n_rec);
+  out->n_nodes = n_nodes;
+  out->n_ops = n_ops;
+  out->del_nodes = st.del_nodes;
+  out->n_del = uint32_t(st.del_lines);
+  t0 = now();
+  const uint32_t n = uint32_t(n_rec);
+  if (n == 0) {
+    out->hdr = hdr0.hand_over<LineHdr>();
+    out->node_off = node_off0.hand_over<uint32_t>();
+    out->op_off = op_off0.hand_over<uint32_t>();
+    out->nodes = nodes0.hand_over<uint32_t>();
+    out->ops = ops0.hand_over<uint32_t>();
+    DevBuf del(pool);
+    del.alloc(16);
+    out->del_idx = del.hand_over<uint32_t>();
+  } else {
+    DevBuf key(pool), idx(pool), key2(pool), idx2(pool), sort_tmp(pool);
+    key.alloc(size_t(n) * 4); idx.alloc(size_t(n) * 4);
+    hipLaunchKernelGGL(bucket_keys_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, node_off0.as<uint32_t>(), nodes0.as<uint32_t>(), key.as<uint32_t>(), idx.as<uint32_t>());
+    HIP_OK(hipGetLastError());
+    if (!getenv("PANTAS_NO_BUCKET")) {
+      key2.alloc(size_t(n) * 4); idx2.alloc(size_t(n) * 4);
+      int bits = 1;
+      while (bits < 32 && (uint64_t(1) << bits) < uint64_t(gi.V)) ++bits;
+      size_t need = 0;
+      HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key.as<uint32_t>(), key2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), int(n), 0, bits, s));
+      sort_tmp.alloc(need);
+      HIP_OK(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, need, key.as<uint32_t>(), key2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), int(n), 0, bits, s));
+      // idx2 = records by locus; idx <- the same with every 2048-block reordered
+      hipLaunchKernelGGL(order_blocks_kernel, dim3((n + SORT_BLOCK - 1) / SORT_BLOCK), dim3(TPB), 0, s, n, idx2.as<uint32_t>(), hdr0.as<LineHdr>(),
+                         node_off0.as<uint32_t>(), idx.as<uint32_t>());
+      HIP_OK(hipGetLastError());
+    }
+    DevBuf nn(pool), no(pool), dl(pool), dscan(pool), node_off1(pool), op_off1(pool);
+    nn.alloc((size_t(n) + 1) * 4); no.alloc((size_t(n) + 1) * 4); dl.alloc((size_t(n) + 1) * 4); dscan.alloc((size_t(n) + 1) * 4);
+    node_off1.alloc((size_t(n) + 1) * 4); op_off1.alloc((size_t(n) + 1) * 4);
+    HIP_OK(hipMemsetAsync(nn.as<uint32_t>() + n, 0, 4, s));
+    HIP_OK(hipMemsetAsync(no.as<uint32_t>() + n, 0, 4, s));
+    HIP_OK(hipMemsetAsync(dl.as<uint32_t>() + n, 0, 4, s));
+    hipLaunchKernelGGL(sorted_sizes_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, idx.as<uint32_t>(), hdr0.as<LineHdr>(), node_off0.as<uint32_t>(),
+                       op_off0.as<uint32_t>(), nn.as<uint32_t>(), no.as<uint32_t>(), dl.as<uint32_t>());
+    HIP_OK(hipGetLastError());
+    scan.run(nn.as<uint32_t>(), node_off1.as<uint32_t>(), size_t(n) + 1, s);
+    scan.run(no.as<uint32_t>(), op_off1.as<uint32_t>(), size_t(n) + 1, s);
+    scan.run(dl.as<uint32_t>(), dscan.as<uint32_t>(), size_t(n) + 1, s);
+    DevBuf hdr1(pool), nodes1(pool), ops1(pool), del(pool);
+    hdr1.alloc((n_rec + 1) * sizeof(LineHdr)); nodes1.alloc((n_nodes + 1) * 4); ops1.alloc((n_ops + 1) * 4);
+    del.alloc((size_t(out->n_del) + 1) * 4);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, idx.as<uint32_t>(), hdr0.as<LineHdr>(), node_off0.as<uint32_t>(),
+                       op_off0.as<uint32_t>(), nodes0.as<uint32_t>(), ops0.as<uint32_t>(), node_off1.as<uint32_t>(), op_off1.as<uint32_t>(),
+                       dscan.as<uint32_t>(), hdr1.as<LineHdr>(), nodes1.as<uint32_t>(), ops1.as<uint32_t>(), del.as<uint32_t>());
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(s));
+    out->hdr = hdr1.hand_over<LineHdr>();
+    out->node_off = node_off1.hand_over<uint32_t>();
+    out->op_off = op_off1.hand_over<uint32_t>();
+    out->nodes = nodes1.hand_over<uint32_t>();
+    out->ops = ops1.hand_over<uint32_t>();
+    out->del_idx = del.hand_over<uint32_t>();
+  }
+  tm.bucket_s = now() - t0;
+  pt.lap("bucket by locus");
+  tm.total_s = now() - t_begin;
+  if (times) *times = tm;
+  return out;
+}
+
+}  // namespace pantas

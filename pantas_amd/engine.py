@@ -73,6 +73,25 @@ class Graph:
                                               C.byref(b), C.byref(st)))
         return Batch(b, st)
 
+    TOKENIZER = {"auto": 0, "host": 1, "device": 2}
+
+    def set_tokenizer(self, where: str):
+        """Where GAF text becomes records: "device" (GPU kernels), "host" (threads) or "auto"."""
+        check(lib.pantas_augment_tokenizer(self._h, self.TOKENIZER[where]))
+
+    def download_batch(self, batch: Batch):
+        """(hdr[n,4] int32 {start, tail, line_id, flags}, node_off, op_off, nodes, ops) of a resident batch."""
+        import numpy as np
+        st = batch.stats
+        hdr = np.empty((st.records, 4), dtype=np.int32)
+        node_off = np.empty(st.records + 1, dtype=np.uint32)
+        op_off = np.empty(st.records + 1, dtype=np.uint32)
+        nodes = np.empty(max(1, st.path_nodes), dtype=np.uint32)
+        ops = np.empty(max(1, st.cs_ops), dtype=np.uint32)
+        check(lib.pantas_batch_download(self._h, batch._h, hdr.ctypes.data, node_off.ctypes.data, op_off.ctypes.data,
+                                        nodes.ctypes.data, ops.ctypes.data))
+        return hdr, node_off, op_off, nodes[:st.path_nodes], ops[:st.cs_ops]
+
     def launch(self, batch: Batch) -> LaunchStats:
         st = LaunchStats()
         check(lib.pantas_augment_launch(self._h, batch._h, C.byref(st)))
