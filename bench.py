@@ -231,6 +231,15 @@ def main():
                      "gaf_text_bytes": bs.text_bytes, "gfa_text_bytes": gs.text_bytes,
                      "tokenize_reads_per_s": bs.lines / bs.tokenize_seconds if bs.tokenize_seconds else None,
                      "cores": os.cpu_count()},
+            # the step in front of the path: GAF text -> records; never part of `value`
+            "tokenizer": {"where": {1: "host threads (gaf.cpp)", 2: "GPU kernels (tokenize.hip)"}.get(bs.tokenizer),
+                          "text_to_hbm_s": bs.upload_seconds if bs.tokenizer == 2 else None,
+                          "line_index_s": bs.tok_index_seconds, "measure_and_scans_s": bs.tok_measure_seconds,
+                          "write_s": bs.tok_write_seconds, "bucket_s": bs.tok_bucket_seconds,
+                          "text_GBps_kernels": (bs.text_bytes / 1e9 / (bs.tok_index_seconds + bs.tok_measure_seconds +
+                                                                        bs.tok_write_seconds + bs.tok_bucket_seconds)
+                                                if bs.tokenizer == 2 else None),
+                          "pcie_inclusive_reads_per_s": bs.lines / (bs.tokenize_seconds + bs.upload_seconds + ms_per_step * 1e-3)},
         })
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)

@@ -1,0 +1,80 @@
+"""The device line parser (pantas_amd/csrc/gaf_device.h, what tokenize.hip runs per GPU thread) compiled for the CPU
+under ASan/UBSan and compared, array by array, with the host tokeniser on the same text
+(tests/hostsim/hostsim_tokenize.cpp).  The GPU kernels themselves are checked under -m gpu (test_gpu_tokenize.py)."""
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+import fuzz_gaf
+from conftest import CASES, GOLDEN, ROOT
+from test_hostsim import BUILD, CSRC, CXX
+
+
+@pytest.fixture(scope="module")
+def tokenize_sim():
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "hostsim_tokenize")
+    subprocess.check_call(CXX + ["-o", exe, os.path.join(ROOT, "tests/hostsim/hostsim_tokenize.cpp"),
+                                 *[os.path.join(CSRC, f) for f in ("graph.cpp", "common.cpp", "gaf.cpp")], "-lpthread"])
+    return exe
+
+
+def run(exe, *args):
+    r = subprocess.run([exe, *args], capture_output=True, text=True)
+    assert r.returncode == 0, (args, r.stdout, r.stderr[-2000:])
+    return r.stdout
+
+
+def test_dv_threshold_on_decimal_digits(tokenize_sim):
+    """float(text) > 0.1 decided on the digits agrees with strtod on 200 k strings around the rounding boundary"""
+    assert run(tokenize_sim, "--dv").startswith("OK dv")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_goldens(tokenize_sim, case):
+    d = os.path.join(GOLDEN, case)
+    out = run(tokenize_sim, f"{d}/in.gaf", f"{d}/in.gfa")
+    assert out.startswith("OK"), out
+    for thr in ("0", "61"):
+        assert run(tokenize_sim, f"{d}/in.gaf", f"{d}/in.gfa", thr).startswith("OK")
+
+
+def test_crash_inputs_same_class_same_line(tokenize_sim):
+    cd = os.path.join(GOLDEN, "crashes")
+    seen = set()
+    for c in json.load(open(os.path.join(GOLDEN, "crashes.json"))):
+        if c["stage"] != "augment":
+            continue
+        out = run(tokenize_sim, f"{cd}/{c['name']}.gaf", f"{cd}/{c['name']}.gfa")
+        seen.add(out.strip().split("error=")[-1])
+    assert {"IndexError", "ValueError", "KeyError", "AssertionError"} <= seen, seen
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzzed_text(tokenize_sim, tmp_path, seed):
+    rng = random.Random(seed)
+    gfa, gaf = str(tmp_path / "g.gfa"), str(tmp_path / "r.gaf")
+    fuzz_gaf.write_graph(gfa)
+    kinds = {}
+    for _ in range(250):
+        nl = rng.choice([1, 2, 5, 30, 200])
+        with open(gaf, "w", encoding="latin-1", newline="") as f:
+            for i in range(nl):
+                l = fuzz_gaf.random_line(rng, i)
+                if rng.random() < (0.6 if nl < 10 else 0.02):
+                    l = fuzz_gaf.mutate_text(rng, l)
+                f.write(l + ("\n" if (i < nl - 1 or rng.random() < 0.9) else ""))
+        k = run(tokenize_sim, gaf, gfa).strip().split("error=")[-1]
+        kinds[k] = kinds.get(k, 0) + 1
+    assert kinds.get("none", 0) > 50 and len(kinds) >= 4, kinds
+
+
+def test_multithreaded_host_tokeniser_same_records(tokenize_sim, tmp_path):
+    """host tokeniser with 4 threads (chunk merge) against the per-line device parser"""
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "s")
+    Synth(seed=41, n_genes=50, n_lines=60000, p_indel=0.2, p_novel_skip=0.05).write(pre)
+    assert run(tokenize_sim, pre + ".gaf", pre + ".gfa", "20", "4").startswith("OK lines=60000")
