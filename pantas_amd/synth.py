@@ -423,10 +423,11 @@ def write_gaf(model: Model, path: str, **kw) -> int:
 
 def write_all(prefix: str, seed: int = 1, n_genes: int = 20, n_lines: int = 500, **kw) -> Model:
     model_kw = {k: kw.pop(k) for k in list(kw) if k in ("base_id", "bubble_rate", "max_exons", "intergenic")}
+    read_seed = kw.pop("read_seed", seed)     # other reads over the same graph (replicates)
     m = make_model(seed=seed, n_genes=n_genes, **model_kw)
     write_gfa(m, prefix + ".gfa")
     write_gtf(m, prefix + ".gtf")
-    write_gaf(m, prefix + ".gaf", seed=seed, n_lines=n_lines, **kw)
+    write_gaf(m, prefix + ".gaf", seed=read_seed, n_lines=n_lines, **kw)
     return m
 
 

@@ -1,0 +1,99 @@
+"""`pantas quant` / `pantas remap` mirrors against outputs of the real reference scripts (tools/make_golden_quant.py
+ran scripts/quantify.py and scripts/remap.py in the build container; tests/golden/quant holds inputs and outputs)."""
+import gzip
+import io
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+Q = os.path.join(GOLDEN, "quant")
+META = json.load(open(os.path.join(Q, "expected.json")))
+C1 = [os.path.join(Q, f"c1_r{i}.csv") for i in (1, 2, 3)]
+C2 = [os.path.join(Q, f"c2_r{i}.csv") for i in (1, 2, 3)]
+
+
+def expected(name):
+    return gzip.open(os.path.join(Q, name + ".gz"), "rt").read()
+
+
+@pytest.mark.parametrize("case", META["quant"], ids=lambda c: c["expected"])
+def test_quantify_bytes(case):
+    from pantas_amd import quantify
+    n = case["replicates"]
+    out = io.StringIO()
+    a = quantify.build_parser().parse_args([*case["flags"], "--c1", *C1[:n], "--c2", *C2[:n]])
+    quantify.quantify(a.c1, a.c2, a.w, a.both, out)
+    assert out.getvalue() == expected(case["expected"])
+    assert case["rows"] > 50
+
+
+def test_quantify_cli_and_unequal_replicates():
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.quantify", "--both", "--c1", *C1, "--c2", *C2], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout == expected("quant_1_3.csv")
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.quantify", "--c1", *C1, "--c2", *C2[:2]], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == META["unequal"]["returncode"] and r.stdout == META["unequal"]["stdout"]
+
+
+@pytest.mark.parametrize("case", META["remap"], ids=lambda c: c["expected"])
+def test_remap_bytes(case, tmp_path):
+    from pantas_amd import remap
+    src = str(tmp_path / case["input"])
+    open(src, "w").write(expected(case["input"]))
+    out = io.StringIO()
+    a = remap.build_parser().parse_args([*case["flags"], src, os.path.join(Q, "anno.gtf")])
+    remap.remap(a.CSV, a.GTF, a.min_intron_size, out)
+    assert out.getvalue() == expected(case["expected"])
+
+
+def test_inputs_the_reference_raises_on():
+    from pantas_amd import quantify, remap
+    classes = {"TypeError": TypeError, "ValueError": ValueError, "AttributeError": AttributeError, "IndexError": IndexError,
+               "KeyError": KeyError, "AssertionError": AssertionError}
+    for c in META["crashes"]:
+        path = os.path.join(Q, c["input"])
+        with pytest.raises(classes[c["exception"]]):
+            if c["script"] == "quantify":
+                quantify.quantify([path], [C2[0]], 0, False, io.StringIO())
+            else:
+                remap.remap(path, os.path.join(Q, "anno.gtf"), 100, io.StringIO())
+
+
+def test_dispatcher_quant_and_remap(tmp_path):
+    """bin/pantas quant / remap: the reference dispatcher's argument handling (pantas:176-232)"""
+    exe = os.path.join(ROOT, "bin", "pantas")
+    r = subprocess.run([exe, "quant", *C1, *C2], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == expected("quant_1_3.csv")        # default: only events in both conditions
+    r = subprocess.run([exe, "quant", "-a", *C1, *C2], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == expected("quant_0_3.csv")
+    r = subprocess.run([exe, "quant", *C1, *C2[:2]], capture_output=True, text=True)
+    assert r.returncode == 1 and "Wrong number of replicates" in r.stderr
+    src = str(tmp_path / "q.csv")
+    open(src, "w").write(expected("quant_0_3.csv"))
+    r = subprocess.run([exe, "remap", "-i", "1", src, os.path.join(Q, "anno.gtf")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == expected("remap_quant_0_3_1.csv")
+
+
+def test_merge_is_a_join_not_a_scan(tmp_path):
+    """40 k distinct events per replicate: the reference's pairwise eq_event scan would need ~10^9 comparisons"""
+    import time
+    from pantas_amd import quantify
+    paths = []
+    for rep in range(2):
+        p = str(tmp_path / f"big{rep}.csv")
+        with open(p, "w") as f:
+            f.write("event_type,annotation_type,chrom,gene,strand,junction1_name,junction2_name,junction3_name,junction1_nodes,"
+                    "junction1_coverage,junction2_nodes,junction2_coverage,junction3_nodes,junction3_coverage\n")
+            for i in range(40000):
+                a = 1000 + 10 * i
+                f.write(f"ES,annotated,chr1,g{i % 300},+,T{i}_R1.1.3,T{i}_R1.1.2,T{i}_R1.2.3,{a}>{a + 5},{3 + i % 7 + rep},{a}>{a + 2},{5 + rep},{a + 3}>{a + 5},6\n")
+        paths.append(p)
+    t0 = time.perf_counter()
+    out = io.StringIO()
+    quantify.quantify(paths, list(reversed(paths)), 0, True, out)
+    assert time.perf_counter() - t0 < 20
+    assert len(out.getvalue().splitlines()) == 40001
