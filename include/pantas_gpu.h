@@ -53,6 +53,12 @@ typedef struct {
 
 /* alignments_augmentation_from_gaf.py:121-126 (first GFA pass) / call.py:145-181 */
 int pantas_graph_load(const char* gfa_path, pantas_graph** out);
+/* Binary cache of the parsed graph (the graph is shared by all replicates).  Loads `cache_path` when
+ * it was made from exactly this GFA file (size, mtime, hash of both ends); otherwise parses the GFA and, if
+ * write_if_missing, writes the cache.  *used_cache (may be NULL) = 1 when the text was not parsed.  Graphs whose
+ * segment names are not canonical decimals are parsed every time. */
+int pantas_graph_load_cached(const char* gfa_path, const char* cache_path, int write_if_missing, pantas_graph** out,
+                             int* used_cache);
 void pantas_graph_free(pantas_graph* g);
 int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out);
 /* copies node_len / row_ptr / col to the HBM of `device` and allocates the counters */

@@ -119,6 +119,7 @@ def _load():
         "pantas_call_prepare_mem": (i32, [vp, C.c_char_p, u64, i32]),
         "pantas_call_prepare_fused": (i32, [vp, C.c_char_p, C.c_char_p, u64, i32]),
         "pantas_augment_tokenizer": (i32, [vp, i32]),
+        "pantas_graph_load_cached": (i32, [C.c_char_p, C.c_char_p, i32, P(vp), P(i32)]),
         "pantas_batch_download": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

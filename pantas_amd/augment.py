@@ -9,7 +9,7 @@ from __future__ import annotations
 import os
 import sys
 
-from .engine import Graph, PantasError
+from .engine import Graph, PantasError, graph_cache_path
 
 
 def main(argv) -> int:
@@ -19,7 +19,7 @@ def main(argv) -> int:
     device = int(os.environ.get("PANTAS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     print("Read GFA", file=sys.stderr)
     try:
-        g = Graph(gfa_file)
+        g = Graph(gfa_file, cache=graph_cache_path(gfa_file))   # PANTAS_GRAPH_CACHE: the graph is shared by all replicates
         g.to_device(device)
         print("Augmentation by GAF alignments", file=sys.stderr)
         bs, _ = g.augment(gaf_file, thr, fd_out=-1)

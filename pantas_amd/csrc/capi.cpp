@@ -111,6 +111,23 @@ __attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_pat
   });
 }
 
+__attribute__((visibility("default"))) int pantas_graph_load_cached(const char* gfa_path, const char* cache_path, int write_if_missing,
+                                                                     pantas_graph** out, int* used_cache) {
+  return guarded([&] {
+    need(gfa_path && cache_path && out, "null argument");
+    double t0 = now_s();
+    auto h = std::make_unique<pantas_graph>();
+    h->g = load_graph_cached(gfa_path, cache_path);
+    if (used_cache) *used_cache = h->g ? 1 : 0;
+    if (!h->g) {
+      h->g = load_graph(gfa_path);
+      if (write_if_missing) save_graph_cache(*h->g, cache_path);
+    }
+    h->load_s = now_s() - t0;
+    *out = h.release();
+  });
+}
+
 __attribute__((visibility("default"))) void pantas_graph_free(pantas_graph* g) { delete g; }
 
 __attribute__((visibility("default"))) int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out) {

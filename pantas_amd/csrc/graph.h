@@ -68,4 +68,9 @@ std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
 // Same over text already in memory (the buffer must outlive the graph).
 std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads = 0);
 
+// Binary cache of the parsed arrays (graph_cache.cpp).  save: false when the graph cannot be cached (names that are not
+// decimals, text not from a file).  load: nullptr when there is no usable cache for exactly this GFA file.
+bool save_graph_cache(const Graph& g, const char* cache_path);
+std::unique_ptr<Graph> load_graph_cached(const char* gfa_path, const char* cache_path, unsigned threads = 0);
+
 }  // namespace pantas

@@ -26,9 +26,9 @@ class LibBackend:
     """libpantas_gpu on one GPU."""
 
     def __init__(self, gfa_path: str, device: int):
-        from .engine import Graph
+        from .engine import Graph, graph_cache_path
         self.device = device
-        self.g = Graph(gfa_path).to_device(device)
+        self.g = Graph(gfa_path, cache=graph_cache_path(gfa_path)).to_device(device)
         self.g.augment_reset()
         self.batch = None
 

@@ -23,13 +23,31 @@ class Batch:
         self.free()
 
 
+def graph_cache_path(gfa_path: str):
+    """Where the binary graph cache of `gfa_path` lives according to PANTAS_GRAPH_CACHE: unset/0 = no cache,
+    1 = next to the GFA (<gfa>.pgc), anything else = a directory for the cache files."""
+    where = os.environ.get("PANTAS_GRAPH_CACHE", "")
+    if where in ("", "0"):
+        return None
+    if where == "1":
+        return gfa_path + ".pgc"
+    os.makedirs(where, exist_ok=True)
+    return os.path.join(where, os.path.basename(gfa_path) + ".pgc")
+
+
 class Graph:
     """A GFA loaded into the CSR node/link layout (host) and, after ``to_device``, HBM."""
 
-    def __init__(self, gfa_path: str = None, *, text=None):
-        """From a GFA file, or from (address, size) of GFA text kept alive by the caller."""
+    def __init__(self, gfa_path: str = None, *, text=None, cache: str = None):
+        """From a GFA file, or from (address, size) of GFA text kept alive by the caller.  ``cache``: path of the
+        binary cache of the parsed arrays (used when it matches the file, written otherwise)."""
         h = C.c_void_p()
-        if text is not None:
+        self.used_cache = False
+        if cache is not None and text is None:
+            used = C.c_int32()
+            check(lib.pantas_graph_load_cached(os.fsencode(gfa_path), os.fsencode(cache), 1, C.byref(h), C.byref(used)))
+            self.used_cache = bool(used.value)
+        elif text is not None:
             self._keep = text
             check(lib.pantas_graph_load_mem(C.c_char_p(text[0]), text[1], C.byref(h)))
         else:

@@ -63,7 +63,17 @@ int main(int argc, char** argv) {
     int thr = argc > 3 ? atoi(argv[3]) : 20;
     unsigned threads = getenv("HOSTSIM_THREADS") ? unsigned(atoi(getenv("HOSTSIM_THREADS"))) : 3;
     fprintf(stderr, "Read GFA\n");
-    auto g = load_graph(argv[2], threads);
+    std::unique_ptr<Graph> g;
+    if (const char* cache = getenv("HOSTSIM_GRAPH_CACHE")) {   // the binary graph cache (graph_cache.cpp) in front of the parser
+      g = load_graph_cached(argv[2], cache, threads);
+      fprintf(stderr, "graph cache: %s\n", g ? "used" : "parsed");
+      if (!g) {
+        g = load_graph(argv[2], threads);
+        save_graph_cache(*g, cache);
+      }
+    } else {
+      g = load_graph(argv[2], threads);
+    }
     fprintf(stderr, "Augmentation by GAF alignments\n");
     MappedFile gaf;
     gaf.open(argv[1]);

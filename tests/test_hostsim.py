@@ -26,7 +26,7 @@ CXX = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-s
 @pytest.fixture(scope="session")
 def hostsim():
     os.makedirs(BUILD, exist_ok=True)
-    common = [os.path.join(CSRC, f) for f in ("graph.cpp", "common.cpp")]
+    common = [os.path.join(CSRC, f) for f in ("graph.cpp", "graph_cache.cpp", "common.cpp")]
     aug = os.path.join(BUILD, "hostsim_augment")
     call = os.path.join(BUILD, "hostsim_call")
     subprocess.check_call(CXX + ["-o", aug, os.path.join(ROOT, "tests/hostsim/hostsim_augment.cpp"), *common,
@@ -160,3 +160,46 @@ def test_call_source_parameter_sweep(hostsim, tmp_path):
         assert mine == ref, (kw, flags)
         total += len(want)
     assert total > 500
+
+
+def test_graph_cache_round_trip(hostsim, tmp_path):
+    """binary graph cache: first run parses and writes it, the second reads it -- same bytes out; a changed GFA is
+    parsed again; the C ABI entry reports which happened"""
+    import ctypes as C
+    import shutil
+    import time
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "c")
+    Synth(seed=51, n_genes=30, n_lines=4000, p_indel=0.2, p_novel_skip=0.05).write(pre)
+    cache = pre + ".pgc"
+    env = dict(os.environ, HOSTSIM_GRAPH_CACHE=cache)
+    plain = run([hostsim["augment"], pre + ".gaf", pre + ".gfa"])
+    first = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+    second = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+    assert "graph cache: parsed" in first.stderr and "graph cache: used" in second.stderr
+    assert plain.returncode == 0 and plain.stdout == first.stdout == second.stdout
+    # the same bytes under a new mtime, then different bytes: both must be parsed again
+    time.sleep(0.01)
+    os.utime(pre + ".gfa")
+    third = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+    assert "graph cache: parsed" in third.stderr and third.stdout == plain.stdout
+    with open(pre + ".gfa", "a") as f:
+        f.write("S\t999999\tACGT\n")
+    fourth = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+    assert "graph cache: parsed" in fourth.stderr and fourth.stdout.count("\n") == plain.stdout.count("\n") + 1
+    # through the C ABI (host only)
+    from pantas_amd._lib import lib, check, GraphStats
+    for want in (1, 1):
+        h, used = C.c_void_p(), C.c_int32()
+        check(lib.pantas_graph_load_cached(os.fsencode(pre + ".gfa"), os.fsencode(cache), 1, C.byref(h), C.byref(used)))
+        st = GraphStats()
+        check(lib.pantas_graph_get_stats(h, C.byref(st)))
+        assert used.value == want and st.segments > 100
+        lib.pantas_graph_free(h)
+    # a truncated cache is ignored
+    with open(cache, "r+b") as f:
+        f.truncate(os.path.getsize(cache) // 2)
+    h, used = C.c_void_p(), C.c_int32()
+    check(lib.pantas_graph_load_cached(os.fsencode(pre + ".gfa"), os.fsencode(cache), 0, C.byref(h), C.byref(used)))
+    assert used.value == 0
+    lib.pantas_graph_free(h)
