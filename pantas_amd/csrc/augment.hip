@@ -155,11 +155,18 @@ constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
 // base it covers is a mismatch, none -- so no op list has to be built.  Both walks fetch the node's
 // length word and its CSR row bounds together when the node is first touched; only the col[] scan of the
 // link lookup depends on an earlier load.
-template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F>
+// PACKED: the four counters of a node entry are 16-bit fields of ONE 64-bit LDS word, so that a kept node costs one
+// ds_add_u64 instead of up to four ds_add_u32 (same-address LDS atomics serialise, and reads of one locus hit the
+// same few nodes).  No field can carry into the next: a record adds at most 1 per field per visit (larger steps go to
+// memory directly), only records with at most PACKED_MAX_PATH path nodes use the table, a chunk has 2048 records:
+// 2048 * 31 < 65536.
+constexpr uint32_t PACKED_MAX_PATH = 31;
+
+template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, bool PACKED = false>
 struct AggSink {
   static constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CF = 1u << LOG_F;
   const GraphView& g;
-  uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN | RC of the node's first out-slot CN]
+  uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN | RC of the node's first out-slot CN]; PACKED: CN x u64 {NC, IL0, OLL, RC first slot}
   uint32_t* skey; uint32_t* scnt;
   uint32_t* fkey; unsigned long long* fmin;
   unsigned long long* vkey; uint32_t* vcnt; unsigned long long* vmin;   // links absent from the graph (CF entries)
@@ -218,9 +225,40 @@ struct AggSink {
     }
     return LDS_EMPTY;
   }
+  // PACKED: all four increments of a kept node (each 0 or 1; a_r0 = the link to the next node is the node's first
+  // out-slot) in one LDS atomic
+  __device__ __forceinline__ void bump_packed(uint32_t n, uint32_t row_lo, uint32_t a_nc, uint32_t a_il, uint32_t a_ol, uint32_t a_r0) const {
+    if (g.ablate & 8u) return;
+    const uint32_t h = probe<LOG_N>(nkey, n);
+    if (h != LDS_EMPTY) {
+      const unsigned long long inc = static_cast<unsigned long long>(a_nc) | (static_cast<unsigned long long>(a_il) << 16) |
+                                     (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
+      atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
+    } else {
+      if (a_nc) atomicAdd(&g.nc[n], a_nc);
+      if (a_il) atomicAdd(&g.il0[n], a_il);
+      if (a_ol) atomicAdd(&g.oll[n], a_ol);
+      if (a_r0) atomicAdd(&g.rc[row_lo], a_r0);
+    }
+  }
+  // link (a -> b) that is not a's first out-slot: the other slots, else a link the graph does not have
+  __device__ __forceinline__ void link_rest(uint32_t a, uint32_t lo, uint32_t hi, uint32_t b, uint64_t order) const {
+    if (g.ablate & 4u) return;
+    for (uint32_t s = lo + 1; s < hi; ++s) {
+      if (g.col[s] == b) { bump_slot(s); return; }
+    }
+    novel(a, b, order);
+  }
   // returns the node's table slot (LDS_EMPTY when the increments went to memory)
   __device__ __forceinline__ uint32_t bump_node(uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol) const {
     if (g.ablate & 8u) return LDS_EMPTY;
+    if constexpr (PACKED) {
+      // general walk: steps above 1 bypass the 16-bit fields
+      if (a_il > 1u) { atomicAdd(&g.il0[n], a_il); a_il = 0; }
+      if (a_ol > 1u) { atomicAdd(&g.oll[n], a_ol); a_ol = 0; }
+      if (a_nc | a_il | a_ol) bump_packed(n, 0u, a_nc, a_il, a_ol, 0u);
+      return LDS_EMPTY;
+    }
     const uint32_t h = probe<LOG_N>(nkey, n);
     if (h != LDS_EMPTY) {
       if (a_nc) atomicAdd(&ncnt[h], a_nc);
@@ -335,8 +373,9 @@ __device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h,
     if (pending) {
       const uint32_t hp = flush_simple(pend, kept - 1u, false, h, sink);
       const uint64_t ord = event_order(h.line_id, kept - 1u, 0);
-      if (rev) sink.link_pf(node, LDS_EMPTY, row_lo, row_hi, col0, pend.node, ord);
-      else sink.link_pf(pend.node, hp, pend.row_lo, pend.row_hi, pend.col0, node, ord);
+      // one copy of the link code for both strands (a wave holds reads of both: two inlined calls would both run)
+      sink.link_pf(rev ? node : pend.node, rev ? LDS_EMPTY : hp, rev ? row_lo : pend.row_lo, rev ? row_hi : pend.row_hi,
+                   rev ? col0 : pend.col0, rev ? pend.node : node, ord);
     }
     pend = SimplePend{node, word, row_lo, row_hi, col0, stars_in < le};
     pending = true;
@@ -347,22 +386,106 @@ __device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h,
   return WALK_OK;
 }
 
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1>
+// The short walk over PACKED node entries: NC, IL[0], OL[len] and the count of the first out-slot of a kept node go
+// to LDS as one 64-bit add, issued when the next kept node is known.  On a forward read the link pend -> node is
+// pend's own first slot in the usual case; on a reverse read the link is node -> pend, i.e. the first slot of the
+// node just reached, which carries it until it is flushed itself.
+struct PackedPend {
+  uint32_t node, word, row_lo, row_hi, col0;
+  bool has_colon;
+  uint32_t r0;      // first-slot hits already owed to this node (reverse reads)
+};
+
+template <class Sink>
+__device__ __forceinline__ void flush_packed(const PackedPend& p, uint32_t idx, bool is_last, const LineHdr& h, const Sink& sink, uint32_t r0) {
+  const bool rev = (h.flags & LINE_REV) != 0;
+  const bool is_first = idx == 0;
+  const bool enter = p.has_colon && !is_first, leave = p.has_colon && !is_last;
+  const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
+  const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
+  sink.bump_packed(p.node, p.row_lo, 1u, a_il, a_ol, r0);
+  if (a_il && (p.word & FLAG_IL)) sink.order_min(p.node, SIDE_IL, event_order(h.line_id, idx, 1));
+  if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
+}
+
+template <class Sink>
+__device__ __forceinline__ int walk_simple_packed(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
+                                                  const uint32_t* ops, uint32_t nops, const Sink& sink) {
+  uint32_t T = 0, ns = 0;
+  uint32_t star[SIMPLE_MAX_STARS];
+#pragma unroll 1
+  for (uint32_t j = 0; j < nops; ++j) {
+    const uint32_t w = ops[j];
+    if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
+    T += w >> 3;
+  }
+  const bool rev = (h.flags & LINE_REV) != 0;
+  const bool links = !(g.ablate & 4u);
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  PackedPend pend{};
+  uint32_t nx_node = nodes[0];
+  uint32_t nx_word = g.word[nx_node];
+  uint32_t nx_lo = g.row_ptr[nx_node], nx_hi = g.row_ptr[nx_node + 1];
+#pragma unroll 1
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = nx_node, word = nx_word, row_lo = nx_lo, row_hi = nx_hi;
+    const uint32_t col0 = row_lo < row_hi ? g.col[row_lo] : 0u;
+    if (i + 1 < k) {
+      nx_node = nodes[i + 1];
+      nx_word = g.word[nx_node];
+      nx_lo = g.row_ptr[nx_node];
+      nx_hi = g.row_ptr[nx_node + 1];
+    }
+    int64_t room = int64_t(word & LEN_MASK);
+    if (i == 0) room -= h.start;
+    if (i == k - 1) room = room - h.tail + 1;
+    if (room <= 0) continue;
+    if (P >= T) return WALK_OPS_EXHAUSTED;
+    const uint32_t le = uint32_t(min(room, int64_t(T - P)));
+    uint32_t stars_in = 0;
+    for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
+    uint32_t r0_here = 0;
+    if (pending) {
+      const uint64_t ord = event_order(h.line_id, kept - 1u, 0);
+      // link a -> b, strand by select so that the code below exists once
+      const uint32_t a = rev ? node : pend.node, bnode = rev ? pend.node : node;
+      const uint32_t a_lo = rev ? row_lo : pend.row_lo, a_hi = rev ? row_hi : pend.row_hi, a_c0 = rev ? col0 : pend.col0;
+      const bool first_slot = links && a_lo < a_hi && a_c0 == bnode;
+      flush_packed(pend, kept - 1u, false, h, sink, rev ? pend.r0 : (first_slot ? 1u : 0u));
+      if (rev && first_slot) r0_here = 1u;
+      if (links && !first_slot) sink.link_rest(a, a_lo, a_hi, bnode, ord);
+    }
+    pend = PackedPend{node, word, row_lo, row_hi, col0, stars_in < le, r0_here};
+    pending = true;
+    ++kept;
+    P = (room >= int64_t(T - P)) ? T : P + uint32_t(room);
+  }
+  if (pending) flush_packed(pend, kept - 1u, true, h, sink, rev ? pend.r0 : 0u);
+  return WALK_OK;
+}
+
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g, BatchView b) {
-  using Sink = AggSink<LOG_N, LOG_S, LOG_F>;
+  using Sink = AggSink<LOG_N, LOG_S, LOG_F, PACKED>;
   constexpr uint32_t CN = Sink::CN, CS = Sink::CS, CF = Sink::CF;
+  static_assert(!PACKED || CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
   __shared__ unsigned long long fmin[CF];
   __shared__ unsigned long long vkey[CF];
   __shared__ unsigned long long vmin[CF];
   __shared__ uint32_t vcnt[CF];
   __shared__ uint32_t nkey[CN];
-  __shared__ uint32_t ncnt[4 * CN];
+  __shared__ __attribute__((aligned(8))) uint32_t ncnt[(PACKED ? 2 : 4) * CN];
   __shared__ uint32_t skey[CS];
   __shared__ uint32_t scnt[CS];
   __shared__ uint32_t fkey[CF];
   const uint32_t n_chunks = (b.n + CHUNK - 1) / CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) { nkey[i] = LDS_EMPTY; ncnt[i] = 0u; ncnt[CN + i] = 0u; ncnt[2 * CN + i] = 0u; ncnt[3 * CN + i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
+      nkey[i] = LDS_EMPTY;
+      ncnt[i] = 0u; ncnt[CN + i] = 0u;
+      if constexpr (!PACKED) { ncnt[2 * CN + i] = 0u; ncnt[3 * CN + i] = 0u; }
+    }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
     __syncthreads();
@@ -374,15 +497,29 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
       const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
       int st;
-      if ((h.flags & LINE_SIMPLE) && !(g.ablate & 16u)) st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-      else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+      if constexpr (ONLY == 1) { if (!(h.flags & LINE_SIMPLE)) continue; }   // timing experiments: one record class only
+      if constexpr (ONLY == 2) { if (h.flags & LINE_SIMPLE) continue; }
+      if (ONLY != 1 && PACKED && n1 - n0 > PACKED_MAX_PATH) {
+        // a path this long could overflow a 16-bit field of the LDS entries: straight to memory
+        MainSink direct{g};
+        st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, direct);
+      } else if (ONLY == 1 || (ONLY == 0 && (h.flags & LINE_SIMPLE) && !(g.ablate & 16u))) {
+        if constexpr (PACKED) st = walk_simple_packed(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+        else st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+      } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       const uint32_t n = nkey[i];
       if (n == LDS_EMPTY) continue;
-      const uint32_t a = ncnt[i], il = ncnt[CN + i], ol = ncnt[2 * CN + i], r0 = ncnt[3 * CN + i];
+      uint32_t a, il, ol, r0;
+      if constexpr (PACKED) {
+        const unsigned long long v = reinterpret_cast<const unsigned long long*>(ncnt)[i];
+        a = uint32_t(v) & 0xFFFFu; il = uint32_t(v >> 16) & 0xFFFFu; ol = uint32_t(v >> 32) & 0xFFFFu; r0 = uint32_t(v >> 48);
+      } else {
+        a = ncnt[i]; il = ncnt[CN + i]; ol = ncnt[2 * CN + i]; r0 = ncnt[3 * CN + i];
+      }
       if (a) atomicAdd(&g.nc[n], a);
       if (il) atomicAdd(&g.il0[n], il);
       if (ol) atomicAdd(&g.oll[n], ol);
@@ -710,13 +847,18 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else {
-#define PANTAS_AGG(ID, T, CH, LN, LS, LF, MW) \
-      case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
+#define PANTAS_AGG(ID, T, CH, LN, LS, LF, MW, ...) \
+      case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
       switch (variant) {
         PANTAS_AGG(8, 1024, 4096, 12, 12, 9, 1)
         PANTAS_AGG(9, 512, 2048, 11, 11, 7, 1)
         PANTAS_AGG(20, 256, 1024, 9, 9, 7, 8)
         PANTAS_AGG(22, 512, 2048, 10, 9, 7, 8)
+        PANTAS_AGG(40, 512, 2048, 10, 10, 7, 8, true)    // packed node entries
+        PANTAS_AGG(41, 512, 2048, 11, 10, 7, 8, true)    // ... with a larger node table (same LDS as 18)
+        PANTAS_AGG(42, 1024, 2048, 10, 10, 7, 8, true)
+        PANTAS_AGG(50, 512, 2048, 10, 10, 7, 8, true, 1)  // timing only: short-walk records alone
+        PANTAS_AGG(51, 512, 2048, 10, 10, 7, 8, true, 2)  // timing only: general-walk records alone
         default:
         PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
       }
