@@ -81,11 +81,15 @@ typedef struct {
    * upload_seconds = text -> HBM, then line index, measure pass + scans, write pass, locus bucketing */
   int32_t tokenizer, reserved_;
   double tok_index_seconds, tok_measure_seconds, tok_write_seconds, tok_bucket_seconds;
+  /* the short-walk class (records the dominant kernel takes: cs of ':' and '*' only, at most 31 path nodes) */
+  uint64_t short_records, short_alg_bytes;
 } pantas_batch_stats;
 
 typedef struct {
   float rare_ms;           /* augment_rare_kernel, HIP events on the launch stream */
-  float main_ms;           /* augment_main_kernel */
+  float main_ms;           /* all main kernels of the launch */
+  float main_short_ms;     /* of which the short-walk kernel (the dominant one); 0 when one kernel took every record */
+  float reserved_;
 } pantas_launch_stats;
 
 /* Where the GAF text is turned into records (:142-197, :10-50).  AUTO = on the GPU when the graph's segment names are

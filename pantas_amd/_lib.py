@@ -36,11 +36,12 @@ class BatchStats(C.Structure):
                 ("del_records", C.c_uint64), ("del_path_nodes", C.c_uint64), ("text_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
                 ("tokenize_seconds", C.c_double), ("upload_seconds", C.c_double),
                 ("tokenizer", C.c_int32), ("reserved_", C.c_int32), ("tok_index_seconds", C.c_double),
-                ("tok_measure_seconds", C.c_double), ("tok_write_seconds", C.c_double), ("tok_bucket_seconds", C.c_double)]
+                ("tok_measure_seconds", C.c_double), ("tok_write_seconds", C.c_double), ("tok_bucket_seconds", C.c_double),
+                ("short_records", C.c_uint64), ("short_alg_bytes", C.c_uint64)]
 
 
 class LaunchStats(C.Structure):
-    _fields_ = [("rare_ms", C.c_float), ("main_ms", C.c_float)]
+    _fields_ = [("rare_ms", C.c_float), ("main_ms", C.c_float), ("main_short_ms", C.c_float), ("reserved_", C.c_float)]
 
 
 class CallOpts(C.Structure):

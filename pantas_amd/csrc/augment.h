@@ -80,7 +80,10 @@ void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 struct CounterPtrs { void* nc; void* rc; void* il0; void* oll; uint64_t V, A; };
 CounterPtrs counter_ptrs(DeviceGraph& dg);
 uint64_t batch_lines(const DeviceBatch& db);
+uint64_t batch_short_records(const DeviceBatch& db);   // records of the short-walk class (walk.h), first in the batch
+float last_short_kernel_ms(const DeviceGraph& dg);      // short-walk kernel of the last launch_main alone
 void batch_sizes(const DeviceBatch& db, uint64_t* path_nodes, uint64_t* cs_ops);
-uint64_t batch_alg_bytes(const DeviceBatch& db);      // algorithmic bytes of the main kernel
+uint64_t batch_alg_bytes(const DeviceBatch& db);
+uint64_t batch_alg_bytes_short(const DeviceBatch& db);   // the same for the short-walk class alone      // algorithmic bytes of the main kernel
 
 }  // namespace pantas

@@ -160,7 +160,7 @@ constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
 // same few nodes).  No field can carry into the next: a record adds at most 1 per field per visit (larger steps go to
 // memory directly), only records with at most PACKED_MAX_PATH path nodes use the table, a chunk has 2048 records:
 // 2048 * 31 < 65536.
-constexpr uint32_t PACKED_MAX_PATH = 31;
+constexpr uint32_t PACKED_MAX_PATH = SHORT_MAX_PATH;
 
 template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, bool PACKED = false>
 struct AggSink {
@@ -466,7 +466,7 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
 }
 
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0>
-__global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g, BatchView b) {
+__global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g, BatchView b, uint32_t begin, uint32_t end) {
   using Sink = AggSink<LOG_N, LOG_S, LOG_F, PACKED>;
   constexpr uint32_t CN = Sink::CN, CS = Sink::CS, CF = Sink::CF;
   static_assert(!PACKED || CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   __shared__ uint32_t skey[CS];
   __shared__ uint32_t scnt[CS];
   __shared__ uint32_t fkey[CF];
-  const uint32_t n_chunks = (b.n + CHUNK - 1) / CHUNK;
+  const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       nkey[i] = LDS_EMPTY;
@@ -490,15 +490,14 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
     __syncthreads();
     const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin};
-    const uint32_t lo = c * CHUNK;
-    const uint32_t hi = min(b.n, lo + CHUNK);
+    const uint32_t lo = begin + c * CHUNK;
+    const uint32_t hi = min(end, lo + CHUNK);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
       const LineHdr h = b.hdr[i];
       const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
       const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
       int st;
-      if constexpr (ONLY == 1) { if (!(h.flags & LINE_SIMPLE)) continue; }   // timing experiments: one record class only
-      if constexpr (ONLY == 2) { if (h.flags & LINE_SIMPLE) continue; }
+      // ONLY == 1: the range holds short-walk records only (walk.h short_walk_class)
       if (ONLY != 1 && PACKED && n1 - n0 > PACKED_MAX_PATH) {
         // a path this long could overflow a 16-bit field of the LDS entries: straight to memory
         MainSink direct{g};
@@ -572,7 +571,9 @@ struct Table {
 struct DeviceGraph {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream2 = nullptr;  // the general-walk kernel runs here, beside the short-walk kernel on `stream`
+  float last_short_ms = 0.f;      // duration of the short-walk kernel of the last launch_main (0 when one kernel did everything)
   uint32_t V = 0;
   uint64_t A = 0;
   uint32_t* word = nullptr;
@@ -627,6 +628,7 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   d->novel.free_all();
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
+  if (d->stream2) (void)hipStreamDestroy(d->stream2);
   delete d;
 }
 
@@ -676,6 +678,7 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   d->V = g.V;
   d->A = g.A;
   HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
   for (auto& e : d->ev) HIP_OK(hipEventCreate(&e));
   HIP_OK(hipMalloc(&d->word, std::max<size_t>(1, g.V) * 4));
   HIP_OK(hipMalloc(&d->row_ptr, (size_t(g.V) + 1) * 4));
@@ -740,6 +743,9 @@ DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
     throw Error("InternalError", "batch offsets do not match its arrays");
   DeviceBatchPtr p(new DeviceBatch());
   p->n = uint32_t(b.size());
+  p->n_short = uint32_t(std::min<uint64_t>(b.n_short, b.size()));
+  p->short_nodes = b.node_off[p->n_short];
+  p->short_ops = b.op_off[p->n_short];
   p->n_nodes = b.nodes.size();
   p->n_ops = b.ops.size();
   p->del_nodes = b.del_nodes;
@@ -775,12 +781,18 @@ void download_batch(const DeviceGraph& d, const DeviceBatch& b, GafBatch& out) {
 }
 
 uint64_t batch_lines(const DeviceBatch& db) { return db.n; }
+uint64_t batch_short_records(const DeviceBatch& db) { return db.n_short; }
 void batch_sizes(const DeviceBatch& db, uint64_t* path_nodes, uint64_t* cs_ops) { *path_nodes = db.n_nodes; *cs_ops = db.n_ops; }
 
 uint64_t batch_alg_bytes(const DeviceBatch& db) {
   // B_line = 16 + 16 k + 4 c + 21 (k - 1)
   const uint64_t n = db.n;
   return 16 * n + 16 * db.n_nodes + 4 * db.n_ops + 21 * (db.n_nodes - std::min<uint64_t>(n, db.n_nodes));
+}
+
+uint64_t batch_alg_bytes_short(const DeviceBatch& db) {
+  const uint64_t n = db.n_short;
+  return 16 * n + 16 * db.short_nodes + 4 * db.short_ops + 21 * (db.short_nodes - std::min<uint64_t>(n, db.short_nodes));
 }
 
 static BatchView batch_view(const DeviceBatch& b) {
@@ -839,39 +851,66 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
+  d.last_short_ms = 0.f;
   if (b.n) {
-    // PANTAS_MAIN_KERNEL: 0 = direct global atomics (reference point for A/B), otherwise the aggregating kernel
-    // in one of a few occupancy / table-size configurations (default 18; profiles/README.md has the A/B)
-    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 18;
+    // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = direct global atomics; 8..42 = ONE aggregating kernel over all
+    // records in a few occupancy / table configurations; 60.. (default 60) = the two record classes in their own
+    // kernels: the short-walk class [0, n_short) with packed LDS entries, the rest with the general kernel.  The
+    // short-walk kernel then needs no registers, scalar spills or code of the general walk, and no chunk waits for
+    // the few slow general-walk waves that used to sit at its end.
+    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 60;
+#define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
+    do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
+                                               dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
+#define PANTAS_AGG(ID, ...) case ID: PANTAS_AGG_RANGE(d.stream, 0u, b.n, __VA_ARGS__); break;
+    // one after the other on the launch stream
+#define PANTAS_SPLIT_SEQ(ID, SHORT_ARGS, GENERAL_ARGS) case ID: \
+      PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; PANTAS_AGG_RANGE GENERAL_ARGS; break;
+    // side by side: the general-walk kernel (few records, slow waves, often too few workgroups to fill the chip) on a
+    // second stream fills what the short-walk kernel leaves; both add to the same counters with atomics
+#define PANTAS_SPLIT(ID, SHORT_ARGS, GENERAL_ARGS) case ID: \
+      HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0)); \
+      PANTAS_AGG_RANGE GENERAL_ARGS; HIP_OK(hipEventRecord(d.ev[4], d.stream2)); \
+      PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; \
+      HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0)); break;
+    bool split = false;
     if (variant == 0) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else {
-#define PANTAS_AGG(ID, T, CH, LN, LS, LF, MW, ...) \
-      case ID: hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), dim3((b.n + CH - 1) / CH), dim3(T), 0, d.stream, g, bv); break;
       switch (variant) {
         PANTAS_AGG(8, 1024, 4096, 12, 12, 9, 1)
         PANTAS_AGG(9, 512, 2048, 11, 11, 7, 1)
+        PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
         PANTAS_AGG(20, 256, 1024, 9, 9, 7, 8)
         PANTAS_AGG(22, 512, 2048, 10, 9, 7, 8)
-        PANTAS_AGG(40, 512, 2048, 10, 10, 7, 8, true)    // packed node entries
-        PANTAS_AGG(41, 512, 2048, 11, 10, 7, 8, true)    // ... with a larger node table (same LDS as 18)
-        PANTAS_AGG(42, 1024, 2048, 10, 10, 7, 8, true)
-        PANTAS_AGG(50, 512, 2048, 10, 10, 7, 8, true, 1)  // timing only: short-walk records alone
-        PANTAS_AGG(51, 512, 2048, 10, 10, 7, 8, true, 2)  // timing only: general-walk records alone
+        PANTAS_AGG(40, 512, 2048, 10, 10, 7, 8, true)    // packed node entries, one kernel
+        PANTAS_AGG(41, 512, 2048, 11, 10, 7, 8, true)
+        PANTAS_SPLIT(61, (d.stream, 0u, b.n_short, 512, 2048, 11, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(63, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 256, 1024, 9, 9, 7, 8))
+        PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         default:
-        PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
+        PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
       }
-#undef PANTAS_AGG
     }
+#undef PANTAS_SPLIT_SEQ
+#undef PANTAS_SPLIT
+#undef PANTAS_AGG
+#undef PANTAS_AGG_RANGE
     HIP_OK(hipGetLastError());
+    HIP_OK(hipEventRecord(d.ev[2], d.stream));
+    HIP_OK(hipEventSynchronize(d.ev[2]));
+    if (split) HIP_OK(hipEventElapsedTime(&d.last_short_ms, d.ev[1], d.ev[3]));
+  } else {
+    HIP_OK(hipEventRecord(d.ev[2], d.stream));
+    HIP_OK(hipEventSynchronize(d.ev[2]));
   }
-  HIP_OK(hipEventRecord(d.ev[2], d.stream));
-  HIP_OK(hipEventSynchronize(d.ev[2]));
   float m = 0;
   HIP_OK(hipEventElapsedTime(&m, d.ev[1], d.ev[2]));
   return m;
 }
+
+float last_short_kernel_ms(const DeviceGraph& d) { return d.last_short_ms; }
 
 float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_main) {
   const float a = launch_rare(d, b);

@@ -249,6 +249,8 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
   s.del_path_nodes = b.del_nodes;
   s.text_bytes = b.bytes;
   s.alg_bytes = batch_alg_bytes(*h->dev);
+  s.short_records = batch_short_records(*h->dev);
+  s.short_alg_bytes = batch_alg_bytes_short(*h->dev);
   g->lines += b.lines_total;
   g->rejected += b.rejected;
   g->skipped += b.skipped;
@@ -311,7 +313,7 @@ __attribute__((visibility("default"))) int pantas_augment_launch(pantas_graph* g
     need(b && b->dev, "null batch");
     float r = 0, m = 0;
     launch_augment(*g->dev, *b->dev, &r, &m);
-    if (out) { out->rare_ms = r; out->main_ms = m; }
+    if (out) { out->rare_ms = r; out->main_ms = m; out->main_short_ms = last_short_kernel_ms(*g->dev); out->reserved_ = 0; }
   });
 }
 

@@ -22,7 +22,9 @@ struct DeviceBatch {
   LineHdr* hdr = nullptr;
   uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
   uint32_t n = 0, n_del = 0;
+  uint32_t n_short = 0;          // records [0, n_short) are the short-walk class (walk.h), bucketed apart from the rest
   uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
+  uint64_t short_nodes = 0, short_ops = 0;   // path nodes / cs ops of the short-walk class
 };
 
 // Scratch memory of the GPU tokeniser, kept with the DeviceGraph between batches: hipMalloc / hipFree / hipHostMalloc

@@ -302,7 +302,10 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
 void bucket_by_locus(GafBatch& b, unsigned threads) {
   PhaseTimer pt("bucket_by_locus");
   const size_t n = b.size();
-  if (n < 2) return;
+  if (n < 2) {
+    b.n_short = (n == 1 && short_walk_class(b.hdr[0].flags, b.node_off[1] - b.node_off[0])) ? 1 : 0;
+    return;
+  }
   if (threads == 0) threads = hw_threads();
   std::vector<uint32_t> key(n), idx(n);
   parallel_chunks(n, n < (1u << 16) ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
@@ -315,21 +318,37 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
   pt.lap("keys");
   radix_sort_pairs(key, idx, threads);
   pt.lap("radix sort");
-  // inside every block of PARTITION_BLOCK sorted records, the records eligible for the short walk
-  // come first, so that a wave seldom holds both kinds
+  // the two classes apart (stable), then inside every block of PARTITION_BLOCK records of a class by path length:
+  // the lanes of a wave then loop alike
+  size_t n_short = 0;
+  {
+    std::vector<uint32_t> part(n);
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t s = idx[i];
+      n_short += short_walk_class(b.hdr[s].flags, b.node_off[s + 1] - b.node_off[s]) ? 1u : 0u;
+    }
+    size_t a = 0, g = n_short;
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t s = idx[i];
+      if (short_walk_class(b.hdr[s].flags, b.node_off[s + 1] - b.node_off[s])) part[a++] = s; else part[g++] = s;
+    }
+    idx.swap(part);
+  }
+  b.n_short = n_short;
   {
     constexpr size_t PARTITION_BLOCK = 2048;
-    const size_t nb = (n + PARTITION_BLOCK - 1) / PARTITION_BLOCK;
+    // blocks are counted from the start of each class
+    const size_t nb0 = (n_short + PARTITION_BLOCK - 1) / PARTITION_BLOCK, nb1 = (n - n_short + PARTITION_BLOCK - 1) / PARTITION_BLOCK;
+    const size_t nb = nb0 + nb1;
     parallel_chunks(nb, nb < 64 ? 1 : threads, [&](unsigned, size_t lo, size_t hi) {
-      std::vector<std::pair<uint32_t, uint32_t>> tmp;   // (class/length rank, record)
+      std::vector<std::pair<uint32_t, uint32_t>> tmp;   // (length rank, record)
       for (size_t blk = lo; blk < hi; ++blk) {
-        const size_t a = blk * PARTITION_BLOCK, e = std::min(n, a + PARTITION_BLOCK);
+        const size_t a = blk < nb0 ? blk * PARTITION_BLOCK : n_short + (blk - nb0) * PARTITION_BLOCK;
+        const size_t e = std::min(blk < nb0 ? n_short : n, a + PARTITION_BLOCK);
         tmp.clear();
         for (size_t i = a; i < e; ++i) {
           const uint32_t s = idx[i];
-          const uint32_t k = std::min<uint32_t>(b.node_off[s + 1] - b.node_off[s], 0xFFFFu);
-          // short-walk records first, each kind by path length: the lanes of a wave then loop alike
-          tmp.emplace_back(((b.hdr[s].flags & LINE_SIMPLE) ? 0u : 0x10000u) | k, s);
+          tmp.emplace_back(std::min<uint32_t>(b.node_off[s + 1] - b.node_off[s], 0xFFFFu), s);
         }
         std::stable_sort(tmp.begin(), tmp.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
         for (size_t i = a; i < e; ++i) idx[i] = tmp[i - a].second;

@@ -25,6 +25,7 @@ struct GafBatch {
   uint64_t del_lines = 0;     // records with a '-' op
   uint64_t del_nodes = 0;     // sum of path lengths over those records
   uint64_t bytes = 0;         // text bytes tokenised
+  uint64_t n_short = 0;       // after bucket_by_locus: records [0, n_short) are the short-walk class (walk.h)
   // A line the reference raises on while splitting / filtering it.  The batch then holds the records of the
   // lines BEFORE it: they still have to be walked, because an earlier line that only fails in the walk is what
   // the reference would report (it handles the file line by line).
@@ -32,8 +33,9 @@ struct GafBatch {
   size_t size() const { return hdr.size(); }
 };
 
-// Reorders the records of a batch by the index of their first path node (stable), so that a
-// workgroup's consecutive records touch the same few hundred counters and graph rows.  The
+// Reorders the records of a batch: short-walk class first, then the rest; inside each class by the lowest end node of
+// the path (stable), so that a workgroup's consecutive records touch the same few hundred counters and graph rows;
+// inside every block of 2048 of a class by path length, so that the lanes of a wave loop alike.  The
 // result of a run does not depend on record order (line_id carries the file order).
 void bucket_by_locus(GafBatch& b, unsigned threads = 0);
 

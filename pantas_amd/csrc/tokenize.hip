@@ -225,7 +225,23 @@ __global__ void __launch_bounds__(TPB) bucket_keys_kernel(uint32_t n, const uint
   idx[i] = i;
 }
 
-// inside every block of 2048 sorted records: short-walk records first, each kind by path length, stable
+// 1 for records of the short-walk class (walk.h), in locus order
+__global__ void __launch_bounds__(TPB) class_flags_kernel(uint32_t n, const uint32_t* idx, const LineHdr* hdr, const uint32_t* node_off, uint32_t* cls) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = idx[i];
+  cls[i] = short_walk_class(hdr[s].flags, node_off[s + 1] - node_off[s]) ? 1u : 0u;
+}
+
+// stable partition: short-walk class first
+__global__ void __launch_bounds__(TPB) partition_kernel(uint32_t n, const uint32_t* idx, const uint32_t* cls, const uint32_t* before, uint32_t n_short, uint32_t* out) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t b = before[i];
+  out[cls[i] ? b : n_short + (i - b)] = idx[i];
+}
+
+// inside every block of 2048 records of a class: by path length, stable
 __global__ void __launch_bounds__(TPB) order_blocks_kernel(uint32_t n, const uint32_t* idx_in, const LineHdr* hdr, const uint32_t* node_off, uint32_t* idx_out) {
   __shared__ uint32_t sh[SORT_BLOCK];
   const uint32_t a = blockIdx.x * SORT_BLOCK;
@@ -234,7 +250,7 @@ __global__ void __launch_bounds__(TPB) order_blocks_kernel(uint32_t n, const uin
     if (a + j < n) {
       const uint32_t s = idx_in[a + j];
       const uint32_t k = min(node_off[s + 1] - node_off[s], 0xFFFFu);
-      v = ((((hdr[s].flags & LINE_SIMPLE) ? 0u : 0x10000u) | k) << 11) | j;
+      v = (k << 11) | j;
     }
     sh[j] = v;
   }
@@ -492,6 +508,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
     del.alloc(16);
     out->del_idx = del.hand_over<uint32_t>();
   } else {
+    uint32_t n_short = 0;
     DevBuf key(pool), idx(pool), key2(pool), idx2(pool), sort_tmp(pool);
     key.alloc(size_t(n) * 4); idx.alloc(size_t(n) * 4);
     hipLaunchKernelGGL(bucket_keys_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, node_off0.as<uint32_t>(), nodes0.as<uint32_t>(), key.as<uint32_t>(), idx.as<uint32_t>());
@@ -504,10 +521,27 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
       HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key.as<uint32_t>(), key2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), int(n), 0, bits, s));
       sort_tmp.alloc(need);
       HIP_OK(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, need, key.as<uint32_t>(), key2.as<uint32_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), int(n), 0, bits, s));
-      // idx2 = records by locus; idx <- the same with every 2048-block reordered
-      hipLaunchKernelGGL(order_blocks_kernel, dim3((n + SORT_BLOCK - 1) / SORT_BLOCK), dim3(TPB), 0, s, n, idx2.as<uint32_t>(), hdr0.as<LineHdr>(),
-                         node_off0.as<uint32_t>(), idx.as<uint32_t>());
+      // idx2 = records by locus -> key = the two classes apart (stable) -> idx = every 2048-block of a class by path length
+      DevBuf cls(pool), before(pool);
+      cls.alloc((size_t(n) + 1) * 4); before.alloc((size_t(n) + 1) * 4);
+      HIP_OK(hipMemsetAsync(cls.as<uint32_t>() + n, 0, 4, s));
+      hipLaunchKernelGGL(class_flags_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, idx2.as<uint32_t>(), hdr0.as<LineHdr>(), node_off0.as<uint32_t>(), cls.as<uint32_t>());
       HIP_OK(hipGetLastError());
+      scan.run(cls.as<uint32_t>(), before.as<uint32_t>(), size_t(n) + 1, s);
+      HIP_OK(hipMemcpyAsync(&n_short, before.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, s));
+      HIP_OK(hipStreamSynchronize(s));
+      hipLaunchKernelGGL(partition_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, idx2.as<uint32_t>(), cls.as<uint32_t>(), before.as<uint32_t>(), n_short, key.as<uint32_t>());
+      HIP_OK(hipGetLastError());
+      if (n_short) {
+        hipLaunchKernelGGL(order_blocks_kernel, dim3((n_short + SORT_BLOCK - 1) / SORT_BLOCK), dim3(TPB), 0, s, n_short, key.as<uint32_t>(), hdr0.as<LineHdr>(),
+                           node_off0.as<uint32_t>(), idx.as<uint32_t>());
+        HIP_OK(hipGetLastError());
+      }
+      if (n > n_short) {
+        hipLaunchKernelGGL(order_blocks_kernel, dim3((n - n_short + SORT_BLOCK - 1) / SORT_BLOCK), dim3(TPB), 0, s, n - n_short, key.as<uint32_t>() + n_short,
+                           hdr0.as<LineHdr>(), node_off0.as<uint32_t>(), idx.as<uint32_t>() + n_short);
+        HIP_OK(hipGetLastError());
+      }
     }
     DevBuf nn(pool), no(pool), dl(pool), dscan(pool), node_off1(pool), op_off1(pool);
     nn.alloc((size_t(n) + 1) * 4); no.alloc((size_t(n) + 1) * 4); dl.alloc((size_t(n) + 1) * 4); dscan.alloc((size_t(n) + 1) * 4);
@@ -528,7 +562,13 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
                        op_off0.as<uint32_t>(), nodes0.as<uint32_t>(), ops0.as<uint32_t>(), node_off1.as<uint32_t>(), op_off1.as<uint32_t>(),
                        dscan.as<uint32_t>(), hdr1.as<LineHdr>(), nodes1.as<uint32_t>(), ops1.as<uint32_t>(), del.as<uint32_t>());
     HIP_OK(hipGetLastError());
+    out->n_short = n_short;
+    uint32_t ext[2] = {0, 0};
+    HIP_OK(hipMemcpyAsync(&ext[0], node_off1.as<uint32_t>() + n_short, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&ext[1], op_off1.as<uint32_t>() + n_short, 4, hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
+    out->short_nodes = ext[0];
+    out->short_ops = ext[1];
     out->hdr = hdr1.hand_over<LineHdr>();
     out->node_off = node_off1.hand_over<uint32_t>();
     out->op_off = op_off1.hand_over<uint32_t>();

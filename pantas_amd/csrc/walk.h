@@ -42,6 +42,11 @@ constexpr uint32_t LINE_HAS_DEL = 2u;   // cs string holds a '-' op
 constexpr uint32_t LINE_SLOW = 4u;      // cs holds a zero-length or '~' op: walked by the scalar code only
 constexpr uint32_t LINE_SIMPLE = 8u;    // cs holds only ':' and at most 4 '*' ops (no zero lengths): eligible for the short walk
 constexpr uint32_t SIMPLE_MAX_STARS = 4;
+// Records of a batch come in two classes, each bucketed by locus: first the ones the short-walk kernel takes
+// (LINE_SIMPLE and at most SHORT_MAX_PATH path nodes: its LDS entries hold 16-bit counts, 2048 records x 31 visits
+// < 65536), then the rest (general walk).
+constexpr uint32_t SHORT_MAX_PATH = 31;
+PANTAS_HD bool short_walk_class(uint32_t flags, uint32_t path_nodes) { return (flags & LINE_SIMPLE) != 0 && path_nodes <= SHORT_MAX_PATH; }
 
 struct LineHdr {
   int32_t start;     // start position on the first node (after the 2-op clipping rule)
