@@ -34,6 +34,12 @@ struct TableView {
   uint32_t* overflow;   // set when an insert found no free slot
 };
 
+// the two global hash tables and the status word (rare paths of the kernels)
+struct SlowTables {
+  TableView hist, novel;
+  unsigned long long* status; // min over failing lines of (line_id << 8 | code)
+};
+
 struct GraphView {
   uint32_t* word;             // [V] segment length | FLAG_IL | FLAG_OL
   const uint32_t* row_ptr;    // [V+1]
@@ -42,8 +48,8 @@ struct GraphView {
   uint32_t* il0;              // [V]
   uint32_t* oll;              // [V]
   uint32_t* rc;               // [A]
-  TableView hist, novel;
-  unsigned long long* status; // min over failing lines of (line_id << 8 | code)
+  const struct SlowTables* slow;   // what only rare paths touch, kept in memory: as kernel arguments these 24 words
+                                   // stayed live in scalar registers across the walk loop and were spilled there
   uint32_t ablate;            // timing experiments only (PANTAS_ABLATE): 1 no flagged-key order, 2 no novel insert, 4 no link lookup, 8 no counter updates
 };
 
@@ -98,7 +104,7 @@ struct RareSink {
   __device__ void nc(uint32_t) const {}
   __device__ void common(uint32_t, uint32_t, uint32_t, uint32_t, uint64_t) const {}
   __device__ void rare(uint32_t n, uint32_t side, int32_t pos, uint64_t order) const {
-    table_update(g.hist, hist_key(n, side, uint32_t(pos + 1) & 0x7FFFFFFFu), 1u, order);
+    table_update(g.slow->hist, hist_key(n, side, uint32_t(pos + 1) & 0x7FFFFFFFu), 1u, order);
     atomicOr(&g.word[n], side == SIDE_IL ? FLAG_IL : FLAG_OL);
   }
   __device__ void edge(uint32_t, uint32_t, uint64_t) const {}
@@ -110,7 +116,7 @@ struct MainSink {
   __device__ void nc(uint32_t n) const { atomicAdd(&g.nc[n], 1u); }
   __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
     atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
-    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+    if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.slow->hist, hist_key(n, side, COMMON_POS), 0u, order);
   }
   __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
   __device__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
@@ -118,7 +124,7 @@ struct MainSink {
     for (uint32_t s = lo; s < hi; ++s) {
       if (g.col[s] == b) { atomicAdd(&g.rc[s], 1u); return; }
     }
-    table_update(g.novel, (uint64_t(a) << 32) | b, 1u, order);
+    table_update(g.slow->novel, (uint64_t(a) << 32) | b, 1u, order);
   }
 };
 
@@ -129,7 +135,7 @@ __device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b,
   const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
   Sink sink{g};
   const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-  if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+  if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
 }
 
 __global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchView b) {
@@ -190,7 +196,7 @@ struct AggSink {
       }
       h = (h + 1) & (CF - 1);
     }
-    table_update(g.novel, key, 1u, order);
+    table_update(g.slow->novel, key, 1u, order);
   }
   // link (a -> b): the target of a's first slot was fetched when a was first touched; ha = a's node-table
   // slot if known.  A hit on the first slot (the usual n -> n+1 step) is counted in a's own entry.
@@ -282,7 +288,7 @@ struct AggSink {
     if (h != LDS_EMPTY) {
       if (order < __atomic_load_n(&fmin[h], __ATOMIC_RELAXED)) atomicMin(&fmin[h], static_cast<unsigned long long>(order));
     } else {
-      table_update(g.hist, hist_key(n, side, COMMON_POS), 0u, order);
+      table_update(g.slow->hist, hist_key(n, side, COMMON_POS), 0u, order);
     }
   }
   // link (a -> b) given a's CSR row bounds
@@ -465,8 +471,11 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
   return WALK_OK;
 }
 
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0>
-__global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g, BatchView b, uint32_t begin, uint32_t end) {
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false>
+__global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
+  // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
+  GraphView g = g_in;
+  if constexpr (!ABL) g.ablate = 0u;
   using Sink = AggSink<LOG_N, LOG_S, LOG_F, PACKED>;
   constexpr uint32_t CN = Sink::CN, CS = Sink::CS, CF = Sink::CF;
   static_assert(!PACKED || CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
@@ -506,7 +515,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
         if constexpr (PACKED) st = walk_simple_packed(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
         else st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-      if (st != WALK_OK) atomicMin(g.status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+      if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
@@ -530,8 +539,8 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     }
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) {
       const uint32_t k = fkey[i];
-      if (k != LDS_EMPTY && fmin[i] != ~0ull) table_update(g.hist, hist_key(k >> 1, k & 1u, COMMON_POS), 0u, fmin[i]);
-      if (vkey[i] != EMPTY_KEY) table_update(g.novel, vkey[i], vcnt[i], vmin[i]);
+      if (k != LDS_EMPTY && fmin[i] != ~0ull) table_update(g.slow->hist, hist_key(k >> 1, k & 1u, COMMON_POS), 0u, fmin[i]);
+      if (vkey[i] != EMPTY_KEY) table_update(g.slow->novel, vkey[i], vcnt[i], vmin[i]);
     }
     __syncthreads();
   }
@@ -590,12 +599,22 @@ struct DeviceGraph {
   uint64_t novel_boost = 1;       // grown after a TableOverflow("novel") retry
   uint64_t imported_flags = 0;    // node flags received from other ranks this run
   uint64_t reserved_hist = 0;     // caller's bound on distinct IL/OL keys (sharded runs)
+  SlowTables* slow_dev = nullptr;   // device copy of {hist, novel, status}
+  SlowTables slow_host{};           // what slow_dev holds
+  // brings the device copy up to date (table pointers change when a table grows); ordered on `stream`
+  void sync_slow() {
+    SlowTables t{hist.v, novel.v, reinterpret_cast<unsigned long long*>(small)};
+    if (memcmp(&t, &slow_host, sizeof t) != 0) {
+      slow_host = t;
+      HIP_OK(hipMemcpyAsync(slow_dev, &slow_host, sizeof t, hipMemcpyHostToDevice, stream));
+      HIP_OK(hipStreamSynchronize(stream));   // slow_host is the staging buffer
+    }
+  }
   GraphView view() const {
     GraphView g{};
     g.word = word; g.row_ptr = row_ptr; g.col = col;
     g.nc = counters; g.il0 = counters + V; g.oll = counters + 2 * size_t(V); g.rc = counters + 3 * size_t(V);
-    g.hist = hist.v; g.novel = novel.v;
-    g.status = reinterpret_cast<unsigned long long*>(small);
+    g.slow = slow_dev;
     g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;
     return g;
   }
@@ -621,7 +640,7 @@ uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
 void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->word, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table})
+  for (void* p : {(void*)d->word, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->slow_dev})
     if (p) (void)hipFree(p);
   d->scratch.reset();
   d->hist.free_all();
@@ -685,6 +704,7 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   HIP_OK(hipMalloc(&d->col, std::max<size_t>(1, g.A) * 4));
   HIP_OK(hipMalloc(&d->counters, std::max<size_t>(1, 3 * size_t(g.V) + g.A) * 4));
   HIP_OK(hipMalloc(&d->small, 64));
+  HIP_OK(hipMalloc(&d->slow_dev, sizeof(SlowTables)));
   HIP_OK(hipMemcpyAsync(d->word, g.seg_len.data(), size_t(g.V) * 4, hipMemcpyHostToDevice, d->stream));
   HIP_OK(hipMemcpyAsync(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, hipMemcpyHostToDevice, d->stream));
   HIP_OK(hipMemcpyAsync(d->col, g.col.data(), size_t(g.A) * 4, hipMemcpyHostToDevice, d->stream));
@@ -827,6 +847,7 @@ float launch_rare(DeviceGraph& d, DeviceBatch& b) {
                                  "come too late for the batches already walked (launch_rare for every batch first)");
   if (!seen) d.rare_done.push_back(&b);
   ensure_tables(d, b);
+  d.sync_slow();
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[0], d.stream));
@@ -848,6 +869,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     throw Error("ProtocolError", "main kernel of a batch whose rare-key kernel has not run");
   d.main_started = true;
   ensure_tables(d, b);
+  d.sync_slow();
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
@@ -861,6 +883,9 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 60;
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
+                                               dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
+#define PANTAS_AGG_RANGE_ABL(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, PK, ON) \
+    do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, PK, ON, true>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
 #define PANTAS_AGG(ID, ...) case ID: PANTAS_AGG_RANGE(d.stream, 0u, b.n, __VA_ARGS__); break;
     // one after the other on the launch stream
@@ -878,7 +903,13 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else {
-      switch (variant) {
+      if (g.ablate) {
+        // timing experiments: the default pair of kernels with the ablation switches compiled in, one after the other
+        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1);
+        HIP_OK(hipEventRecord(d.ev[3], d.stream));
+        split = true;
+        PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 0);
+      } else switch (variant) {
         PANTAS_AGG(8, 1024, 4096, 12, 12, 9, 1)
         PANTAS_AGG(9, 512, 2048, 11, 11, 7, 1)
         PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
@@ -897,6 +928,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
 #undef PANTAS_SPLIT
 #undef PANTAS_AGG
 #undef PANTAS_AGG_RANGE
+#undef PANTAS_AGG_RANGE_ABL
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(d.ev[2], d.stream));
     HIP_OK(hipEventSynchronize(d.ev[2]));
