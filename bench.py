@@ -7,7 +7,8 @@ A "step" is one pass of the two augment kernels over one batch of tokenised GAF 
 already resident in HBM (graph CSR and records are uploaded before the timed region).  With
 N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds a replica of the
 graph and its own batch of the same size (weak scaling: read shards), and the timed region ends
-with the ONE all-reduce over the coverage arrays that a sharded replicate needs.
+with the ONE sum over the coverage arrays that a sharded replicate needs: the ranks all-gather a
+bitmap of the counter blocks they touched and all-reduce only the union's blocks (pantas_amd/csrc/exchange.hip).
 After the timed region rank 0 runs the call kernels on the accumulated coverage (fused path, no
 GFA text round trip) and reports events/s beside it.  Rank 0 prints one JSON line.
 
@@ -129,13 +130,12 @@ def main():
     batch = g.load_gaf_mem(syn.gaf, first_line=rank * kw["n_lines"])
     bs = batch.stats
 
-    counters_t = None
-    if world > 1:
-        ptr, words = g.counters()
-
-        class _Dev:  # zero-copy view of the library's counter allocation for RCCL
-            __cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-        counters_t = torch.as_tensor(_Dev(), device=torch.device("cuda", local_rank))
+    class _Exchange:   # what pantas_amd.distributed.allreduce_counters drives (zero-copy views of the library's buffers)
+        def counters_tensor(self): return g.counters_tensor(local_rank)
+        def touched_bitmap(self, bw): return g.touched_bitmap(bw, local_rank)
+        def counters_pack(self, bm, n): return g.counters_pack(bm, n, local_rank)
+        def counters_unpack(self): g.counters_unpack()
+    exchange = None
 
     def sync():
         torch.cuda.synchronize()
@@ -154,9 +154,12 @@ def main():
         rare_ms.append(ls.rare_ms)
         short_ms.append(ls.main_short_ms)
     allreduce_ms = 0.0
-    if counters_t is not None:
+    if dist is not None:
+        # the ONE sum over the coverage arrays that ends a read-sharded replicate: bitmap of touched blocks ->
+        # all-reduce of the union's blocks (dense all-reduce when most blocks are touched)
+        from pantas_amd.distributed import allreduce_counters
         t1 = time.perf_counter()
-        dist.all_reduce(counters_t)
+        exchange = allreduce_counters(_Exchange(), dist)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - t1) * 1e3
     sync()
@@ -221,12 +224,12 @@ def main():
                                    f"{kw['n_genes']} genes; {bs.lines} GAF lines per GPU per step "
                                    f"({bs.records} walked, {bs.path_nodes / max(1, bs.records):.2f} nodes/line, "
                                    f"{bs.cs_ops / max(1, bs.records):.2f} cs ops/line), gene expression Zipf a={kw.get('zipf_a', 1.2)}",
-                       "parallelism": f"read shards x{world}, graph replicated, one all-reduce per replicate"},
+                       "parallelism": f"read shards x{world}, graph replicated, one block-sparse all-reduce of the coverage counters per replicate"},
             "kernel_ms": {"augment_main": avg_main, "augment_main_short_walk": avg_short, "augment_main_general": avg_main - avg_short if avg_short else None,
                           "augment_rare": sum(rare_ms) / len(rare_ms),
                           "augment_main_min": min(main_ms), "augment_main_max": max(main_ms),
                           "augment_main_all": [round(x, 3) for x in main_ms]},
-            "allreduce_ms": allreduce_ms,
+            "allreduce_ms": allreduce_ms, "allreduce": exchange,
             "records_per_s_kernel_only": bs.records / (avg_main * 1e-3),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -239,7 +242,8 @@ def main():
                      "gaf_upload_s": bs.upload_seconds, "finish_download_s": t_fin,
                      "gaf_text_bytes": bs.text_bytes, "gfa_text_bytes": gs.text_bytes,
                      "tokenize_reads_per_s": bs.lines / bs.tokenize_seconds if bs.tokenize_seconds else None,
-                     "cores": os.cpu_count()},
+                     "cores": os.cpu_count(), "ram_gb": host_ram_gb(),
+                     "peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             # the step in front of the path: GAF text -> records; never part of `value`
             "tokenizer": {"where": {1: "host threads (gaf.cpp)", 2: "GPU kernels (tokenize.hip)"}.get(bs.tokenizer),
                           "text_to_hbm_s": bs.upload_seconds if bs.tokenizer == 2 else None,

@@ -136,6 +136,16 @@ int pantas_augment_flags_import(pantas_graph* g, const uint32_t* codes, uint64_t
 /* device address of the dense counters [NC V | IL0 V | OLL V | RC A] (uint32) for a
  * caller-run all-reduce (RCCL through torch.distributed); words = 3V + A */
 int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words);
+/* Block-sparse form of that all-reduce (reads cover exons only, so nearly all counters are zero and a
+ * ring over point-to-point xGMI links should not carry them).  All pointers are device addresses.
+ *   1. pantas_counters_bitmap: one bit per block of block_words (8, 16, 32 or 64) counters that holds a non-zero word;
+ *      the caller all-gathers the bitmaps of all ranks (uint32 words, rank-major);
+ *   2. pantas_counters_pack: ORs the n_bitmaps gathered bitmaps and copies the union's blocks into a staging buffer
+ *      (same layout on every rank); the caller all-reduces staging_words uint32 sums (staging_words may be 0);
+ *   3. pantas_counters_unpack: staging -> counters.  Skipping 3 leaves the counters as they were. */
+int pantas_counters_bitmap(pantas_graph* g, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words);
+int pantas_counters_pack(pantas_graph* g, const void* dev_bitmaps, uint32_t n_bitmaps, void** dev_staging, uint64_t* staging_words);
+int pantas_counters_unpack(pantas_graph* g);
 /* sparse side results (links absent from the GFA, rare IL/OL keys): export from one rank /
  * merge into another.  Rows are 4 x uint64: {key, count, first_seen, kind (0 hist, 1 novel)} */
 int pantas_augment_sparse_count(pantas_graph* g, uint64_t* rows);

@@ -101,6 +101,9 @@ def _load():
         "pantas_augment_flags_export": (i32, [vp, vp, u64, P(u64)]),
         "pantas_augment_flags_import": (i32, [vp, vp, u64]),
         "pantas_augment_counters": (i32, [vp, P(vp), P(u64)]),
+        "pantas_counters_bitmap": (i32, [vp, C.c_uint32, P(vp), P(u64)]),
+        "pantas_counters_pack": (i32, [vp, vp, C.c_uint32, P(vp), P(u64)]),
+        "pantas_counters_unpack": (i32, [vp]),
         "pantas_augment_sparse_count": (i32, [vp, P(u64)]),
         "pantas_augment_sparse_export": (i32, [vp, P(u64), u64]),
         "pantas_augment_sparse_import": (i32, [vp, P(u64), u64]),

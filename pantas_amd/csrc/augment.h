@@ -79,6 +79,16 @@ void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 // device pointers of the dense counters, for collectives run by the caller (RCCL via torch.distributed)
 struct CounterPtrs { void* nc; void* rc; void* il0; void* oll; uint64_t V, A; };
 CounterPtrs counter_ptrs(DeviceGraph& dg);
+// Block-sparse exchange of the counters between ranks (exchange.hip): bitmap of touched blocks -> (caller all-gathers)
+// -> pack the union's blocks into a staging buffer -> (caller all-reduces it) -> unpack.  The allocation behind
+// counter_ptrs is zero-padded to a multiple of COUNTER_PAD_WORDS so that whole blocks can be read.
+constexpr uint64_t COUNTER_PAD_WORDS = 2048;
+struct CounterExchange;
+struct CounterExchangeDeleter { void operator()(CounterExchange*) const; };
+using CounterExchangePtr = std::unique_ptr<CounterExchange, CounterExchangeDeleter>;
+void exchange_bitmap(DeviceGraph& dg, CounterExchangePtr& x, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words);
+void exchange_pack(DeviceGraph& dg, CounterExchange& x, const void* dev_bitmaps, uint32_t n_bitmaps, void** dev_staging, uint64_t* staging_words);
+void exchange_unpack(DeviceGraph& dg, CounterExchange& x);
 uint64_t batch_lines(const DeviceBatch& db);
 uint64_t batch_short_records(const DeviceBatch& db);   // records of the short-walk class (walk.h), first in the batch
 float last_short_kernel_ms(const DeviceGraph& dg);      // short-walk kernel of the last launch_main alone

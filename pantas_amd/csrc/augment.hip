@@ -702,7 +702,13 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   HIP_OK(hipMalloc(&d->word, std::max<size_t>(1, g.V) * 4));
   HIP_OK(hipMalloc(&d->row_ptr, (size_t(g.V) + 1) * 4));
   HIP_OK(hipMalloc(&d->col, std::max<size_t>(1, g.A) * 4));
-  HIP_OK(hipMalloc(&d->counters, std::max<size_t>(1, 3 * size_t(g.V) + g.A) * 4));
+  {
+    // zero padding behind the counters: the exchange kernels (exchange.hip) read whole blocks
+    const size_t w = 3 * size_t(g.V) + g.A;
+    const size_t padded = std::max<size_t>(1, (w + COUNTER_PAD_WORDS - 1) / COUNTER_PAD_WORDS) * COUNTER_PAD_WORDS;
+    HIP_OK(hipMalloc(&d->counters, padded * 4));
+    HIP_OK(hipMemsetAsync(d->counters + w, 0, (padded - w) * 4, d->stream));
+  }
   HIP_OK(hipMalloc(&d->small, 64));
   HIP_OK(hipMalloc(&d->slow_dev, sizeof(SlowTables)));
   HIP_OK(hipMemcpyAsync(d->word, g.seg_len.data(), size_t(g.V) * 4, hipMemcpyHostToDevice, d->stream));

@@ -16,6 +16,7 @@ using namespace pantas;
 struct pantas_graph {
   std::unique_ptr<Graph> g;
   DeviceGraphPtr dev;
+  CounterExchangePtr xchg;           // block-sparse counter exchange in flight (its buffers belong to dev's scratch pool)
   AugmentResult res;
   bool have_result = false;
   uint64_t lines = 0, rejected = 0, skipped = 0;
@@ -371,6 +372,32 @@ __attribute__((visibility("default"))) int pantas_augment_counters(pantas_graph*
     CounterPtrs p = counter_ptrs(*g->dev);
     *dev_ptr = p.nc;
     *words = 3 * p.V + p.A;
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_counters_bitmap(pantas_graph* g, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words) {
+  return guarded([&] {
+    need_device(g);
+    need(dev_bitmap && bitmap_words, "null argument");
+    exchange_bitmap(*g->dev, g->xchg, block_words, dev_bitmap, bitmap_words);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_counters_pack(pantas_graph* g, const void* dev_bitmaps, uint32_t n_bitmaps, void** dev_staging,
+                                                                uint64_t* staging_words) {
+  return guarded([&] {
+    need_device(g);
+    need(dev_staging && staging_words, "null argument");
+    if (!g->xchg) throw Error("ProtocolError", "pantas_counters_pack before pantas_counters_bitmap");
+    exchange_pack(*g->dev, *g->xchg, dev_bitmaps, n_bitmaps, dev_staging, staging_words);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_counters_unpack(pantas_graph* g) {
+  return guarded([&] {
+    need_device(g);
+    if (!g->xchg) throw Error("ProtocolError", "pantas_counters_unpack before pantas_counters_pack");
+    exchange_unpack(*g->dev, *g->xchg);
   });
 }
 

@@ -7,7 +7,8 @@ line starts; global line index = lines before the shard + local index (first-see
     rank r:  tokenise shard r -> rare-key kernel
     all:     all-gather the node flags the rare kernels set      (tiny, variable length)
     rank r:  main kernel over shard r
-    all:     ONE all-reduce(sum) over the dense counters [NC | IL0 | OLL | RC]
+    all:     ONE sum over the dense counters [NC | IL0 | OLL | RC]: bitmap of touched blocks (all-gather) ->
+             all-reduce of the union's blocks only (allreduce_counters; dense all-reduce when most are touched)
     rank 0:  gathers the sparse side results (novel links, rare IL/OL keys; counts add,
              first-seen takes the minimum) and writes the GFA
 
@@ -53,13 +54,10 @@ class LibBackend:
     def flags_export(self): return self.g.flags_export()
     def flags_import(self, codes): self.g.flags_import(codes)
 
-    def counters_tensor(self):
-        import torch
-        ptr, words = self.g.counters()
-
-        class _Dev:  # zero-copy view of the library's counter allocation
-            __cuda_array_interface__ = {"shape": (words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-        return torch.as_tensor(_Dev(), device=torch.device("cuda", self.device))
+    def counters_tensor(self): return self.g.counters_tensor(self.device)
+    def touched_bitmap(self, block_words): return self.g.touched_bitmap(block_words, self.device)
+    def counters_pack(self, bitmaps, n): return self.g.counters_pack(bitmaps, n, self.device)
+    def counters_unpack(self): self.g.counters_unpack()
 
     def finish(self): self.g.finish()
     def sparse_export(self): return self.g.sparse_export()
@@ -86,6 +84,59 @@ def _gather_var(dist, arr: np.ndarray, device):
     return [o[:s].cpu().numpy() for o, s in zip(outs, sizes)]
 
 
+EXCHANGE_BLOCK_WORDS = 16      # counters per exchanged block (64 B); PANTAS_EXCHANGE_BLOCK = 8 | 16 | 32 | 64 | 0 (dense)
+
+
+def allreduce_counters(backend, dist, block_words=None) -> dict:
+    """THE data-path collective of a read-sharded replicate: sums the dense counters [NC | IL0 | OLL | RC] over the
+    ranks (uint32 sums as int32 bit patterns), in place.
+
+    Reads cover exons only, so almost every counter is zero on every rank, and xGMI is point-to-point: a ring
+    all-reduce over the whole array (4 GB at human whole-genome scale) is bound by one link.  The ranks therefore
+    exchange a bitmap of the blocks they touched (all-gather, W / block_words bits each), derive the same union,
+    and all-reduce only those blocks (exchange.hip).  When more than half of the blocks are touched the dense
+    all-reduce is used instead."""
+    import time
+    import torch
+    if block_words is None:
+        block_words = int(os.environ.get("PANTAS_EXCHANGE_BLOCK", EXCHANGE_BLOCK_WORDS))
+    world = dist.get_world_size()
+    ct = backend.counters_tensor()
+    info = {"mode": "dense", "counter_bytes": ct.numel() * 4, "exchanged_bytes": ct.numel() * 4, "block_words": block_words}
+
+    def wait():
+        if ct.is_cuda:
+            torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if block_words and ct.numel():
+        bm = backend.touched_bitmap(block_words)
+        allbm = torch.empty(world * bm.numel(), dtype=bm.dtype, device=bm.device)
+        dist.all_gather_into_tensor(allbm, bm)
+        wait()
+        info["bitmap_ms"] = (time.perf_counter() - t0) * 1e3
+        t1 = time.perf_counter()
+        staging = backend.counters_pack(allbm, world)
+        info["pack_ms"] = (time.perf_counter() - t1) * 1e3
+        if 2 * staging.numel() <= ct.numel():
+            t1 = time.perf_counter()
+            if staging.numel():
+                dist.all_reduce(staging)
+                wait()
+            info["allreduce_ms"] = (time.perf_counter() - t1) * 1e3
+            t1 = time.perf_counter()
+            backend.counters_unpack()
+            info["unpack_ms"] = (time.perf_counter() - t1) * 1e3
+            info.update(mode="block-sparse", exchanged_bytes=staging.numel() * 4 + allbm.numel() * 4,
+                        touched_fraction=staging.numel() / max(1, ct.numel()), total_ms=(time.perf_counter() - t0) * 1e3)
+            return info
+    t1 = time.perf_counter()
+    dist.all_reduce(ct)
+    wait()
+    info["allreduce_ms"] = (time.perf_counter() - t1) * 1e3
+    info["total_ms"] = (time.perf_counter() - t0) * 1e3
+    return info
+
+
 def augment_sharded(backend, gaf_path: str, thr: int, out_fd: int, dist, device=None) -> dict:
     """Runs one sharded augment; rank 0 writes the augmented GFA to out_fd.  Returns totals."""
     import torch
@@ -102,10 +153,7 @@ def augment_sharded(backend, gaf_path: str, thr: int, out_fd: int, dist, device=
     union = np.unique(np.concatenate(codes)).astype(np.uint32) if codes else np.zeros(0, np.uint32)
     backend.flags_import(union)
     backend.launch_main()
-    ct = backend.counters_tensor()
-    dist.all_reduce(ct)                      # THE data-path collective: uint32 sums as int32 bit patterns
-    if ct.is_cuda:
-        torch.cuda.synchronize()
+    xinfo = allreduce_counters(backend, dist)    # THE data-path collective
     backend.finish()
     rows = _gather_var(dist, backend.sparse_export(), device)
     if rank == 0:
@@ -115,7 +163,7 @@ def augment_sharded(backend, gaf_path: str, thr: int, out_fd: int, dist, device=
         if out_fd is not None and out_fd >= 0:
             backend.write_gfa(out_fd)
     dist.barrier()
-    return dict(lines=lines, rejected=rejected)
+    return dict(lines=lines, rejected=rejected, exchange=xinfo)
 
 
 def call_sharded(run_shard, out, dist) -> int:

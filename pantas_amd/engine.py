@@ -149,6 +149,38 @@ class Graph:
         check(lib.pantas_augment_counters(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def _device_i32(self, ptr, words, device):
+        """zero-copy int32 torch view of `words` words of library-owned device memory"""
+        import torch
+
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (max(int(words), 1),), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        try:
+            return torch.as_tensor(_Dev(), device=torch.device("cuda", device))[:int(words)]
+        except RuntimeError as e:
+            if "No HIP GPUs" in str(e):
+                raise RuntimeError("torch.cuda cannot start: torch bundles its own HIP runtime, which must be the first one a "
+                                   "process loads -- `import torch` before `pantas_amd` wherever device tensors are shared") from e
+            raise
+
+    def counters_tensor(self, device: int = 0):
+        ptr, words = self.counters()
+        return self._device_i32(ptr, words, device)
+
+    # block-sparse counter exchange (exchange.hip; the collectives between the three steps are the caller's)
+    def touched_bitmap(self, block_words: int = 16, device: int = 0):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib.pantas_counters_bitmap(self._h, block_words, C.byref(p), C.byref(n)))
+        return self._device_i32(p.value, n.value, device)
+
+    def counters_pack(self, bitmaps, n_bitmaps: int, device: int = 0):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(lib.pantas_counters_pack(self._h, bitmaps.data_ptr(), n_bitmaps, C.byref(p), C.byref(n)))
+        return self._device_i32(p.value, n.value, device)
+
+    def counters_unpack(self):
+        check(lib.pantas_counters_unpack(self._h))
+
     def finish(self):
         check(lib.pantas_augment_finish(self._h))
 

@@ -79,6 +79,29 @@ class HostsimBackend:
         p = self.L.hs_counters(self.h, C.byref(w))
         a = np.ctypeslib.as_array(p, shape=(w.value,)).view(np.int32)
         return torch.from_numpy(a)          # shares memory: the all-reduce lands in the harness' array
+    # numpy stand-ins for the exchange kernels (pantas_amd/csrc/exchange.hip), same contract
+    def touched_bitmap(self, block_words):
+        c = self.counters_tensor().numpy()
+        self._bw = block_words
+        per_word = 32 * block_words
+        padded = np.zeros((c.shape[0] + 2047) // 2048 * 2048, dtype=np.int32)
+        padded[:c.shape[0]] = c
+        bits = (padded.reshape(-1, block_words) != 0).any(axis=1)
+        return torch.from_numpy(np.packbits(bits.reshape(-1, 32), axis=1, bitorder="little").view(np.uint32).reshape(-1).view(np.int32).copy())
+    def counters_pack(self, bitmaps, n):
+        c = self.counters_tensor().numpy()
+        u = np.bitwise_or.reduce(bitmaps.numpy().view(np.uint32).reshape(n, -1), axis=0)
+        self._blocks = np.flatnonzero(np.unpackbits(u.view(np.uint8), bitorder="little"))
+        padded = np.zeros(u.shape[0] * 32 * self._bw, dtype=np.int32)
+        padded[:c.shape[0]] = c
+        self._staging = torch.from_numpy(padded.reshape(-1, self._bw)[self._blocks].reshape(-1).copy())
+        return self._staging
+    def counters_unpack(self):
+        c = self.counters_tensor().numpy()
+        padded = np.zeros((c.shape[0] + 2047) // 2048 * 2048, dtype=np.int32)
+        padded[:c.shape[0]] = c
+        padded.reshape(-1, self._bw)[self._blocks] = self._staging.numpy().reshape(-1, self._bw)
+        c[:] = padded[:c.shape[0]]
     def finish(self): assert self.L.hs_finish(self.h) == 0
     def sparse_export(self):
         n = self.L.hs_sparse_count(self.h)
@@ -98,12 +121,13 @@ tot = augment_sharded(be, gaf, 20, fd, dist)
 if dist.get_rank() == 0:
     os.close(fd)
     open(out + ".rej", "w").write(str(tot["rejected"]))
+    open(out + ".mode", "w").write(tot["exchange"]["mode"])
 dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("case,world", [("synth_a", 2), ("quirks", 2), ("synth_b", 3), ("micro", 2)])
-def test_sharded_augment_gloo(hostsim_lib, tmp_path, case, world):
+@pytest.mark.parametrize("case,world,block", [("synth_a", 2, 16), ("quirks", 2, 8), ("synth_b", 3, 64), ("micro", 2, 32), ("synth_a", 2, 0)])
+def test_sharded_augment_gloo(hostsim_lib, tmp_path, case, world, block):
     import json
     d = os.path.join(GOLDEN, case)
     worker = tmp_path / "worker.py"
@@ -113,8 +137,10 @@ def test_sharded_augment_gloo(hostsim_lib, tmp_path, case, world):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker), ROOT, hostsim_lib,
                         f"{d}/in.gfa", f"{d}/in.gaf", out], capture_output=True, text=True, timeout=300,
-                       env={**os.environ, "OMP_NUM_THREADS": "1"})
+                       env={**os.environ, "OMP_NUM_THREADS": "1", "PANTAS_EXCHANGE_BLOCK": str(block)})
     assert r.returncode == 0, r.stderr[-3000:]
+    # block 0 = the dense all-reduce; otherwise bitmap -> pack -> all-reduce -> unpack unless most blocks are touched
+    assert open(out + ".mode").read() in (("dense",) if block == 0 else ("block-sparse", "dense"))
     assert open(out).read() == open(f"{d}/expected.aug.gfa").read()
     assert int(open(out + ".rej").read()) == json.load(open(f"{d}/expected.json"))["rejected"]
 

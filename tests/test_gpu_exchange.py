@@ -1,0 +1,147 @@
+"""Block-sparse counter exchange (pantas_amd/csrc/exchange.hip, pantas_amd/distributed.py allreduce_counters).
+
+Two read shards of one GAF are walked into two device graphs on the one GPU of the box; the exchange kernels run
+through the C ABI on both, and torch ops stand in for the two collectives (concatenation for the all-gather, an
+addition for the all-reduce).  Result: both graphs hold counts(A) + counts(B) = counts(whole), bit for bit, at
+every block size.  A one-rank RCCL group then runs the product's own allreduce_counters.
+
+The checks run in child processes that import torch BEFORE the library: torch bundles its own HIP runtime, and a
+process that loads /opt/rocm's first (as the other GPU tests do) cannot initialise torch.cuda afterwards."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = dict(seed=41, n_genes=1200, n_lines=300_000, base_id=10**7, intron_long_max=320, n_chrom=3, zipf_a=1.0,
+              p_indel=0.05, p_novel_skip=0.03)
+
+
+
+def run_child(code, timeout=600, env=None):
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, env={**os.environ, **(env or {})})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return r.stdout
+
+
+CHECK = r"""
+import ctypes as C, sys
+import numpy as np
+import torch
+sys.path.insert(0, ROOT)
+from pantas_amd.engine import Graph, PantasError, Synth
+torch.cuda.set_device(0)
+syn = Synth(**PARAMS)
+addr, size = syn.gaf
+raw = np.ctypeslib.as_array((C.c_char * size).from_address(addr)).view(np.uint8)
+half = int(np.flatnonzero(raw[size // 2:] == 10)[0]) + size // 2 + 1
+lines_a = int((raw[:half] == 10).sum())
+ga, gb, gw = (Graph(text=syn.gfa).to_device(0) for _ in range(3))
+parts = [(addr, half, 0), (addr + half, size - half, lines_a), (addr, size, 0)]
+
+def run_shard(g, part):
+    a, n, first = part
+    g.augment_reset()
+    b = g.load_gaf_mem((a, n), first_line=first)
+    g.launch(b)
+    return b
+
+for block in (8, 16, 32, 64):
+    keep = [run_shard(g, p) for g, p in zip((ga, gb, gw), parts)]
+    ca, cb, cw = (g.counters_tensor(0) for g in (ga, gb, gw))
+    want = (ca + cb).cpu()
+    assert torch.equal(want, cw.cpu())                      # shard additivity (the kernels themselves)
+    bms = [g.touched_bitmap(block, 0) for g in (ga, gb)]
+    for g_c, bm in zip((ca, cb), bms):                      # the bitmap is exactly "block holds a non-zero word"
+        pad = torch.zeros(bm.numel() * 32 * block, dtype=torch.int32, device="cuda")
+        pad[:g_c.numel()] = g_c
+        bits = (pad.view(-1, block) != 0).any(dim=1).cpu().numpy()
+        got = np.unpackbits(bm.cpu().numpy().view(np.uint8), bitorder="little").astype(bool)
+        assert (bits == got).all()
+    gathered = torch.cat(bms).contiguous()                  # stands in for all_gather_into_tensor
+    torch.cuda.synchronize()
+    sa = ga.counters_pack(gathered, 2, 0)
+    sb = gb.counters_pack(gathered, 2, 0)
+    assert sa.numel() == sb.numel() and sa.numel() % block == 0 and 0 < sa.numel() < ca.numel()
+    total = sa + sb                                         # stands in for all_reduce(sum)
+    sa.copy_(total)
+    sb.copy_(total)
+    torch.cuda.synchronize()
+    ga.counters_unpack()
+    gb.counters_unpack()
+    assert torch.equal(ga.counters_tensor(0).cpu(), want)
+    assert torch.equal(gb.counters_tensor(0).cpu(), want)
+    print("block", block, "touched", sa.numel() / ca.numel())
+    del keep
+
+def raises(f):
+    try:
+        f()
+    except PantasError:
+        return True
+    return False
+
+assert raises(lambda: ga.touched_bitmap(12, 0))
+ga.touched_bitmap(16, 0)
+ga.counters_pack(ga.touched_bitmap(16, 0), 1, 0)
+ga.counters_unpack()
+assert raises(lambda: ga.counters_unpack())                  # nothing packed any more
+print("ok")
+"""
+
+
+def test_block_sparse_sum_equals_dense():
+    out = run_child(f"ROOT = {ROOT!r}\nPARAMS = {PARAMS!r}\n" + CHECK)
+    assert out.strip().endswith("ok"), out
+
+
+def test_allreduce_counters_one_rank_rccl(tmp_path):
+    """the product's exchange routine over a real RCCL communicator (one rank: the sum is the identity)"""
+    code = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch, torch.distributed as dist
+from pantas_amd.engine import Graph, Synth
+from pantas_amd.distributed import allreduce_counters
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+syn = Synth(**{PARAMS!r})
+g = Graph(text=syn.gfa).to_device(0)
+g.augment_reset()
+b = g.load_gaf_mem(syn.gaf)
+g.launch(b)
+class BE:
+    def counters_tensor(self): return g.counters_tensor(0)
+    def touched_bitmap(self, bw): return g.touched_bitmap(bw, 0)
+    def counters_pack(self, bm, n): return g.counters_pack(bm, n, 0)
+    def counters_unpack(self): g.counters_unpack()
+before = g.counters_tensor(0).cpu()
+info = allreduce_counters(BE(), dist, 16)
+assert info["mode"] == "block-sparse", info
+assert info["exchanged_bytes"] < info["counter_bytes"] // 4, info
+assert torch.equal(g.counters_tensor(0).cpu(), before)
+info = allreduce_counters(BE(), dist, 0)
+assert info["mode"] == "dense"
+assert torch.equal(g.counters_tensor(0).cpu(), before)
+g.finish()
+dist.destroy_process_group()
+print("ok", info)
+"""
+    run_child(code, env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29577", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    """two real ranks (both on cuda:0, gloo carrying the device tensors): the exchange at every block size
+    against the dense all-reduce of the same counters (tools/exchange_probe.py asserts equality)"""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29613", os.path.join(ROOT, "tools", "exchange_probe.py"), "--scale", "s2", "--lines", "400000",
+                        "--backend", "gloo"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    rows = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(rows) == 6 and all(x["equal_to_dense"] and x["world"] == 2 for x in rows)
+    assert any(x["mode"] == "block-sparse" for x in rows)
