@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-call", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with gloo carrying the device tensors: exercises the sharded path on a "
+                         "one-GPU box; the number it prints is not a scaling measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,8 +112,13 @@ def main():
     import torch
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     from pantas_amd.engine import Graph, Synth
 
     scale = args.scale

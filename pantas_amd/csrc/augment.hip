@@ -471,7 +471,11 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
   return WALK_OK;
 }
 
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false>
+// SPREAD: which record of the chunk a lane takes.  0: lane l of a pass takes position l (neighbouring lanes hold
+// neighbouring records of the locus order, i.e. nearly the same path: their LDS atomics hit the same few addresses
+// and serialise); 1: the 64 lanes of a wave take every 8th record of the pass's 512; 2: every 32nd of the chunk.
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
+          int SPREAD = 0>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -501,7 +505,13 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin};
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+    for (uint32_t pass = 0; pass < CHUNK / THREADS; ++pass) {
+      uint32_t off;
+      if constexpr (SPREAD == 1) off = pass * THREADS + (threadIdx.x & 63u) * (THREADS / 64u) + (threadIdx.x >> 6);
+      else if constexpr (SPREAD == 2) off = (threadIdx.x & 63u) * (CHUNK / 64u) + pass * (THREADS / 64u) + (threadIdx.x >> 6);
+      else off = pass * THREADS + threadIdx.x;
+      const uint32_t i = lo + off;
+      if (i >= hi) continue;
       const LineHdr h = b.hdr[i];
       const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
       const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
@@ -886,7 +896,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // kernels: the short-walk class [0, n_short) with packed LDS entries, the rest with the general kernel.  The
     // short-walk kernel then needs no registers, scalar spills or code of the general walk, and no chunk waits for
     // the few slow general-walk waves that used to sit at its end.
-    static const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 60;
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 60;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -926,6 +936,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_SPLIT(61, (d.stream, 0u, b.n_short, 512, 2048, 11, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(63, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 256, 1024, 9, 9, 7, 8))
         PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(70, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(71, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         default:
         PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
       }
