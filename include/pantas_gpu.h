@@ -133,8 +133,10 @@ int pantas_augment_launch_rare(pantas_graph* g, pantas_batch* b, float* ms);
 int pantas_augment_launch_main(pantas_graph* g, pantas_batch* b, float* ms);
 int pantas_augment_flags_export(pantas_graph* g, uint32_t* codes, uint64_t capacity, uint64_t* n);
 int pantas_augment_flags_import(pantas_graph* g, const uint32_t* codes, uint64_t n);
-/* device address of the dense counters [NC V | IL0 V | OLL V | RC A] (uint32) for a
- * caller-run all-reduce (RCCL through torch.distributed); words = 3V + A */
+/* device address of the dense counters (uint32) for a caller-run all-reduce (RCCL through torch.distributed):
+ * {NC, IL0, OLL, RC of the first out-slot} per node, then RC per adjacency slot; words = 4V + A.  The layout is
+ * the library's own (one 16-byte slot per node keeps a node's counters in one HBM line); any elementwise sum over
+ * ranks merges it.  Host-side planar copies: pantas_augment_read after pantas_augment_finish. */
 int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words);
 /* Block-sparse form of that all-reduce (reads cover exons only, so nearly all counters are zero and a
  * ring over point-to-point xGMI links should not carry them).  All pointers are device addresses.

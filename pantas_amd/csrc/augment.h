@@ -77,7 +77,9 @@ void boost_novel_table(DeviceGraph& dg);
 void reserve_hist(DeviceGraph& dg, uint64_t keys);   // bound on distinct IL/OL keys of the whole (sharded) run              // next sizing of the novel-link table is 4x larger
 void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 // device pointers of the dense counters, for collectives run by the caller (RCCL via torch.distributed)
-struct CounterPtrs { void* nc; void* rc; void* il0; void* oll; uint64_t V, A; };
+// base[0 .. words): {NC, IL0, OLL, RC of the first out-slot} per node (4 V words), then RC per adjacency slot (A words).
+// Any elementwise sum over ranks is a valid merge; the planar arrays only exist on the host (download_result).
+struct CounterPtrs { void* base; uint64_t words; uint64_t V, A; };
 CounterPtrs counter_ptrs(DeviceGraph& dg);
 // Block-sparse exchange of the counters between ranks (exchange.hip): bitmap of touched blocks -> (caller all-gathers)
 // -> pack the union's blocks into a staging buffer -> (caller all-reduces it) -> unpack.  The allocation behind

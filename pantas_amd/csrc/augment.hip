@@ -44,10 +44,10 @@ struct GraphView {
   uint32_t* word;             // [V] segment length | FLAG_IL | FLAG_OL
   const uint32_t* row_ptr;    // [V+1]
   const uint32_t* col;        // [A]
-  uint32_t* nc;               // [V]
-  uint32_t* il0;              // [V]
-  uint32_t* oll;              // [V]
-  uint32_t* rc;               // [A]
+  uint32_t* cnt4;             // [4 V] per node {NC, IL[0], OL[len], RC of the node's first out-slot}: the counters one kept node
+                              // bumps sit in ONE 16-byte slot -- at whole-genome scale every flushed counter is an HBM
+                              // read-modify-write of its own cache line, and four planar arrays made that four lines per node
+  uint32_t* rc;               // [A] RC per adjacency slot; a first slot's count is cnt4[4 n + 3] + rc[row_ptr[n]]
   const struct SlowTables* slow;   // what only rare paths touch, kept in memory: as kernel arguments these 24 words
                                    // stayed live in scalar registers across the walk loop and were spilled there
   uint32_t ablate;            // timing experiments only (PANTAS_ABLATE): 1 no flagged-key order, 2 no novel insert, 4 no link lookup, 8 no counter updates
@@ -62,6 +62,19 @@ struct BatchView {
   const uint32_t* del_idx;    // records holding a '-' op
   uint32_t n, n_del;
 };
+
+__device__ __forceinline__ uint32_t* nc_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n); }
+__device__ __forceinline__ uint32_t* il0_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n) + 1; }
+__device__ __forceinline__ uint32_t* oll_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n) + 2; }
+__device__ __forceinline__ uint32_t* rc0_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n) + 3; }
+// the four counters of node n as two 64-bit adds (counts stay below 2^31, so the low half never carries)
+__device__ __forceinline__ void add_node4(const GraphView& g, uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol, uint32_t a_r0) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(g.cnt4 + 4 * size_t(n));
+  const unsigned long long lo = a_nc | (static_cast<unsigned long long>(a_il) << 32);
+  const unsigned long long hi = a_ol | (static_cast<unsigned long long>(a_r0) << 32);
+  if (lo) atomicAdd(p, lo);
+  if (hi) atomicAdd(p + 1, hi);
+}
 
 __device__ __forceinline__ uint32_t mix64(uint64_t k) {
   k ^= k >> 33;
@@ -94,6 +107,11 @@ __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, u
   atomicExch(t.overflow, 1u);
 }
 
+// out-of-line copy for paths that almost never run (an LDS table is full): keeps their callers' loops small
+__device__ __attribute__((noinline)) void table_update_cold(const TableView* t, uint64_t key, uint32_t add, uint64_t order) {
+  table_update(*t, key, add, order);
+}
+
 __device__ __forceinline__ uint64_t hist_key(uint32_t node, uint32_t side, uint32_t pos_code) {
   return (uint64_t(node) << 32) | (uint64_t(side) << 31) | pos_code;
 }
@@ -113,9 +131,9 @@ struct RareSink {
 struct MainSink {
   const GraphView& g;
   __device__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
-  __device__ void nc(uint32_t n) const { atomicAdd(&g.nc[n], 1u); }
+  __device__ void nc(uint32_t n) const { atomicAdd(nc_of(g, n), 1u); }
   __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
-    atomicAdd(side == SIDE_IL ? &g.il0[n] : &g.oll[n], times);
+    atomicAdd(side == SIDE_IL ? il0_of(g, n) : oll_of(g, n), times);
     if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.slow->hist, hist_key(n, side, COMMON_POS), 0u, order);
   }
   __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
@@ -241,10 +259,7 @@ struct AggSink {
                                      (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
       atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
     } else {
-      if (a_nc) atomicAdd(&g.nc[n], a_nc);
-      if (a_il) atomicAdd(&g.il0[n], a_il);
-      if (a_ol) atomicAdd(&g.oll[n], a_ol);
-      if (a_r0) atomicAdd(&g.rc[row_lo], a_r0);
+      add_node4(g, n, a_nc, a_il, a_ol, a_r0);
     }
   }
   // link (a -> b) that is not a's first out-slot: the other slots, else a link the graph does not have
@@ -260,8 +275,8 @@ struct AggSink {
     if (g.ablate & 8u) return LDS_EMPTY;
     if constexpr (PACKED) {
       // general walk: steps above 1 bypass the 16-bit fields
-      if (a_il > 1u) { atomicAdd(&g.il0[n], a_il); a_il = 0; }
-      if (a_ol > 1u) { atomicAdd(&g.oll[n], a_ol); a_ol = 0; }
+      if (a_il > 1u) { atomicAdd(il0_of(g, n), a_il); a_il = 0; }
+      if (a_ol > 1u) { atomicAdd(oll_of(g, n), a_ol); a_ol = 0; }
       if (a_nc | a_il | a_ol) bump_packed(n, 0u, a_nc, a_il, a_ol, 0u);
       return LDS_EMPTY;
     }
@@ -271,9 +286,7 @@ struct AggSink {
       if (a_il) atomicAdd(&ncnt[CN + h], a_il);
       if (a_ol) atomicAdd(&ncnt[2u * CN + h], a_ol);
     } else {
-      if (a_nc) atomicAdd(&g.nc[n], a_nc);
-      if (a_il) atomicAdd(&g.il0[n], a_il);
-      if (a_ol) atomicAdd(&g.oll[n], a_ol);
+      add_node4(g, n, a_nc, a_il, a_ol, 0u);
     }
     return h;
   }
@@ -471,6 +484,247 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
   return WALK_OK;
 }
 
+// ---- short-walk kernel with deferred link lookups ---------------------------------------------------------
+// The short-walk class again (walk_simple_packed above is its specification), rebuilt around what a wave pays for:
+// a block of code runs for the whole wave as soon as ONE of its 64 lanes needs it.  In the kernel above every step of
+// the per-node loop drags the rare work along -- the scan of a CSR row beyond its first slot (junction links, SNP
+// bubbles: ~1 link in 8), the slot table, links the graph does not have, the first-seen order of flagged nodes --
+// each with a handful of active lanes.  Here
+//   * the per-node loop is uniform (it runs to the longest path of the wave, lanes past their path end are masked),
+//     so every lane is at the same point when something has to be agreed on;
+//   * a link that is not the first out-slot of its node is only QUEUED (wave-private LDS queue, slots handed out with
+//     one ballot, no atomics); the wave drains the queue with all lanes busy -- one lane per queued link -- when the
+//     walk of its 64 records is done (or the queue is nearly full);
+//   * the first-seen order of the common IL/OL key on a flagged node is one ds_min on an array indexed by the node's
+//     table slot (the line id is all that can decide between lines; a short-walk line has no other key on the node).
+// Same counters, same tables, same flush as the kernel above.
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_V, uint32_t QCAP>
+__global__ __launch_bounds__(THREADS, 8) void augment_short_kernel(GraphView g, BatchView b, uint32_t begin, uint32_t end) {
+  constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CV = 1u << LOG_V, WAVES = THREADS / 64u;
+  static_assert(CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
+  static_assert(QCAP >= 64u && CHUNK % THREADS == 0u, "queue must take one push per lane");
+  __shared__ unsigned long long ncnt[CN];            // {NC, IL0, OLL, RC of the first out-slot} x 16 bit
+  __shared__ unsigned long long vkey[CV];
+  __shared__ unsigned long long vmin[CV];
+  __shared__ unsigned long long q_ab[WAVES][QCAP];   // queued links (a << 32 | b)
+  __shared__ uint32_t nkey[CN];
+  __shared__ uint32_t omin[2][CN];                   // min line id that bumped IL[0] / OL[len] of a flagged node
+  __shared__ uint32_t skey[CS];
+  __shared__ uint32_t scnt[CS];
+  __shared__ uint32_t vcnt[CV];
+  __shared__ uint16_t q_meta[WAVES][QCAP];           // owner lane | index of the link's earlier kept node << 6
+  using Tab = AggSink<LOG_N, LOG_S, LOG_V, true>;     // probe()
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
+
+  auto bump_slot = [&](uint32_t s) {
+    const uint32_t h = Tab::template probe<LOG_S>(skey, s);
+    if (h != LDS_EMPTY) atomicAdd(&scnt[h], 1u); else atomicAdd(&g.rc[s], 1u);
+  };
+  auto novel = [&](uint32_t a, uint32_t bn, uint64_t order) {
+    const unsigned long long key = (static_cast<unsigned long long>(a) << 32) | bn;
+    uint32_t h = mix64(key) & (CV - 1);
+#pragma unroll 1
+    for (uint32_t p = 0; p < 8; ++p) {
+      unsigned long long cur = __atomic_load_n(&vkey[h], __ATOMIC_RELAXED);
+      if (cur == EMPTY_KEY) {
+        cur = atomicCAS(&vkey[h], EMPTY_KEY, key);
+        if (cur == EMPTY_KEY) cur = key;
+      }
+      if (cur == key) {
+        atomicAdd(&vcnt[h], 1u);
+        if (order < __atomic_load_n(&vmin[h], __ATOMIC_RELAXED)) atomicMin(&vmin[h], static_cast<unsigned long long>(order));
+        return;
+      }
+      h = (h + 1) & (CV - 1);
+    }
+    table_update_cold(&g.slow->novel, key, 1u, order);
+  };
+
+  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) { nkey[i] = LDS_EMPTY; ncnt[i] = 0ull; omin[0][i] = ~0u; omin[1][i] = ~0u; }
+    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < CV; i += THREADS) { vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
+    __syncthreads();
+    const uint32_t lo = begin + c * CHUNK;
+    const uint32_t hi = min(end, lo + CHUNK);
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < CHUNK / THREADS; ++pass) {
+      const uint32_t base = lo + pass * THREADS + wave * 64u;       // first record of this wave's 64
+      if (base >= hi) break;
+      const uint32_t i = base + lane;
+      const bool has_rec = i < hi;
+      LineHdr h{0, 0, 0, 0};
+      uint32_t n0 = 0, k = 0, o0 = 0, nops = 0;
+      if (has_rec) {
+        h = b.hdr[i];
+        n0 = b.node_off[i]; k = b.node_off[i + 1] - n0;
+        o0 = b.op_off[i]; nops = b.op_off[i + 1] - o0;
+      }
+      const uint32_t* nodes = b.nodes + n0;
+      // cs ops of the class: ':' runs and up to SIMPLE_MAX_STARS single '*' positions
+      uint32_t T = 0, ns = 0;
+      uint32_t star[SIMPLE_MAX_STARS];
+#pragma unroll 1
+      for (uint32_t j = 0; j < nops; ++j) {
+        const uint32_t w = b.ops[o0 + j];
+        if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
+        T += w >> 3;
+      }
+      const bool rev = (h.flags & LINE_REV) != 0;
+      uint32_t qn = 0;                                   // wave-uniform: links queued so far
+
+      // the wave's queued links, one per lane: CSR row of a beyond its first slot, else a link the graph lacks
+      auto drain = [&](uint32_t n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t j = lane; j < n; j += 64u) {
+          const unsigned long long ab = q_ab[wave][j];
+          const uint32_t meta = q_meta[wave][j];
+          const uint32_t a = uint32_t(ab >> 32), bn = uint32_t(ab);
+          const uint32_t r_lo = g.row_ptr[a], r_hi = g.row_ptr[a + 1];
+          bool found = false;
+          for (uint32_t s = r_lo + 1; s < r_hi; ++s) {
+            if (g.col[s] == bn) { bump_slot(s); found = true; break; }
+          }
+          if (!found) novel(a, bn, event_order(b.hdr[base + (meta & 63u)].line_id, meta >> 6, 0));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      };
+      // all increments of a kept node: one probe, one 64-bit LDS add, ds_min for a flagged side
+      auto flush_node = [&](uint32_t node, uint32_t word, uint32_t row_lo, bool has_colon, uint32_t idx, bool is_last, uint32_t r0) {
+        const bool enter = has_colon && idx != 0, leave = has_colon && !is_last;
+        const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
+        const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
+        const uint32_t hs = Tab::template probe<LOG_N>(nkey, node);
+        if (hs != LDS_EMPTY) {
+          const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) | (static_cast<unsigned long long>(a_ol) << 32) |
+                                         (static_cast<unsigned long long>(r0) << 48);
+          atomicAdd(&ncnt[hs], inc);
+          if (a_il && (word & FLAG_IL)) atomicMin(&omin[0][hs], h.line_id);
+          if (a_ol && (word & FLAG_OL)) atomicMin(&omin[1][hs], h.line_id);
+        } else {
+          add_node4(g, node, 1u, a_il, a_ol, r0);
+          if (a_il && (word & FLAG_IL)) table_update_cold(&g.slow->hist, hist_key(node, SIDE_IL, COMMON_POS), 0u, event_order(h.line_id, 0, 1));
+          if (a_ol && (word & FLAG_OL)) table_update_cold(&g.slow->hist, hist_key(node, SIDE_OL, COMMON_POS), 0u, event_order(h.line_id, 0, 1));
+        }
+      };
+
+      uint32_t P = 0, kept = 0;
+      bool pending = false, live = k != 0;
+      int st = WALK_OK;
+      // the kept node waiting to learn whether it is the read's last (walk_simple_packed's PackedPend)
+      uint32_t p_node = 0, p_word = 0, p_lo = 0, p_hi = 0, p_c0 = 0, p_r0 = 0;
+      bool p_colon = false;
+      uint32_t nx_node = 0, nx_word = 0, nx_lo = 0, nx_hi = 0;
+      if (live) {
+        nx_node = nodes[0];
+        nx_word = g.word[nx_node];
+        nx_lo = g.row_ptr[nx_node];
+        nx_hi = g.row_ptr[nx_node + 1];
+      }
+      // One pass of the loop per path position, for all lanes together; position k (one past the path) is where a lane
+      // flushes its last kept node.  The queue is drained at the top, when it could not take another push per lane or
+      // when no lane has work left -- the only place the drain code exists.
+#pragma unroll 1
+      for (uint32_t it = 0;; ++it) {
+        const bool more = __ballot(live && it <= k) != 0ull;
+        if (!more || qn + 64u > QCAP) {
+          drain(qn);
+          qn = 0;
+          if (!more) break;
+        }
+        const bool in = live && it < k;
+        const uint32_t node = nx_node, word = nx_word, row_lo = nx_lo, row_hi = nx_hi;
+        uint32_t col0 = 0;
+        if (in && row_lo < row_hi) col0 = g.col[row_lo];
+        if (in && it + 1 < k) {
+          nx_node = nodes[it + 1];
+          nx_word = g.word[nx_node];
+          nx_lo = g.row_ptr[nx_node];
+          nx_hi = g.row_ptr[nx_node + 1];
+        }
+        bool keep = false, colon = true;
+        uint32_t adv = 0;
+        if (in) {
+          int64_t room = int64_t(word & LEN_MASK);
+          if (it == 0) room -= h.start;
+          if (it == k - 1) room = room - h.tail + 1;
+          if (room > 0) {
+            if (P >= T) {
+              st = WALK_OPS_EXHAUSTED;
+              live = false;          // like the early return of walk_simple_packed: the pending node is not flushed
+            } else {
+              keep = true;
+              const uint32_t le = uint32_t(min(room, int64_t(T - P)));
+              if (le <= ns) {        // all-'*' needs le <= ns <= 4
+                uint32_t stars_in = 0;
+                for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
+                colon = stars_in < le;
+              }
+              adv = (room >= int64_t(T - P)) ? T - P : uint32_t(room);
+            }
+          }
+        }
+        const bool fin = live && it == k && pending;      // past the path end: the pending node was the last kept one
+        bool push = false;
+        uint32_t q_a = 0, q_b = 0, r0_here = 0;
+        if ((keep && pending) || fin) {
+          uint32_t r0 = rev ? p_r0 : 0u;
+          if (!fin) {
+            const uint32_t a = rev ? node : p_node, bn = rev ? p_node : node;
+            const uint32_t a_lo = rev ? row_lo : p_lo, a_hi = rev ? row_hi : p_hi, a_c0 = rev ? col0 : p_c0;
+            const bool first_slot = a_lo < a_hi && a_c0 == bn;
+            if (!rev && first_slot) r0 = 1u;
+            if (rev && first_slot) r0_here = 1u;
+            if (!first_slot) { push = true; q_a = a; q_b = bn; }
+          }
+          flush_node(p_node, p_word, p_lo, p_colon, kept - 1u, fin, r0);
+        }
+        if (fin) live = false;
+        if (keep) {
+          p_node = node; p_word = word; p_lo = row_lo; p_hi = row_hi; p_c0 = col0; p_r0 = r0_here; p_colon = colon;
+          pending = true;
+          ++kept;
+          P += adv;
+        }
+        // every lane of the wave is here: hand out queue slots with one ballot
+        const unsigned long long m = __ballot(push);
+        if (m != 0ull) {
+          if (push) {
+            const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+            q_ab[wave][idx] = (static_cast<unsigned long long>(q_a) << 32) | q_b;
+            q_meta[wave][idx] = uint16_t(lane | ((kept - 2u) << 6));     // kept was advanced: the link's earlier node is kept - 2
+          }
+          qn += uint32_t(__popcll(m));
+        }
+      }
+      if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
+      const uint32_t n = nkey[i];
+      if (n == LDS_EMPTY) continue;
+      const unsigned long long v = ncnt[i];
+      const uint32_t a = uint32_t(v) & 0xFFFFu, il = uint32_t(v >> 16) & 0xFFFFu, ol = uint32_t(v >> 32) & 0xFFFFu, r0 = uint32_t(v >> 48);
+      add_node4(g, n, a, il, ol, r0);
+      if (omin[0][i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(omin[0][i], 0, 1));
+      if (omin[1][i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(omin[1][i], 0, 1));
+    }
+    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
+      const uint32_t s = skey[i];
+      if (s != LDS_EMPTY && scnt[i]) atomicAdd(&g.rc[s], scnt[i]);
+    }
+    for (uint32_t i = threadIdx.x; i < CV; i += THREADS) {
+      if (vkey[i] != EMPTY_KEY) table_update(g.slow->novel, vkey[i], vcnt[i], vmin[i]);
+    }
+    __syncthreads();
+  }
+}
+
 // SPREAD: which record of the chunk a lane takes.  0: lane l of a pass takes position l (neighbouring lanes hold
 // neighbouring records of the locus order, i.e. nearly the same path: their LDS atomics hit the same few addresses
 // and serialise); 1: the 64 lanes of a wave take every 8th record of the pass's 512; 2: every 32nd of the chunk.
@@ -538,10 +792,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       } else {
         a = ncnt[i]; il = ncnt[CN + i]; ol = ncnt[2 * CN + i]; r0 = ncnt[3 * CN + i];
       }
-      if (a) atomicAdd(&g.nc[n], a);
-      if (il) atomicAdd(&g.il0[n], il);
-      if (ol) atomicAdd(&g.oll[n], ol);
-      if (r0) atomicAdd(&g.rc[g.row_ptr[n]], r0);
+      add_node4(g, n, a, il, ol, r0);
     }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
       const uint32_t s = skey[i];
@@ -598,7 +849,7 @@ struct DeviceGraph {
   uint32_t* word = nullptr;
   uint32_t* row_ptr = nullptr;
   uint32_t* col = nullptr;
-  uint32_t* counters = nullptr;   // [NC V | IL0 V | OLL V | RC A]
+  uint32_t* counters = nullptr;   // [{NC, IL0, OLL, RC first slot} x V | RC A]  (GraphView::cnt4, ::rc)
   std::unique_ptr<ScratchPool> scratch;   // tokenize.hip temporaries
   uint32_t* name_table = nullptr; // dense segment-name table for the GPU tokeniser (tokenize.hip), uploaded on first use
   uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
@@ -623,7 +874,7 @@ struct DeviceGraph {
   GraphView view() const {
     GraphView g{};
     g.word = word; g.row_ptr = row_ptr; g.col = col;
-    g.nc = counters; g.il0 = counters + V; g.oll = counters + 2 * size_t(V); g.rc = counters + 3 * size_t(V);
+    g.cnt4 = counters; g.rc = counters + 4 * size_t(V);
     g.slow = slow_dev;
     g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;
     return g;
@@ -714,7 +965,7 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   HIP_OK(hipMalloc(&d->col, std::max<size_t>(1, g.A) * 4));
   {
     // zero padding behind the counters: the exchange kernels (exchange.hip) read whole blocks
-    const size_t w = 3 * size_t(g.V) + g.A;
+    const size_t w = 4 * size_t(g.V) + g.A;
     const size_t padded = std::max<size_t>(1, (w + COUNTER_PAD_WORDS - 1) / COUNTER_PAD_WORDS) * COUNTER_PAD_WORDS;
     HIP_OK(hipMalloc(&d->counters, padded * 4));
     HIP_OK(hipMemsetAsync(d->counters + w, 0, (padded - w) * 4, d->stream));
@@ -733,7 +984,7 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
 
 void reset_counters(DeviceGraph& d) {
   HIP_OK(hipSetDevice(d.device));
-  HIP_OK(hipMemsetAsync(d.counters, 0, (3 * size_t(d.V) + d.A) * 4, d.stream));
+  HIP_OK(hipMemsetAsync(d.counters, 0, (4 * size_t(d.V) + d.A) * 4, d.stream));
   HIP_OK(hipMemsetAsync(d.small, 0xFF, 8, d.stream));
   HIP_OK(hipMemsetAsync(d.small + 2, 0, 56, d.stream));
   table_clear(d.hist, d.stream);
@@ -938,11 +1189,20 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(70, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(71, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+#define PANTAS_SHORT(ID, LS, QC) case ID: \
+      HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0)); \
+      PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8); HIP_OK(hipEventRecord(d.ev[4], d.stream2)); \
+      if (b.n_short) hipLaunchKernelGGL((augment_short_kernel<512, 2048, 10, LS, 7, QC>), dim3((b.n_short + 2047u) / 2048u), dim3(512), 0, d.stream, g, bv, 0u, b.n_short); \
+      HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; \
+      HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0)); break;
+        PANTAS_SHORT(80, 9, 128)
+        PANTAS_SHORT(82, 9, 64)
         default:
         PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
       }
     }
 #undef PANTAS_SPLIT_SEQ
+#undef PANTAS_SHORT
 #undef PANTAS_SPLIT
 #undef PANTAS_AGG
 #undef PANTAS_AGG_RANGE
@@ -1060,19 +1320,38 @@ static void download_table(DeviceGraph& d, Table& t, uint32_t n_keys, std::vecto
   (void)hipFree(dk); (void)hipFree(df); (void)hipFree(dc);
 }
 
+// node-interleaved counters -> the planar arrays the host side works with: nc / il0 / oll [V], and rc [A] with the
+// first-slot counts kept in the node slots added in
+__global__ void planar_nodes_kernel(const uint4* __restrict__ cnt4, const uint32_t* __restrict__ row_ptr, uint32_t V,
+                                    uint32_t* __restrict__ nc, uint32_t* __restrict__ il0, uint32_t* __restrict__ oll, uint32_t* __restrict__ rc_out) {
+  for (uint32_t n = blockIdx.x * 256u + threadIdx.x; n < V; n += gridDim.x * 256u) {
+    const uint4 c = cnt4[n];
+    nc[n] = c.x; il0[n] = c.y; oll[n] = c.z;
+    if (c.w) rc_out[row_ptr[n]] += c.w;      // after the copy kernel on the same stream; one node per first slot
+  }
+}
+
 void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   HIP_OK(hipSetDevice(d.device));
   const size_t V = d.V;
   r.nc.resize(V); r.il0.resize(V); r.oll.resize(V); r.rc.resize(d.A);
+  uint32_t* planar = nullptr;       // [nc V | il0 V | oll V | rc A]
+  HIP_OK(hipMalloc(&planar, std::max<size_t>(1, 3 * V + d.A) * 4));
+  if (d.A) HIP_OK(hipMemcpyAsync(planar + 3 * V, d.counters + 4 * V, size_t(d.A) * 4, hipMemcpyDeviceToDevice, d.stream));
   if (V) {
-    HIP_OK(hipMemcpyAsync(r.nc.data(), d.counters, V * 4, hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(r.il0.data(), d.counters + V, V * 4, hipMemcpyDeviceToHost, d.stream));
-    HIP_OK(hipMemcpyAsync(r.oll.data(), d.counters + 2 * V, V * 4, hipMemcpyDeviceToHost, d.stream));
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(V) + 255) / 256, 1u << 16));
+    hipLaunchKernelGGL(planar_nodes_kernel, dim3(blocks), dim3(256), 0, d.stream, reinterpret_cast<const uint4*>(d.counters), d.row_ptr, d.V,
+                       planar, planar + V, planar + 2 * V, planar + 3 * V);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(r.nc.data(), planar, V * 4, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(r.il0.data(), planar + V, V * 4, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipMemcpyAsync(r.oll.data(), planar + 2 * V, V * 4, hipMemcpyDeviceToHost, d.stream));
   }
-  if (d.A) HIP_OK(hipMemcpyAsync(r.rc.data(), d.counters + 3 * V, size_t(d.A) * 4, hipMemcpyDeviceToHost, d.stream));
+  if (d.A) HIP_OK(hipMemcpyAsync(r.rc.data(), planar + 3 * V, size_t(d.A) * 4, hipMemcpyDeviceToHost, d.stream));
   uint32_t s[8];
   HIP_OK(hipMemcpyAsync(s, d.small, 32, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
+  (void)hipFree(planar);
   std::vector<uint64_t> keys, first;
   std::vector<uint32_t> cnt;
   download_table(d, d.hist, s[2], keys, cnt, first);
@@ -1096,10 +1375,8 @@ void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
 
 CounterPtrs counter_ptrs(DeviceGraph& d) {
   CounterPtrs p{};
-  p.nc = d.counters;
-  p.il0 = d.counters + d.V;
-  p.oll = d.counters + 2 * size_t(d.V);
-  p.rc = d.counters + 3 * size_t(d.V);
+  p.base = d.counters;
+  p.words = 4 * uint64_t(d.V) + d.A;
   p.V = d.V;
   p.A = d.A;
   return p;

@@ -370,8 +370,8 @@ __attribute__((visibility("default"))) int pantas_augment_counters(pantas_graph*
     need_device(g);
     need(dev_ptr && words, "null argument");
     CounterPtrs p = counter_ptrs(*g->dev);
-    *dev_ptr = p.nc;
-    *words = 3 * p.V + p.A;
+    *dev_ptr = p.base;
+    *words = p.words;
   });
 }
 

@@ -1,6 +1,6 @@
 // Block-sparse exchange of the dense coverage counters between the GPUs of one node.
 //
-// A read-sharded replicate ends with ONE sum over [NC | IL0 | OLL | RC] (reference: the single-process dicts of
+// A read-sharded replicate ends with ONE sum over [{NC, IL0, OLL, RC first slot} per node | RC per slot] (reference: the single-process dicts of
 // scripts/alignments_augmentation_from_gaf.py:263-363 become per-GPU arrays that must be added up).  On a spliced
 // pangenome the reads cover exons only: at human whole-genome scale about 1 % of the 10^9 counters is ever non-zero,
 // and xGMI is point-to-point -- a ring all-reduce of the whole 4 GB array is bound by one link (SURVEY 8-e,
@@ -116,14 +116,14 @@ void exchange_bitmap(DeviceGraph& dg, CounterExchangePtr& xp, uint32_t block_wor
   x.drop();
   x.pool = &scratch_pool(dg);
   x.group = block_words / 4;
-  const uint64_t w = 3 * cp.V + cp.A;
+  const uint64_t w = cp.words;
   x.words = (w + COUNTER_PAD_WORDS - 1) / COUNTER_PAD_WORDS * COUNTER_PAD_WORDS;
   if (x.words == 0) x.words = COUNTER_PAD_WORDS;
   x.bitmap_words = x.words / (32ull * block_words);
   x.bitmap = static_cast<uint32_t*>(x.pool->take(x.bitmap_words * 4));
   const uint64_t waves_needed = x.bitmap_words;
   const uint32_t blocks = uint32_t(std::min<uint64_t>((waves_needed + 3) / 4, 1u << 16));
-  const uint4* c = static_cast<const uint4*>(cp.nc);
+  const uint4* c = static_cast<const uint4*>(cp.base);
   switch (x.group) {
     case 2: hipLaunchKernelGGL(touched_bitmap_kernel<2>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, x.bitmap); break;
     case 4: hipLaunchKernelGGL(touched_bitmap_kernel<4>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, x.bitmap); break;
@@ -170,7 +170,7 @@ void exchange_pack(DeviceGraph& dg, CounterExchange& x, const void* dev_bitmaps,
     const uint32_t lg = x.group == 2 ? 1u : x.group == 4 ? 2u : x.group == 8 ? 3u : 4u;
     const CounterPtrs cp = counter_ptrs(dg);
     hipLaunchKernelGGL(move_blocks_kernel<true>, dim3(grid_for(x.words / 4)), dim3(256), 0, gi.stream,
-                       static_cast<uint4*>(cp.nc), x.staging, x.uni, x.off, x.words / 4, lg);
+                       static_cast<uint4*>(cp.base), x.staging, x.uni, x.off, x.words / 4, lg);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(gi.stream));
   }
@@ -187,7 +187,7 @@ void exchange_unpack(DeviceGraph& dg, CounterExchange& x) {
     const uint32_t lg = x.group == 2 ? 1u : x.group == 4 ? 2u : x.group == 8 ? 3u : 4u;
     const CounterPtrs cp = counter_ptrs(dg);
     hipLaunchKernelGGL(move_blocks_kernel<false>, dim3(grid_for(x.words / 4)), dim3(256), 0, gi.stream,
-                       static_cast<uint4*>(cp.nc), x.staging, x.uni, x.off, x.words / 4, lg);
+                       static_cast<uint4*>(cp.base), x.staging, x.uni, x.off, x.words / 4, lg);
     HIP_OK(hipGetLastError());
     HIP_OK(hipStreamSynchronize(gi.stream));
   }
