@@ -211,7 +211,7 @@ def main():
         avg_short = sum(short_ms) / len(short_ms)
         if avg_short > 0:
             # two main kernels: the short-walk kernel takes ~93 % of the records and of the time -- the dominant one
-            dom_name, dom_ms, dom_bytes = "augment_main_agg_kernel<512,2048,10,10,7,8,packed,short-walk class>", avg_short, bs.short_alg_bytes
+            dom_name, dom_ms, dom_bytes = "augment_main_agg_kernel<512,2048,10,10,7,8,packed,short-walk class,info gathers 2 ahead>", avg_short, bs.short_alg_bytes
         else:
             dom_name, dom_ms, dom_bytes = "augment_main_agg_kernel<512,2048,10,10,7,8>", avg_main, bs.alg_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9

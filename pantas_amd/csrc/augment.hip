@@ -42,6 +42,9 @@ struct SlowTables {
 
 struct GraphView {
   uint32_t* word;             // [V] segment length | FLAG_IL | FLAG_OL
+  uint2* info;                // [V] {word, target of the node's first out-slot or NONE32}: all the short walk needs to know about a
+                              // node in ONE 8-byte gather (instead of word, two row bounds and the dependent col[] load from three
+                              // arrays); the flag bits of .x mirror word[]
   const uint32_t* row_ptr;    // [V+1]
   const uint32_t* col;        // [A]
   uint32_t* cnt4;             // [4 V] per node {NC, IL[0], OL[len], RC of the node's first out-slot}: the counters one kept node
@@ -124,6 +127,7 @@ struct RareSink {
   __device__ void rare(uint32_t n, uint32_t side, int32_t pos, uint64_t order) const {
     table_update(g.slow->hist, hist_key(n, side, uint32_t(pos + 1) & 0x7FFFFFFFu), 1u, order);
     atomicOr(&g.word[n], side == SIDE_IL ? FLAG_IL : FLAG_OL);
+    atomicOr(&g.info[n].x, side == SIDE_IL ? FLAG_IL : FLAG_OL);
   }
   __device__ void edge(uint32_t, uint32_t, uint64_t) const {}
 };
@@ -194,6 +198,7 @@ struct AggSink {
   uint32_t* skey; uint32_t* scnt;
   uint32_t* fkey; unsigned long long* fmin;
   unsigned long long* vkey; uint32_t* vcnt; unsigned long long* vmin;   // links absent from the graph (CF entries)
+  uint32_t* omin = nullptr;   // INFO kernels: [2][CN] min line id that bumped IL[0] / OL[len] of a flagged node, by node-table slot
 
   // link (a, b) that is not in the graph: aggregate in LDS, else straight to the global table
   __device__ __forceinline__ void novel(uint32_t a, uint32_t b, uint64_t order) const {
@@ -260,6 +265,23 @@ struct AggSink {
       atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
     } else {
       add_node4(g, n, a_nc, a_il, a_ol, a_r0);
+    }
+  }
+  // the same, plus the first-seen order of the common IL / OL key where the node is flagged: the line id alone decides
+  // between lines, and a short-walk line has no other key on the node, so one ds_min on the node's own slot replaces a
+  // probe of the order table per flagged side
+  __device__ __forceinline__ void bump_packed_flagged(uint32_t n, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t a_r0) const {
+    const uint32_t h = probe<LOG_N>(nkey, n);
+    if (h != LDS_EMPTY) {
+      const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) |
+                                     (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
+      atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
+      if (a_il && (word & FLAG_IL)) atomicMin(&omin[h], line_id);
+      if (a_ol && (word & FLAG_OL)) atomicMin(&omin[CN + h], line_id);
+    } else {
+      add_node4(g, n, 1u, a_il, a_ol, a_r0);
+      if (a_il && (word & FLAG_IL)) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(line_id, 0, 1));
+      if (a_ol && (word & FLAG_OL)) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(line_id, 0, 1));
     }
   }
   // link (a -> b) that is not a's first out-slot: the other slots, else a link the graph does not have
@@ -427,9 +449,103 @@ __device__ __forceinline__ void flush_packed(const PackedPend& p, uint32_t idx, 
   if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
 }
 
-template <class Sink>
+// The short walk over g.info: per path node ONE 8-byte gather {length word, first out-target}; the CSR row bounds are only
+// fetched for a link that is not its node's first out-slot.  PF = how many nodes ahead the gathers run (the walk waits
+// on the chain nodes[] -> info[]; at whole-genome scale nearly half of these gathers miss the L2):
+//   PF 1: while node i is processed, info of node i+1 is in flight;
+//   PF 2: info of i+1 and i+2 and the id of i+3 are in flight.
+template <class Sink, int PF>
+__device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
+                                               const uint32_t* ops, uint32_t nops, const Sink& sink) {
+  uint32_t T = 0, ns = 0;
+  uint32_t star[SIMPLE_MAX_STARS];
+#pragma unroll 1
+  for (uint32_t j = 0; j < nops; ++j) {
+    const uint32_t w = ops[j];
+    if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
+    T += w >> 3;
+  }
+  const bool rev = (h.flags & LINE_REV) != 0;
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  uint32_t p_node = 0, p_word = 0, p_c0 = 0, p_r0 = 0;
+  bool p_colon = false;
+  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351)
+  auto flush = [&](bool is_last, uint32_t r0) {
+    const bool enter = p_colon && kept != 1u, leave = p_colon && !is_last;      // the pending node is kept node number kept - 1
+    sink.bump_packed_flagged(p_node, p_word, h.line_id, (rev ? leave : enter) ? 1u : 0u, (rev ? enter : leave) ? 1u : 0u, r0);
+  };
+  // pipeline registers: c = node i, 1 = node i+1, 2 = node i+2 (PF 2 only); ids are requested before the info gather of
+  // the same pass so that waiting for an id never waits for the younger gather
+  uint32_t node_c = nodes[0], node_1 = 0, node_2 = 0;
+  if (k > 1) node_1 = nodes[1];
+  if (PF >= 2 && k > 2) node_2 = nodes[2];
+  uint2 inf_c = g.info[node_c], inf_1 = make_uint2(0u, 0u);
+  if (k > 1) inf_1 = g.info[node_1];
+#pragma unroll 1
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = node_c, word = inf_c.x, col0 = inf_c.y;
+    uint2 inf_2 = make_uint2(0u, 0u);
+    uint32_t node_3 = 0;
+    if constexpr (PF >= 2) {
+      if (i + 3 < k) node_3 = nodes[i + 3];
+      if (i + 2 < k) inf_2 = g.info[node_2];
+    } else {
+      if (i + 2 < k) node_2 = nodes[i + 2];
+    }
+    // room the node offers to the ops, as min(room, 2^32 - 1): every use compares it with T - P <= 2^32 - 1
+    const uint32_t len = word & LEN_MASK;
+    bool has_room = len != 0u;
+    uint32_t room = len;
+    if (i == 0 || i == k - 1) {
+      int64_t r = int64_t(len);
+      if (i == 0) r -= h.start;
+      if (i == k - 1) r = r - h.tail + 1;
+      has_room = r > 0;
+      room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
+    }
+    if (has_room) {
+      if (P >= T) return WALK_OPS_EXHAUSTED;
+      const uint32_t left = T - P;
+      const uint32_t le = min(room, left);
+      bool colon = true;            // an all-'*' node needs le <= ns <= 4
+      if (le <= ns) {
+        uint32_t stars_in = 0;
+        for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
+        colon = stars_in < le;
+      }
+      uint32_t r0_here = 0;
+      if (pending) {
+        const uint32_t a = rev ? node : p_node, bnode = rev ? p_node : node;
+        const bool first_slot = (rev ? col0 : p_c0) == bnode;          // NONE32 for a node without out-links
+        flush(false, rev ? p_r0 : (first_slot ? 1u : 0u));
+        if (rev && first_slot) r0_here = 1u;
+        if (!first_slot) sink.link_rest(a, g.row_ptr[a], g.row_ptr[a + 1], bnode, event_order(h.line_id, kept - 1u, 0));
+      }
+      p_node = node; p_word = word; p_c0 = col0; p_colon = colon; p_r0 = r0_here;
+      pending = true;
+      ++kept;
+      P += le;                      // == T when the ops end inside this node
+    }
+    // advance the pipeline
+    node_c = node_1; inf_c = inf_1;
+    if constexpr (PF >= 2) {
+      node_1 = node_2; inf_1 = inf_2; node_2 = node_3;
+    } else {
+      node_1 = node_2;
+      if (i + 2 < k) inf_1 = g.info[node_1];
+    }
+  }
+  if (pending) flush(true, rev ? p_r0 : 0u);
+  return WALK_OK;
+}
+
+// INFO: the node's length word and first out-target come from g.info (one 8-byte gather, no dependent col[] load); the
+// CSR row bounds are only fetched for a link that is not its node's first out-slot.
+template <class Sink, bool INFO = false, int PF = 1>
 __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
                                                   const uint32_t* ops, uint32_t nops, const Sink& sink) {
+  if constexpr (INFO) return walk_short_info<Sink, PF>(g, h, nodes, k, ops, nops, sink);
   uint32_t T = 0, ns = 0;
   uint32_t star[SIMPLE_MAX_STARS];
 #pragma unroll 1
@@ -498,7 +614,7 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
 //   * the first-seen order of the common IL/OL key on a flagged node is one ds_min on an array indexed by the node's
 //     table slot (the line id is all that can decide between lines; a short-walk line has no other key on the node).
 // Same counters, same tables, same flush as the kernel above.
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_V, uint32_t QCAP>
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_V, uint32_t QCAP, bool DEFER = true>
 __global__ __launch_bounds__(THREADS, 8) void augment_short_kernel(GraphView g, BatchView b, uint32_t begin, uint32_t end) {
   constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CV = 1u << LOG_V, WAVES = THREADS / 64u;
   static_assert(CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
@@ -680,7 +796,16 @@ __global__ __launch_bounds__(THREADS, 8) void augment_short_kernel(GraphView g, 
             const bool first_slot = a_lo < a_hi && a_c0 == bn;
             if (!rev && first_slot) r0 = 1u;
             if (rev && first_slot) r0_here = 1u;
-            if (!first_slot) { push = true; q_a = a; q_b = bn; }
+            if (!first_slot) {
+              if constexpr (DEFER) { push = true; q_a = a; q_b = bn; }
+              else {          // A/B: the lookup where it arises, as in walk_simple_packed
+                bool found = false;
+                for (uint32_t sl = a_lo + 1; sl < a_hi; ++sl) {
+                  if (g.col[sl] == bn) { bump_slot(sl); found = true; break; }
+                }
+                if (!found) novel(a, bn, event_order(h.line_id, kept - 1u, 0));
+              }
+            }
           }
           flush_node(p_node, p_word, p_lo, p_colon, kept - 1u, fin, r0);
         }
@@ -729,7 +854,7 @@ __global__ __launch_bounds__(THREADS, 8) void augment_short_kernel(GraphView g, 
 // neighbouring records of the locus order, i.e. nearly the same path: their LDS atomics hit the same few addresses
 // and serialise); 1: the 64 lanes of a wave take every 8th record of the pass's 512; 2: every 32nd of the chunk.
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          int SPREAD = 0>
+          int SPREAD = 0, bool INFO = false, int PF = 1>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -746,9 +871,12 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   __shared__ uint32_t skey[CS];
   __shared__ uint32_t scnt[CS];
   __shared__ uint32_t fkey[CF];
+  __shared__ uint32_t omin[INFO ? 2 * CN : 2];
+  static_assert(!INFO || (PACKED && ONLY == 1), "the info walk exists for the short-walk class over packed entries");
   const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
+      if constexpr (INFO) { omin[i] = ~0u; omin[CN + i] = ~0u; }
       nkey[i] = LDS_EMPTY;
       ncnt[i] = 0u; ncnt[CN + i] = 0u;
       if constexpr (!PACKED) { ncnt[2 * CN + i] = 0u; ncnt[3 * CN + i] = 0u; }
@@ -756,7 +884,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
     __syncthreads();
-    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin};
+    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin};
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
     for (uint32_t pass = 0; pass < CHUNK / THREADS; ++pass) {
@@ -776,7 +904,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
         MainSink direct{g};
         st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, direct);
       } else if (ONLY == 1 || (ONLY == 0 && (h.flags & LINE_SIMPLE) && !(g.ablate & 16u))) {
-        if constexpr (PACKED) st = walk_simple_packed(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+        if constexpr (PACKED) st = walk_simple_packed<Sink, INFO, PF>(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
         else st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
@@ -793,6 +921,10 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
         a = ncnt[i]; il = ncnt[CN + i]; ol = ncnt[2 * CN + i]; r0 = ncnt[3 * CN + i];
       }
       add_node4(g, n, a, il, ol, r0);
+      if constexpr (INFO) {
+        if (omin[i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(omin[i], 0, 1));
+        if (omin[CN + i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(omin[CN + i], 0, 1));
+      }
     }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
       const uint32_t s = skey[i];
@@ -807,8 +939,15 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   }
 }
 
-__global__ void clear_flags_kernel(uint32_t* word, uint32_t n) {
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) word[i] &= LEN_MASK;
+__global__ void clear_flags_kernel(uint32_t* word, uint2* info, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { word[i] &= LEN_MASK; info[i].x &= LEN_MASK; }
+}
+
+__global__ void build_info_kernel(const uint32_t* word, const uint32_t* row_ptr, const uint32_t* col, uint2* info, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t lo = row_ptr[i], hi = row_ptr[i + 1];
+    info[i] = make_uint2(word[i], lo < hi ? col[lo] : 0xFFFFFFFFu);
+  }
 }
 
 __global__ void compact_table_kernel(TableView t, uint64_t* keys, uint32_t* cnt, uint64_t* first, uint32_t* cursor) {
@@ -847,6 +986,7 @@ struct DeviceGraph {
   uint32_t V = 0;
   uint64_t A = 0;
   uint32_t* word = nullptr;
+  uint2* info = nullptr;          // {word, first out-target} per node (GraphView::info)
   uint32_t* row_ptr = nullptr;
   uint32_t* col = nullptr;
   uint32_t* counters = nullptr;   // [{NC, IL0, OLL, RC first slot} x V | RC A]  (GraphView::cnt4, ::rc)
@@ -873,7 +1013,7 @@ struct DeviceGraph {
   }
   GraphView view() const {
     GraphView g{};
-    g.word = word; g.row_ptr = row_ptr; g.col = col;
+    g.word = word; g.info = info; g.row_ptr = row_ptr; g.col = col;
     g.cnt4 = counters; g.rc = counters + 4 * size_t(V);
     g.slow = slow_dev;
     g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;
@@ -901,7 +1041,7 @@ uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
 void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->word, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->slow_dev})
+  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->slow_dev})
     if (p) (void)hipFree(p);
   d->scratch.reset();
   d->hist.free_all();
@@ -975,6 +1115,12 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   HIP_OK(hipMemcpyAsync(d->word, g.seg_len.data(), size_t(g.V) * 4, hipMemcpyHostToDevice, d->stream));
   HIP_OK(hipMemcpyAsync(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, hipMemcpyHostToDevice, d->stream));
   HIP_OK(hipMemcpyAsync(d->col, g.col.data(), size_t(g.A) * 4, hipMemcpyHostToDevice, d->stream));
+  HIP_OK(hipMalloc(&d->info, std::max<size_t>(1, g.V) * 8));
+  if (g.V) {
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(g.V) + 255) / 256, 1u << 16));
+    hipLaunchKernelGGL(build_info_kernel, dim3(blocks), dim3(256), 0, d->stream, d->word, d->row_ptr, d->col, d->info, g.V);
+    HIP_OK(hipGetLastError());
+  }
   table_alloc(d->hist, 1024, d->small + 2, d->small + 3);
   table_alloc(d->novel, 1024, d->small + 4, d->small + 5);
   HIP_OK(hipStreamSynchronize(d->stream));
@@ -991,7 +1137,7 @@ void reset_counters(DeviceGraph& d) {
   table_clear(d.novel, d.stream);
   if (d.V) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(d.V) + 255) / 256, 4096));
-    hipLaunchKernelGGL(clear_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.V);
+    hipLaunchKernelGGL(clear_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, d.V);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
@@ -1147,7 +1293,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // kernels: the short-walk class [0, n_short) with packed LDS entries, the rest with the general kernel.  The
     // short-walk kernel then needs no registers, scalar spills or code of the general walk, and no chunk waits for
     // the few slow general-walk waves that used to sit at its end.
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 60;   // read per launch: tools/ab_variants.py switches it
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 73;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1188,17 +1334,20 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_SPLIT(63, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 256, 1024, 9, 9, 7, 8))
         PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(70, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 0, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(71, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-#define PANTAS_SHORT(ID, LS, QC) case ID: \
+#define PANTAS_SHORT(ID, LS, QC, ...) case ID: \
       HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0)); \
       PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8); HIP_OK(hipEventRecord(d.ev[4], d.stream2)); \
-      if (b.n_short) hipLaunchKernelGGL((augment_short_kernel<512, 2048, 10, LS, 7, QC>), dim3((b.n_short + 2047u) / 2048u), dim3(512), 0, d.stream, g, bv, 0u, b.n_short); \
+      if (b.n_short) hipLaunchKernelGGL((augment_short_kernel<512, 2048, 10, LS, 7, QC, ##__VA_ARGS__>), dim3((b.n_short + 2047u) / 2048u), dim3(512), 0, d.stream, g, bv, 0u, b.n_short); \
       HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; \
       HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0)); break;
         PANTAS_SHORT(80, 9, 128)
         PANTAS_SHORT(82, 9, 64)
-        default:
+        PANTAS_SHORT(83, 9, 64, false)
         PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        default:   // 73: short walk over g.info, gathers two nodes ahead
+        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 0, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
       }
     }
 #undef PANTAS_SPLIT_SEQ
@@ -1240,10 +1389,13 @@ __global__ void collect_flags_kernel(const uint32_t* word, uint32_t n, uint32_t*
   }
 }
 
-__global__ void apply_flags_kernel(uint32_t* word, const uint32_t* codes, uint32_t n, uint32_t V) {
+__global__ void apply_flags_kernel(uint32_t* word, uint2* info, const uint32_t* codes, uint32_t n, uint32_t V) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t c = codes[i];
-    if ((c >> 1) < V) atomicOr(&word[c >> 1], (c & 1u) ? FLAG_OL : FLAG_IL);
+    if ((c >> 1) < V) {
+      atomicOr(&word[c >> 1], (c & 1u) ? FLAG_OL : FLAG_IL);
+      atomicOr(&info[c >> 1].x, (c & 1u) ? FLAG_OL : FLAG_IL);
+    }
   }
 }
 
@@ -1276,7 +1428,7 @@ void import_flags(DeviceGraph& d, const uint32_t* codes, size_t n) {
   HIP_OK(hipMalloc(&in, n * 4));
   HIP_OK(hipMemcpyAsync(in, codes, n * 4, hipMemcpyHostToDevice, d.stream));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((n + 255) / 256, 4096));
-  hipLaunchKernelGGL(apply_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, in, uint32_t(n), d.V);
+  hipLaunchKernelGGL(apply_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, in, uint32_t(n), d.V);
   HIP_OK(hipStreamSynchronize(d.stream));
   (void)hipFree(in);
   d.imported_flags += n;
