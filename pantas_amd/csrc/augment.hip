@@ -270,18 +270,29 @@ struct AggSink {
   // the same, plus the first-seen order of the common IL / OL key where the node is flagged: the line id alone decides
   // between lines, and a short-walk line has no other key on the node, so one ds_min on the node's own slot replaces a
   // probe of the order table per flagged side
-  __device__ __forceinline__ void bump_packed_flagged(uint32_t n, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t a_r0) const {
+  __device__ __forceinline__ void bump_packed_flagged(uint32_t n, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t a_r0,
+                                                      uint64_t exact_order) const {
+    // a_il / a_ol: 0 .. 3 steps (a node holding a '+' between ':' runs counts each compacted entry); walk.h bounds what a
+    // line can add to one field so that 2048 lines stay below 2^16
+    const bool f_il = a_il && (word & FLAG_IL), f_ol = a_ol && (word & FLAG_OL);
     const uint32_t h = probe<LOG_N>(nkey, n);
     if (h != LDS_EMPTY) {
       const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) |
                                      (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
       atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
-      if (a_il && (word & FLAG_IL)) atomicMin(&omin[h], line_id);
-      if (a_ol && (word & FLAG_OL)) atomicMin(&omin[CN + h], line_id);
+      if (exact_order == 0) {
+        if (f_il) atomicMin(&omin[h], line_id);
+        if (f_ol) atomicMin(&omin[CN + h], line_id);
+      }
     } else {
       add_node4(g, n, 1u, a_il, a_ol, a_r0);
-      if (a_il && (word & FLAG_IL)) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(line_id, 0, 1));
-      if (a_ol && (word & FLAG_OL)) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(line_id, 0, 1));
+    }
+    // a line with a '-' op has rare keys of its own on the nodes it flags: its common key needs the exact within-line
+    // order, through the order table of the general walk
+    if (exact_order != 0 || h == LDS_EMPTY) {
+      const uint64_t ord = exact_order != 0 ? exact_order : event_order(line_id, 0, 1);
+      if (f_il) order_min(n, SIDE_IL, ord);
+      if (f_ol) order_min(n, SIDE_OL, ord);
     }
   }
   // link (a -> b) that is not a's first out-slot: the other slots, else a link the graph does not have
@@ -457,23 +468,20 @@ __device__ __forceinline__ void flush_packed(const PackedPend& p, uint32_t idx, 
 template <class Sink, int PF>
 __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
                                                const uint32_t* ops, uint32_t nops, const Sink& sink) {
-  uint32_t T = 0, ns = 0;
-  uint32_t star[SIMPLE_MAX_STARS];
-#pragma unroll 1
-  for (uint32_t j = 0; j < nops; ++j) {
-    const uint32_t w = ops[j];
-    if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
-    T += w >> 3;
-  }
+  ShortOps so;                      // ':' runs, '*' positions, at most one '+' / '-' (walk.h)
+  short_ops_scan(ops, nops, so);
+  const uint32_t T = so.T;
   const bool rev = (h.flags & LINE_REV) != 0;
+  const bool exact = (h.flags & LINE_HAS_DEL) != 0;
   uint32_t P = 0, kept = 0;
   bool pending = false;
-  uint32_t p_node = 0, p_word = 0, p_c0 = 0, p_r0 = 0;
-  bool p_colon = false;
-  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351)
+  uint32_t p_node = 0, p_word = 0, p_c0 = 0, p_r0 = 0, p_plain = 0;
+  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351), once per
+  // compacted entry that is neither '-' nor '*' (p_plain of them)
   auto flush = [&](bool is_last, uint32_t r0) {
-    const bool enter = p_colon && kept != 1u, leave = p_colon && !is_last;      // the pending node is kept node number kept - 1
-    sink.bump_packed_flagged(p_node, p_word, h.line_id, (rev ? leave : enter) ? 1u : 0u, (rev ? enter : leave) ? 1u : 0u, r0);
+    const bool enter = p_plain != 0u && kept != 1u, leave = p_plain != 0u && !is_last;      // the pending node is kept node number kept - 1
+    sink.bump_packed_flagged(p_node, p_word, h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, r0,
+                             exact ? event_order(h.line_id, kept - 1u, 1) : 0ull);
   };
   // pipeline registers: c = node i, 1 = node i+1, 2 = node i+2 (PF 2 only); ids are requested before the info gather of
   // the same pass so that waiting for an id never waits for the younger gather
@@ -508,12 +516,11 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
       if (P >= T) return WALK_OPS_EXHAUSTED;
       const uint32_t left = T - P;
       const uint32_t le = min(room, left);
-      bool colon = true;            // an all-'*' node needs le <= ns <= 4
-      if (le <= ns) {
-        uint32_t stars_in = 0;
-        for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
-        colon = stars_in < le;
-      }
+      bool keep;
+      uint32_t plain;
+      short_node_summary(so, P, le, keep, plain);
+      P += le;                      // == T when the ops end inside this node
+      if (keep) {
       uint32_t r0_here = 0;
       if (pending) {
         const uint32_t a = rev ? node : p_node, bnode = rev ? p_node : node;
@@ -522,10 +529,10 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
         if (rev && first_slot) r0_here = 1u;
         if (!first_slot) sink.link_rest(a, g.row_ptr[a], g.row_ptr[a + 1], bnode, event_order(h.line_id, kept - 1u, 0));
       }
-      p_node = node; p_word = word; p_c0 = col0; p_colon = colon; p_r0 = r0_here;
+      p_node = node; p_word = word; p_c0 = col0; p_plain = plain; p_r0 = r0_here;
       pending = true;
       ++kept;
-      P += le;                      // == T when the ops end inside this node
+      }                             // else: the node holds the lone '+' / '-' piece and is dropped (:101-102)
     }
     // advance the pipeline
     node_c = node_1; inf_c = inf_1;
@@ -600,256 +607,6 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
   return WALK_OK;
 }
 
-// ---- short-walk kernel with deferred link lookups ---------------------------------------------------------
-// The short-walk class again (walk_simple_packed above is its specification), rebuilt around what a wave pays for:
-// a block of code runs for the whole wave as soon as ONE of its 64 lanes needs it.  In the kernel above every step of
-// the per-node loop drags the rare work along -- the scan of a CSR row beyond its first slot (junction links, SNP
-// bubbles: ~1 link in 8), the slot table, links the graph does not have, the first-seen order of flagged nodes --
-// each with a handful of active lanes.  Here
-//   * the per-node loop is uniform (it runs to the longest path of the wave, lanes past their path end are masked),
-//     so every lane is at the same point when something has to be agreed on;
-//   * a link that is not the first out-slot of its node is only QUEUED (wave-private LDS queue, slots handed out with
-//     one ballot, no atomics); the wave drains the queue with all lanes busy -- one lane per queued link -- when the
-//     walk of its 64 records is done (or the queue is nearly full);
-//   * the first-seen order of the common IL/OL key on a flagged node is one ds_min on an array indexed by the node's
-//     table slot (the line id is all that can decide between lines; a short-walk line has no other key on the node).
-// Same counters, same tables, same flush as the kernel above.
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_V, uint32_t QCAP, bool DEFER = true>
-__global__ __launch_bounds__(THREADS, 8) void augment_short_kernel(GraphView g, BatchView b, uint32_t begin, uint32_t end) {
-  constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CV = 1u << LOG_V, WAVES = THREADS / 64u;
-  static_assert(CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
-  static_assert(QCAP >= 64u && CHUNK % THREADS == 0u, "queue must take one push per lane");
-  __shared__ unsigned long long ncnt[CN];            // {NC, IL0, OLL, RC of the first out-slot} x 16 bit
-  __shared__ unsigned long long vkey[CV];
-  __shared__ unsigned long long vmin[CV];
-  __shared__ unsigned long long q_ab[WAVES][QCAP];   // queued links (a << 32 | b)
-  __shared__ uint32_t nkey[CN];
-  __shared__ uint32_t omin[2][CN];                   // min line id that bumped IL[0] / OL[len] of a flagged node
-  __shared__ uint32_t skey[CS];
-  __shared__ uint32_t scnt[CS];
-  __shared__ uint32_t vcnt[CV];
-  __shared__ uint16_t q_meta[WAVES][QCAP];           // owner lane | index of the link's earlier kept node << 6
-  using Tab = AggSink<LOG_N, LOG_S, LOG_V, true>;     // probe()
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
-
-  auto bump_slot = [&](uint32_t s) {
-    const uint32_t h = Tab::template probe<LOG_S>(skey, s);
-    if (h != LDS_EMPTY) atomicAdd(&scnt[h], 1u); else atomicAdd(&g.rc[s], 1u);
-  };
-  auto novel = [&](uint32_t a, uint32_t bn, uint64_t order) {
-    const unsigned long long key = (static_cast<unsigned long long>(a) << 32) | bn;
-    uint32_t h = mix64(key) & (CV - 1);
-#pragma unroll 1
-    for (uint32_t p = 0; p < 8; ++p) {
-      unsigned long long cur = __atomic_load_n(&vkey[h], __ATOMIC_RELAXED);
-      if (cur == EMPTY_KEY) {
-        cur = atomicCAS(&vkey[h], EMPTY_KEY, key);
-        if (cur == EMPTY_KEY) cur = key;
-      }
-      if (cur == key) {
-        atomicAdd(&vcnt[h], 1u);
-        if (order < __atomic_load_n(&vmin[h], __ATOMIC_RELAXED)) atomicMin(&vmin[h], static_cast<unsigned long long>(order));
-        return;
-      }
-      h = (h + 1) & (CV - 1);
-    }
-    table_update_cold(&g.slow->novel, key, 1u, order);
-  };
-
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) { nkey[i] = LDS_EMPTY; ncnt[i] = 0ull; omin[0][i] = ~0u; omin[1][i] = ~0u; }
-    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
-    for (uint32_t i = threadIdx.x; i < CV; i += THREADS) { vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
-    __syncthreads();
-    const uint32_t lo = begin + c * CHUNK;
-    const uint32_t hi = min(end, lo + CHUNK);
-#pragma unroll 1
-    for (uint32_t pass = 0; pass < CHUNK / THREADS; ++pass) {
-      const uint32_t base = lo + pass * THREADS + wave * 64u;       // first record of this wave's 64
-      if (base >= hi) break;
-      const uint32_t i = base + lane;
-      const bool has_rec = i < hi;
-      LineHdr h{0, 0, 0, 0};
-      uint32_t n0 = 0, k = 0, o0 = 0, nops = 0;
-      if (has_rec) {
-        h = b.hdr[i];
-        n0 = b.node_off[i]; k = b.node_off[i + 1] - n0;
-        o0 = b.op_off[i]; nops = b.op_off[i + 1] - o0;
-      }
-      const uint32_t* nodes = b.nodes + n0;
-      // cs ops of the class: ':' runs and up to SIMPLE_MAX_STARS single '*' positions
-      uint32_t T = 0, ns = 0;
-      uint32_t star[SIMPLE_MAX_STARS];
-#pragma unroll 1
-      for (uint32_t j = 0; j < nops; ++j) {
-        const uint32_t w = b.ops[o0 + j];
-        if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
-        T += w >> 3;
-      }
-      const bool rev = (h.flags & LINE_REV) != 0;
-      uint32_t qn = 0;                                   // wave-uniform: links queued so far
-
-      // the wave's queued links, one per lane: CSR row of a beyond its first slot, else a link the graph lacks
-      auto drain = [&](uint32_t n) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (uint32_t j = lane; j < n; j += 64u) {
-          const unsigned long long ab = q_ab[wave][j];
-          const uint32_t meta = q_meta[wave][j];
-          const uint32_t a = uint32_t(ab >> 32), bn = uint32_t(ab);
-          const uint32_t r_lo = g.row_ptr[a], r_hi = g.row_ptr[a + 1];
-          bool found = false;
-          for (uint32_t s = r_lo + 1; s < r_hi; ++s) {
-            if (g.col[s] == bn) { bump_slot(s); found = true; break; }
-          }
-          if (!found) novel(a, bn, event_order(b.hdr[base + (meta & 63u)].line_id, meta >> 6, 0));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-      };
-      // all increments of a kept node: one probe, one 64-bit LDS add, ds_min for a flagged side
-      auto flush_node = [&](uint32_t node, uint32_t word, uint32_t row_lo, bool has_colon, uint32_t idx, bool is_last, uint32_t r0) {
-        const bool enter = has_colon && idx != 0, leave = has_colon && !is_last;
-        const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
-        const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
-        const uint32_t hs = Tab::template probe<LOG_N>(nkey, node);
-        if (hs != LDS_EMPTY) {
-          const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) | (static_cast<unsigned long long>(a_ol) << 32) |
-                                         (static_cast<unsigned long long>(r0) << 48);
-          atomicAdd(&ncnt[hs], inc);
-          if (a_il && (word & FLAG_IL)) atomicMin(&omin[0][hs], h.line_id);
-          if (a_ol && (word & FLAG_OL)) atomicMin(&omin[1][hs], h.line_id);
-        } else {
-          add_node4(g, node, 1u, a_il, a_ol, r0);
-          if (a_il && (word & FLAG_IL)) table_update_cold(&g.slow->hist, hist_key(node, SIDE_IL, COMMON_POS), 0u, event_order(h.line_id, 0, 1));
-          if (a_ol && (word & FLAG_OL)) table_update_cold(&g.slow->hist, hist_key(node, SIDE_OL, COMMON_POS), 0u, event_order(h.line_id, 0, 1));
-        }
-      };
-
-      uint32_t P = 0, kept = 0;
-      bool pending = false, live = k != 0;
-      int st = WALK_OK;
-      // the kept node waiting to learn whether it is the read's last (walk_simple_packed's PackedPend)
-      uint32_t p_node = 0, p_word = 0, p_lo = 0, p_hi = 0, p_c0 = 0, p_r0 = 0;
-      bool p_colon = false;
-      uint32_t nx_node = 0, nx_word = 0, nx_lo = 0, nx_hi = 0;
-      if (live) {
-        nx_node = nodes[0];
-        nx_word = g.word[nx_node];
-        nx_lo = g.row_ptr[nx_node];
-        nx_hi = g.row_ptr[nx_node + 1];
-      }
-      // One pass of the loop per path position, for all lanes together; position k (one past the path) is where a lane
-      // flushes its last kept node.  The queue is drained at the top, when it could not take another push per lane or
-      // when no lane has work left -- the only place the drain code exists.
-#pragma unroll 1
-      for (uint32_t it = 0;; ++it) {
-        const bool more = __ballot(live && it <= k) != 0ull;
-        if (!more || qn + 64u > QCAP) {
-          drain(qn);
-          qn = 0;
-          if (!more) break;
-        }
-        const bool in = live && it < k;
-        const uint32_t node = nx_node, word = nx_word, row_lo = nx_lo, row_hi = nx_hi;
-        uint32_t col0 = 0;
-        if (in && row_lo < row_hi) col0 = g.col[row_lo];
-        if (in && it + 1 < k) {
-          nx_node = nodes[it + 1];
-          nx_word = g.word[nx_node];
-          nx_lo = g.row_ptr[nx_node];
-          nx_hi = g.row_ptr[nx_node + 1];
-        }
-        bool keep = false, colon = true;
-        uint32_t adv = 0;
-        if (in) {
-          int64_t room = int64_t(word & LEN_MASK);
-          if (it == 0) room -= h.start;
-          if (it == k - 1) room = room - h.tail + 1;
-          if (room > 0) {
-            if (P >= T) {
-              st = WALK_OPS_EXHAUSTED;
-              live = false;          // like the early return of walk_simple_packed: the pending node is not flushed
-            } else {
-              keep = true;
-              const uint32_t le = uint32_t(min(room, int64_t(T - P)));
-              if (le <= ns) {        // all-'*' needs le <= ns <= 4
-                uint32_t stars_in = 0;
-                for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
-                colon = stars_in < le;
-              }
-              adv = (room >= int64_t(T - P)) ? T - P : uint32_t(room);
-            }
-          }
-        }
-        const bool fin = live && it == k && pending;      // past the path end: the pending node was the last kept one
-        bool push = false;
-        uint32_t q_a = 0, q_b = 0, r0_here = 0;
-        if ((keep && pending) || fin) {
-          uint32_t r0 = rev ? p_r0 : 0u;
-          if (!fin) {
-            const uint32_t a = rev ? node : p_node, bn = rev ? p_node : node;
-            const uint32_t a_lo = rev ? row_lo : p_lo, a_hi = rev ? row_hi : p_hi, a_c0 = rev ? col0 : p_c0;
-            const bool first_slot = a_lo < a_hi && a_c0 == bn;
-            if (!rev && first_slot) r0 = 1u;
-            if (rev && first_slot) r0_here = 1u;
-            if (!first_slot) {
-              if constexpr (DEFER) { push = true; q_a = a; q_b = bn; }
-              else {          // A/B: the lookup where it arises, as in walk_simple_packed
-                bool found = false;
-                for (uint32_t sl = a_lo + 1; sl < a_hi; ++sl) {
-                  if (g.col[sl] == bn) { bump_slot(sl); found = true; break; }
-                }
-                if (!found) novel(a, bn, event_order(h.line_id, kept - 1u, 0));
-              }
-            }
-          }
-          flush_node(p_node, p_word, p_lo, p_colon, kept - 1u, fin, r0);
-        }
-        if (fin) live = false;
-        if (keep) {
-          p_node = node; p_word = word; p_lo = row_lo; p_hi = row_hi; p_c0 = col0; p_r0 = r0_here; p_colon = colon;
-          pending = true;
-          ++kept;
-          P += adv;
-        }
-        // every lane of the wave is here: hand out queue slots with one ballot
-        const unsigned long long m = __ballot(push);
-        if (m != 0ull) {
-          if (push) {
-            const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-            q_ab[wave][idx] = (static_cast<unsigned long long>(q_a) << 32) | q_b;
-            q_meta[wave][idx] = uint16_t(lane | ((kept - 2u) << 6));     // kept was advanced: the link's earlier node is kept - 2
-          }
-          qn += uint32_t(__popcll(m));
-        }
-      }
-      if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
-      const uint32_t n = nkey[i];
-      if (n == LDS_EMPTY) continue;
-      const unsigned long long v = ncnt[i];
-      const uint32_t a = uint32_t(v) & 0xFFFFu, il = uint32_t(v >> 16) & 0xFFFFu, ol = uint32_t(v >> 32) & 0xFFFFu, r0 = uint32_t(v >> 48);
-      add_node4(g, n, a, il, ol, r0);
-      if (omin[0][i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(omin[0][i], 0, 1));
-      if (omin[1][i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(omin[1][i], 0, 1));
-    }
-    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
-      const uint32_t s = skey[i];
-      if (s != LDS_EMPTY && scnt[i]) atomicAdd(&g.rc[s], scnt[i]);
-    }
-    for (uint32_t i = threadIdx.x; i < CV; i += THREADS) {
-      if (vkey[i] != EMPTY_KEY) table_update(g.slow->novel, vkey[i], vcnt[i], vmin[i]);
-    }
-    __syncthreads();
-  }
-}
-
 // SPREAD: which record of the chunk a lane takes.  0: lane l of a pass takes position l (neighbouring lanes hold
 // neighbouring records of the locus order, i.e. nearly the same path: their LDS atomics hit the same few addresses
 // and serialise); 1: the 64 lanes of a wave take every 8th record of the pass's 512; 2: every 32nd of the chunk.
@@ -861,7 +618,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   if constexpr (!ABL) g.ablate = 0u;
   using Sink = AggSink<LOG_N, LOG_S, LOG_F, PACKED>;
   constexpr uint32_t CN = Sink::CN, CS = Sink::CS, CF = Sink::CF;
-  static_assert(!PACKED || CHUNK * PACKED_MAX_PATH < 65536u, "a 16-bit field could overflow");
+  static_assert(!PACKED || (CHUNK * PACKED_MAX_PATH < 65536u && CHUNK * (SHORT_MAX_PATH_INDEL + 2u) < 65536u), "a 16-bit field could overflow");
   __shared__ unsigned long long fmin[CF];
   __shared__ unsigned long long vkey[CF];
   __shared__ unsigned long long vmin[CF];
@@ -904,7 +661,9 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
         MainSink direct{g};
         st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, direct);
       } else if (ONLY == 1 || (ONLY == 0 && (h.flags & LINE_SIMPLE) && !(g.ablate & 16u))) {
-        if constexpr (PACKED) st = walk_simple_packed<Sink, INFO, PF>(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+        // walk_short_info covers the whole short-walk class; the older short walks know ':' and '*' only
+        if (!INFO && !(h.flags & LINE_SIMPLE)) st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+        else if constexpr (PACKED) st = walk_simple_packed<Sink, INFO, PF>(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
         else st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
@@ -1336,22 +1095,12 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_SPLIT(70, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 0, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(71, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-#define PANTAS_SHORT(ID, LS, QC, ...) case ID: \
-      HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0)); \
-      PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8); HIP_OK(hipEventRecord(d.ev[4], d.stream2)); \
-      if (b.n_short) hipLaunchKernelGGL((augment_short_kernel<512, 2048, 10, LS, 7, QC, ##__VA_ARGS__>), dim3((b.n_short + 2047u) / 2048u), dim3(512), 0, d.stream, g, bv, 0u, b.n_short); \
-      HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; \
-      HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0)); break;
-        PANTAS_SHORT(80, 9, 128)
-        PANTAS_SHORT(82, 9, 64)
-        PANTAS_SHORT(83, 9, 64, false)
         PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         default:   // 73: short walk over g.info, gathers two nodes ahead
         PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 0, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
       }
     }
 #undef PANTAS_SPLIT_SEQ
-#undef PANTAS_SHORT
 #undef PANTAS_SPLIT
 #undef PANTAS_AGG
 #undef PANTAS_AGG_RANGE

@@ -190,17 +190,18 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
         fail("Unsupported", this_line, "start / end offsets beyond 32 bits");
       uint32_t flags = rev ? LINE_REV : 0u;
       bool has_del = false;
-      bool simple = out.ops.size() > ops_before;
-      uint32_t stars = 0;
+      uint32_t stars = 0, indels = 0, others = 0;
       uint64_t total = 0;
       for (size_t i = ops_before; i < out.ops.size(); ++i) {
         const uint32_t code = out.ops[i] & 7u;
         has_del |= code == OP_MINUS;
         if ((out.ops[i] >> 3) == 0 || code == OP_TILDE) flags |= LINE_SLOW;
-        if (code == OP_STAR) ++stars; else if (code != OP_COLON) simple = false;
+        if (code == OP_STAR) ++stars;
+        else if (code == OP_PLUS || code == OP_MINUS) ++indels;
+        else if (code != OP_COLON) ++others;
         total += out.ops[i] >> 3;
       }
-      if (simple && !(flags & LINE_SLOW) && stars <= SIMPLE_MAX_STARS && total < (1ull << 31)) flags |= LINE_SIMPLE;
+      flags |= line_class_flags(uint32_t(out.ops.size() - ops_before), stars, indels, others, (flags & LINE_SLOW) != 0, total);
       if (has_del) {
         flags |= LINE_HAS_DEL;
         ++out.del_lines;
@@ -348,7 +349,7 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
         tmp.clear();
         for (size_t i = a; i < e; ++i) {
           const uint32_t s = idx[i];
-          tmp.emplace_back(std::min<uint32_t>(b.node_off[s + 1] - b.node_off[s], 0xFFFFu), s);
+          tmp.emplace_back(block_order_key(b.hdr[s].flags, b.node_off[s + 1] - b.node_off[s]), s);
         }
         std::stable_sort(tmp.begin(), tmp.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
         for (size_t i = a; i < e; ++i) idx[i] = tmp[i - a].second;

@@ -127,15 +127,17 @@ struct CountOnly {
 template <class Out>
 struct OpEmitter {
   Out& out;
-  uint32_t seen = 0, a = 0, b = 0, written = 0, stars = 0;
-  bool has_del = false, slow = false, other = false;
+  uint32_t seen = 0, a = 0, b = 0, written = 0, stars = 0, indels = 0, others = 0;
+  bool has_del = false, slow = false;
   uint64_t total = 0;
   PANTAS_HD explicit OpEmitter(Out& o) : out(o) {}
   PANTAS_HD void settle(uint32_t w) {
     const uint32_t code = w & 7u, len = w >> 3;
     has_del |= code == OP_MINUS;
     if (len == 0 || code == OP_TILDE) slow = true;
-    if (code == OP_STAR) ++stars; else if (code != OP_COLON) other = true;
+    if (code == OP_STAR) ++stars;
+    else if (code == OP_PLUS || code == OP_MINUS) ++indels;
+    else if (code != OP_COLON) ++others;
     total += len;
     out.op(written++, w);
   }
@@ -289,7 +291,7 @@ PANTAS_HD void parse_gaf_line(const uint8_t* b, const uint8_t* e, int thr, const
   if (start < -2147483648ll || start > 2147483647ll || tail < -2147483648ll || tail > 2147483647ll) { r.err = TE_OFFSETS; return; }
   uint32_t flags = rev ? LINE_REV : 0u;
   if (em.slow) flags |= LINE_SLOW;
-  if (em.written > 0 && !em.other && !em.slow && em.stars <= SIMPLE_MAX_STARS && em.total < (1ull << 31)) flags |= LINE_SIMPLE;
+  flags |= line_class_flags(em.written, em.stars, em.indels, em.others, em.slow, em.total);
   if (em.has_del) flags |= LINE_HAS_DEL;
   r.status = TOK_KEEP;
   r.n_nodes = n_nodes;

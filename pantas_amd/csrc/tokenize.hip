@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(TPB) partition_kernel(uint32_t n, const uint32
   out[cls[i] ? b : n_short + (i - b)] = idx[i];
 }
 
-// inside every block of 2048 records of a class: by path length, stable
+// inside every block of 2048 records of a class: by walk.h block_order_key, stable
 __global__ void __launch_bounds__(TPB) order_blocks_kernel(uint32_t n, const uint32_t* idx_in, const LineHdr* hdr, const uint32_t* node_off, uint32_t* idx_out) {
   __shared__ uint32_t sh[SORT_BLOCK];
   const uint32_t a = blockIdx.x * SORT_BLOCK;
@@ -249,8 +249,7 @@ __global__ void __launch_bounds__(TPB) order_blocks_kernel(uint32_t n, const uin
     uint32_t v = 0xFFFFFFFFu;
     if (a + j < n) {
       const uint32_t s = idx_in[a + j];
-      const uint32_t k = min(node_off[s + 1] - node_off[s], 0xFFFFu);
-      v = (k << 11) | j;
+      v = (block_order_key(hdr[s].flags, node_off[s + 1] - node_off[s]) << 11) | j;
     }
     sh[j] = v;
   }

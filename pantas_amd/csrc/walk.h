@@ -41,12 +41,28 @@ constexpr uint32_t LINE_REV = 1u;       // path written with '<'
 constexpr uint32_t LINE_HAS_DEL = 2u;   // cs string holds a '-' op
 constexpr uint32_t LINE_SLOW = 4u;      // cs holds a zero-length or '~' op: walked by the scalar code only
 constexpr uint32_t LINE_SIMPLE = 8u;    // cs holds only ':' and at most 4 '*' ops (no zero lengths): eligible for the short walk
+constexpr uint32_t LINE_ONE_INDEL = 16u;  // cs holds ':' ops, at most 4 '*' ops and exactly ONE '+' or '-' op (no zero lengths): short walk too
 constexpr uint32_t SIMPLE_MAX_STARS = 4;
 // Records of a batch come in two classes, each bucketed by locus: first the ones the short-walk kernel takes
 // (LINE_SIMPLE and at most SHORT_MAX_PATH path nodes: its LDS entries hold 16-bit counts, 2048 records x 31 visits
 // < 65536), then the rest (general walk).
 constexpr uint32_t SHORT_MAX_PATH = 31;
-PANTAS_HD bool short_walk_class(uint32_t flags, uint32_t path_nodes) { return (flags & LINE_SIMPLE) != 0 && path_nodes <= SHORT_MAX_PATH; }
+// A one-indel line can add 2 more IL / OL steps than it has path nodes (the node holding ':' '+' ':' counts three
+// entries), so it may have two path nodes fewer: 2048 x (29 + 2) < 65536 as well.
+constexpr uint32_t SHORT_MAX_PATH_INDEL = SHORT_MAX_PATH - 2;
+PANTAS_HD bool short_walk_class(uint32_t flags, uint32_t path_nodes) {
+  return ((flags & LINE_SIMPLE) != 0 && path_nodes <= SHORT_MAX_PATH) || ((flags & LINE_ONE_INDEL) != 0 && path_nodes <= SHORT_MAX_PATH_INDEL);
+}
+// order of the records inside a block of 2048 of a class (stable): by path length, so that the lanes of a wave loop
+// alike, with the one-indel lines behind the others -- a wave pays for the indel code whenever ONE of its lanes needs it
+PANTAS_HD uint32_t block_order_key(uint32_t flags, uint32_t path_nodes) {
+  return ((flags & LINE_ONE_INDEL) ? 0x10000u : 0u) | (path_nodes < 0xFFFFu ? path_nodes : 0xFFFFu);
+}
+// what the tokenisers set from a line's op statistics (both tokenisers call this: one definition of the classes)
+PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t indels, uint32_t others, bool slow, uint64_t total_len) {
+  if (n_ops == 0 || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= (1ull << 31)) return 0u;
+  return indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u;
+}
 
 struct LineHdr {
   int32_t start;     // start position on the first node (after the 2-op clipping rule)
@@ -63,6 +79,51 @@ enum : uint32_t { SIDE_IL = 0, SIDE_OL = 1 };
 // phase 0 = first compacted entry, 1 = any entry that is neither '-' nor '*', 2 = last entry
 PANTAS_HD uint64_t event_order(uint32_t line_id, uint32_t kept_idx, uint32_t phase) {
   return (uint64_t(line_id) << 32) | (uint64_t(kept_idx) << 2) | phase;
+}
+
+// ---- the short walk's view of a cs string of its class (LINE_SIMPLE / LINE_ONE_INDEL) -------------------------------
+// Op space = the concatenation of all ops; a path node with room takes the interval [P, P + le) of it.  What :63-107 and
+// :276-353 make of the pieces that fall into the interval depends only on (a) whether pieces other than the indel exist
+// (a node holding the lone '+' / '-' piece is dropped), (b) how many compacted entries are neither '-' nor '*': a ':' run
+// before the indel, the indel itself when it is a '+', a ':' run after it.  '*' pieces never make an entry of their own:
+// a leading one is swallowed by the next op, a later one merges into the entry before it.
+struct ShortOps {
+  uint32_t T = 0;                       // total op length
+  uint32_t ns = 0;                      // '*' ops, each one base long
+  uint32_t star[SIMPLE_MAX_STARS] = {0, 0, 0, 0};   // their positions
+  uint32_t x_pos = 0, x_len = 0;        // the indel's interval (x_len == 0: none)
+  bool x_plus = false;
+};
+
+PANTAS_HD void short_ops_scan(const uint32_t* ops, uint32_t n_ops, ShortOps& so) {
+  for (uint32_t j = 0; j < n_ops; ++j) {
+    const uint32_t w = ops[j], code = w & 7u;
+    if (code == OP_STAR) { if (so.ns < SIMPLE_MAX_STARS) so.star[so.ns++] = so.T; }
+    else if (code == OP_PLUS || code == OP_MINUS) { so.x_pos = so.T; so.x_len = w >> 3; so.x_plus = code == OP_PLUS; }
+    so.T += w >> 3;
+  }
+}
+
+// true when [lo, hi) (non-empty) holds a base that is not a '*'
+PANTAS_HD bool short_has_colon(const ShortOps& so, uint32_t lo, uint32_t hi) {
+  const uint32_t len = hi - lo;
+  if (len > so.ns) return true;
+  uint32_t stars_in = 0;
+  for (uint32_t s = 0; s < so.ns; ++s) stars_in += (so.star[s] - lo < len) ? 1u : 0u;
+  return stars_in < len;
+}
+
+// the node that takes [P, P + le), le > 0: is it kept, and how many of its compacted entries are neither '-' nor '*'
+PANTAS_HD void short_node_summary(const ShortOps& so, uint32_t P, uint32_t le, bool& kept, uint32_t& plain) {
+  const uint32_t end = P + le, x_end = so.x_pos + so.x_len;
+  if (so.x_len == 0 || so.x_pos >= end || x_end <= P) {      // no piece of the indel here
+    kept = true;
+    plain = short_has_colon(so, P, end) ? 1u : 0u;
+    return;
+  }
+  const bool before = so.x_pos > P, after = x_end < end;
+  kept = before || after;                                     // else the lone '+' / '-' piece (:101-102)
+  plain = (so.x_plus ? 1u : 0u) + ((before && short_has_colon(so, P, so.x_pos)) ? 1u : 0u) + ((after && short_has_colon(so, x_end, end)) ? 1u : 0u);
 }
 
 struct KeptNode {

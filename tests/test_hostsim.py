@@ -203,3 +203,15 @@ def test_graph_cache_round_trip(hostsim, tmp_path):
     check(lib.pantas_graph_load_cached(os.fsencode(pre + ".gfa"), os.fsencode(cache), 0, C.byref(h), C.byref(used)))
     assert used.value == 0
     lib.pantas_graph_free(h)
+
+
+def test_short_walk_node_summary_vs_piece_compaction():
+    """walk.h short_node_summary (what the short-walk kernel makes of a path node: kept?, how many compacted entries are
+    neither '-' nor '*') against PieceAcc, the piece-by-piece restatement of :63-107, on random cs strings of the
+    short-walk classes (':' runs, up to four '*', at most one '+' / '-') laid over random node lengths."""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "hostsim_shortwalk")
+    subprocess.check_call(CXX + ["-o", exe, os.path.join(ROOT, "tests/hostsim/hostsim_shortwalk.cpp")])
+    r = run([exe, "400000"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("ok ")
