@@ -1,6 +1,13 @@
 #include "call_host.h"
 
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 
 namespace pantas {
@@ -674,6 +681,58 @@ void render_events(const Graph& g, const CallTables& t, const EventRec* recs, si
   for (auto& s2 : parts) total += s2.size();
   csv.reserve(total);
   for (unsigned c = 0; c < T; ++c) { csv += parts[c]; std::string().swap(parts[c]); err += errs[c]; }
+}
+
+void render_events_to_fd(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
+                         const TaskOut* tasks, const uint32_t* paths, int fd_csv, std::string& err) {
+  constexpr size_t BLOCK = 16384;
+  const size_t nb = (n + BLOCK - 1) / BLOCK;
+  const unsigned T = unsigned(std::max<size_t>(1, std::min<size_t>(n < 100000 ? 1 : hw_threads(), nb)));
+  std::atomic<size_t> next{0};
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t turn = 0;                 // next block to be written
+  bool failed = false;
+  std::unique_ptr<Error> first_error;
+  auto work = [&] {
+    std::string buf, e;
+    for (;;) {
+      const size_t b = next.fetch_add(1);
+      if (b >= nb) return;
+      buf.clear();
+      e.clear();
+      std::unique_ptr<Error> mine;
+      try {
+        render_range(g, t, recs, b * BLOCK, std::min(n, (b + 1) * BLOCK), side, tasks, paths, buf, e);
+      } catch (const Error& x) {
+        mine.reset(new Error(x));
+      }
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return turn == b || failed; });
+      if (failed) return;
+      if (!mine && fd_csv >= 0) {
+        const char* p = buf.data();
+        size_t left = buf.size();
+        while (left) {
+          const ssize_t w = ::write(fd_csv, p, left);
+          if (w < 0) { if (errno == EINTR) continue; mine.reset(new Error("OSError", "write failed")); break; }
+          p += w;
+          left -= size_t(w);
+        }
+      }
+      if (mine) { failed = true; first_error = std::move(mine); cv.notify_all(); return; }
+      err += e;
+      ++turn;
+      cv.notify_all();
+    }
+  };
+  if (T == 1) work();
+  else {
+    std::vector<std::thread> pool;
+    for (unsigned i = 0; i < T; ++i) pool.emplace_back(work);
+    for (auto& th : pool) th.join();
+  }
+  if (first_error) throw *first_error;
 }
 
 static void render_range(const Graph& g, const CallTables& t, const EventRec* recs, size_t lo, size_t hi, const uint32_t* side,

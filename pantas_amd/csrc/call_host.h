@@ -75,6 +75,11 @@ void cassette_items(const CallTables& t, const std::vector<uint32_t>& around, st
 // tasks[recs[i].j1] / paths hold the outcome of the deferred intron walks of IR records
 void render_events(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
                    const TaskOut* tasks, const uint32_t* paths, std::string& csv, std::string& err);
+// The same rows straight to a file descriptor: blocks of rows are rendered by a pool of threads into buffers they keep,
+// and written in row order as they become due -- no row ever sits in a 10 GB string (68 M rows at whole-genome scale),
+// whose growth and page faults cost more than the formatting.  fd < 0: rendered (errors are found) and dropped.
+void render_events_to_fd(const Graph& g, const CallTables& t, const EventRec* recs, size_t n, const uint32_t* side,
+                         const TaskOut* tasks, const uint32_t* paths, int fd_csv, std::string& err);
 extern const char* const CALL_CSV_HEADER;
 
 const char* call_error_kind(uint32_t code);

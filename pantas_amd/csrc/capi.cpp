@@ -572,10 +572,13 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     run_call(*g->call_dev, *g->g, *g->call_tables, o, co, times);
     const std::vector<EventRec>& recs = co.recs;
     double t0 = now_s();
-    std::string csv = std::string(CALL_CSV_HEADER) + "\n", err;
-    render_events(*g->g, *g->call_tables, recs.data(), recs.size(), co.side.data(), co.tasks.data(), co.paths.data(), csv, err);
+    // the reference prints rows as it finds them and dies on an input it cannot handle; here nothing may reach stdout
+    // unless the whole call succeeds, and every failure of that kind is known before rendering starts (run_call
+    // raised it) -- so the rows can go to the descriptor block by block instead of through one 10 GB string
+    std::string err;
+    if (fd_csv >= 0) write_fd(fd_csv, std::string(CALL_CSV_HEADER) + "\n");
+    render_events_to_fd(*g->g, *g->call_tables, recs.data(), recs.size(), co.side.data(), co.tasks.data(), co.paths.data(), fd_csv, err);
     double t1 = now_s();
-    if (fd_csv >= 0) write_fd(fd_csv, csv);
     if (fd_err >= 0) write_fd(fd_err, err);
     if (stats) {
       const CallTables& t = *g->call_tables;
