@@ -1,19 +1,22 @@
 // HIP kernels (gfx950) of the augment path and their host-side launchers.
 //
-// Two kernels per batch of tokenised GAF records (reference scripts/alignments_augmentation_from_gaf.py:209-363):
+// Kernels per batch of tokenised GAF records (reference scripts/alignments_augmentation_from_gaf.py:209-363):
 //
 //   augment_rare_kernel      only records whose cs holds a '-' op (a few %).  Records the IL/OL keys that come
 //                            from deletions (key, count, first-seen order) in a device hash table and flags the
-//                            node (two top bits of its node_len word).
-//   augment_main_agg_kernel  every record, one thread each, records bucketed by locus (gaf.cpp).  NC, IL[0], OL[len]
-//                            and RC increments are summed in workgroup-private LDS tables and reach HBM as one
-//                            no-return global atomic per touched counter per chunk of 2048 records; links missing
-//                            from the graph and the first-seen order of the common IL/OL key on flagged nodes are
-//                            aggregated in LDS the same way before they go to the global tables.
-//   augment_main_kernel      the same walk with direct global atomics (A/B reference, PANTAS_MAIN_KERNEL=0).
+//                            node (two top bits of its node_len word, mirrored in g.info).
+//   augment_main_agg_kernel  one thread per record, records bucketed by locus (gaf.cpp / tokenize.hip), in two
+//                            instantiations side by side: the short-walk class (walk_short_info: ':' runs, a few '*',
+//                            at most one '+' / '-'; one 8-byte gather per path node) and the general walk of walk.h
+//                            for the rest.  NC, IL[0], OL[len] and RC increments are summed in workgroup-private LDS
+//                            tables and reach HBM once per touched node per chunk of 2048 records (two 64-bit
+//                            atomics on the node's 16-byte counter slot); links missing from the graph and the
+//                            first-seen order of the common IL/OL key on flagged nodes are aggregated in LDS the
+//                            same way before they go to the global tables.
+//   augment_main_kernel      the general walk with direct global atomics (A/B reference, PANTAS_MAIN_KERNEL=0).
 //
-// The dense counters sit in ONE allocation [NC | IL0 | OLL | RC] so a multi-GPU run needs a single
-// all-reduce.
+// The dense counters sit in ONE allocation [{NC, IL0, OLL, RC first slot} per node | RC per slot] so a multi-GPU run
+// needs a single (block-sparse, exchange.hip) all-reduce.
 #include <hip/hip_runtime.h>
 
 #include "augment.h"
@@ -607,11 +610,8 @@ __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const Line
   return WALK_OK;
 }
 
-// SPREAD: which record of the chunk a lane takes.  0: lane l of a pass takes position l (neighbouring lanes hold
-// neighbouring records of the locus order, i.e. nearly the same path: their LDS atomics hit the same few addresses
-// and serialise); 1: the 64 lanes of a wave take every 8th record of the pass's 512; 2: every 32nd of the chunk.
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          int SPREAD = 0, bool INFO = false, int PF = 1>
+          bool INFO = false, int PF = 1>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -644,13 +644,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin};
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
-    for (uint32_t pass = 0; pass < CHUNK / THREADS; ++pass) {
-      uint32_t off;
-      if constexpr (SPREAD == 1) off = pass * THREADS + (threadIdx.x & 63u) * (THREADS / 64u) + (threadIdx.x >> 6);
-      else if constexpr (SPREAD == 2) off = (threadIdx.x & 63u) * (CHUNK / 64u) + pass * (THREADS / 64u) + (threadIdx.x >> 6);
-      else off = pass * THREADS + threadIdx.x;
-      const uint32_t i = lo + off;
-      if (i >= hi) continue;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
       const LineHdr h = b.hdr[i];
       const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
       const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
@@ -1047,11 +1041,11 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   d.last_short_ms = 0.f;
   if (b.n) {
-    // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = direct global atomics; 8..42 = ONE aggregating kernel over all
-    // records in a few occupancy / table configurations; 60.. (default 60) = the two record classes in their own
-    // kernels: the short-walk class [0, n_short) with packed LDS entries, the rest with the general kernel.  The
-    // short-walk kernel then needs no registers, scalar spills or code of the general walk, and no chunk waits for
-    // the few slow general-walk waves that used to sit at its end.
+    // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = direct global atomics; 18 / 40 = ONE aggregating kernel over all
+    // records (32-bit / packed LDS entries); 60.. = the two record classes in their own kernels, the short-walk class
+    // [0, n_short) and the rest with the general kernel beside it on a second stream: 60 the mid-round short walk
+    // (three planar gathers per node), 72 / 73 (default) the walk over g.info with gathers one / two nodes ahead,
+    // 65 = 60 with the two kernels one after the other (each one's time alone).
     const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 73;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
@@ -1082,22 +1076,13 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         split = true;
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 0);
       } else switch (variant) {
-        PANTAS_AGG(8, 1024, 4096, 12, 12, 9, 1)
-        PANTAS_AGG(9, 512, 2048, 11, 11, 7, 1)
         PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
-        PANTAS_AGG(20, 256, 1024, 9, 9, 7, 8)
-        PANTAS_AGG(22, 512, 2048, 10, 9, 7, 8)
         PANTAS_AGG(40, 512, 2048, 10, 10, 7, 8, true)    // packed node entries, one kernel
-        PANTAS_AGG(41, 512, 2048, 11, 10, 7, 8, true)
-        PANTAS_SPLIT(61, (d.stream, 0u, b.n_short, 512, 2048, 11, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        PANTAS_SPLIT(63, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 256, 1024, 9, 9, 7, 8))
         PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        PANTAS_SPLIT(70, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 0, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        PANTAS_SPLIT(71, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         default:   // 73: short walk over g.info, gathers two nodes ahead
-        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, 0, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
       }
     }
 #undef PANTAS_SPLIT_SEQ
