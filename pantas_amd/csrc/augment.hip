@@ -153,6 +153,61 @@ struct MainSink {
   }
 };
 
+// The rare-key kernel's walk of a one-indel line of the short-walk class: only the nodes that hold a piece of the '-'
+// can own a deletion-derived key, so every other kept node is just counted (its index orders the events) and the
+// piece-by-piece compaction (PieceAcc, exactly as walk_line feeds it) runs for those one or two nodes alone.  Node
+// lengths come from g.info, one gather per path node, requested one node ahead.
+template <class Sink>
+__device__ __forceinline__ int walk_short_rare(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
+                                               const uint32_t* ops, uint32_t nops, Sink& sink) {
+  ShortOps so;
+  short_ops_scan(ops, nops, so);
+  const uint32_t T = so.T, x_end = so.x_pos + so.x_len;
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  KeptNode pend{};
+  uint32_t node_c = nodes[0];
+  uint32_t word_c = g.info[node_c].x, node_1 = 0, word_1 = 0;
+  if (k > 1) { node_1 = nodes[1]; word_1 = g.info[node_1].x; }
+#pragma unroll 1
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = node_c, word = word_c;
+    node_c = node_1; word_c = word_1;
+    if (i + 2 < k) { node_1 = nodes[i + 2]; word_1 = g.info[node_1].x; }
+    const uint32_t len = word & LEN_MASK;
+    int64_t r = int64_t(len);
+    if (i == 0) r -= h.start;
+    if (i == k - 1) r = r - h.tail + 1;
+    if (r <= 0) continue;
+    if (P >= T) return WALK_OPS_EXHAUSTED;
+    const uint32_t room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
+    const uint32_t le = min(room, T - P), end = P + le;
+    KeptNode kn{node, word, 1u, OP_COLON, le, OP_COLON, le, 1u};      // a node without a piece of the indel: no rare key
+    bool keep = true;
+    if (so.x_len != 0 && so.x_pos < end && x_end > P) {
+      PieceAcc acc;
+      acc.begin(node, word);
+      uint32_t q = 0;
+      for (uint32_t j = 0; j < nops && q < end; ++j) {
+        const uint32_t w = ops[j], ol = w >> 3;
+        const uint32_t a = max(q, P), e = min(q + ol, end);
+        if (e > a) acc.add(w & 7u, e - a);
+        q += ol;
+      }
+      keep = acc.kept();
+      kn = acc.kn;
+    }
+    P = end;
+    if (!keep) continue;
+    if (pending) flush_kept(pend, kept - 1u, false, h, sink);
+    pend = kn;
+    pending = true;
+    ++kept;
+  }
+  if (pending) flush_kept(pend, kept - 1u, true, h, sink);
+  return WALK_OK;
+}
+
 template <class Sink>
 __device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b, uint32_t i) {
   const LineHdr h = b.hdr[i];
@@ -163,9 +218,20 @@ __device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b,
   if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
 }
 
-__global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchView b) {
-  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < b.n_del; t += gridDim.x * 256u)
-    run_line<RareSink>(g, b, b.del_idx[t]);
+__global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchView b, uint32_t short_walk) {
+  for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < b.n_del; t += gridDim.x * 256u) {
+    const uint32_t i = b.del_idx[t];
+    const LineHdr h = b.hdr[i];
+    const uint32_t n0 = b.node_off[i], k = b.node_off[i + 1] - n0;
+    if (short_walk && (h.flags & LINE_ONE_INDEL) && k != 0) {
+      const uint32_t o0 = b.op_off[i];
+      RareSink sink{g};
+      const int st = walk_short_rare(g, h, b.nodes + n0, k, b.ops + o0, b.op_off[i + 1] - o0, sink);
+      if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+    } else {
+      run_line<RareSink>(g, b, i);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void augment_main_kernel(GraphView g, BatchView b) {
@@ -1019,7 +1085,9 @@ float launch_rare(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipEventRecord(d.ev[0], d.stream));
   if (b.n_del) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n_del) + 255) / 256, 1u << 20));
-    hipLaunchKernelGGL(augment_rare_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
+    // PANTAS_RARE_KERNEL=0: every line through the general walk (A/B)
+    const uint32_t short_walk = getenv("PANTAS_RARE_KERNEL") ? uint32_t(atoi(getenv("PANTAS_RARE_KERNEL"))) : 1u;
+    hipLaunchKernelGGL(augment_rare_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv, short_walk);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
