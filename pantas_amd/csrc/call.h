@@ -15,8 +15,8 @@ struct CallTimes {
 };
 
 struct CallOutput {
-  std::vector<EventRec> recs;
-  std::vector<uint32_t> side;    // record payloads
+  RawVector<EventRec> recs;      // tens of millions at whole-genome scale: resized once, never value-initialised
+  RawVector<uint32_t> side;      // record payloads
   std::vector<TaskOut> tasks;    // outcome of the deferred intron walks (indexed by EventRec.j1 of IR records)
   std::vector<uint32_t> paths;   // walked paths
 };

@@ -209,14 +209,26 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   return d;
 }
 
+// what one pass leaves on the device until run_call has the totals of all passes and copies everything to the host once
+struct PassOut {
+  std::vector<void*> tmp;            // every device buffer of the pass
+  EventRec* recs = nullptr;
+  uint32_t* side = nullptr;
+  TaskOut* tasks = nullptr;
+  uint32_t* paths = nullptr;
+  uint32_t n_recs = 0, n_words = 0, n_tasks = 0, n_paths = 0;
+  PassOut() = default;
+  PassOut(const PassOut&) = delete;
+  PassOut& operator=(const PassOut&) = delete;
+  ~PassOut() { for (void* p : tmp) (void)hipFree(p); }
+};
+
 template <int PASS>
 static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_t>& slots, const std::vector<uint32_t>* jidx,
-                     CallOutput& out, float& ms) {
+                     PassOut& po, float& ms) {
   const uint32_t n = uint32_t(slots.size());
   if (!n) return;
-  std::vector<void*> tmp;
-  auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 4))); tmp.push_back(p); return p; };
-  struct Free { std::vector<void*>& v; ~Free() { for (void* p : v) (void)hipFree(p); } } guard{tmp};
+  auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 4))); po.tmp.push_back(p); return p; };
   auto u32 = [&](size_t count) { return static_cast<uint32_t*>(dev(count * 4)); };
   uint32_t* d_slots = u32(n);
   uint32_t* d_jidx = jidx ? u32(n) : nullptr;
@@ -273,26 +285,12 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipEventRecord(d.ev1, d.stream));
-  // append to the host arrays; payload / task / path offsets become global
-  const size_t r0 = out.recs.size(), w0 = out.side.size(), t0 = out.tasks.size(), p0 = out.paths.size();
-  out.recs.resize(r0 + totals[0]);
-  out.side.resize(w0 + totals[1]);
-  out.tasks.resize(t0 + nt);
-  out.paths.resize(p0 + path_total);
-  if (totals[0]) HIP_OK(hipMemcpyAsync(out.recs.data() + r0, d_recs, size_t(totals[0]) * sizeof(EventRec), hipMemcpyDeviceToHost, d.stream));
-  if (totals[1]) HIP_OK(hipMemcpyAsync(out.side.data() + w0, d_side, size_t(totals[1]) * 4, hipMemcpyDeviceToHost, d.stream));
-  if (nt) HIP_OK(hipMemcpyAsync(out.tasks.data() + t0, d_tout, size_t(nt) * sizeof(TaskOut), hipMemcpyDeviceToHost, d.stream));
-  if (path_total) HIP_OK(hipMemcpyAsync(out.paths.data() + p0, d_paths, size_t(path_total) * 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
   float t = 0;
   HIP_OK(hipEventElapsedTime(&t, d.ev0, d.ev1));
   ms += t;
-  for (size_t i = r0; i < out.recs.size(); ++i) {
-    EventRec& r = out.recs[i];
-    r.side_off += uint32_t(w0);
-    if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) r.j1 += uint32_t(t0);
-  }
-  for (size_t i = t0; i < out.tasks.size(); ++i) out.tasks[i].path_off += uint32_t(p0);
+  po.recs = d_recs; po.side = d_side; po.tasks = d_tout; po.paths = d_paths;
+  po.n_recs = totals[0]; po.n_words = totals[1]; po.n_tasks = nt; po.n_paths = path_total;
 }
 
 void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, CallOutput& out, CallTimes& times) {
@@ -306,16 +304,56 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   out = CallOutput();
   times = CallTimes();
   size_t extra_items = 0;
-  run_pass<0>(d, c, ann, nullptr, out, times.annotated_ms);
-  run_pass<1>(d, c, nov, nullptr, out, times.novel_ms);
-  run_pass<2>(d, c, around, &around_j, out, times.around_ms);
+  PassOut po[4];
+  run_pass<0>(d, c, ann, nullptr, po[0], times.annotated_ms);
+  run_pass<1>(d, c, nov, nullptr, po[1], times.novel_ms);
+  run_pass<2>(d, c, around, &around_j, po[2], times.around_ms);
   if (o.novel && (o.events & EV_ES)) {
     std::vector<uint32_t> cj, ch;
     cassette_items(t, around, cj, ch);
-    run_pass<3>(d, c, cj, &ch, out, times.around_ms);
+    run_pass<3>(d, c, cj, &ch, po[3], times.around_ms);
     extra_items = cj.size();
   }
   times.junctions = ann.size() + nov.size() + around.size() + extra_items;
+  // ---- one copy to the host: the arrays are sized once (no value-initialising fill, pages touched by many threads), the
+  // passes land behind each other, and payload / task / path offsets become global
+  size_t nr = 0, nw = 0, nt = 0, np = 0;
+  for (const PassOut& p : po) { nr += p.n_recs; nw += p.n_words; nt += p.n_tasks; np += p.n_paths; }
+  if (nr >= 0xFFFFFFFFull || nw >= 0xFFFFFFFFull || nt >= 0xFFFFFFFFull || np >= 0xFFFFFFFFull)
+    throw Error("Unsupported", "more than 2^32-2 event records / payload words in one call");
+  out.recs.resize(nr);
+  out.side.resize(nw);
+  out.tasks.resize(nt);
+  out.paths.resize(np);
+  prefault(out.recs.data(), nr * sizeof(EventRec));
+  prefault(out.side.data(), nw * 4);
+  size_t r0 = 0, w0 = 0, t0 = 0, p0 = 0;
+  size_t base[4][4];
+  for (int k = 0; k < 4; ++k) {
+    const PassOut& p = po[k];
+    base[k][0] = r0; base[k][1] = w0; base[k][2] = t0; base[k][3] = p0;
+    if (p.n_recs) HIP_OK(hipMemcpyAsync(out.recs.data() + r0, p.recs, size_t(p.n_recs) * sizeof(EventRec), hipMemcpyDeviceToHost, d.stream));
+    if (p.n_words) HIP_OK(hipMemcpyAsync(out.side.data() + w0, p.side, size_t(p.n_words) * 4, hipMemcpyDeviceToHost, d.stream));
+    if (p.n_tasks) HIP_OK(hipMemcpyAsync(out.tasks.data() + t0, p.tasks, size_t(p.n_tasks) * sizeof(TaskOut), hipMemcpyDeviceToHost, d.stream));
+    if (p.n_paths) HIP_OK(hipMemcpyAsync(out.paths.data() + p0, p.paths, size_t(p.n_paths) * 4, hipMemcpyDeviceToHost, d.stream));
+    r0 += p.n_recs; w0 += p.n_words; t0 += p.n_tasks; p0 += p.n_paths;
+  }
+  HIP_OK(hipStreamSynchronize(d.stream));
+  for (int k = 0; k < 4; ++k) {
+    const PassOut& p = po[k];
+    const uint32_t bw = uint32_t(base[k][1]), bt = uint32_t(base[k][2]), bp = uint32_t(base[k][3]);
+    if (bw || bt) {
+      EventRec* recs = out.recs.data() + base[k][0];
+      parallel_chunks(p.n_recs, p.n_recs < 100000 ? 1u : hw_threads(), [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+          EventRec& r = recs[i];
+          r.side_off += bw;
+          if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) r.j1 += bt;
+        }
+      });
+    }
+    if (bp) for (size_t i = 0; i < p.n_tasks; ++i) out.tasks[base[k][2] + i].path_off += bp;
+  }
 }
 
 }  // namespace pantas

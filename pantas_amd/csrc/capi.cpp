@@ -570,7 +570,7 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     CallOutput co;
     CallTimes times;
     run_call(*g->call_dev, *g->g, *g->call_tables, o, co, times);
-    const std::vector<EventRec>& recs = co.recs;
+    const RawVector<EventRec>& recs = co.recs;
     double t0 = now_s();
     // the reference prints rows as it finds them and dies on an input it cannot handle; here nothing may reach stdout
     // unless the whole call succeeds, and every failure of that kind is known before rendering starts (run_call
@@ -585,11 +585,19 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
       stats->junctions = t.junctions.size();
       stats->novel_links = t.novels.size();
       stats->evaluated = times.junctions;
+      const unsigned T = recs.size() < 100000 ? 1u : hw_threads();
+      std::vector<uint64_t> part(T, 0);
+      parallel_chunks(recs.size(), T, [&](unsigned c, size_t lo, size_t hi) {
+        uint64_t rows = 0;
+        for (size_t i = lo; i < hi; ++i) {
+          const EventRec& r = recs[i];
+          if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) rows += co.tasks[r.j1].status == 1 ? 1 : 0;
+          else rows += r.type < T_SKIP_ES ? 1 : 0;
+        }
+        part[c] = rows;
+      });
       uint64_t rows = 0;
-      for (const EventRec& r : recs) {
-        if (r.type == T_IR_ANN || r.type == T_IR1_NOV || r.type == T_IR2_NOV) rows += co.tasks[r.j1].status == 1 ? 1 : 0;
-        else rows += r.type < T_SKIP_ES ? 1 : 0;
-      }
+      for (uint64_t x : part) rows += x;
       stats->events = rows;
       stats->ex_entries = t.ex_tag.size();
       stats->jn_entries = t.jn_ftx.size();

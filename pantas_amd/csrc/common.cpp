@@ -80,6 +80,18 @@ std::vector<std::pair<size_t, size_t>> split_at_newlines(const char* data, size_
   return out;
 }
 
+void prefault(void* p, size_t bytes) {
+  if (bytes < (size_t(64) << 20)) return;
+  char* c = static_cast<char*>(p);
+  const size_t pages = (bytes + 4095) / 4096;
+  parallel_chunks(pages, std::min<unsigned>(hw_threads(), 64), [&](unsigned, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      volatile char* q = c + std::min(i * 4096, bytes - 1);
+      *q = 0;
+    }
+  });
+}
+
 PhaseTimer::PhaseTimer(const char* w) : what(w), t0(now_s()), last(t0), on(getenv("PANTAS_TIMING") != nullptr) {}
 void PhaseTimer::lap(const char* phase) {
   if (!on) return;

@@ -111,6 +111,23 @@ inline bool parse_py_int(Span t, int64_t& v, bool saturate = false) {
 
 unsigned hw_threads();
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised: for buffers of gigabytes that are
+// about to be overwritten (a device-to-host copy), where the value-initialising fill would be a serial pass over fresh pages
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+    else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+  }
+};
+template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
+// touches every page of [p, p + bytes) from several threads (first-touch page faults are the cost of a fresh buffer)
+void prefault(void* p, size_t bytes);
+
 // Runs fn(chunk_index, begin, end) over [0, n) split into `chunks` contiguous ranges.
 void parallel_chunks(size_t n, unsigned chunks, const std::function<void(unsigned, size_t, size_t)>& fn);
 
