@@ -82,6 +82,12 @@ __device__ __forceinline__ void add_node4(const GraphView& g, uint32_t n, uint32
   if (hi) atomicAdd(p + 1, hi);
 }
 
+// the graph as the short walks of walk.h see it: one 8-byte gather per node
+struct DevInfo {
+  const GraphView& g;
+  __device__ __forceinline__ NodeInfo info(uint32_t n) const { return reinterpret_cast<const NodeInfo*>(g.info)[n]; }
+};
+
 __device__ __forceinline__ uint32_t mix64(uint64_t k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdULL;
@@ -153,61 +159,6 @@ struct MainSink {
   }
 };
 
-// The rare-key kernel's walk of a one-indel line of the short-walk class: only the nodes that hold a piece of the '-'
-// can own a deletion-derived key, so every other kept node is just counted (its index orders the events) and the
-// piece-by-piece compaction (PieceAcc, exactly as walk_line feeds it) runs for those one or two nodes alone.  Node
-// lengths come from g.info, one gather per path node, requested one node ahead.
-template <class Sink>
-__device__ __forceinline__ int walk_short_rare(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                               const uint32_t* ops, uint32_t nops, Sink& sink) {
-  ShortOps so;
-  short_ops_scan(ops, nops, so);
-  const uint32_t T = so.T, x_end = so.x_pos + so.x_len;
-  uint32_t P = 0, kept = 0;
-  bool pending = false;
-  KeptNode pend{};
-  uint32_t node_c = nodes[0];
-  uint32_t word_c = g.info[node_c].x, node_1 = 0, word_1 = 0;
-  if (k > 1) { node_1 = nodes[1]; word_1 = g.info[node_1].x; }
-#pragma unroll 1
-  for (uint32_t i = 0; i < k; ++i) {
-    const uint32_t node = node_c, word = word_c;
-    node_c = node_1; word_c = word_1;
-    if (i + 2 < k) { node_1 = nodes[i + 2]; word_1 = g.info[node_1].x; }
-    const uint32_t len = word & LEN_MASK;
-    int64_t r = int64_t(len);
-    if (i == 0) r -= h.start;
-    if (i == k - 1) r = r - h.tail + 1;
-    if (r <= 0) continue;
-    if (P >= T) return WALK_OPS_EXHAUSTED;
-    const uint32_t room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
-    const uint32_t le = min(room, T - P), end = P + le;
-    KeptNode kn{node, word, 1u, OP_COLON, le, OP_COLON, le, 1u};      // a node without a piece of the indel: no rare key
-    bool keep = true;
-    if (so.x_len != 0 && so.x_pos < end && x_end > P) {
-      PieceAcc acc;
-      acc.begin(node, word);
-      uint32_t q = 0;
-      for (uint32_t j = 0; j < nops && q < end; ++j) {
-        const uint32_t w = ops[j], ol = w >> 3;
-        const uint32_t a = max(q, P), e = min(q + ol, end);
-        if (e > a) acc.add(w & 7u, e - a);
-        q += ol;
-      }
-      keep = acc.kept();
-      kn = acc.kn;
-    }
-    P = end;
-    if (!keep) continue;
-    if (pending) flush_kept(pend, kept - 1u, false, h, sink);
-    pend = kn;
-    pending = true;
-    ++kept;
-  }
-  if (pending) flush_kept(pend, kept - 1u, true, h, sink);
-  return WALK_OK;
-}
-
 template <class Sink>
 __device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b, uint32_t i) {
   const LineHdr h = b.hdr[i];
@@ -226,7 +177,8 @@ __global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchVie
     if (short_walk && (h.flags & LINE_ONE_INDEL) && k != 0) {
       const uint32_t o0 = b.op_off[i];
       RareSink sink{g};
-      const int st = walk_short_rare(g, h, b.nodes + n0, k, b.ops + o0, b.op_off[i + 1] - o0, sink);
+      const DevInfo ga{g};
+      const int st = walk_short_rare(ga, h, b.nodes + n0, k, b.ops + o0, b.op_off[i + 1] - o0, sink);
       if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
     } else {
       run_line<RareSink>(g, b, i);
@@ -529,91 +481,25 @@ __device__ __forceinline__ void flush_packed(const PackedPend& p, uint32_t idx, 
   if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
 }
 
-// The short walk over g.info: per path node ONE 8-byte gather {length word, first out-target}; the CSR row bounds are only
-// fetched for a link that is not its node's first out-slot.  PF = how many nodes ahead the gathers run (the walk waits
-// on the chain nodes[] -> info[]; at whole-genome scale nearly half of these gathers miss the L2):
-//   PF 1: while node i is processed, info of node i+1 is in flight;
-//   PF 2: info of i+1 and i+2 and the id of i+3 are in flight.
+// The short walk itself lives in walk.h (walk_short: host + device source, so that the CPU harness runs the very same
+// code against the goldens); here are its two device-side views: the graph as g.info gathers, the sink as the packed LDS
+// entries of AggSink.
+template <class Agg>
+struct ShortSinkDev {
+  const Agg& s;
+  __device__ __forceinline__ void kept(uint32_t node, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t r0, uint64_t exact_order) const {
+    s.bump_packed_flagged(node, word, line_id, a_il, a_ol, r0, exact_order);
+  }
+  __device__ __forceinline__ void link_rest(uint32_t a, uint32_t b, uint64_t order) const {
+    s.link_rest(a, s.g.row_ptr[a], s.g.row_ptr[a + 1], b, order);
+  }
+};
 template <class Sink, int PF>
 __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
                                                const uint32_t* ops, uint32_t nops, const Sink& sink) {
-  ShortOps so;                      // ':' runs, '*' positions, at most one '+' / '-' (walk.h)
-  short_ops_scan(ops, nops, so);
-  const uint32_t T = so.T;
-  const bool rev = (h.flags & LINE_REV) != 0;
-  const bool exact = (h.flags & LINE_HAS_DEL) != 0;
-  uint32_t P = 0, kept = 0;
-  bool pending = false;
-  uint32_t p_node = 0, p_word = 0, p_c0 = 0, p_r0 = 0, p_plain = 0;
-  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351), once per
-  // compacted entry that is neither '-' nor '*' (p_plain of them)
-  auto flush = [&](bool is_last, uint32_t r0) {
-    const bool enter = p_plain != 0u && kept != 1u, leave = p_plain != 0u && !is_last;      // the pending node is kept node number kept - 1
-    sink.bump_packed_flagged(p_node, p_word, h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, r0,
-                             exact ? event_order(h.line_id, kept - 1u, 1) : 0ull);
-  };
-  // pipeline registers: c = node i, 1 = node i+1, 2 = node i+2 (PF 2 only); ids are requested before the info gather of
-  // the same pass so that waiting for an id never waits for the younger gather
-  uint32_t node_c = nodes[0], node_1 = 0, node_2 = 0;
-  if (k > 1) node_1 = nodes[1];
-  if (PF >= 2 && k > 2) node_2 = nodes[2];
-  uint2 inf_c = g.info[node_c], inf_1 = make_uint2(0u, 0u);
-  if (k > 1) inf_1 = g.info[node_1];
-#pragma unroll 1
-  for (uint32_t i = 0; i < k; ++i) {
-    const uint32_t node = node_c, word = inf_c.x, col0 = inf_c.y;
-    uint2 inf_2 = make_uint2(0u, 0u);
-    uint32_t node_3 = 0;
-    if constexpr (PF >= 2) {
-      if (i + 3 < k) node_3 = nodes[i + 3];
-      if (i + 2 < k) inf_2 = g.info[node_2];
-    } else {
-      if (i + 2 < k) node_2 = nodes[i + 2];
-    }
-    // room the node offers to the ops, as min(room, 2^32 - 1): every use compares it with T - P <= 2^32 - 1
-    const uint32_t len = word & LEN_MASK;
-    bool has_room = len != 0u;
-    uint32_t room = len;
-    if (i == 0 || i == k - 1) {
-      int64_t r = int64_t(len);
-      if (i == 0) r -= h.start;
-      if (i == k - 1) r = r - h.tail + 1;
-      has_room = r > 0;
-      room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
-    }
-    if (has_room) {
-      if (P >= T) return WALK_OPS_EXHAUSTED;
-      const uint32_t left = T - P;
-      const uint32_t le = min(room, left);
-      bool keep;
-      uint32_t plain;
-      short_node_summary(so, P, le, keep, plain);
-      P += le;                      // == T when the ops end inside this node
-      if (keep) {
-      uint32_t r0_here = 0;
-      if (pending) {
-        const uint32_t a = rev ? node : p_node, bnode = rev ? p_node : node;
-        const bool first_slot = (rev ? col0 : p_c0) == bnode;          // NONE32 for a node without out-links
-        flush(false, rev ? p_r0 : (first_slot ? 1u : 0u));
-        if (rev && first_slot) r0_here = 1u;
-        if (!first_slot) sink.link_rest(a, g.row_ptr[a], g.row_ptr[a + 1], bnode, event_order(h.line_id, kept - 1u, 0));
-      }
-      p_node = node; p_word = word; p_c0 = col0; p_plain = plain; p_r0 = r0_here;
-      pending = true;
-      ++kept;
-      }                             // else: the node holds the lone '+' / '-' piece and is dropped (:101-102)
-    }
-    // advance the pipeline
-    node_c = node_1; inf_c = inf_1;
-    if constexpr (PF >= 2) {
-      node_1 = node_2; inf_1 = inf_2; node_2 = node_3;
-    } else {
-      node_1 = node_2;
-      if (i + 2 < k) inf_1 = g.info[node_1];
-    }
-  }
-  if (pending) flush(true, rev ? p_r0 : 0u);
-  return WALK_OK;
+  const DevInfo ga{g};
+  const ShortSinkDev<Sink> ss{sink};
+  return walk_short<PF>(ga, h, nodes, k, ops, nops, ss);
 }
 
 // INFO: the node's length word and first out-target come from g.info (one 8-byte gather, no dependent col[] load); the

@@ -264,4 +264,162 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
   return WALK_OK;
 }
 
+
+// ---- the short walk (LINE_SIMPLE / LINE_ONE_INDEL lines) ---------------------------------------------------------------
+// Equivalent to walk_line on lines of its classes, without materialising pieces: short_node_summary says what a node keeps.
+//   GraphAcc:  NodeInfo info(node)        {length word with the flag bits, target of the node's first out-slot or NONE}
+//   Sink:      void kept(node, word, line_id, il_steps, ol_steps, first_slot_hits, exact_order)
+//                    one kept node: NC + 1, IL[0] / OL[len] + steps (0 .. 3), RC of the node's FIRST out-slot + hits;
+//                    first-seen order of the common key on a flagged side = exact_order, or, when that is 0, any order
+//                    of this line (event_order(line_id, *, 1)): a line without '-' has no other key on the node
+//              void link_rest(a, b, order)  link a -> b that is NOT a's first out-slot (a later slot, or absent from the graph)
+// PF = how many nodes ahead the info gathers run (the GPU waits on the chain nodes[] -> info[]):
+//   PF 1: while node i is processed, info of node i+1 is in flight;  PF 2: info of i+1 and i+2 and the id of i+3.
+struct alignas(8) NodeInfo {
+  uint32_t word, first;
+};
+
+template <int PF, class GraphAcc, class Sink>
+PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops, uint32_t nops,
+                         const Sink& sink) {
+  if (k == 0) return WALK_OK;
+  ShortOps so;
+  short_ops_scan(ops, nops, so);
+  const uint32_t T = so.T;
+  const bool rev = (h.flags & LINE_REV) != 0;
+  const bool exact = (h.flags & LINE_HAS_DEL) != 0;
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  uint32_t p_node = 0, p_word = 0, p_c0 = 0, p_r0 = 0, p_plain = 0;
+  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351), once per
+  // compacted entry that is neither '-' nor '*' (p_plain of them)
+  auto flush = [&](bool is_last, uint32_t r0) {
+    const bool enter = p_plain != 0u && kept != 1u, leave = p_plain != 0u && !is_last;      // the pending node is kept node number kept - 1
+    sink.kept(p_node, p_word, h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, r0,
+              exact ? event_order(h.line_id, kept - 1u, 1) : 0ull);
+  };
+  // pipeline registers: c = node i, 1 = node i+1, 2 = node i+2 (PF 2 only); ids are requested before the info gather of
+  // the same pass so that waiting for an id never waits for the younger gather
+  uint32_t node_c = nodes[0], node_1 = 0, node_2 = 0;
+  if (k > 1) node_1 = nodes[1];
+  if (PF >= 2 && k > 2) node_2 = nodes[2];
+  NodeInfo inf_c = ga.info(node_c), inf_1{0u, 0u};
+  if (k > 1) inf_1 = ga.info(node_1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = node_c, word = inf_c.word, col0 = inf_c.first;
+    NodeInfo inf_2{0u, 0u};
+    uint32_t node_3 = 0;
+    if (PF >= 2) {
+      if (i + 3 < k) node_3 = nodes[i + 3];
+      if (i + 2 < k) inf_2 = ga.info(node_2);
+    } else {
+      if (i + 2 < k) node_2 = nodes[i + 2];
+    }
+    // room the node offers to the ops, as min(room, 2^32 - 1): every use compares it with T - P <= 2^32 - 1
+    const uint32_t len = word & LEN_MASK;
+    bool has_room = len != 0u;
+    uint32_t room = len;
+    if (i == 0 || i == k - 1) {
+      int64_t r = int64_t(len);
+      if (i == 0) r -= h.start;
+      if (i == k - 1) r = r - h.tail + 1;
+      has_room = r > 0;
+      room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
+    }
+    if (has_room) {
+      if (P >= T) return WALK_OPS_EXHAUSTED;
+      const uint32_t left = T - P;
+      const uint32_t le = room < left ? room : left;
+      bool keep;
+      uint32_t plain;
+      short_node_summary(so, P, le, keep, plain);
+      P += le;                      // == T when the ops end inside this node
+      if (keep) {
+        uint32_t r0_here = 0;
+        if (pending) {
+          const uint32_t a = rev ? node : p_node, bnode = rev ? p_node : node;
+          const bool first_slot = (rev ? col0 : p_c0) == bnode;          // NONE for a node without out-links
+          flush(false, rev ? p_r0 : (first_slot ? 1u : 0u));
+          if (rev && first_slot) r0_here = 1u;
+          if (!first_slot) sink.link_rest(a, bnode, event_order(h.line_id, kept - 1u, 0));
+        }
+        p_node = node; p_word = word; p_c0 = col0; p_plain = plain; p_r0 = r0_here;
+        pending = true;
+        ++kept;
+      }                             // else: the node holds the lone '+' / '-' piece and is dropped (:101-102)
+    }
+    // advance the pipeline
+    node_c = node_1; inf_c = inf_1;
+    if (PF >= 2) {
+      node_1 = node_2; inf_1 = inf_2; node_2 = node_3;
+    } else {
+      node_1 = node_2;
+      if (i + 2 < k) inf_1 = ga.info(node_1);
+    }
+  }
+  if (pending) flush(true, rev ? p_r0 : 0u);
+  return WALK_OK;
+}
+
+// The rare-key pass over a one-indel line: only the nodes that hold a piece of the '-' can own a deletion-derived key, so
+// every other kept node is just counted (its index orders the events) and the piece-by-piece compaction (PieceAcc, fed
+// exactly as walk_line feeds it) runs for those one or two nodes alone.  Sink: the walk_line sink concept (rare() matters).
+template <class GraphAcc, class Sink>
+PANTAS_HD int walk_short_rare(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops, uint32_t nops,
+                              Sink& sink) {
+  if (k == 0) return WALK_OK;
+  ShortOps so;
+  short_ops_scan(ops, nops, so);
+  const uint32_t T = so.T, x_end = so.x_pos + so.x_len;
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  KeptNode pend{};
+  uint32_t node_c = nodes[0];
+  uint32_t word_c = ga.info(node_c).word, node_1 = 0, word_1 = 0;
+  if (k > 1) { node_1 = nodes[1]; word_1 = ga.info(node_1).word; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = node_c, word = word_c;
+    node_c = node_1; word_c = word_1;
+    if (i + 2 < k) { node_1 = nodes[i + 2]; word_1 = ga.info(node_1).word; }
+    const uint32_t len = word & LEN_MASK;
+    int64_t r = int64_t(len);
+    if (i == 0) r -= h.start;
+    if (i == k - 1) r = r - h.tail + 1;
+    if (r <= 0) continue;
+    if (P >= T) return WALK_OPS_EXHAUSTED;
+    const uint32_t room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
+    const uint32_t left = T - P;
+    const uint32_t le = room < left ? room : left, end = P + le;
+    KeptNode kn{node, word, 1u, OP_COLON, le, OP_COLON, le, 1u};      // a node without a piece of the indel: no rare key
+    bool keep = true;
+    if (so.x_len != 0 && so.x_pos < end && x_end > P) {
+      PieceAcc acc;
+      acc.begin(node, word);
+      uint32_t q = 0;
+      for (uint32_t j = 0; j < nops && q < end; ++j) {
+        const uint32_t w = ops[j], ol = w >> 3;
+        const uint32_t a = q > P ? q : P, e = q + ol < end ? q + ol : end;
+        if (e > a) acc.add(w & 7u, e - a);
+        q += ol;
+      }
+      keep = acc.kept();
+      kn = acc.kn;
+    }
+    P = end;
+    if (!keep) continue;
+    if (pending) flush_kept(pend, kept - 1u, false, h, sink);
+    pend = kn;
+    pending = true;
+    ++kept;
+  }
+  if (pending) flush_kept(pend, kept - 1u, true, h, sink);
+  return WALK_OK;
+}
+
 }  // namespace pantas

@@ -2,7 +2,8 @@
 // Compiles the device walk (pantas_amd/csrc/walk.h) together with the product's host-side
 // loader, tokeniser and writer for the CPU, under ASan/UBSan, and drives the walk with a
 // sink that mimics the two-kernel protocol of augment.hip (rare-key pass that sets the
-// node flags, then the main pass).  It lets the `-m "not gpu"` suite check the exact
+// node flags, then the main pass; lines of the short-walk class go through walk_short / walk_short_rare
+// like on the GPU, HOSTSIM_GENERAL_WALK=1 sends everything through walk_line).  It lets the `-m "not gpu"` suite check the exact
 // device-side source against the reference goldens where no GPU exists.
 //
 // usage: hostsim_augment <gaf> <gfa> [thr] > out.gfa     (stderr: "Rejected alignments: N")
@@ -11,6 +12,7 @@
 #include <tuple>
 #include "augment.h"
 #include "walk.h"
+#include "short_walk_host.h"
 
 using namespace pantas;
 
@@ -94,8 +96,9 @@ int main(int argc, char** argv) {
         const uint32_t* nodes = b.nodes.data() + b.node_off[i];
         const uint32_t* ops = b.ops.data() + b.op_off[i];
         uint32_t k = b.node_off[i + 1] - b.node_off[i], c = b.op_off[i + 1] - b.op_off[i];
-        if (pass == 0) { RareSink s{t}; st = walk_line(h, nodes, k, ops, c, s); }
-        else { MainSink s{t, *g}; st = walk_line(h, nodes, k, ops, c, s); }
+        // as the kernels dispatch: short-walk class through walk.h's short walks, the rest through walk_line
+        if (pass == 0) { RareSink s{t}; st = rare_walk(*g, t.word, h, nodes, k, ops, c, s); }
+        else { MainSink s{t, *g}; st = main_walk(*g, t.word, h, nodes, k, ops, c, s); }
         if (st == WALK_OPS_EXHAUSTED) throw Error("IndexError", "GAF line " + std::to_string(h.line_id + 1) + ": cs ops exhausted before the path end");
         if (st == WALK_TILDE) throw Error("Unsupported", "GAF line " + std::to_string(h.line_id + 1) + ": '~' op reached by the walk");
       }

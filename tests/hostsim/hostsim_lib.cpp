@@ -6,6 +6,7 @@
 #include <tuple>
 #include "augment.h"
 #include "walk.h"
+#include "short_walk_host.h"
 
 using namespace pantas;
 
@@ -69,8 +70,10 @@ void pass(HS& h, bool only_del) {
     const LineHdr& hd = h.b.hdr[i];
     if (only_del && !(hd.flags & LINE_HAS_DEL)) continue;
     Sink s{h};
-    int st = walk_line(hd, h.b.nodes.data() + h.b.node_off[i], h.b.node_off[i + 1] - h.b.node_off[i],
-                       h.b.ops.data() + h.b.op_off[i], h.b.op_off[i + 1] - h.b.op_off[i], s);
+    const uint32_t* nodes = h.b.nodes.data() + h.b.node_off[i];
+    const uint32_t* ops = h.b.ops.data() + h.b.op_off[i];
+    const uint32_t k = h.b.node_off[i + 1] - h.b.node_off[i], c = h.b.op_off[i + 1] - h.b.op_off[i];
+    int st = only_del ? rare_walk(*h.g, h.word, hd, nodes, k, ops, c, s) : main_walk(*h.g, h.word, hd, nodes, k, ops, c, s);
     if (st != WALK_OK) throw Error("IndexError", "cs ops exhausted");
   }
 }

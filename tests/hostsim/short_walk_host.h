@@ -1,0 +1,54 @@
+// TEST HARNESS ONLY.  Host-side views for the short walks of walk.h (walk_short, walk_short_rare), so that the CPU harness
+// walks every line the way the kernels do: short-walk class through walk_short, the rest through walk_line.
+#pragma once
+#include "graph.h"
+#include "walk.h"
+
+namespace pantas {
+
+// the graph as one record per node: {length word incl. the flags the rare pass has set, first out-target or NONE}
+struct HostInfo {
+  const Graph& g;
+  const std::vector<uint32_t>& word;
+  NodeInfo info(uint32_t n) const {
+    const uint32_t lo = g.row_ptr[n], hi = g.row_ptr[n + 1];
+    return NodeInfo{word[n], lo < hi ? g.col[lo] : 0xFFFFFFFFu};
+  }
+};
+
+// walk_short's sink in terms of a walk_line sink (nc / common / edge)
+template <class GenSink>
+struct ShortFromGeneral {
+  GenSink& s;
+  const Graph& g;
+  void kept(uint32_t node, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t r0, uint64_t exact_order) const {
+    s.nc(node);
+    const uint64_t order = exact_order ? exact_order : event_order(line_id, 0, 1);
+    if (a_il) s.common(node, word, SIDE_IL, a_il, order);
+    if (a_ol) s.common(node, word, SIDE_OL, a_ol, order);
+    for (uint32_t i = 0; i < r0; ++i) s.edge(node, g.col[g.row_ptr[node]], 0);      // the node's first out-slot
+  }
+  void link_rest(uint32_t a, uint32_t b, uint64_t order) const { s.edge(a, b, order); }
+};
+
+// main pass over one line, as augment.hip dispatches it
+template <class GenSink>
+int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops,
+              uint32_t c, GenSink& s) {
+  if (!short_walk_class(h.flags, k) || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s);
+  const HostInfo ga{g, word};
+  const ShortFromGeneral<GenSink> ss{s, g};
+  return (h.line_id & 1u) ? walk_short<2>(ga, h, nodes, k, ops, c, ss) : walk_short<1>(ga, h, nodes, k, ops, c, ss);
+}
+
+// rare-key pass over one line with a '-'
+template <class GenSink>
+int rare_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops,
+              uint32_t c, GenSink& s) {
+  if (!(h.flags & LINE_ONE_INDEL) || k == 0 || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s);
+  // the rare sink sets flags in `word` while it walks: the short walk only reads lengths from it
+  const HostInfo ga{g, word};
+  return walk_short_rare(ga, h, nodes, k, ops, c, s);
+}
+
+}  // namespace pantas
