@@ -302,8 +302,9 @@ struct AggSink {
                                      (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
       atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
       if (exact_order == 0) {
-        if (f_il) atomicMin(&omin[h], line_id);
-        if (f_ol) atomicMin(&omin[CN + h], line_id);
+        // a running minimum: read first (lanes reading one address do not conflict, lanes doing an atomic on it serialise)
+        if (f_il && line_id < __atomic_load_n(&omin[h], __ATOMIC_RELAXED)) atomicMin(&omin[h], line_id);
+        if (f_ol && line_id < __atomic_load_n(&omin[CN + h], __ATOMIC_RELAXED)) atomicMin(&omin[CN + h], line_id);
       }
     } else {
       add_node4(g, n, 1u, a_il, a_ol, a_r0);
