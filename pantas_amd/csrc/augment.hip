@@ -1034,10 +1034,10 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
         PANTAS_AGG(40, 512, 2048, 10, 10, 7, 8, true)    // packed node entries, one kernel
         PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))
         PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
         default:   // 73: short walk over g.info, gathers two nodes ahead
-        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
+        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // ONLY 2: the general walk alone
       }
     }
 #undef PANTAS_SPLIT_SEQ

@@ -90,7 +90,8 @@ PANTAS_HD uint64_t event_order(uint32_t line_id, uint32_t kept_idx, uint32_t pha
 struct ShortOps {
   uint32_t T = 0;                       // total op length
   uint32_t ns = 0;                      // '*' ops, each one base long
-  uint32_t star[SIMPLE_MAX_STARS] = {0, 0, 0, 0};   // their positions
+  uint32_t star[SIMPLE_MAX_STARS] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // their positions (unused: never inside an interval);
+                                        // only ever indexed by constants, so that the struct stays in registers on the GPU
   uint32_t x_pos = 0, x_len = 0;        // the indel's interval (x_len == 0: none)
   bool x_plus = false;
 };
@@ -98,7 +99,13 @@ struct ShortOps {
 PANTAS_HD void short_ops_scan(const uint32_t* ops, uint32_t n_ops, ShortOps& so) {
   for (uint32_t j = 0; j < n_ops; ++j) {
     const uint32_t w = ops[j], code = w & 7u;
-    if (code == OP_STAR) { if (so.ns < SIMPLE_MAX_STARS) so.star[so.ns++] = so.T; }
+    if (code == OP_STAR) {
+      if (so.ns == 0) so.star[0] = so.T;
+      else if (so.ns == 1) so.star[1] = so.T;
+      else if (so.ns == 2) so.star[2] = so.T;
+      else if (so.ns == 3) so.star[3] = so.T;
+      if (so.ns < SIMPLE_MAX_STARS) ++so.ns;
+    }
     else if (code == OP_PLUS || code == OP_MINUS) { so.x_pos = so.T; so.x_len = w >> 3; so.x_plus = code == OP_PLUS; }
     so.T += w >> 3;
   }
@@ -108,8 +115,9 @@ PANTAS_HD void short_ops_scan(const uint32_t* ops, uint32_t n_ops, ShortOps& so)
 PANTAS_HD bool short_has_colon(const ShortOps& so, uint32_t lo, uint32_t hi) {
   const uint32_t len = hi - lo;
   if (len > so.ns) return true;
-  uint32_t stars_in = 0;
-  for (uint32_t s = 0; s < so.ns; ++s) stars_in += (so.star[s] - lo < len) ? 1u : 0u;
+  static_assert(SIMPLE_MAX_STARS == 4, "unrolled below");
+  const uint32_t stars_in = ((so.star[0] - lo < len) ? 1u : 0u) + ((so.star[1] - lo < len) ? 1u : 0u) + ((so.star[2] - lo < len) ? 1u : 0u) +
+                            ((so.star[3] - lo < len) ? 1u : 0u);       // len <= 4 here: an unused slot (2^32 - 1) is never inside
   return stars_in < len;
 }
 
