@@ -97,26 +97,47 @@ __device__ __forceinline__ uint32_t mix64(uint64_t k) {
   return uint32_t(k);
 }
 
+// The two global tables are reached through pointers loaded from memory (GraphView::slow), which the compiler can only
+// treat as generic: it would emit flat_ instructions, and a flat access that MAY be outstanding makes every later
+// s_waitcnt in the kernel a vmcnt(0) -- which undoes the software pipeline of the walk loops.  Casting to the global
+// address space keeps them global_ instructions.
+#define PANTAS_GLOBAL_AS __attribute__((address_space(1)))
+
 // count += add, first = min(first, order) for `key`; inserts the key if absent.
 __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, uint32_t add, uint64_t order) {
+  PANTAS_GLOBAL_AS unsigned long long* keys = (PANTAS_GLOBAL_AS unsigned long long*)t.keys;
+  PANTAS_GLOBAL_AS uint32_t* cnt = (PANTAS_GLOBAL_AS uint32_t*)t.cnt;
+  PANTAS_GLOBAL_AS unsigned long long* first = (PANTAS_GLOBAL_AS unsigned long long*)t.first;
   uint32_t h = mix64(key) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask && probe < 8192u; ++probe) {
-    uint64_t cur = t.keys[h];
+    unsigned long long cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == EMPTY_KEY) {
-      cur = atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[h]), EMPTY_KEY, key);
-      if (cur == EMPTY_KEY) { atomicAdd(t.n_keys, 1u); cur = key; }
+      unsigned long long expected = EMPTY_KEY;
+      if (__hip_atomic_compare_exchange_strong(&keys[h], &expected, static_cast<unsigned long long>(key), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)t.n_keys, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cur = key;
+      } else {
+        cur = expected;
+      }
     }
     if (cur == key) {
-      if (add) atomicAdd(&t.cnt[h], add);
+      if (add) __hip_atomic_fetch_add(&cnt[h], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // first-seen is a running minimum: once the early lines have landed nearly every later
       // candidate loses, and a (possibly stale, hence too large) read is enough to know it
-      if (order < __atomic_load_n(&t.first[h], __ATOMIC_RELAXED))
-        atomicMin(reinterpret_cast<unsigned long long*>(&t.first[h]), order);
+      if (order < __hip_atomic_load(&first[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_min(&first[h], static_cast<unsigned long long>(order), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
     h = (h + 1) & t.mask;
   }
-  atomicExch(t.overflow, 1u);
+  __hip_atomic_exchange((PANTAS_GLOBAL_AS uint32_t*)t.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// a line the walk refuses: min over failing lines of (line_id << 8 | code)
+__device__ __forceinline__ void report_status(const GraphView& g, uint32_t line_id, int st) {
+  __hip_atomic_fetch_min((PANTAS_GLOBAL_AS unsigned long long*)g.slow->status, (static_cast<unsigned long long>(line_id) << 8) | unsigned(st),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out-of-line copy for paths that almost never run (an LDS table is full): keeps their callers' loops small
@@ -166,7 +187,7 @@ __device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b,
   const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
   Sink sink{g};
   const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-  if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+  if (st != WALK_OK) report_status(g, h.line_id, st);
 }
 
 __global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchView b, uint32_t short_walk) {
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256) void augment_rare_kernel(GraphView g, BatchVie
       RareSink sink{g};
       const DevInfo ga{g};
       const int st = walk_short_rare(ga, h, b.nodes + n0, k, b.ops + o0, b.op_off[i + 1] - o0, sink);
-      if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+      if (st != WALK_OK) report_status(g, h.line_id, st);
     } else {
       run_line<RareSink>(g, b, i);
     }
@@ -348,7 +369,11 @@ struct AggSink {
   __device__ __forceinline__ void bump_slot(uint32_t s) const {
     if (g.ablate & 8u) return;
     const uint32_t h = probe<LOG_S>(skey, s);
-    if (h != LDS_EMPTY) atomicAdd(&scnt[h], 1u); else atomicAdd(&g.rc[s], 1u);
+    // two different instructions on purpose (scopes differ): written as atomicAdd on either pointer the compiler selects
+    // the POINTER and emits one flat_atomic_add, and a flat access that may be outstanding turns the waits of the walk
+    // loop into vmcnt(0)
+    if (h != LDS_EMPTY) __hip_atomic_fetch_add(&scnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)g.rc + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ void order_min(uint32_t n, uint32_t side, uint64_t order) const {
     if (g.ablate & 1u) return;
@@ -613,7 +638,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
         else if constexpr (PACKED) st = walk_simple_packed<Sink, INFO, PF>(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
         else st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-      if (st != WALK_OK) atomicMin(g.slow->status, (static_cast<unsigned long long>(h.line_id) << 8) | unsigned(st));
+      if (st != WALK_OK) report_status(g, h.line_id, st);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {

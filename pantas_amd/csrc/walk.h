@@ -21,8 +21,10 @@
 
 #if defined(__HIPCC__)
 #define PANTAS_HD __host__ __device__ __forceinline__
+#define PANTAS_UNROLL _Pragma("unroll")
 #else
 #define PANTAS_HD inline
+#define PANTAS_UNROLL
 #endif
 
 namespace pantas {
@@ -281,8 +283,8 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
 //                    first-seen order of the common key on a flagged side = exact_order, or, when that is 0, any order
 //                    of this line (event_order(line_id, *, 1)): a line without '-' has no other key on the node
 //              void link_rest(a, b, order)  link a -> b that is NOT a's first out-slot (a later slot, or absent from the graph)
-// PF = how many nodes ahead the info gathers run (the GPU waits on the chain nodes[] -> info[]):
-//   PF 1: while node i is processed, info of node i+1 is in flight;  PF 2: info of i+1 and i+2 and the id of i+3.
+// PF >= 1 = how many nodes ahead the info gathers run (the GPU waits on the chain nodes[] -> info[]): while node i is
+// processed, the infos of nodes i+1 .. i+PF and the id of node i+PF+1 are in flight.
 struct alignas(8) NodeInfo {
   uint32_t word, first;
 };
@@ -306,26 +308,26 @@ PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* n
     sink.kept(p_node, p_word, h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, r0,
               exact ? event_order(h.line_id, kept - 1u, 1) : 0ull);
   };
-  // pipeline registers: c = node i, 1 = node i+1, 2 = node i+2 (PF 2 only); ids are requested before the info gather of
-  // the same pass so that waiting for an id never waits for the younger gather
-  uint32_t node_c = nodes[0], node_1 = 0, node_2 = 0;
-  if (k > 1) node_1 = nodes[1];
-  if (PF >= 2 && k > 2) node_2 = nodes[2];
-  NodeInfo inf_c = ga.info(node_c), inf_1{0u, 0u};
-  if (k > 1) inf_1 = ga.info(node_1);
+  // Pipeline registers: at the top of pass i, nid[j] = id of node i+j (j = 0 .. PF) and inf[j] = info of node i+j
+  // (j = 0 .. PF-1).  The pass requests id i+PF+1 and info i+PF, then works on node i.  Every load is unconditional
+  // (indices clamped to the path): a load that may or may not have been issued forces the compiler to wait for ALL
+  // outstanding loads (s_waitcnt vmcnt(0)) wherever an older one is needed, which undoes the pipeline.  Arrays are only
+  // indexed by constants (unrolled), so they are registers.
+  const uint32_t last = k - 1u;
+  uint32_t nid[PF + 1];
+  NodeInfo inf[PF];
+PANTAS_UNROLL
+  for (int j = 0; j <= PF; ++j) nid[j] = nodes[uint32_t(j) < last ? uint32_t(j) : last];
+PANTAS_UNROLL
+  for (int j = 0; j < PF; ++j) inf[j] = ga.info(nid[j]);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
   for (uint32_t i = 0; i < k; ++i) {
-    const uint32_t node = node_c, word = inf_c.word, col0 = inf_c.first;
-    NodeInfo inf_2{0u, 0u};
-    uint32_t node_3 = 0;
-    if (PF >= 2) {
-      if (i + 3 < k) node_3 = nodes[i + 3];
-      if (i + 2 < k) inf_2 = ga.info(node_2);
-    } else {
-      if (i + 2 < k) node_2 = nodes[i + 2];
-    }
+    const uint32_t node = nid[0], word = inf[0].word, col0 = inf[0].first;
+    const uint32_t ahead = i + uint32_t(PF) + 1u;
+    const uint32_t new_id = nodes[ahead < last ? ahead : last];
+    const NodeInfo new_inf = ga.info(nid[PF]);
     // room the node offers to the ops, as min(room, 2^32 - 1): every use compares it with T - P <= 2^32 - 1
     const uint32_t len = word & LEN_MASK;
     bool has_room = len != 0u;
@@ -360,13 +362,12 @@ PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* n
       }                             // else: the node holds the lone '+' / '-' piece and is dropped (:101-102)
     }
     // advance the pipeline
-    node_c = node_1; inf_c = inf_1;
-    if (PF >= 2) {
-      node_1 = node_2; inf_1 = inf_2; node_2 = node_3;
-    } else {
-      node_1 = node_2;
-      if (i + 2 < k) inf_1 = ga.info(node_1);
-    }
+PANTAS_UNROLL
+    for (int j = 0; j < PF; ++j) nid[j] = nid[j + 1];
+    nid[PF] = new_id;
+PANTAS_UNROLL
+    for (int j = 0; j + 1 < PF; ++j) inf[j] = inf[j + 1];
+    inf[PF - 1] = new_inf;
   }
   if (pending) flush(true, rev ? p_r0 : 0u);
   return WALK_OK;
@@ -385,16 +386,19 @@ PANTAS_HD int walk_short_rare(const GraphAcc& ga, const LineHdr& h, const uint32
   uint32_t P = 0, kept = 0;
   bool pending = false;
   KeptNode pend{};
+  // unconditional, clamped loads: see walk_short
+  const uint32_t last = k - 1u;
   uint32_t node_c = nodes[0];
-  uint32_t word_c = ga.info(node_c).word, node_1 = 0, word_1 = 0;
-  if (k > 1) { node_1 = nodes[1]; word_1 = ga.info(node_1).word; }
+  uint32_t node_1 = nodes[last < 1u ? last : 1u];
+  uint32_t word_c = ga.info(node_c).word, word_1 = ga.info(node_1).word;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
   for (uint32_t i = 0; i < k; ++i) {
     const uint32_t node = node_c, word = word_c;
     node_c = node_1; word_c = word_1;
-    if (i + 2 < k) { node_1 = nodes[i + 2]; word_1 = ga.info(node_1).word; }
+    node_1 = nodes[i + 2 < last ? i + 2 : last];
+    word_1 = ga.info(node_1).word;
     const uint32_t len = word & LEN_MASK;
     int64_t r = int64_t(len);
     if (i == 0) r -= h.start;
