@@ -110,7 +110,9 @@ __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, u
   PANTAS_GLOBAL_AS unsigned long long* first = (PANTAS_GLOBAL_AS unsigned long long*)t.first;
   uint32_t h = mix64(key) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask && probe < 8192u; ++probe) {
-    unsigned long long cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // plain loads (an agent-scope atomic load is an sc1 load that goes past the caches): a stale EMPTY is settled by the
+    // compare-and-swap, and a key never changes once it is set
+    unsigned long long cur = keys[h];
     if (cur == EMPTY_KEY) {
       unsigned long long expected = EMPTY_KEY;
       if (__hip_atomic_compare_exchange_strong(&keys[h], &expected, static_cast<unsigned long long>(key), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
@@ -125,7 +127,7 @@ __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, u
       if (add) __hip_atomic_fetch_add(&cnt[h], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // first-seen is a running minimum: once the early lines have landed nearly every later
       // candidate loses, and a (possibly stale, hence too large) read is enough to know it
-      if (order < __hip_atomic_load(&first[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      if (order < first[h])
         __hip_atomic_fetch_min(&first[h], static_cast<unsigned long long>(order), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }

@@ -386,19 +386,16 @@ PANTAS_HD int walk_short_rare(const GraphAcc& ga, const LineHdr& h, const uint32
   uint32_t P = 0, kept = 0;
   bool pending = false;
   KeptNode pend{};
-  // unconditional, clamped loads: see walk_short
-  const uint32_t last = k - 1u;
   uint32_t node_c = nodes[0];
-  uint32_t node_1 = nodes[last < 1u ? last : 1u];
-  uint32_t word_c = ga.info(node_c).word, word_1 = ga.info(node_1).word;
+  uint32_t word_c = ga.info(node_c).word, node_1 = 0, word_1 = 0;
+  if (k > 1) { node_1 = nodes[1]; word_1 = ga.info(node_1).word; }
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
   for (uint32_t i = 0; i < k; ++i) {
     const uint32_t node = node_c, word = word_c;
     node_c = node_1; word_c = word_1;
-    node_1 = nodes[i + 2 < last ? i + 2 : last];
-    word_1 = ga.info(node_1).word;
+    if (i + 2 < k) { node_1 = nodes[i + 2]; word_1 = ga.info(node_1).word; }     // (unconditional loads measured slower here)
     const uint32_t len = word & LEN_MASK;
     int64_t r = int64_t(len);
     if (i == 0) r -= h.start;
