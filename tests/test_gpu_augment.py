@@ -71,6 +71,20 @@ def test_oracle_parity_larger(tmp_path, seed, genes, lines, kw):
     assert got == want.getvalue()
 
 
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_around_the_short_walk_bounds(tmp_path, seed):
+    """tests/long_path_case.py: paths of 27 .. 40 nodes (the short-walk class ends at 31, at 29 with an indel), one
+    '+' / '-' at every position class with mismatches around it, both strands -- engine against the oracle, byte for byte."""
+    import long_path_case
+    pre = str(tmp_path / "lp")
+    long_path_case.write_case(pre, seed, 20000)
+    got, bs, _ = run_engine(pre + ".gfa", pre + ".gaf")
+    want = io.StringIO()
+    a = augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    assert bs.rejected == a.rejected
+    assert got == want.getvalue()
+
+
 def test_threshold_argument(tmp_path):
     d = os.path.join(GOLDEN, "synth_b")
     for thr in (0, 5, 61):

@@ -215,3 +215,19 @@ def test_short_walk_node_summary_vs_piece_compaction():
     r = run([exe, "400000"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.startswith("ok ")
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_walk_source_around_the_short_walk_bounds(hostsim, tmp_path, seed):
+    """tests/long_path_case.py: paths of 27 .. 40 nodes (the short-walk class ends at 31, at 29 with an indel), one
+    '+' / '-' at every position class with mismatches around it, both strands -- harness (which dispatches lines to the
+    short walks like the kernels) against the oracle, byte for byte; and with every line through the general walk."""
+    import long_path_case
+    pre = str(tmp_path / "lp")
+    long_path_case.write_case(pre, seed, 4000)
+    want = io.StringIO()
+    augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    for env in ({}, {"HOSTSIM_BUCKET": "1"}, {"HOSTSIM_GENERAL_WALK": "1"}):
+        r = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == want.getvalue(), env
