@@ -26,6 +26,7 @@
 namespace pantas {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr uint32_t REC_OPS_MAX = SHORT_MAX_OPS - 1u;     // BatchView::rec holds the op count in 24 bits (saturated; only short-walk records are read through it)
 constexpr uint32_t COMMON_POS = 0x7FFFFFFFu;
 
 struct TableView {
@@ -66,6 +67,7 @@ struct BatchView {
   const uint32_t* nodes;
   const uint32_t* ops;
   const uint32_t* del_idx;    // records holding a '-' op
+  const uint4* rec;           // DeviceBatch::rec
   uint32_t n, n_del;
 };
 
@@ -524,10 +526,10 @@ struct ShortSinkDev {
 };
 template <class Sink, int PF>
 __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                               const uint32_t* ops, uint32_t nops, const Sink& sink) {
+                                               const uint32_t* ops, uint32_t nops, const Sink& sink, uint32_t first_id) {
   const DevInfo ga{g};
   const ShortSinkDev<Sink> ss{sink};
-  return walk_short<PF>(ga, h, nodes, k, ops, nops, ss);
+  return walk_short<PF>(ga, h, nodes, k, ops, nops, ss, first_id);
 }
 
 // INFO: the node's length word and first out-target come from g.info (one 8-byte gather, no dependent col[] load); the
@@ -535,7 +537,7 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
 template <class Sink, bool INFO = false, int PF = 1>
 __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
                                                   const uint32_t* ops, uint32_t nops, const Sink& sink) {
-  if constexpr (INFO) return walk_short_info<Sink, PF>(g, h, nodes, k, ops, nops, sink);
+  if constexpr (INFO) return walk_short_info<Sink, PF>(g, h, nodes, k, ops, nops, sink, k ? nodes[0] : 0u);
   uint32_t T = 0, ns = 0;
   uint32_t star[SIMPLE_MAX_STARS];
 #pragma unroll 1
@@ -626,6 +628,14 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     const uint32_t hi = min(end, lo + CHUNK);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
       const LineHdr h = b.hdr[i];
+      if constexpr (INFO) {
+        // the record's offsets, sizes and first node id in one 16-byte load beside the header
+        // (a line of the short-walk class has at most 31 path nodes and fewer than SHORT_MAX_OPS ops: both fit)
+        const uint4 r = b.rec[i];
+        const int st = walk_short_info<Sink, PF>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, r.w);
+        if (st != WALK_OK) report_status(g, h.line_id, st);
+        continue;
+      }
       const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
       const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
       int st;
@@ -787,7 +797,7 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
 
 void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   if (!b) return;
-  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx})
+  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx, (void*)b->rec})
     if (p) (void)hipFree(p);
   delete b;
 }
@@ -898,6 +908,25 @@ static void size_tables(DeviceGraph& d, uint64_t hist_keys_bound, uint64_t novel
   if (grew) { table_clear(d.hist, d.stream); table_clear(d.novel, d.stream); }
 }
 
+__global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, uint4* rec) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t n0 = node_off[i], k = node_off[i + 1] - n0, o0 = op_off[i], c = op_off[i + 1] - o0;
+    rec[i] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), k ? nodes[n0] : 0u);
+  }
+}
+
+void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
+  HIP_OK(hipSetDevice(d.device));
+  if (b.rec) { (void)hipFree(b.rec); b.rec = nullptr; }
+  HIP_OK(hipMalloc(&b.rec, std::max<size_t>(1, b.n) * sizeof(uint4)));
+  if (b.n) {
+    const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 16));
+    hipLaunchKernelGGL(build_rec_kernel, dim3(blocks), dim3(256), 0, d.stream, b.n, b.node_off, b.op_off, b.nodes, b.rec);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipStreamSynchronize(d.stream));
+}
+
 DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
   HIP_OK(hipSetDevice(d.device));
   if (b.size() >= NONE32) throw Error("Unsupported", "more than 2^32-2 records in one batch");
@@ -926,6 +955,7 @@ DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
   p->ops = to_device(b.ops, d.stream);
   p->del_idx = to_device(del, d.stream);
   HIP_OK(hipStreamSynchronize(d.stream));
+  build_batch_rec(d, *p);
   return p;
 }
 
@@ -963,7 +993,7 @@ uint64_t batch_alg_bytes_short(const DeviceBatch& db) {
 
 static BatchView batch_view(const DeviceBatch& b) {
   BatchView v{};
-  v.hdr = b.hdr; v.node_off = b.node_off; v.op_off = b.op_off; v.nodes = b.nodes; v.ops = b.ops; v.del_idx = b.del_idx;
+  v.hdr = b.hdr; v.node_off = b.node_off; v.op_off = b.op_off; v.nodes = b.nodes; v.ops = b.ops; v.del_idx = b.del_idx; v.rec = b.rec;
   v.n = b.n; v.n_del = b.n_del;
   return v;
 }

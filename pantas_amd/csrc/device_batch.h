@@ -21,6 +21,9 @@ namespace pantas {
 struct DeviceBatch {
   LineHdr* hdr = nullptr;
   uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
+  uint4* rec = nullptr;          // derived per record: {node_off, op_off, path nodes (8 bits, saturated) | cs ops << 8, first node id}
+                                 // -- with hdr[] everything the short-walk kernel needs to start a record, in two 16-byte loads
+                                 // (instead of hdr, two offset pairs and then nodes[0]: one dependent load level less per record)
   uint32_t n = 0, n_del = 0;
   uint32_t n_short = 0;          // records [0, n_short) are the short-walk class (walk.h), bucketed apart from the rest
   uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
@@ -81,6 +84,8 @@ struct DeviceGraphInfo {
 };
 struct DeviceGraph;
 DeviceGraphInfo graph_info(DeviceGraph& dg);
+// fills db.rec from the batch's own arrays (augment.hip); both ways a batch comes to be call it last
+void build_batch_rec(DeviceGraph& dg, DeviceBatch& db);
 struct Graph;
 // dense name table (id - base -> node) in HBM, uploaded on first use and owned by the DeviceGraph
 uint32_t* device_name_table(DeviceGraph& dg, const Graph& g);

@@ -575,6 +575,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
     out->ops = ops1.hand_over<uint32_t>();
     out->del_idx = del.hand_over<uint32_t>();
   }
+  build_batch_rec(dg, *out);
   tm.bucket_s = now() - t0;
   pt.lap("bucket by locus");
   tm.total_s = now() - t_begin;

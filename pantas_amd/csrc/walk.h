@@ -49,6 +49,7 @@ constexpr uint32_t SIMPLE_MAX_STARS = 4;
 // (LINE_SIMPLE and at most SHORT_MAX_PATH path nodes: its LDS entries hold 16-bit counts, 2048 records x 31 visits
 // < 65536), then the rest (general walk).
 constexpr uint32_t SHORT_MAX_PATH = 31;
+constexpr uint32_t SHORT_MAX_OPS = 1u << 24;    // the short-walk kernel reads a record's op count from 24 bits (':' runs may repeat)
 // A one-indel line can add 2 more IL / OL steps than it has path nodes (the node holding ':' '+' ':' counts three
 // entries), so it may have two path nodes fewer: 2048 x (29 + 2) < 65536 as well.
 constexpr uint32_t SHORT_MAX_PATH_INDEL = SHORT_MAX_PATH - 2;
@@ -62,7 +63,7 @@ PANTAS_HD uint32_t block_order_key(uint32_t flags, uint32_t path_nodes) {
 }
 // what the tokenisers set from a line's op statistics (both tokenisers call this: one definition of the classes)
 PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t indels, uint32_t others, bool slow, uint64_t total_len) {
-  if (n_ops == 0 || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= (1ull << 31)) return 0u;
+  if (n_ops == 0 || n_ops >= SHORT_MAX_OPS || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= (1ull << 31)) return 0u;
   return indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u;
 }
 
@@ -291,7 +292,7 @@ struct alignas(8) NodeInfo {
 
 template <int PF, class GraphAcc, class Sink>
 PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops, uint32_t nops,
-                         const Sink& sink) {
+                         const Sink& sink, uint32_t first_id) {        // first_id = nodes[0], which the caller may already hold
   if (k == 0) return WALK_OK;
   ShortOps so;
   short_ops_scan(ops, nops, so);
@@ -316,8 +317,9 @@ PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* n
   const uint32_t last = k - 1u;
   uint32_t nid[PF + 1];
   NodeInfo inf[PF];
+  nid[0] = first_id;
 PANTAS_UNROLL
-  for (int j = 0; j <= PF; ++j) nid[j] = nodes[uint32_t(j) < last ? uint32_t(j) : last];
+  for (int j = 1; j <= PF; ++j) nid[j] = nodes[uint32_t(j) < last ? uint32_t(j) : last];
 PANTAS_UNROLL
   for (int j = 0; j < PF; ++j) inf[j] = ga.info(nid[j]);
 #if defined(__HIP_DEVICE_COMPILE__)

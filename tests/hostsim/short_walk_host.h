@@ -38,7 +38,7 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
   if (!short_walk_class(h.flags, k) || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s);
   const HostInfo ga{g, word};
   const ShortFromGeneral<GenSink> ss{s, g};
-  return (h.line_id & 1u) ? walk_short<2>(ga, h, nodes, k, ops, c, ss) : walk_short<1>(ga, h, nodes, k, ops, c, ss);
+  return (h.line_id & 1u) ? walk_short<2>(ga, h, nodes, k, ops, c, ss, k ? nodes[0] : 0u) : walk_short<1>(ga, h, nodes, k, ops, c, ss, k ? nodes[0] : 0u);
 }
 
 // rare-key pass over one line with a '-'
