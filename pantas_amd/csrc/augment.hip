@@ -160,8 +160,12 @@ struct RareSink {
   __device__ void common(uint32_t, uint32_t, uint32_t, uint32_t, uint64_t) const {}
   __device__ void rare(uint32_t n, uint32_t side, int32_t pos, uint64_t order) const {
     table_update(g.slow->hist, hist_key(n, side, uint32_t(pos + 1) & 0x7FFFFFFFu), 1u, order);
-    atomicOr(&g.word[n], side == SIDE_IL ? FLAG_IL : FLAG_OL);
-    atomicOr(&g.info[n].x, side == SIDE_IL ? FLAG_IL : FLAG_OL);
+    // set once: thousands of deletions land on the same node of an expressed gene, and atomics on one address serialise
+    const uint32_t flag = side == SIDE_IL ? FLAG_IL : FLAG_OL;
+    if (!(__builtin_nontemporal_load(&g.word[n]) & flag)) {
+      atomicOr(&g.word[n], flag);
+      atomicOr(&g.info[n].x, flag);
+    }
   }
   __device__ void edge(uint32_t, uint32_t, uint64_t) const {}
 };
