@@ -1132,10 +1132,23 @@ float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_m
 // (node << 1 | side) of every node flag the rare kernel has set so far -- what other ranks need
 // before THEIR main kernel so that the first-seen order of the common key is recorded everywhere
 __global__ void collect_flags_kernel(const uint32_t* word, uint32_t n, uint32_t* out, uint32_t* cursor, uint32_t cap) {
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const uint32_t w = word[i];
-    if (w & FLAG_IL) { const uint32_t o = atomicAdd(cursor, 1u); if (o < cap) out[o] = i << 1; }
-    if (w & FLAG_OL) { const uint32_t o = atomicAdd(cursor, 1u); if (o < cap) out[o] = (i << 1) | 1u; }
+  // one atomic per wave and side (every lane adding to the one cursor would serialise): ballot, the first lane claims room
+  const uint32_t lane = threadIdx.x & 63u;
+  for (uint32_t base = blockIdx.x * 256u + (threadIdx.x & ~63u); base < n; base += gridDim.x * 256u) {
+    const uint32_t i = base + lane;
+    const uint32_t w = i < n ? word[i] : 0u;
+    for (uint32_t side = 0; side < 2; ++side) {
+      const bool has = (w & (side ? FLAG_OL : FLAG_IL)) != 0;
+      const unsigned long long m = __ballot(has);
+      if (m == 0ull) continue;
+      uint32_t start = 0;
+      if (lane == 0) start = atomicAdd(cursor, uint32_t(__popcll(m)));
+      start = __builtin_amdgcn_readfirstlane(start);
+      if (has) {
+        const uint32_t o = start + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+        if (o < cap) out[o] = (i << 1) | side;
+      }
+    }
   }
 }
 
