@@ -532,10 +532,10 @@ struct ShortSinkDev {
 };
 template <class Sink, int PF>
 __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                               const uint32_t* ops, uint32_t nops, const Sink& sink, uint32_t first_id) {
+                                               const uint32_t* ops, uint32_t nops, const Sink& sink, const uint32_t* first_ids) {
   const DevInfo ga{g};
   const ShortSinkDev<Sink> ss{sink};
-  return walk_short<PF>(ga, h, nodes, k, ops, nops, ss, first_id);
+  return walk_short<PF>(ga, h, nodes, k, ops, nops, ss, first_ids);
 }
 
 // INFO: the node's length word and first out-target come from g.info (one 8-byte gather, no dependent col[] load); the
@@ -543,7 +543,11 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
 template <class Sink, bool INFO = false, int PF = 1>
 __device__ __forceinline__ int walk_simple_packed(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
                                                   const uint32_t* ops, uint32_t nops, const Sink& sink) {
-  if constexpr (INFO) return walk_short_info<Sink, PF>(g, h, nodes, k, ops, nops, sink, k ? nodes[0] : 0u);
+  if constexpr (INFO) {
+    uint32_t first_ids[PF + 1];
+    for (int j = 0; j <= PF; ++j) first_ids[j] = k ? nodes[uint32_t(j) < k - 1u ? uint32_t(j) : k - 1u] : 0u;
+    return walk_short_info<Sink, PF>(g, h, nodes, k, ops, nops, sink, first_ids);
+  }
   uint32_t T = 0, ns = 0;
   uint32_t star[SIMPLE_MAX_STARS];
 #pragma unroll 1
@@ -637,8 +641,10 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       if constexpr (INFO) {
         // the record's offsets, sizes and first node id in one 16-byte load beside the header
         // (a line of the short-walk class has at most 31 path nodes and fewer than SHORT_MAX_OPS ops: both fit)
-        const uint4 r = b.rec[i];
-        const int st = walk_short_info<Sink, PF>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, r.w);
+        const uint4 r = b.rec[2 * size_t(i)], r2 = b.rec[2 * size_t(i) + 1];
+        const uint32_t first_ids[5] = {r.w, r2.x, r2.y, r2.z, r2.w};
+        static_assert(PF <= 4, "rec holds the ids of the first five path nodes");
+        const int st = walk_short_info<Sink, PF>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids);
         if (st != WALK_OK) report_status(g, h.line_id, st);
         continue;
       }
@@ -917,14 +923,17 @@ static void size_tables(DeviceGraph& d, uint64_t hist_keys_bound, uint64_t novel
 __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, uint4* rec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t n0 = node_off[i], k = node_off[i + 1] - n0, o0 = op_off[i], c = op_off[i + 1] - o0;
-    rec[i] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), k ? nodes[n0] : 0u);
+    const uint32_t last = k ? k - 1u : 0u;
+    auto id = [&](uint32_t j) { return k ? nodes[n0 + (j < last ? j : last)] : 0u; };
+    rec[2 * size_t(i)] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
+    rec[2 * size_t(i) + 1] = make_uint4(id(1), id(2), id(3), id(4));
   }
 }
 
 void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
   if (b.rec) { (void)hipFree(b.rec); b.rec = nullptr; }
-  HIP_OK(hipMalloc(&b.rec, std::max<size_t>(1, b.n) * sizeof(uint4)));
+  HIP_OK(hipMalloc(&b.rec, std::max<size_t>(1, b.n) * 2 * sizeof(uint4)));
   if (b.n) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 16));
     hipLaunchKernelGGL(build_rec_kernel, dim3(blocks), dim3(256), 0, d.stream, b.n, b.node_off, b.op_off, b.nodes, b.rec);

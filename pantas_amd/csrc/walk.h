@@ -292,7 +292,8 @@ struct alignas(8) NodeInfo {
 
 template <int PF, class GraphAcc, class Sink>
 PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops, uint32_t nops,
-                         const Sink& sink, uint32_t first_id) {        // first_id = nodes[0], which the caller may already hold
+                         const Sink& sink, const uint32_t* first_ids) {  // first_ids[j] = nodes[min(j, k - 1)], j = 0 .. PF: the caller may
+                                                                         // already hold them (the GPU batch keeps them beside the offsets)
   if (k == 0) return WALK_OK;
   ShortOps so;
   short_ops_scan(ops, nops, so);
@@ -317,9 +318,8 @@ PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* n
   const uint32_t last = k - 1u;
   uint32_t nid[PF + 1];
   NodeInfo inf[PF];
-  nid[0] = first_id;
 PANTAS_UNROLL
-  for (int j = 1; j <= PF; ++j) nid[j] = nodes[uint32_t(j) < last ? uint32_t(j) : last];
+  for (int j = 0; j <= PF; ++j) nid[j] = first_ids[j];
 PANTAS_UNROLL
   for (int j = 0; j < PF; ++j) inf[j] = ga.info(nid[j]);
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -38,7 +38,9 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
   if (!short_walk_class(h.flags, k) || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s);
   const HostInfo ga{g, word};
   const ShortFromGeneral<GenSink> ss{s, g};
-  return (h.line_id & 1u) ? walk_short<2>(ga, h, nodes, k, ops, c, ss, k ? nodes[0] : 0u) : walk_short<1>(ga, h, nodes, k, ops, c, ss, k ? nodes[0] : 0u);
+  uint32_t first_ids[4] = {0, 0, 0, 0};
+  for (uint32_t j = 0; j < 4 && k; ++j) first_ids[j] = nodes[j < k - 1 ? j : k - 1];
+  return (h.line_id & 1u) ? walk_short<2>(ga, h, nodes, k, ops, c, ss, first_ids) : walk_short<1>(ga, h, nodes, k, ops, c, ss, first_ids);
 }
 
 // rare-key pass over one line with a '-'
