@@ -148,3 +148,19 @@ def test_two_ranks_share_the_gpu_over_gloo():
     rows = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(rows) == 6 and all(x["equal_to_dense"] and x["world"] == 2 for x in rows)
     assert any(x["mode"] == "block-sparse" for x in rows)
+
+
+def test_bench_sharded_path_rehearsal():
+    """bench.py's N > 1 code path (per-rank batch, the block-sparse sum inside the timed region, MAX over ranks, one JSON
+    line from rank 0) with two ranks on the one GPU over gloo -- what the 8-GPU run does, minus RCCL."""
+    import json
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "s2", "--lines", "300000",
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["unit"] == "reads/s"
+    assert d["allreduce"]["mode"] in ("block-sparse", "dense") and d["allreduce_ms"] > 0
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["call"]["events"] > 0
