@@ -325,8 +325,10 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   CallView c = d.view;
   c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
   c.arena = d.arena; c.arena_next = d.arena_next; c.arena_slots = ARENA_SLOTS; c.arena_cap = ARENA_CAP;
+  PhaseTimer pt("run_call");
   std::vector<uint32_t> ann, nov, around, around_j;
   pass_lists(g, t, o, ann, nov, around, around_j);
+  pt.lap("pass lists");
   HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));
   out = CallOutput();
   times = CallTimes();
@@ -342,6 +344,7 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
     extra_items = cj.size();
   }
   times.junctions = ann.size() + nov.size() + around.size() + extra_items;
+  pt.lap("kernels");
   // ---- one copy to the host: the arrays are sized once (no value-initialising fill, pages touched by many threads), the
   // passes land behind each other, and payload / task / path offsets become global
   size_t nr = 0, nw = 0, nt = 0, np = 0;
@@ -354,6 +357,7 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   out.paths.resize(np);
   prefault(out.recs.data(), nr * sizeof(EventRec));
   prefault(out.side.data(), nw * 4);
+  pt.lap("host arrays");
   size_t r0 = 0, w0 = 0, t0 = 0, p0 = 0;
   size_t base[4][4];
   for (int k = 0; k < 4; ++k) {
@@ -366,6 +370,7 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
     r0 += p.n_recs; w0 += p.n_words; t0 += p.n_tasks; p0 += p.n_paths;
   }
   HIP_OK(hipStreamSynchronize(d.stream));
+  pt.lap("device -> host");
   for (int k = 0; k < 4; ++k) {
     const PassOut& p = po[k];
     const uint32_t bw = uint32_t(base[k][1]), bt = uint32_t(base[k][2]), bp = uint32_t(base[k][3]);
@@ -381,6 +386,7 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
     }
     if (bp) for (size_t i = 0; i < p.n_tasks; ++i) out.tasks[base[k][2] + i].path_off += bp;
   }
+  pt.lap("offset fix-ups");
 }
 
 }  // namespace pantas
