@@ -154,6 +154,17 @@ def main():
     warm_ms = []
     for _ in range(args.warmup):
         warm_ms.append(round(g.launch(batch).main_ms, 3))
+    if dist is not None:
+        # warm-up of the two collectives of the counter exchange on buffers of their sizes (the library sets up channels and
+        # protocols on first use); the counters themselves are not touched before the timed region
+        dev = torch.device("cuda", local_rank)
+        words = g.counters()[1]
+        bm = torch.zeros(words // 512 + 1, dtype=torch.int32, device=dev)
+        allbm = torch.empty(world * bm.numel(), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(allbm, bm)
+        st = torch.zeros(max(1 << 20, words // 32), dtype=torch.int32, device=dev)
+        dist.all_reduce(st)
+        del bm, allbm, st
     sync()
     main_ms, rare_ms, short_ms = [], [], []
     t0 = time.perf_counter()
