@@ -40,8 +40,17 @@ const char* pantas_last_error_kind(void);
 const char* pantas_version(void);
 int pantas_device_count(void);
 
+/* Structs cross this boundary by pointer and have grown between releases.  Every struct below therefore starts with
+ * struct_size, which the CALLER sets to the sizeof() of the struct it was compiled (or, for a ctypes binding, declared)
+ * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
+ * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
+ * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
+#define PANTAS_ABI_VERSION 2
+int pantas_abi_version(void);
+
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
 typedef struct {
+  uint32_t struct_size, reserved0_;
   uint64_t segments;       /* distinct S names (V) */
   uint64_t link_slots;     /* L lines with both ends known (A) */
   uint64_t lines, s_lines, l_lines, p_lines;
@@ -66,6 +75,7 @@ int pantas_graph_to_device(pantas_graph* g, int device);
 
 /* ---- augment: alignments_augmentation_from_gaf.py main() :110-427 ------------------------- */
 typedef struct {
+  uint32_t struct_size, reserved0_;
   uint64_t lines;          /* GAF lines read */
   uint64_t rejected;       /* mapq < thr            (:143-146, "Rejected alignments: N") */
   uint64_t skipped;        /* '*' path or dv > 0.1  (:147-148, :179-180) */
@@ -86,6 +96,7 @@ typedef struct {
 } pantas_batch_stats;
 
 typedef struct {
+  uint32_t struct_size, reserved0_;
   float rare_ms;           /* augment_rare_kernel, HIP events on the launch stream */
   float main_ms;           /* all main kernels of the launch */
   float main_short_ms;     /* of which the short-walk kernel (the dominant one); 0 when one kernel took every record */
@@ -159,12 +170,26 @@ int pantas_augment_finish(pantas_graph* g);
 int pantas_augment_read(pantas_graph* g, uint32_t* nc, uint32_t* il0, uint32_t* oll, uint32_t* rc);
 /* :377-427 second GFA pass: echo + NC/IL/OL/RC tags + novel links, to fd */
 int pantas_augment_write_gfa(pantas_graph* g, int fd);
-/* whole script: reset, load, launch, finish, write.  stats may be NULL */
+/* :135-371 over a GAF of ANY size (the reference reads line by line, :135-138): the byte range [begin, end) (end = 0: to
+ * EOF; cut at line starts as pantas_gaf_split does) is cut into batches of at most PANTAS_BATCH_BYTES of text (default
+ * 2 GiB).  stream_rare tokenises batch after batch (the next batch's text is copied to HBM meanwhile) and runs each one's
+ * rare-key kernel; the records stay in HBM while they fit PANTAS_RESIDENT_BYTES (default 60 % of the free HBM), later
+ * batches are dropped and tokenised again by stream_main, which runs every batch's main kernel.  Between the two a
+ * sharded run exchanges node flags exactly as with launch_rare / launch_main.  One streamed range per run
+ * (pantas_augment_reset starts the next); stats (may be NULL) = totals over the batches, *_ms = summed kernel times. */
+int pantas_augment_stream_rare(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,
+                               uint64_t first_line, pantas_batch_stats* stats, float* rare_ms);
+int pantas_augment_stream_main(pantas_graph* g, float* main_ms);
+/* batches of the streamed run, how many stayed resident, how many were tokenised twice (any pointer may be NULL) */
+int pantas_augment_stream_info(const pantas_graph* g, uint64_t* batches, uint64_t* resident, uint64_t* retokenised);
+/* whole script: reset, stream_rare + stream_main over the whole file, finish, write (fd_out < 0: no write).
+ * stats and launch may be NULL */
 int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
                        pantas_launch_stats* launch);
 
 /* ---- call: scripts/call.py main() :132-1105 ------------------------------------------------ */
 typedef struct {
+  uint32_t struct_size, reserved0_;
   int32_t rca;            /* --rca (default -1) */
   int32_t isw;            /* --isw (default 5) */
   int32_t minintronsize;  /* --minintronsize (default 100) */
@@ -177,6 +202,7 @@ typedef struct {
 } pantas_call_opts;
 
 typedef struct {
+  uint32_t struct_size, reserved0_;
   uint64_t junctions;       /* annotated junction links (JN) */
   uint64_t novel_links;     /* links with ID:Z:N */
   uint64_t evaluated;       /* junction evaluations launched over the three passes */
@@ -200,6 +226,7 @@ int pantas_call_run(pantas_graph* g, const pantas_call_opts* opts, int fd_csv, i
  * built from them. */
 typedef struct pantas_synth pantas_synth;
 typedef struct {
+  uint32_t struct_size, reserved0_;
   uint64_t seed;
   uint32_t n_genes;
   uint32_t n_chrom;
@@ -217,6 +244,7 @@ typedef struct {
   uint64_t line_offset;    /* lines [line_offset, line_offset + n_lines) of the read stream */
 } pantas_synth_params;
 typedef struct {
+  uint32_t struct_size, reserved0_;
   uint64_t nodes, links, junction_links, transcripts, gaf_lines;
   uint64_t gfa_bytes, gtf_bytes, gaf_bytes;
   double seconds;

@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+ABI_VERSION = 2      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
 
@@ -23,15 +24,27 @@ class PantasError(RuntimeError):
         self.kind = kind
 
 
-class GraphStats(C.Structure):
-    _fields_ = [("segments", C.c_uint64), ("link_slots", C.c_uint64), ("lines", C.c_uint64),
+class _Sized(C.Structure):
+    """A struct of the C ABI: starts with struct_size, which the library reads to know how many bytes of this
+    declaration it may touch (include/pantas_gpu.h).  Set on construction."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(self)
+
+
+_HEAD = [("struct_size", C.c_uint32), ("reserved0_", C.c_uint32)]
+
+
+class GraphStats(_Sized):
+    _fields_ = _HEAD + [("segments", C.c_uint64), ("link_slots", C.c_uint64), ("lines", C.c_uint64),
                 ("s_lines", C.c_uint64), ("l_lines", C.c_uint64), ("p_lines", C.c_uint64),
                 ("text_bytes", C.c_uint64), ("max_segment_len", C.c_uint32), ("dense_names", C.c_uint32),
                 ("load_seconds", C.c_double)]
 
 
-class BatchStats(C.Structure):
-    _fields_ = [("lines", C.c_uint64), ("rejected", C.c_uint64), ("skipped", C.c_uint64),
+class BatchStats(_Sized):
+    _fields_ = _HEAD + [("lines", C.c_uint64), ("rejected", C.c_uint64), ("skipped", C.c_uint64),
                 ("records", C.c_uint64), ("path_nodes", C.c_uint64), ("cs_ops", C.c_uint64),
                 ("del_records", C.c_uint64), ("del_path_nodes", C.c_uint64), ("text_bytes", C.c_uint64), ("alg_bytes", C.c_uint64),
                 ("tokenize_seconds", C.c_double), ("upload_seconds", C.c_double),
@@ -40,25 +53,25 @@ class BatchStats(C.Structure):
                 ("short_records", C.c_uint64), ("short_alg_bytes", C.c_uint64)]
 
 
-class LaunchStats(C.Structure):
-    _fields_ = [("rare_ms", C.c_float), ("main_ms", C.c_float), ("main_short_ms", C.c_float), ("reserved_", C.c_float)]
+class LaunchStats(_Sized):
+    _fields_ = _HEAD + [("rare_ms", C.c_float), ("main_ms", C.c_float), ("main_short_ms", C.c_float), ("reserved_", C.c_float)]
 
 
-class CallOpts(C.Structure):
-    _fields_ = [("rca", C.c_int32), ("isw", C.c_int32), ("minintronsize", C.c_int32), ("events", C.c_uint32),
+class CallOpts(_Sized):
+    _fields_ = _HEAD + [("rca", C.c_int32), ("isw", C.c_int32), ("minintronsize", C.c_int32), ("events", C.c_uint32),
                 ("novel", C.c_int32), ("no_annotated", C.c_int32), ("junction", C.c_char_p),
                 ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32)]
 
 
-class CallStats(C.Structure):
-    _fields_ = [("junctions", C.c_uint64), ("novel_links", C.c_uint64), ("evaluated", C.c_uint64),
+class CallStats(_Sized):
+    _fields_ = _HEAD + [("junctions", C.c_uint64), ("novel_links", C.c_uint64), ("evaluated", C.c_uint64),
                 ("events", C.c_uint64), ("ex_entries", C.c_uint64), ("jn_entries", C.c_uint64),
                 ("parse_seconds", C.c_double), ("upload_seconds", C.c_double), ("render_seconds", C.c_double),
                 ("annotated_ms", C.c_float), ("novel_ms", C.c_float), ("around_ms", C.c_float)]
 
 
-class SynthParams(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("n_genes", C.c_uint32), ("n_chrom", C.c_uint32), ("n_lines", C.c_uint64),
+class SynthParams(_Sized):
+    _fields_ = _HEAD + [("seed", C.c_uint64), ("n_genes", C.c_uint32), ("n_chrom", C.c_uint32), ("n_lines", C.c_uint64),
                 ("base_id", C.c_uint64), ("bubble_rate", C.c_double), ("max_exons", C.c_uint32),
                 ("intron_long_max", C.c_uint32), ("intergenic_min", C.c_uint32), ("intergenic_max", C.c_uint32),
                 ("read_len", C.c_uint32), ("with_path", C.c_int32), ("zipf_a", C.c_double),
@@ -68,8 +81,8 @@ class SynthParams(C.Structure):
                 ("line_offset", C.c_uint64)]
 
 
-class SynthStats(C.Structure):
-    _fields_ = [("nodes", C.c_uint64), ("links", C.c_uint64), ("junction_links", C.c_uint64),
+class SynthStats(_Sized):
+    _fields_ = _HEAD + [("nodes", C.c_uint64), ("links", C.c_uint64), ("junction_links", C.c_uint64),
                 ("transcripts", C.c_uint64), ("gaf_lines", C.c_uint64), ("gfa_bytes", C.c_uint64),
                 ("gtf_bytes", C.c_uint64), ("gaf_bytes", C.c_uint64), ("seconds", C.c_double)]
 
@@ -86,6 +99,7 @@ def _load():
         "pantas_last_error_kind": (C.c_char_p, []),
         "pantas_version": (C.c_char_p, []),
         "pantas_device_count": (i32, []),
+        "pantas_abi_version": (i32, []),
         "pantas_graph_load": (i32, [C.c_char_p, P(vp)]),
         "pantas_graph_free": (None, [vp]),
         "pantas_graph_get_stats": (i32, [vp, P(GraphStats)]),
@@ -111,6 +125,9 @@ def _load():
         "pantas_augment_read": (i32, [vp, vp, vp, vp, vp]),
         "pantas_augment_write_gfa": (i32, [vp, i32]),
         "pantas_augment_run": (i32, [vp, C.c_char_p, i32, i32, P(BatchStats), P(LaunchStats)]),
+        "pantas_augment_stream_rare": (i32, [vp, C.c_char_p, i32, u64, u64, u64, P(BatchStats), P(C.c_float)]),
+        "pantas_augment_stream_main": (i32, [vp, P(C.c_float)]),
+        "pantas_augment_stream_info": (i32, [vp, P(u64), P(u64), P(u64)]),
         "pantas_call_prepare": (i32, [vp, C.c_char_p, i32]),
         "pantas_call_run": (i32, [vp, P(CallOpts), i32, i32, P(CallStats)]),
         "pantas_synth_defaults": (None, [P(SynthParams)]),
@@ -130,6 +147,9 @@ def _load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.pantas_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} was built for ABI version {lib.pantas_abi_version()}, this binding declares "
+                          f"{ABI_VERSION} (include/pantas_gpu.h PANTAS_ABI_VERSION): rebuild with `make -C pantas_amd/csrc`")
     return lib, sig
 
 

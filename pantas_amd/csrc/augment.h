@@ -59,8 +59,21 @@ DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);
 // GPU tokeniser (tokenize.hip): text of whole lines -> bucketed records resident on dg's device.  `counts` receives the
 // batch counters and a deferred tokeniser error, its arrays stay empty.  Needs a graph with dense (decimal) names.
 struct DeviceTokenizeTimes { double h2d_s = 0, index_s = 0, measure_s = 0, write_s = 0, bucket_s = 0, total_s = 0; };
+// text of whole lines already in HBM (zero-padded as the tokeniser's kernels need it): what a TextPrefetcher hands out
+struct DeviceText { uint8_t* dev = nullptr; size_t size = 0; };
+// `resident`: the same bytes as [data, data + size), already on the device (data is still read for error wording)
 DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
-                                   GafBatch& counts, DeviceTokenizeTimes* times = nullptr);
+                                   GafBatch& counts, DeviceTokenizeTimes* times = nullptr, const DeviceText* resident = nullptr);
+// Copies the text of the NEXT batch to HBM (own stream, own pinned staging, a worker thread) while the current batch is
+// tokenised and walked.  At most two ranges in flight: start, start, get, (use), start, get, ...; a buffer handed out
+// by get() is overwritten by the second start() after it.
+struct TextPrefetcher;
+struct TextPrefetcherDeleter { void operator()(TextPrefetcher*) const; };
+using TextPrefetcherPtr = std::unique_ptr<TextPrefetcher, TextPrefetcherDeleter>;
+TextPrefetcherPtr make_text_prefetcher(DeviceGraph& dg, size_t max_bytes);
+void prefetch_start(TextPrefetcher& p, const char* data, size_t size);
+DeviceText prefetch_get(TextPrefetcher& p);
+double prefetch_copy_seconds(const TextPrefetcher& p);
 // copies a resident batch back (tests: the two tokenisers must produce the same arrays)
 void download_batch(const DeviceGraph& dg, const DeviceBatch& db, GafBatch& out);
 // Launches the two augment kernels over a resident batch; accumulates into dg's counters.
@@ -73,8 +86,13 @@ void export_flags(DeviceGraph& dg, std::vector<uint32_t>& codes);          // (n
 void import_flags(DeviceGraph& dg, const uint32_t* codes, size_t n);
 // Raises Error if a kernel reported a line the reference would have died on.
 void check_device_status(DeviceGraph& dg, const DeviceBatch* db);
-void boost_novel_table(DeviceGraph& dg);
-void reserve_hist(DeviceGraph& dg, uint64_t keys);   // bound on distinct IL/OL keys of the whole (sharded) run              // next sizing of the novel-link table is 4x larger
+void boost_novel_table(DeviceGraph& dg);              // next sizing of the novel-link table is 4x larger
+void boost_hist_table(DeviceGraph& dg);               // the same for the IL/OL key table (its bound should never be exceeded)
+uint64_t device_free_bytes(DeviceGraph& dg);          // HBM not allocated right now on dg's device
+// `b` holds the same records as a batch whose rare-key kernel already ran this run (a streamed run tokenises a dropped
+// batch again for its main pass): it may be launched with launch_main
+void adopt_rare_done(DeviceGraph& dg, DeviceBatch& b);
+void reserve_hist(DeviceGraph& dg, uint64_t keys);   // bound on distinct IL/OL keys of the whole (sharded) run
 void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 // device pointers of the dense counters, for collectives run by the caller (RCCL via torch.distributed)
 // base[0 .. words): {NC, IL0, OLL, RC of the first out-slot} per node (4 V words), then RC per adjacency slot (A words).

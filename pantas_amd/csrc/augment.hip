@@ -750,9 +750,13 @@ struct DeviceGraph {
   uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
   Table hist, novel;
   // multi-batch protocol: every batch's rare-key kernel must run before the first main kernel of the run
-  std::vector<const void*> rare_done;
+  std::vector<uint64_t> main_done;   // ids of the batches whose main kernel has run at least once this run
+  std::vector<uint64_t> rare_done;   // ids of the batches whose rare-key kernel has run (DeviceBatch::id: never reused, unlike addresses)
   bool main_started = false;
+  uint64_t hist_bound = 0;        // bound on the distinct IL/OL keys of the batches registered so far this run (4 per path node of a record with a '-')
+  uint64_t novel_room = 0;        // keys the novel-link table must be able to take (what it held when the last batch registered + that batch's guess)
   uint64_t novel_boost = 1;       // grown after a TableOverflow("novel") retry
+  uint64_t hist_boost = 1;        // grown after a TableOverflow("hist") retry
   uint64_t imported_flags = 0;    // node flags received from other ranks this run
   uint64_t reserved_hist = 0;     // caller's bound on distinct IL/OL keys (sharded runs)
   SlowTables* slow_dev = nullptr;   // device copy of {hist, novel, status}
@@ -899,7 +903,10 @@ void reset_counters(DeviceGraph& d) {
   d.imported_flags = 0;
   d.reserved_hist = 0;
   d.rare_done.clear();
+  d.main_done.clear();
   d.main_started = false;
+  d.hist_bound = 0;
+  d.novel_room = 0;
 }
 
 template <class T>
@@ -910,14 +917,33 @@ static T* to_device(const std::vector<T>& v, hipStream_t s) {
   return p;
 }
 
-// Grows the two tables for the batch about to run.  Only legal while they are empty.
-static void size_tables(DeviceGraph& d, uint64_t hist_keys_bound, uint64_t novel_keys_guess) {
-  const uint32_t hc = pow2_at_least(2 * hist_keys_bound + 1024);
-  const uint32_t nc = pow2_at_least(2 * novel_keys_guess + 1024);
-  bool grew = false;
-  if (hc > d.hist.cap) { table_alloc(d.hist, hc, d.small + 2, d.small + 3); grew = true; }
-  if (nc > d.novel.cap) { table_alloc(d.novel, nc, d.small + 4, d.small + 5); grew = true; }
-  if (grew) { table_clear(d.hist, d.stream); table_clear(d.novel, d.stream); }
+// every live entry of `from` into `to` (to is empty and larger): counts add, first-seen minima carry over
+__global__ void rehash_kernel(TableView from, TableView to) {
+  const uint32_t cap = from.mask + 1u;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cap; i += gridDim.x * 256u) {
+    const uint64_t k = from.keys[i];
+    if (k != EMPTY_KEY) table_update(to, k, from.cnt[i], from.first[i]);
+  }
+}
+
+// Grows a table to `cap` slots keeping what it holds (a run over several batches learns its sizes batch by batch).
+static void table_grow(DeviceGraph& d, Table& t, uint32_t cap, uint32_t* n_keys, uint32_t* overflow) {
+  if (t.cap >= cap) return;
+  Table big;
+  table_alloc(big, cap, n_keys, overflow);
+  table_clear(big, d.stream);
+  if (t.cap) {
+    // the rehash counts the keys again as it inserts them
+    HIP_OK(hipMemsetAsync(n_keys, 0, 4, d.stream));
+    TableView from = t.v;
+    from.n_keys = n_keys; from.overflow = overflow;
+    const uint32_t blocks = std::min<uint32_t>((t.cap + 255) / 256, 8192);
+    hipLaunchKernelGGL(rehash_kernel, dim3(blocks), dim3(256), 0, d.stream, from, big.v);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipStreamSynchronize(d.stream));
+  t.free_all();
+  t = big;
 }
 
 __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, uint4* rec) {
@@ -1013,21 +1039,45 @@ static BatchView batch_view(const DeviceBatch& b) {
   return v;
 }
 
-static void ensure_tables(DeviceGraph& d, DeviceBatch& b) {
-  // capacity: every rare event and every flagged dense key is at most one key per (node, side) visit
-  const uint64_t hist_bound = std::max<uint64_t>(4 * b.del_nodes, d.reserved_hist);
+// A batch enters the run (its rare-key kernel is about to be launched for the first time): account for the IL/OL keys it
+// can add -- every rare event and every flagged common key is at most one key per (node, side) visit of a record with a
+// '-' op: a true bound, summed over the batches of the run.
+static void register_batch(DeviceGraph& d, const DeviceBatch& b) { d.hist_bound += 4 * b.del_nodes; }
+
+// The first main kernel of a batch is about to run: room in the novel-link table for what it holds now plus a guess for
+// this batch (a quarter of its links; an overflow is reported by finish and the caller redoes the run with novel_boost
+// raised).  Sized batch by batch: a streamed run does not know its length when it starts.
+static void register_batch_main(DeviceGraph& d, const DeviceBatch& b) {
   const uint64_t edges = b.n_nodes > b.n ? b.n_nodes - b.n : 0;
-  const uint64_t novel_guess = std::min<uint64_t>(edges, std::max<uint64_t>(1u << 16, edges / 4 * d.novel_boost));
-  if (hist_bound * 2 + 1024 > d.hist.cap || novel_guess * 2 + 1024 > d.novel.cap) {
-    // growing drops what the tables hold: only allowed right after a reset
-    uint32_t nk[4];
-    HIP_OK(hipMemcpy(nk, d.small + 2, 16, hipMemcpyDeviceToHost));
-    if (nk[0] || nk[2]) throw Error("InternalError", "device tables must be sized before the first batch of a run");
-    size_tables(d, hist_bound, novel_guess);
+  const uint64_t guess = std::min<uint64_t>(edges, std::max<uint64_t>(1u << 16, edges / 4 * d.novel_boost));
+  uint32_t held = 0;
+  if (!d.main_done.empty()) {    // not the first batch of the run (whose table is empty: no round trip)
+    HIP_OK(hipMemcpyAsync(&held, d.small + 4, 4, hipMemcpyDeviceToHost, d.stream));   // behind the kernels of the batches before
+    HIP_OK(hipStreamSynchronize(d.stream));
   }
+  d.novel_room = std::max<uint64_t>(d.novel_room, uint64_t(held) + guess);
+}
+
+// Tables large enough for everything registered so far; growing keeps their contents (rehash on the device).
+static void ensure_tables(DeviceGraph& d) {
+  const uint64_t hist_keys = std::max<uint64_t>(d.hist_bound, d.reserved_hist) * d.hist_boost;
+  const uint32_t hc = pow2_at_least(2 * hist_keys + 1024);
+  const uint32_t nc = pow2_at_least(2 * d.novel_room + 1024);
+  if (hc > d.hist.cap) table_grow(d, d.hist, hc, d.small + 2, d.small + 3);
+  if (nc > d.novel.cap) table_grow(d, d.novel, nc, d.small + 4, d.small + 5);
 }
 
 void boost_novel_table(DeviceGraph& d) { d.novel_boost *= 4; }
+void boost_hist_table(DeviceGraph& d) { d.hist_boost *= 4; }
+uint64_t device_free_bytes(DeviceGraph& d) {
+  HIP_OK(hipSetDevice(d.device));
+  size_t free_b = 0, total_b = 0;
+  HIP_OK(hipMemGetInfo(&free_b, &total_b));
+  return free_b;
+}
+void adopt_rare_done(DeviceGraph& d, DeviceBatch& b) {
+  if (std::find(d.rare_done.begin(), d.rare_done.end(), b.id) == d.rare_done.end()) d.rare_done.push_back(b.id);
+}
 void reserve_hist(DeviceGraph& d, uint64_t keys) { d.reserved_hist = keys; }
 
 static float launch_rare_impl(DeviceGraph& d, DeviceBatch& b, bool wait);
@@ -1037,12 +1087,12 @@ float launch_rare(DeviceGraph& d, DeviceBatch& b) { return launch_rare_impl(d, b
 // events once, instead of two host round trips per step)
 static float launch_rare_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
   HIP_OK(hipSetDevice(d.device));
-  const bool seen = std::find(d.rare_done.begin(), d.rare_done.end(), static_cast<const void*>(&b)) != d.rare_done.end();
+  const bool seen = std::find(d.rare_done.begin(), d.rare_done.end(), b.id) != d.rare_done.end();
   if (d.main_started && !seen)
     throw Error("ProtocolError", "rare-key kernel of a new batch after a main kernel of the same run: the node flags it sets "
                                  "come too late for the batches already walked (launch_rare for every batch first)");
-  if (!seen) d.rare_done.push_back(&b);
-  ensure_tables(d, b);
+  if (!seen) { d.rare_done.push_back(b.id); register_batch(d, b); }
+  ensure_tables(d);
   d.sync_slow();
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
@@ -1064,10 +1114,11 @@ static float launch_rare_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
 
 float launch_main(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
-  if (std::find(d.rare_done.begin(), d.rare_done.end(), static_cast<const void*>(&b)) == d.rare_done.end())
+  if (std::find(d.rare_done.begin(), d.rare_done.end(), b.id) == d.rare_done.end())
     throw Error("ProtocolError", "main kernel of a batch whose rare-key kernel has not run");
   d.main_started = true;
-  ensure_tables(d, b);
+  if (std::find(d.main_done.begin(), d.main_done.end(), b.id) == d.main_done.end()) { register_batch_main(d, b); d.main_done.push_back(b.id); }
+  ensure_tables(d);
   d.sync_slow();
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);

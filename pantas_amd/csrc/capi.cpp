@@ -23,6 +23,7 @@ struct pantas_graph {
   std::shared_ptr<Error> deferred;   // tokeniser error of a loaded batch, reported by finish (see gaf.h)
   int tokenizer = PANTAS_TOKENIZER_AUTO;
   double load_s = 0;
+  std::unique_ptr<struct StreamState> stream;   // a run over a GAF byte range in several batches (pantas_augment_stream_*)
   // call
   std::unique_ptr<CallTables> call_tables;
   DeviceCallPtr call_dev;
@@ -36,6 +37,24 @@ struct pantas_synth {
 struct pantas_batch {
   DeviceBatchPtr dev;
   pantas_batch_stats st{};
+};
+
+// One byte range of the GAF handled as a batch.  After the rare-key pass the batch either stays in HBM (resident) or, when
+// the residency budget is spent, is dropped and tokenised again for the main pass.
+struct StreamBatch {
+  uint64_t begin = 0, end = 0, first_line = 0;
+  std::unique_ptr<pantas_batch> resident;
+  uint64_t device_bytes = 0;
+};
+struct StreamState {
+  MappedFile file;
+  int thr = 20;
+  std::vector<StreamBatch> batches;
+  uint64_t max_batch_bytes = 0;
+  uint64_t resident_bytes = 0, resident_budget = 0;
+  uint64_t retokenised = 0;
+  bool main_done = false;
+  pantas_batch_stats total{};
 };
 
 namespace {
@@ -78,6 +97,29 @@ void need_device(pantas_graph* g) {
   if (!g->dev) throw Error("NoDevice", "graph is not on a device: call pantas_graph_to_device first");
 }
 
+// Structs of the ABI start with the size their owner declared (include/pantas_gpu.h): copy out / in that many bytes.
+template <class T>
+uint32_t declared_size(const T* p, const char* what) {
+  const uint32_t n = p->struct_size;
+  if (n < 8 || n > 4096 || (n & 3u)) throw Error("ArgumentError", std::string(what) + ".struct_size is not set (set it to sizeof(" + what + ") before the call)");
+  return n;
+}
+template <class T>
+void put_out(T* dst, T src, const char* what) {
+  if (!dst) return;
+  const uint32_t n = declared_size(dst, what);
+  src.struct_size = n;
+  src.reserved0_ = 0;
+  memcpy(dst, &src, std::min<size_t>(n, sizeof(T)));
+}
+template <class T>
+T get_in(const T* src, const char* what) {
+  T v;
+  memset(&v, 0, sizeof v);
+  memcpy(&v, src, std::min<size_t>(declared_size(src, what), sizeof(T)));
+  return v;
+}
+
 constexpr uint64_t KIND_HIST = 0, KIND_NOVEL = 1;
 constexpr uint32_t COMMON_CODE = 0x7FFFFFFFu;
 
@@ -100,6 +142,7 @@ __attribute__((visibility("default"))) const char* pantas_last_error(void) { ret
 __attribute__((visibility("default"))) const char* pantas_last_error_kind(void) { return g_kind.c_str(); }
 __attribute__((visibility("default"))) const char* pantas_version(void) { return "pantas-mi355x 0.1 (gfx950)"; }
 __attribute__((visibility("default"))) int pantas_device_count(void) { return device_count(); }
+__attribute__((visibility("default"))) int pantas_abi_version(void) { return PANTAS_ABI_VERSION; }
 
 __attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_path, pantas_graph** out) {
   return guarded([&] {
@@ -135,16 +178,18 @@ __attribute__((visibility("default"))) int pantas_graph_get_stats(const pantas_g
   return guarded([&] {
     need(g && g->g && out, "null argument");
     const Graph& G = *g->g;
-    out->segments = G.V;
-    out->link_slots = G.A;
-    out->lines = G.n_lines;
-    out->s_lines = G.n_s_lines;
-    out->l_lines = G.n_l_lines;
-    out->p_lines = G.n_p_lines;
-    out->text_bytes = G.text.size;
-    out->max_segment_len = G.max_seg_len;
-    out->dense_names = G.names.dense ? 1u : 0u;
-    out->load_seconds = g->load_s;
+    pantas_graph_stats o{};
+    o.segments = G.V;
+    o.link_slots = G.A;
+    o.lines = G.n_lines;
+    o.s_lines = G.n_s_lines;
+    o.l_lines = G.n_l_lines;
+    o.p_lines = G.n_p_lines;
+    o.text_bytes = G.text.size;
+    o.max_segment_len = G.max_seg_len;
+    o.dense_names = G.names.dense ? 1u : 0u;
+    o.load_seconds = g->load_s;
+    put_out(out, o, "pantas_graph_stats");
   });
 }
 
@@ -163,6 +208,7 @@ __attribute__((visibility("default"))) int pantas_augment_reset(pantas_graph* g)
     g->res = AugmentResult();
     g->lines = g->rejected = g->skipped = 0;
     g->deferred.reset();
+    g->stream.reset();
   });
 }
 
@@ -210,7 +256,7 @@ static int effective_tokenizer(const pantas_graph* g) {
 }
 
 static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int thr, uint64_t first_line,
-                            pantas_batch** out, pantas_batch_stats* stats) {
+                            pantas_batch** out, pantas_batch_stats* stats, const DeviceText* resident_text = nullptr, bool account = true) {
   GafBatch b;
   auto h = std::make_unique<pantas_batch>();
   pantas_batch_stats& s = h->st;
@@ -218,7 +264,7 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
   s.tokenizer = mode;
   if (mode == PANTAS_TOKENIZER_DEVICE) {
     DeviceTokenizeTimes tm;
-    h->dev = tokenize_gaf_device(*g->dev, *g->g, data, size, thr, first_line, b, &tm);
+    h->dev = tokenize_gaf_device(*g->dev, *g->g, data, size, thr, first_line, b, &tm, resident_text);
     s.records = batch_lines(*h->dev);
     s.tokenize_seconds = tm.total_s - tm.h2d_s;
     s.upload_seconds = tm.h2d_s;
@@ -252,11 +298,13 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
   s.alg_bytes = batch_alg_bytes(*h->dev);
   s.short_records = batch_short_records(*h->dev);
   s.short_alg_bytes = batch_alg_bytes_short(*h->dev);
-  g->lines += b.lines_total;
-  g->rejected += b.rejected;
-  g->skipped += b.skipped;
-  if (b.deferred && !g->deferred) g->deferred = b.deferred;
-  if (stats) *stats = s;
+  if (account) {   // (a batch tokenised a second time for the main pass of a streamed run was counted the first time)
+    g->lines += b.lines_total;
+    g->rejected += b.rejected;
+    g->skipped += b.skipped;
+    if (b.deferred && !g->deferred) g->deferred = b.deferred;
+  }
+  if (stats) put_out(stats, s, "pantas_batch_stats");
   *out = h.release();
 }
 
@@ -314,7 +362,9 @@ __attribute__((visibility("default"))) int pantas_augment_launch(pantas_graph* g
     need(b && b->dev, "null batch");
     float r = 0, m = 0;
     launch_augment(*g->dev, *b->dev, &r, &m);
-    if (out) { out->rare_ms = r; out->main_ms = m; out->main_short_ms = last_short_kernel_ms(*g->dev); out->reserved_ = 0; }
+    pantas_launch_stats o{};
+    o.rare_ms = r; o.main_ms = m; o.main_short_ms = last_short_kernel_ms(*g->dev);
+    put_out(out, o, "pantas_launch_stats");
   });
 }
 
@@ -508,29 +558,210 @@ __attribute__((visibility("default"))) int pantas_augment_write_gfa(pantas_graph
   });
 }
 
+// ---- a run over a GAF of any size (alignments_augmentation_from_gaf.py:135-138 reads line by line, no limit) ---------------------
+// The byte range is cut at line starts into batches of at most PANTAS_BATCH_BYTES of text (default 2 GiB; the GPU tokeniser's
+// own limits are ~8.6 GB of text and 2^32 path nodes per batch).  Rare-key pass: batch by batch, tokenise -> rare-key kernel,
+// with the text of the next batch on its way to HBM meanwhile (TextPrefetcher).  The tokenised records stay in HBM as long as
+// they fit the residency budget (PANTAS_RESIDENT_BYTES, default 60 % of the memory free at the start): records are smaller than
+// their text and 288 GB hold billions of reads beside a whole-genome graph.  Main pass: resident batches are launched as they
+// are, dropped ones are tokenised again first.  The rare-before-main order is what the first-seen order of the common IL/OL
+// key needs (augment.hip): every flag must be set before the first main kernel runs.
+
+static uint64_t env_u64(const char* name, uint64_t dflt) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  char* end = nullptr;
+  const unsigned long long v = strtoull(e, &end, 10);
+  if (end == e || *end) throw Error("ValueError", std::string(name) + " must be a non-negative integer");
+  return v;
+}
+
+static void add_stats(pantas_batch_stats& t, const pantas_batch_stats& s) {
+  t.lines += s.lines; t.rejected += s.rejected; t.skipped += s.skipped; t.records += s.records; t.path_nodes += s.path_nodes;
+  t.cs_ops += s.cs_ops; t.del_records += s.del_records; t.del_path_nodes += s.del_path_nodes; t.text_bytes += s.text_bytes;
+  t.alg_bytes += s.alg_bytes; t.tokenize_seconds += s.tokenize_seconds; t.upload_seconds += s.upload_seconds;
+  t.tokenizer = s.tokenizer;
+  t.tok_index_seconds += s.tok_index_seconds; t.tok_measure_seconds += s.tok_measure_seconds; t.tok_write_seconds += s.tok_write_seconds;
+  t.tok_bucket_seconds += s.tok_bucket_seconds; t.short_records += s.short_records; t.short_alg_bytes += s.short_alg_bytes;
+}
+
+// next cut at or behind `want`: a position that follows a '\n' (or the range end)
+static uint64_t cut_at_line_start(const MappedFile& f, uint64_t want, uint64_t end) {
+  if (want >= end) return end;
+  if (want == 0) return 0;
+  const void* nl = memchr(f.data + want - 1, '\n', size_t(end - (want - 1)));
+  return nl ? uint64_t(static_cast<const char*>(nl) - f.data) + 1 : end;
+}
+
+static uint64_t batch_device_bytes(const pantas_batch_stats& s) {
+  // hdr 16 + offsets 8 + rec 32 per record, 4 per path node and cs op, 4 per record with a '-'
+  return 56 * s.records + 4 * (s.path_nodes + s.cs_ops) + 4 * s.del_records + 4096;
+}
+
+static void stream_rare_pass(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end, uint64_t first_line,
+                             pantas_batch_stats* stats, float* rare_ms) {
+  auto st = std::make_unique<StreamState>();
+  st->file.open(gaf_path);
+  st->thr = thr;
+  if (end == 0 || end > st->file.size) end = st->file.size;
+  need(begin <= end, "bad byte range");
+  const uint64_t cap = std::max<uint64_t>(1, env_u64("PANTAS_BATCH_BYTES", uint64_t(2) << 30));
+  if (cap > (uint64_t(8) << 30)) throw Error("ValueError", "PANTAS_BATCH_BYTES above 8 GiB (the tokeniser's limit per batch)");
+  for (uint64_t b = begin; b < end;) {
+    const uint64_t e = cut_at_line_start(st->file, std::min(end, b + cap), end);
+    StreamBatch sb;
+    sb.begin = b; sb.end = e;
+    st->batches.push_back(std::move(sb));
+    st->max_batch_bytes = std::max(st->max_batch_bytes, e - b);
+    b = e;
+  }
+  st->resident_budget = env_u64("PANTAS_RESIDENT_BYTES", device_free_bytes(*g->dev) / 10 * 6);
+  const bool on_device = effective_tokenizer(g) == PANTAS_TOKENIZER_DEVICE;
+  TextPrefetcherPtr pf;
+  // one batch: nothing to overlap, the tokeniser copies the text itself (and needs no second text buffer)
+  if (on_device && st->batches.size() > 1) pf = make_text_prefetcher(*g->dev, size_t(st->max_batch_bytes));
+  PhaseTimer pt("augment_stream rare pass");
+  size_t started = 0;
+  auto start_next = [&] {
+    if (pf && started < st->batches.size()) {
+      const StreamBatch& nb = st->batches[started++];
+      prefetch_start(*pf, st->file.data + nb.begin, size_t(nb.end - nb.begin));
+    }
+  };
+  start_next();
+  float ms_total = 0;
+  uint64_t line = first_line;
+  size_t n_loaded = 0;
+  for (size_t i = 0; i < st->batches.size(); ++i) {
+    StreamBatch& sb = st->batches[i];
+    sb.first_line = line;
+    DeviceText txt;
+    if (pf) { txt = prefetch_get(*pf); start_next(); }
+    pantas_batch* raw = nullptr;
+    pantas_batch_stats bs{};
+    bs.struct_size = sizeof bs;
+    load_gaf_common(g, st->file.data + sb.begin, size_t(sb.end - sb.begin), thr, line, &raw, &bs, pf ? &txt : nullptr, true);
+    std::unique_ptr<pantas_batch> b(raw);
+    add_stats(st->total, bs);
+    line += bs.lines;
+    ms_total += launch_rare(*g->dev, *b->dev);
+    sb.device_bytes = batch_device_bytes(bs);
+    if (st->resident_bytes + sb.device_bytes <= st->resident_budget) {
+      st->resident_bytes += sb.device_bytes;
+      sb.resident = std::move(b);
+    }
+    ++n_loaded;
+    if (g->deferred) break;    // the reference dies at this line: what follows it in the file is never read
+  }
+  if (pf && started > n_loaded) {
+    // a range was already on its way when the run stopped at a raising line: let its copy finish before the buffers go
+    for (size_t k = n_loaded; k < started; ++k) (void)prefetch_get(*pf);
+  }
+  st->batches.resize(n_loaded);
+  pt.lap("tokenise + rare-key kernels");
+  put_out(stats, st->total, "pantas_batch_stats");
+  if (rare_ms) *rare_ms = ms_total;
+  g->stream = std::move(st);
+}
+
+static void stream_main_pass(pantas_graph* g, float* main_ms) {
+  if (!g->stream) throw Error("ProtocolError", "pantas_augment_stream_main before pantas_augment_stream_rare");
+  StreamState& st = *g->stream;
+  if (st.main_done) throw Error("ProtocolError", "pantas_augment_stream_main twice in one run");
+  PhaseTimer pt("augment_stream main pass");
+  const bool on_device = effective_tokenizer(g) == PANTAS_TOKENIZER_DEVICE;
+  std::vector<size_t> redo;
+  for (size_t i = 0; i < st.batches.size(); ++i) if (!st.batches[i].resident) redo.push_back(i);
+  TextPrefetcherPtr pf;
+  if (on_device && redo.size() > 1) pf = make_text_prefetcher(*g->dev, size_t(st.max_batch_bytes));
+  size_t started = 0;
+  auto start_next = [&] {
+    if (pf && started < redo.size()) {
+      const StreamBatch& nb = st.batches[redo[started++]];
+      prefetch_start(*pf, st.file.data + nb.begin, size_t(nb.end - nb.begin));
+    }
+  };
+  float ms_total = 0;
+  // resident batches first: their records are where they are
+  for (StreamBatch& sb : st.batches)
+    if (sb.resident) ms_total += launch_main(*g->dev, *sb.resident->dev);
+  pt.lap("main kernels (resident batches)");
+  start_next();
+  for (size_t k = 0; k < redo.size(); ++k) {
+    StreamBatch& sb = st.batches[redo[k]];
+    DeviceText txt;
+    if (pf) { txt = prefetch_get(*pf); start_next(); }
+    pantas_batch* raw = nullptr;
+    load_gaf_common(g, st.file.data + sb.begin, size_t(sb.end - sb.begin), st.thr, sb.first_line, &raw, nullptr, pf ? &txt : nullptr, false);
+    std::unique_ptr<pantas_batch> b(raw);
+    // the same records in the same order as in the rare-key pass: it stands in for the batch whose rare-key kernel ran
+    adopt_rare_done(*g->dev, *b->dev);
+    ms_total += launch_main(*g->dev, *b->dev);
+    ++st.retokenised;
+  }
+  if (!redo.empty()) pt.lap("re-tokenise + main kernels (dropped batches)");
+  st.main_done = true;
+  if (main_ms) *main_ms = ms_total;
+}
+
+__attribute__((visibility("default"))) int pantas_augment_stream_rare(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end,
+                                                                       uint64_t first_line, pantas_batch_stats* stats, float* rare_ms) {
+  return guarded([&] {
+    need_device(g);
+    need(gaf_path != nullptr, "null argument");
+    if (g->stream) throw Error("ProtocolError", "one streamed byte range per run: pantas_augment_reset first");
+    stream_rare_pass(g, gaf_path, thr, begin, end, first_line, stats, rare_ms);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_stream_main(pantas_graph* g, float* main_ms) {
+  return guarded([&] {
+    need_device(g);
+    stream_main_pass(g, main_ms);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_stream_info(const pantas_graph* g, uint64_t* batches, uint64_t* resident, uint64_t* retokenised) {
+  return guarded([&] {
+    need(g && g->stream, "no streamed run on this handle");
+    uint64_t r = 0;
+    for (const StreamBatch& sb : g->stream->batches) r += sb.resident ? 1 : 0;
+    if (batches) *batches = g->stream->batches.size();
+    if (resident) *resident = r;
+    if (retokenised) *retokenised = g->stream->retokenised;
+  });
+}
+
 __attribute__((visibility("default"))) int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
                        pantas_launch_stats* launch) {
-  int rc = pantas_augment_reset(g);
-  if (rc) return rc;
-  pantas_batch* b = nullptr;
-  rc = pantas_augment_load_gaf(g, gaf_path, thr, 0, 0, 0, &b, stats);
-  if (rc) return rc;
+  int rc = PANTAS_OK;
   for (int attempt = 0; attempt < 6; ++attempt) {
-    rc = pantas_augment_launch(g, b, launch);
-    if (rc) break;
+    rc = pantas_augment_reset(g);
+    if (rc) return rc;
+    float rare = 0, mainms = 0;
+    rc = pantas_augment_stream_rare(g, gaf_path, thr, 0, 0, 0, stats, &rare);
+    if (rc) return rc;
+    rc = pantas_augment_stream_main(g, &mainms);
+    if (rc) return rc;
+    if (launch) {
+      pantas_launch_stats o{};
+      o.rare_ms = rare; o.main_ms = mainms;
+      const int r2 = guarded([&] { put_out(launch, o, "pantas_launch_stats"); });
+      if (r2) return r2;
+    }
     rc = pantas_augment_finish(g);
     if (rc == PANTAS_E_INTERNAL && g_kind == "TableOverflow") {
-      // the novel-link table was sized from a guess: enlarge and redo the run
-      uint64_t lines = g->lines, rej = g->rejected, skip = g->skipped;
-      boost_novel_table(*g->dev);
-      int r2 = pantas_augment_reset(g);
-      if (r2) { rc = r2; break; }
-      g->lines = lines; g->rejected = rej; g->skipped = skip;
+      // a table sized from a guess was too small: enlarge it and redo the run from the text (every batch is tokenised
+      // again, so a deferred tokeniser error comes back with it)
+      if (g_err.find("hist") != std::string::npos) boost_hist_table(*g->dev); else boost_novel_table(*g->dev);
       continue;
     }
     break;
   }
-  pantas_batch_free(b);
+  if (g->stream) {   // the records are not needed once the counters are final
+    for (StreamBatch& sb : g->stream->batches) sb.resident.reset();
+    g->stream->file.close();
+  }
   if (rc) return rc;
   if (fd_out >= 0) rc = pantas_augment_write_gfa(g, fd_out);
   return rc;
@@ -549,11 +780,14 @@ __attribute__((visibility("default"))) int pantas_call_prepare(pantas_graph* g, 
   });
 }
 
-__attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, const pantas_call_opts* opts, int fd_csv, int fd_err,
-                                                            pantas_call_stats* stats) {
+__attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, const pantas_call_opts* opts_in, int fd_csv, int fd_err,
+                                                            pantas_call_stats* stats_out) {
   return guarded([&] {
-    need(g && g->g && opts, "null argument");
+    need(g && g->g && opts_in, "null argument");
     if (!g->call_dev || !g->call_tables) throw Error("NoDevice", "call tables are not on a device: call pantas_call_prepare first");
+    const pantas_call_opts opts_v = get_in(opts_in, "pantas_call_opts");   // fields the caller's declaration lacks read as 0
+    const pantas_call_opts* opts = &opts_v;
+    if (stats_out) (void)declared_size(stats_out, "pantas_call_stats");   // refuse before any work is done
     CallOptions o;
     o.rca = opts->rca;
     o.isw = opts->isw;
@@ -580,7 +814,9 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     render_events_to_fd(*g->g, *g->call_tables, recs.data(), recs.size(), co.side.data(), co.tasks.data(), co.paths.data(), fd_csv, err);
     double t1 = now_s();
     if (fd_err >= 0) write_fd(fd_err, err);
-    if (stats) {
+    if (stats_out) {
+      pantas_call_stats st_local{};
+      pantas_call_stats* stats = &st_local;
       const CallTables& t = *g->call_tables;
       stats->junctions = t.junctions.size();
       stats->novel_links = t.novels.size();
@@ -607,14 +843,17 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
       stats->annotated_ms = times.annotated_ms;
       stats->novel_ms = times.novel_ms;
       stats->around_ms = times.around_ms;
+      put_out(stats_out, st_local, "pantas_call_stats");
     }
   });
 }
 
 
-__attribute__((visibility("default"))) void pantas_synth_defaults(pantas_synth_params* p) {
-  if (!p) return;
+__attribute__((visibility("default"))) void pantas_synth_defaults(pantas_synth_params* out) {
+  if (!out) return;
   SynthParams d;
+  pantas_synth_params v{};
+  pantas_synth_params* p = &v;
   p->seed = d.seed; p->n_genes = d.n_genes; p->n_chrom = d.n_chrom; p->n_lines = d.n_lines; p->base_id = d.base_id;
   p->bubble_rate = d.bubble_rate; p->max_exons = d.max_exons; p->intron_long_max = d.intron_long_max;
   p->intergenic_min = d.intergenic_min; p->intergenic_max = d.intergenic_max; p->read_len = d.read_len;
@@ -623,12 +862,15 @@ __attribute__((visibility("default"))) void pantas_synth_defaults(pantas_synth_p
   p->p_novel_skip = d.p_novel_skip; p->p_novel_ce = d.p_novel_ce; p->p_intron = d.p_intron; p->p_novel_ss = d.p_novel_ss;
   p->p_clip = d.p_clip;
   p->line_offset = 0;
+  (void)guarded([&] { put_out(out, v, "pantas_synth_params"); });   // a declaration without struct_size is left untouched
 }
 
-__attribute__((visibility("default"))) int pantas_synth_generate(const pantas_synth_params* p, pantas_synth** out,
-                                                                  pantas_synth_stats* stats) {
+__attribute__((visibility("default"))) int pantas_synth_generate(const pantas_synth_params* p_in, pantas_synth** out,
+                                                                  pantas_synth_stats* stats_out) {
   return guarded([&] {
-    need(p && out, "null argument");
+    need(p_in && out, "null argument");
+    const pantas_synth_params pv = get_in(p_in, "pantas_synth_params");
+    const pantas_synth_params* p = &pv;
     SynthParams d;
     d.seed = p->seed; d.n_genes = p->n_genes; d.n_chrom = p->n_chrom ? p->n_chrom : 1; d.n_lines = p->n_lines; d.base_id = p->base_id;
     d.bubble_rate = p->bubble_rate; d.max_exons = p->max_exons; d.intron_long_max = p->intron_long_max;
@@ -641,11 +883,14 @@ __attribute__((visibility("default"))) int pantas_synth_generate(const pantas_sy
     auto h = std::make_unique<pantas_synth>();
     double t0 = now_s();
     synth_generate(d, h->out);
-    if (stats) {
+    if (stats_out) {
+      pantas_synth_stats st_local{};
+      pantas_synth_stats* stats = &st_local;
       stats->nodes = h->out.nodes; stats->links = h->out.links; stats->junction_links = h->out.junction_links;
       stats->transcripts = h->out.transcripts; stats->gaf_lines = h->out.gaf_lines;
       stats->gfa_bytes = h->out.gfa.size(); stats->gtf_bytes = h->out.gtf.size(); stats->gaf_bytes = h->out.gaf.size();
       stats->seconds = now_s() - t0;
+      put_out(stats_out, st_local, "pantas_synth_stats");
     }
     *out = h.release();
   });

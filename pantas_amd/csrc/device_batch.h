@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <memory>
 #include <vector>
 
@@ -18,7 +19,14 @@ namespace pantas {
       throw Error("HipError", std::string(#expr) + ": " + hipGetErrorString(e__));                     \
   } while (0)
 
+// identity of a resident batch for the rare-before-main protocol of a run (an address can be reused after a free)
+inline uint64_t next_batch_id() {
+  static std::atomic<uint64_t> n{1};
+  return n.fetch_add(1);
+}
+
 struct DeviceBatch {
+  uint64_t id = next_batch_id();
   LineHdr* hdr = nullptr;
   uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
   uint4* rec = nullptr;          // derived per record, 32 bytes: {node_off, op_off, path nodes (8 bits, saturated) | cs ops << 8, id of

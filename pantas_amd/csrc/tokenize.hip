@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <thread>
+
 #include "augment.h"
 #include "device_batch.h"
 #include "gaf_device.h"
@@ -314,15 +316,15 @@ double now() { return now_s(); }
 
 // host text -> HBM through two pinned staging buffers (kept with the graph); several host threads fill one buffer while
 // the other is in flight
-void upload_text(ScratchPool& sp, const char* data, size_t size, uint8_t* dst, hipStream_t stream) {
+void upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinned_bytes, const char* data, size_t size, uint8_t* dst, hipStream_t stream) {
   constexpr size_t STAGE = size_t(32) << 20;
   if (size == 0) return;
-  if (!sp.pinned[0]) {
+  if (!pinned[0]) {
     for (int k = 0; k < 2; ++k) {
-      HIP_OK(hipHostMalloc(&sp.pinned[k], STAGE, hipHostMallocDefault));
-      HIP_OK(hipEventCreateWithFlags(&sp.pinned_done[k], hipEventDisableTiming));
+      HIP_OK(hipHostMalloc(&pinned[k], STAGE, hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&pinned_done[k], hipEventDisableTiming));
     }
-    sp.pinned_bytes = STAGE;
+    pinned_bytes = STAGE;
   }
   size_t off = 0;
   int k = 0;
@@ -330,12 +332,12 @@ void upload_text(ScratchPool& sp, const char* data, size_t size, uint8_t* dst, h
   const unsigned threads = std::min<unsigned>(hw_threads(), 16);
   while (off < size) {
     const size_t len = std::min(STAGE, size - off);
-    if (used[k]) HIP_OK(hipEventSynchronize(sp.pinned_done[k]));
-    char* dstp = static_cast<char*>(sp.pinned[k]);
+    if (used[k]) HIP_OK(hipEventSynchronize(pinned_done[k]));
+    char* dstp = static_cast<char*>(pinned[k]);
     const char* src = data + off;
     parallel_chunks(len, len < (size_t(4) << 20) ? 1u : threads, [&](unsigned, size_t b, size_t e) { memcpy(dstp + b, src + b, e - b); });
-    HIP_OK(hipMemcpyAsync(dst + off, sp.pinned[k], len, hipMemcpyHostToDevice, stream));
-    HIP_OK(hipEventRecord(sp.pinned_done[k], stream));
+    HIP_OK(hipMemcpyAsync(dst + off, pinned[k], len, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipEventRecord(pinned_done[k], stream));
     used[k] = true;
     off += len;
     k ^= 1;
@@ -343,12 +345,97 @@ void upload_text(ScratchPool& sp, const char* data, size_t size, uint8_t* dst, h
   HIP_OK(hipStreamSynchronize(stream));
 }
 
+// the kernels read whole tiles, and a line index entry may point one past the text: zero padding to a tile bound + one tile
+inline size_t text_padded_bytes(size_t size) { return (size + TILE - 1) / TILE * TILE + TILE; }
+
 inline uint32_t blocks_for(uint64_t n) { return uint32_t((n + TPB - 1) / TPB); }
 
 }  // namespace
 
+// ---- text of the NEXT batch on its way to HBM while the current one is tokenised and walked --------------------------
+// A run over a GAF larger than one batch (pantas_augment_run) is bound by getting the text to the GPU: page-cache reads,
+// the copy into pinned memory, PCIe.  The prefetcher owns two device text buffers, a copy stream and its own pinned
+// staging buffers; start() hands a byte range to a worker thread, get() waits for the oldest started range.
+struct TextPrefetcher {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* pinned[2] = {nullptr, nullptr};
+  hipEvent_t pinned_done[2] = {nullptr, nullptr};
+  size_t pinned_bytes = 0;
+  uint8_t* buf[2] = {nullptr, nullptr};
+  size_t cap = 0;                 // bytes of each device buffer
+  struct Job { std::thread th; std::shared_ptr<Error> err; size_t size = 0; double seconds = 0; };
+  Job job[2];
+  unsigned head = 0, tail = 0;    // ranges started / handed out (slot = index & 1)
+  double copy_seconds = 0;
+};
+
+void TextPrefetcherDeleter::operator()(TextPrefetcher* p) const {
+  if (!p) return;
+  for (auto& j : p->job) if (j.th.joinable()) j.th.join();
+  (void)hipSetDevice(p->device);
+  for (int k = 0; k < 2; ++k) {
+    if (p->buf[k]) (void)hipFree(p->buf[k]);
+    if (p->pinned[k]) (void)hipHostFree(p->pinned[k]);
+    if (p->pinned_done[k]) (void)hipEventDestroy(p->pinned_done[k]);
+  }
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+
+TextPrefetcherPtr make_text_prefetcher(DeviceGraph& dg, size_t max_bytes) {
+  const DeviceGraphInfo gi = graph_info(dg);
+  HIP_OK(hipSetDevice(gi.device));
+  TextPrefetcherPtr p(new TextPrefetcher());
+  p->device = gi.device;
+  p->cap = text_padded_bytes(max_bytes);
+  HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) HIP_OK(hipMalloc(&p->buf[k], p->cap));
+  return p;
+}
+
+void prefetch_start(TextPrefetcher& p, const char* data, size_t size) {
+  if (p.head - p.tail >= 2) throw Error("InternalError", "text prefetcher: both buffers are in use");
+  if (text_padded_bytes(size) > p.cap) throw Error("InternalError", "text prefetcher: range larger than its buffers");
+  const unsigned k = p.head & 1u;
+  TextPrefetcher::Job& j = p.job[k];
+  if (j.th.joinable()) j.th.join();
+  j.err.reset();
+  j.size = size;
+  TextPrefetcher* pp = &p;
+  j.th = std::thread([pp, k, data, size] {
+    TextPrefetcher::Job& job = pp->job[k];
+    const double t0 = now_s();
+    try {
+      HIP_OK(hipSetDevice(pp->device));
+      HIP_OK(hipMemsetAsync(pp->buf[k] + size, 0, text_padded_bytes(size) - size, pp->stream));
+      upload_text(pp->pinned, pp->pinned_done, pp->pinned_bytes, data, size, pp->buf[k], pp->stream);
+      HIP_OK(hipStreamSynchronize(pp->stream));
+    } catch (const Error& e) {
+      job.err = std::make_shared<Error>(e);
+    } catch (const std::exception& e) {
+      job.err = std::make_shared<Error>("InternalError", e.what());
+    }
+    job.seconds = now_s() - t0;
+  });
+  ++p.head;
+}
+
+DeviceText prefetch_get(TextPrefetcher& p) {
+  if (p.tail == p.head) throw Error("InternalError", "text prefetcher: nothing was started");
+  const unsigned k = p.tail & 1u;
+  TextPrefetcher::Job& j = p.job[k];
+  if (j.th.joinable()) j.th.join();
+  ++p.tail;
+  p.copy_seconds += j.seconds;
+  if (j.err) throw *j.err;
+  return DeviceText{p.buf[k], j.size};
+}
+
+double prefetch_copy_seconds(const TextPrefetcher& p) { return p.copy_seconds; }
+
 DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
-                                   GafBatch& st, DeviceTokenizeTimes* times) {
+                                   GafBatch& st, DeviceTokenizeTimes* times, const DeviceText* resident) {
   if (!g.names.dense)
     throw Error("Unsupported", "the GPU tokeniser needs segment names that are canonical decimals (this graph's are not): use the host tokeniser");
   const DeviceGraphInfo gi = graph_info(dg);
@@ -364,12 +451,21 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   const DenseNames names{d_table, g.names.base, uint64_t(g.names.table.size())};
 
   // ---- text
-  const size_t padded = (size + TILE - 1) / TILE * TILE + TILE;
+  const size_t padded = text_padded_bytes(size);
   DevBuf text(pool);
-  text.alloc(padded);
-  HIP_OK(hipMemsetAsync(text.as<uint8_t>() + size, 0, padded - size, s));
   double t0 = now();
-  upload_text(pool, data, size, text.as<uint8_t>(), s);
+  const uint8_t* d_text;
+  if (resident) {
+    // the text is in HBM already (TextPrefetcher copied it while the batch before this one was being handled)
+    if (resident->size != size || !resident->dev) throw Error("InternalError", "resident text does not match the range");
+    d_text = resident->dev;
+  } else {
+    text.alloc(padded);
+    HIP_OK(hipMemsetAsync(text.as<uint8_t>() + size, 0, padded - size, s));
+    upload_text(pool.pinned, pool.pinned_done, pool.pinned_bytes, data, size, text.as<uint8_t>(), s);
+    d_text = text.as<uint8_t>();
+  }
+  const uint4* d_text4 = reinterpret_cast<const uint4*>(d_text);
   tm.h2d_s = now() - t0;
   pt.lap("text -> HBM");
 
@@ -383,7 +479,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   HIP_OK(hipMemsetAsync(tile_cnt.p, 0, (size_t(tiles) + 1) * 4, s));
   t0 = now();
   if (tiles) {
-    hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, text.as<uint4>(), tile_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, d_text4, tile_cnt.as<uint32_t>());
     HIP_OK(hipGetLastError());
   }
   scan.run(tile_cnt.as<uint32_t>(), tile_off.as<uint32_t>(), size_t(tiles) + 1, s);
@@ -399,7 +495,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   ls.alloc((size_t(n_lines) + 2) * 8);
   HIP_OK(hipMemsetAsync(ls.p, 0, 8, s));
   if (tiles) {
-    hipLaunchKernelGGL(line_starts_kernel, dim3(tiles), dim3(TPB), 0, s, text.as<uint4>(), tile_off.as<uint32_t>(), ls.as<uint64_t>());
+    hipLaunchKernelGGL(line_starts_kernel, dim3(tiles), dim3(TPB), 0, s, d_text4, tile_off.as<uint32_t>(), ls.as<uint64_t>());
     HIP_OK(hipGetLastError());
   }
   if (open_tail) {
@@ -425,7 +521,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   HIP_OK(hipMemsetAsync(small.as<uint8_t>() + 8, 0, 56, s));
   t0 = now();
   if (n_lines) {
-    hipLaunchKernelGGL(measure_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, text.as<uint8_t>(), ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
+    hipLaunchKernelGGL(measure_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
                        kept.as<uint32_t>(), cnt_nodes.as<uint32_t>(), cnt_ops.as<uint32_t>(), meta.as<uint8_t>(), small.as<unsigned long long>());
     HIP_OK(hipGetLastError());
     hipLaunchKernelGGL(limit_and_totals_kernel, dim3(std::min<uint32_t>(blocks_for(n_lines), 2048)), dim3(TPB), 0, s, n_lines,
@@ -475,7 +571,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   nodes0.alloc((n_nodes + 1) * 4); ops0.alloc((n_ops + 1) * 4);
   t0 = now();
   if (n_lines) {
-    hipLaunchKernelGGL(write_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, text.as<uint8_t>(), ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
+    hipLaunchKernelGGL(write_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
                        kept.as<uint32_t>(), rec_of.as<uint32_t>(), node_scan.as<uint32_t>(), op_scan.as<uint32_t>(), uint32_t(first_line_id),
                        hdr0.as<LineHdr>(), node_off0.as<uint32_t>(), op_off0.as<uint32_t>(), nodes0.as<uint32_t>(), ops0.as<uint32_t>());
     HIP_OK(hipGetLastError());

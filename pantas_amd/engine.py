@@ -211,9 +211,27 @@ class Graph:
         check(lib.pantas_augment_write_gfa(self._h, fd))
 
     def augment(self, gaf_path: str, thr: int = 20, fd_out: int = -1):
+        """The whole script on a GAF of any size (cut into batches of PANTAS_BATCH_BYTES of text)."""
         bs, ls = BatchStats(), LaunchStats()
         check(lib.pantas_augment_run(self._h, os.fsencode(gaf_path), thr, fd_out, C.byref(bs), C.byref(ls)))
         return bs, ls
+
+    def stream_rare(self, gaf_path: str, thr: int = 20, begin: int = 0, end: int = 0, first_line: int = 0):
+        """Rare-key pass of a streamed run over bytes [begin, end) of the GAF: (totals over its batches, kernel ms)."""
+        bs, ms = BatchStats(), C.c_float()
+        check(lib.pantas_augment_stream_rare(self._h, os.fsencode(gaf_path), thr, begin, end, first_line, C.byref(bs), C.byref(ms)))
+        return bs, ms.value
+
+    def stream_main(self) -> float:
+        ms = C.c_float()
+        check(lib.pantas_augment_stream_main(self._h, C.byref(ms)))
+        return ms.value
+
+    def stream_info(self):
+        """(batches, resident after the rare-key pass, tokenised twice) of the streamed run."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.pantas_augment_stream_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     # ---- call ----------------------------------------------------------------------------
     def call_prepare(self, gtf_path: str, device: int = 0):
@@ -235,8 +253,9 @@ class Graph:
         mask = 0
         for e in events:
             mask |= {"ES": 1, "SS": 2, "IR": 4}.get(e, 0)
-        o = CallOpts(rca, isw, minintronsize, mask, int(bool(novel)), int(bool(no_annotated)),
-                     None if junction is None else os.fsencode(junction), shard[0], shard[1])
+        o = CallOpts(rca=rca, isw=isw, minintronsize=minintronsize, events=mask, novel=int(bool(novel)),
+                     no_annotated=int(bool(no_annotated)), junction=None if junction is None else os.fsencode(junction),
+                     shard_rank=shard[0], shard_world=shard[1])
         st = CallStats()
         check(lib.pantas_call_run(self._h, C.byref(o), fd_csv, fd_err, C.byref(st)))
         return st

@@ -1,0 +1,129 @@
+"""`pantas augment` over a GAF cut into many batches (pantas_augment_run = stream_rare + stream_main): the reference
+reads line by line with no size limit (alignments_augmentation_from_gaf.py:135-138), so the result must not depend on
+where the batches are cut, on whether a batch stayed in HBM between the two passes or was tokenised twice, or on the
+tokeniser.  First-seen order (IL/OL entries, novel links: A11/A12) is decided between lines of DIFFERENT batches here."""
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+import augment_oracle
+from conftest import CASES, GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_streamed(monkeypatch, gfa, gaf, batch_bytes, resident_bytes=None, tokenizer=None, thr=20):
+    from pantas_amd.engine import Graph
+    monkeypatch.setenv("PANTAS_BATCH_BYTES", str(batch_bytes))
+    if resident_bytes is None:
+        monkeypatch.delenv("PANTAS_RESIDENT_BYTES", raising=False)
+    else:
+        monkeypatch.setenv("PANTAS_RESIDENT_BYTES", str(resident_bytes))
+    g = Graph(gfa).to_device(0)
+    if tokenizer:
+        g.set_tokenizer(tokenizer)
+    with tempfile.TemporaryFile() as f:
+        bs, ls = g.augment(gaf, thr, f.fileno())
+        f.seek(0)
+        return f.read().decode(), bs, g.stream_info()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mode", ["resident", "dropped", "mixed"])
+def test_golden_bytes_in_tiny_batches(monkeypatch, case, mode):
+    d = os.path.join(GOLDEN, case)
+    size = os.path.getsize(f"{d}/in.gaf")
+    batch = max(64, size // 23)      # about two dozen batches, cut wherever the lines fall
+    resident = {"resident": None, "dropped": 0, "mixed": 40000}[mode]
+    want = open(f"{d}/expected.aug.gfa").read()
+    exp = json.load(open(f"{d}/expected.json"))
+    for tok in ("auto", "host"):      # auto = the GPU tokeniser wherever the segment names allow it
+        got, bs, (batches, kept, redone) = run_streamed(monkeypatch, f"{d}/in.gfa", f"{d}/in.gaf", batch, resident, tok)
+        assert got == want, (case, mode, tok)
+        assert bs.rejected == exp["rejected"]
+        if size > 2000:
+            assert batches >= 10
+        if mode == "resident":
+            assert kept == batches and redone == 0
+        if mode == "dropped":
+            assert kept == 0 and redone == batches
+
+
+def test_one_line_per_batch(monkeypatch):
+    """the smallest batches there are: every line its own batch (PANTAS_BATCH_BYTES=1 cuts at the next line start)"""
+    d = os.path.join(GOLDEN, "quirks")
+    got, bs, (batches, kept, redone) = run_streamed(monkeypatch, f"{d}/in.gfa", f"{d}/in.gaf", 1, 0)
+    assert got == open(f"{d}/expected.aug.gfa").read()
+    n_lines = open(f"{d}/in.gaf", "rb").read().count(b"\n")
+    assert batches >= n_lines - 1 and redone == batches
+
+
+def test_crash_inputs_in_tiny_batches(monkeypatch):
+    """a line the reference dies on ends the run with the same error class wherever the batch cuts fall; the lines
+    behind it are never read"""
+    from pantas_amd.engine import PantasError
+    crashes = [c for c in json.load(open(os.path.join(GOLDEN, "crashes.json"))) if c["stage"] == "augment"]
+    cd = os.path.join(GOLDEN, "crashes")
+    for c in crashes:
+        for resident in (None, 0):
+            with pytest.raises(PantasError) as ei:
+                run_streamed(monkeypatch, f"{cd}/{c['name']}.gfa", f"{cd}/{c['name']}.gaf", 100, resident)
+            assert ei.value.kind == c["exception"], c["name"]
+
+
+@pytest.mark.parametrize("seed,genes,lines,kw", [
+    (21, 40, 30000, dict(p_indel=0.3, p_sub=0.5, bubble_rate=0.15, p_novel_skip=0.1, p_novel_ce=0.05)),
+    (22, 5, 20000, dict(zipf_a=3.0, p_indel=0.2)),     # heavy skew + many deletions: the IL/OL key table grows batch by batch
+])
+def test_oracle_parity_streamed(monkeypatch, tmp_path, seed, genes, lines, kw):
+    from pantas_amd import synth
+    pre = str(tmp_path / "s")
+    synth.write_all(pre, seed=seed, n_genes=genes, n_lines=lines, **kw)
+    want = io.StringIO()
+    a = augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    size = os.path.getsize(pre + ".gaf")
+    for resident in (None, 0, size // 40):
+        got, bs, info = run_streamed(monkeypatch, pre + ".gfa", pre + ".gaf", size // 37, resident)
+        assert bs.rejected == a.rejected and bs.lines == lines
+        assert got == want.getvalue(), (resident, info)
+
+
+def test_cli_streams_in_batches(tmp_path):
+    d = os.path.join(GOLDEN, "synth_a")
+    env = {**os.environ, "PANTAS_BATCH_BYTES": "5000", "PANTAS_RESIDENT_BYTES": "100000"}
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", f"{d}/in.gaf", f"{d}/in.gfa"],
+                       capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(f"{d}/expected.aug.gfa").read()
+    assert r.stderr.splitlines() == json.load(open(f"{d}/expected.json"))["stderr"]
+
+
+def test_stream_api_protocol(monkeypatch):
+    from pantas_amd.engine import Graph, PantasError
+    d = os.path.join(GOLDEN, "synth_b")
+    monkeypatch.setenv("PANTAS_BATCH_BYTES", "20000")
+    g = Graph(f"{d}/in.gfa").to_device(0)
+    g.augment_reset()
+    with pytest.raises(PantasError):
+        g.stream_main()                      # nothing streamed yet
+    bs, _ = g.stream_rare(f"{d}/in.gaf")
+    with pytest.raises(PantasError):
+        g.stream_rare(f"{d}/in.gaf")         # one range per run
+    g.stream_main()
+    with pytest.raises(PantasError):
+        g.stream_main()
+    g.finish()
+    with tempfile.TemporaryFile() as f:
+        g.write_gfa(f.fileno())
+        f.seek(0)
+        assert f.read().decode() == open(f"{d}/expected.aug.gfa").read()
+    # the next run on the same handle starts clean
+    with tempfile.TemporaryFile() as f:
+        g.augment(f"{d}/in.gaf", 20, f.fileno())
+        f.seek(0)
+        assert f.read().decode() == open(f"{d}/expected.aug.gfa").read()
