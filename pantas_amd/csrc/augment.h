@@ -84,8 +84,10 @@ float launch_rare(DeviceGraph& dg, DeviceBatch& db);
 float launch_main(DeviceGraph& dg, DeviceBatch& db);
 void export_flags(DeviceGraph& dg, std::vector<uint32_t>& codes);          // (node << 1 | side), sorted
 void import_flags(DeviceGraph& dg, const uint32_t* codes, size_t n);
-// Raises Error if a kernel reported a line the reference would have died on.
-void check_device_status(DeviceGraph& dg, const DeviceBatch* db);
+// Raises Error if a kernel reported a line the reference would have died on (or one this engine refuses).
+// first_record_line: line id of the run's first record in file order (walk.h WALK_TILDE_FIRST: only there the reference
+// raises UnboundLocalError; on a later line it reuses a length left over from the line before, which is refused here).
+void check_device_status(DeviceGraph& dg, uint64_t first_record_line);
 void boost_novel_table(DeviceGraph& dg);              // next sizing of the novel-link table is 4x larger
 void boost_hist_table(DeviceGraph& dg);               // the same for the IL/OL key table (its bound should never be exceeded)
 uint64_t device_free_bytes(DeviceGraph& dg);          // HBM not allocated right now on dg's device

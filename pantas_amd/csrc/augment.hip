@@ -1267,7 +1267,7 @@ void import_flags(DeviceGraph& d, const uint32_t* codes, size_t n) {
   d.imported_flags += n;
 }
 
-void check_device_status(DeviceGraph& d, const DeviceBatch*) {
+void check_device_status(DeviceGraph& d, uint64_t first_record_line) {
   HIP_OK(hipSetDevice(d.device));
   uint32_t s[8];
   HIP_OK(hipMemcpy(s, d.small, 32, hipMemcpyDeviceToHost));
@@ -1277,7 +1277,10 @@ void check_device_status(DeviceGraph& d, const DeviceBatch*) {
     const unsigned code = unsigned(st & 0xFF);
     if (code == WALK_OPS_EXHAUSTED)
       throw Error("IndexError", "GAF line " + std::to_string(line) + ": cs ops exhausted before the path end");
-    throw Error("Unsupported", "GAF line " + std::to_string(line) + ": '~' op reached by the walk");
+    if (line - 1 == first_record_line)
+      throw Error("UnboundLocalError", "GAF line " + std::to_string(line) + ": '~' is the first cs op the walk reaches and no line before it left a length behind");
+    throw Error("Unsupported", "GAF line " + std::to_string(line) + ": '~' is the first cs op the walk of this line reaches; the reference lays it out with a length "
+                               "left over from the GAF line before (alignments_augmentation_from_gaf.py:228-233), which a line-parallel walk does not have");
   }
   if (s[3]) throw Error("TableOverflow", "hist");
   if (s[5]) throw Error("TableOverflow", "novel");

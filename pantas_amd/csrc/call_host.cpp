@@ -154,6 +154,8 @@ void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t) {
     ++lineno;
     Span line{p, le};
     p = nl ? nl + 1 : end;
+    if (lone_cr(line.b, line.e))
+      throw Error("Unsupported", "GTF line " + std::to_string(lineno) + ": lone carriage return (Python's universal newlines end a line there; this engine splits at \\n only)");
     if (line.size() && *line.b == '#') continue;
     // split on '\t' only (:194)
     std::vector<Span> col;

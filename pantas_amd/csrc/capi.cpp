@@ -20,6 +20,7 @@ struct pantas_graph {
   AugmentResult res;
   bool have_result = false;
   uint64_t lines = 0, rejected = 0, skipped = 0;
+  uint64_t first_record_line = UINT64_MAX;   // of the run, over its batches (walk.h WALK_TILDE_FIRST)
   std::shared_ptr<Error> deferred;   // tokeniser error of a loaded batch, reported by finish (see gaf.h)
   int tokenizer = PANTAS_TOKENIZER_AUTO;
   double load_s = 0;
@@ -203,10 +204,12 @@ __attribute__((visibility("default"))) int pantas_graph_to_device(pantas_graph* 
 __attribute__((visibility("default"))) int pantas_augment_reset(pantas_graph* g) {
   return guarded([&] {
     need_device(g);
+    require_augmentable(*g->g);
     reset_counters(*g->dev);
     g->have_result = false;
     g->res = AugmentResult();
     g->lines = g->rejected = g->skipped = 0;
+    g->first_record_line = UINT64_MAX;
     g->deferred.reset();
     g->stream.reset();
   });
@@ -302,6 +305,7 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
     g->lines += b.lines_total;
     g->rejected += b.rejected;
     g->skipped += b.skipped;
+    g->first_record_line = std::min(g->first_record_line, b.first_record_line);
     if (b.deferred && !g->deferred) g->deferred = b.deferred;
   }
   if (stats) put_out(stats, s, "pantas_batch_stats");
@@ -454,7 +458,7 @@ __attribute__((visibility("default"))) int pantas_counters_unpack(pantas_graph* 
 __attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g) {
   return guarded([&] {
     need_device(g);
-    check_device_status(*g->dev, nullptr);      // a line that fails in the walk, before ...
+    check_device_status(*g->dev, g->first_record_line);      // a line that fails in the walk, before ...
     if (g->deferred) {                          // ... the line the tokeniser stopped at
       Error e = *g->deferred;
       g->deferred.reset();

@@ -57,6 +57,21 @@ inline Span strip(Span s) {
   return s;
 }
 
+// Python reads text files with universal newlines: a '\r' that is not followed by '\n' ends a line too.  This engine splits
+// at '\n' only ('\r' is whitespace to it), so a text with such a byte would silently be read differently: every reader
+// refuses it instead.  [b, e) = one line without its '\n' (a '\r' as its last byte is the CR of a CRLF).  Returns the
+// offending byte or nullptr.
+inline const char* lone_cr(const char* b, const char* e) {
+  const char* p = b;
+  while (p < e) {
+    const char* q = static_cast<const char*>(memchr(p, '\r', size_t(e - p)));
+    if (!q) return nullptr;
+    if (q + 1 < e && q[1] != '\n') return q;
+    p = q + 1;
+  }
+  return nullptr;
+}
+
 // Iterates whitespace-separated tokens of a (stripped or not) line.
 struct Tokens {
   const char* p;

@@ -88,6 +88,7 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
   while (p < end) {
     const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
     const char* le = nl ? nl : end;
+    const char* const p_line = p;
     ck.err_line = line;
     tok.clear();
     {
@@ -101,6 +102,7 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
     // state to fall back to if this line raises
     ck.keep_hdr = out.hdr.size(); ck.keep_nodes = out.nodes.size(); ck.keep_ops = out.ops.size();
     ck.keep_del_lines = out.del_lines; ck.keep_del_nodes = out.del_nodes;
+    if (lone_cr(p_line, le)) fail("Unsupported", this_line, "lone carriage return (Python's universal newlines end a line there; this engine splits at \\n only)");
     if (tok.size() < 12) fail("IndexError", this_line, "fewer than 12 columns");
     int64_t mapq;
     if (!parse_py_int(tok[11], mapq, true)) fail("ValueError", this_line, "mapq is not an integer");
@@ -296,6 +298,7 @@ void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64
   });
   out.node_off[n] = uint32_t(nn);
   out.op_off[n] = uint32_t(no);
+  if (n) out.first_record_line = out.hdr[0].line_id;     // records are in file order here (bucket_by_locus comes later)
   pt.lap("merge chunks");
 }
 

@@ -25,6 +25,7 @@ struct GafBatch {
   uint64_t del_lines = 0;     // records with a '-' op
   uint64_t del_nodes = 0;     // sum of path lengths over those records
   uint64_t bytes = 0;         // text bytes tokenised
+  uint64_t first_record_line = UINT64_MAX;   // line id of the first record in FILE order (none: UINT64_MAX); see walk.h WALK_TILDE_FIRST
   uint64_t n_short = 0;       // after bucket_by_locus: records [0, n_short) are the short-walk class (walk.h)
   // A line the reference raises on while splitting / filtering it.  The batch then holds the records of the
   // lines BEFORE it: they still have to be walked, because an earlier line that only fails in the walk is what

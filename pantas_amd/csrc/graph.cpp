@@ -23,6 +23,8 @@ void scan_chunk(const char* base, size_t b, size_t e, ChunkOut& out) {
     const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
     const char* le = nl ? nl : end;
     Span raw{p, le};
+    if (const char* cr = lone_cr(p, le))
+      throw Error("Unsupported", "GFA byte " + std::to_string(cr - base) + ": lone carriage return (Python's universal newlines end a line there; this engine splits at \\n only)");
     Span st = strip(raw);
     ++out.lines;
     if (st.size() > 0) {
@@ -177,9 +179,10 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
         slot = &ix.map.emplace(nm.sv(), NONE32).first->second;
       }
       if (*slot == NONE32) {
-        if (!s.defines)
-          throw Error("KeyError", "GFA byte " + std::to_string(s.line_off) +
-                                      ": S line behind leading whitespace names a segment no plain S line defines");
+        // an S line behind leading whitespace that no plain S line backs: call.py strips the line before it looks at its
+        // first byte (:146-147) and takes it; the augment script misses it in its first pass (:123) and dies with a
+        // KeyError in the second (:387) -- the segment exists, and pantas_augment_reset refuses the graph
+        if (!s.defines && g->ws_only_seg_off == UINT64_MAX) g->ws_only_seg_off = s.line_off;
         *slot = uint32_t(g->seg_len.size());
         g->seg_len.push_back(s.seq_len);
         g->seg_line_off.push_back(s.line_off);

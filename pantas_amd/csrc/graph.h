@@ -55,6 +55,7 @@ struct Graph {
   uint64_t links_unknown_end = 0;      // L lines naming a segment without S line
   uint64_t first_bad_p_off = UINT64_MAX;   // first P line without exactly 4 tokens
   uint64_t first_short_l_off = UINT64_MAX; // first non-bare L line with fewer than 6 tokens
+  uint64_t ws_only_seg_off = UINT64_MAX;   // first S line behind leading whitespace whose name no plain S line defines
   uint32_t max_seg_len = 0;
 
   Span name_of(uint32_t node) const {
@@ -62,6 +63,12 @@ struct Graph {
     return Span{b, b + seg_name_len[node]};
   }
 };
+
+// what the augment script cannot take although call.py can (both the C ABI and the CPU harness of the tests ask this)
+inline void require_augmentable(const Graph& g) {
+  if (g.ws_only_seg_off != UINT64_MAX)     // alignments_augmentation_from_gaf.py:123 misses the line, :387 dies on it
+    throw Error("KeyError", "GFA byte " + std::to_string(g.ws_only_seg_off) + ": S line behind leading whitespace names a segment no plain S line defines");
+}
 
 // Parses the GFA at `path`.  Throws Error on inputs the reference's first GFA pass dies on.
 std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);

@@ -2,10 +2,13 @@
 // (reference exps/*/pantas.smk runs `pantas augment` per sample on one graph), parsing its text is the largest
 // host cost of a run (19 GB -> 11 s at the S4 scale), and everything the parse produces is plain arrays.
 // The cache holds those arrays; the GFA text itself is still mapped (the second pass echoes its lines) but
-// not read.  A cache is only used for the exact file it was made from: size, mtime and a hash of both ends.
+// not read.  A cache is only used for the exact file it was made from (size, mtime, a hash of both ends and of 4 KB
+// samples spread over the file), and its arrays are range-checked before anything indexes with them: a stale or damaged
+// cache is parsed again, never trusted.
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 
 #include "graph.h"
@@ -15,13 +18,14 @@ namespace pantas {
 namespace {
 
 constexpr uint64_t MAGIC = 0x3143475041544E50ull;   // "PNTAPGC1"
+constexpr uint64_t CACHE_VERSION = 2;
 
 struct Header {
   uint64_t magic, version;
   uint64_t gfa_size, gfa_mtime_ns, gfa_ends_hash;
   uint64_t V, A, n_lines, n_s_lines, n_l_lines, n_p_lines;
   uint64_t names_base, names_size;
-  uint64_t links_unknown_end, first_bad_p_off, first_short_l_off;
+  uint64_t links_unknown_end, first_bad_p_off, first_short_l_off, ws_only_seg_off;
   uint32_t max_seg_len;
   uint8_t dup_names, link_before_segment, pad_[2];
   uint64_t sections;      // number of arrays that follow: each {uint64 bytes; data; pad to 64}
@@ -35,6 +39,10 @@ uint64_t ends_hash(const char* data, size_t size) {
   const size_t span = std::min<size_t>(size, 65536);
   mix(data, span);
   mix(data + size - span, span);
+  // 4 KB out of every 16 MB in between: an edit in the middle of the file that keeps its size is caught with the
+  // probability of hitting a sample -- and whatever slips through still has to pass the range checks of the loader
+  constexpr size_t STEP = size_t(16) << 20, SAMPLE = 4096;
+  for (size_t at = STEP; at + SAMPLE <= size; at += STEP) mix(data + at, SAMPLE);
   return h;
 }
 
@@ -53,13 +61,14 @@ template <class T> Section sec(const std::vector<T>& v) { return Section{v.data(
 bool save_graph_cache(const Graph& g, const char* cache_path) {
   if (!g.names.dense || g.text.borrowed || g.path.empty()) return false;   // only file-backed graphs with decimal names
   Header h{};
-  h.magic = MAGIC; h.version = 1;
+  h.magic = MAGIC; h.version = CACHE_VERSION;
   h.gfa_size = g.text.size;
   h.gfa_mtime_ns = mtime_ns(g.path.c_str());
   h.gfa_ends_hash = ends_hash(g.text.data, g.text.size);
   h.V = g.V; h.A = g.A; h.n_lines = g.n_lines; h.n_s_lines = g.n_s_lines; h.n_l_lines = g.n_l_lines; h.n_p_lines = g.n_p_lines;
   h.names_base = g.names.base; h.names_size = g.names.table.size();
   h.links_unknown_end = g.links_unknown_end; h.first_bad_p_off = g.first_bad_p_off; h.first_short_l_off = g.first_short_l_off;
+  h.ws_only_seg_off = g.ws_only_seg_off;
   h.max_seg_len = g.max_seg_len; h.dup_names = g.dup_names; h.link_before_segment = g.link_before_segment;
   const Section secs[] = {sec(g.names.table), sec(g.seg_len), sec(g.seg_line_off), sec(g.seg_name_off), sec(g.seg_name_len),
                           sec(g.row_ptr), sec(g.col), sec(g.slot_off), sec(g.irow_ptr), sec(g.icol), sec(g.islot)};
@@ -101,7 +110,7 @@ std::unique_ptr<Graph> load_graph_cached(const char* gfa_path, const char* cache
   if (c.size < sizeof(Header)) return nullptr;
   Header h;
   memcpy(&h, c.data, sizeof h);
-  if (h.magic != MAGIC || h.version != 1 || h.sections != 11) return nullptr;
+  if (h.magic != MAGIC || h.version != CACHE_VERSION || h.sections != 11) return nullptr;
   auto g = std::make_unique<Graph>();
   g->path = gfa_path;
   g->text.open(gfa_path);
@@ -110,6 +119,7 @@ std::unique_ptr<Graph> load_graph_cached(const char* gfa_path, const char* cache
   g->V = uint32_t(h.V); g->A = h.A; g->n_lines = h.n_lines; g->n_s_lines = h.n_s_lines; g->n_l_lines = h.n_l_lines; g->n_p_lines = h.n_p_lines;
   g->names.dense = true; g->names.base = h.names_base;
   g->links_unknown_end = h.links_unknown_end; g->first_bad_p_off = h.first_bad_p_off; g->first_short_l_off = h.first_short_l_off;
+  g->ws_only_seg_off = h.ws_only_seg_off;
   g->max_seg_len = h.max_seg_len; g->dup_names = h.dup_names; g->link_before_segment = h.link_before_segment;
   size_t pos = (sizeof h + 63) / 64 * 64;
   bool bad = false;
@@ -139,6 +149,32 @@ std::unique_ptr<Graph> load_graph_cached(const char* gfa_path, const char* cache
   take(g->islot, h.A);
   if (bad) return nullptr;
   pt.lap("arrays from cache");
+  // ---- range checks: everything that is later used as an index or an offset (a damaged cache must not become an
+  // out-of-bounds access on the host or, worse, in a kernel)
+  {
+    const uint64_t V = h.V, A = h.A, T = g->text.size;
+    if (V >= NONE32 || A >= NONE32) return nullptr;
+    std::atomic<bool> ok{true};
+    auto fail = [&] { ok.store(false, std::memory_order_relaxed); };
+    if (g->row_ptr[0] != 0 || g->row_ptr[V] != A || g->irow_ptr[0] != 0 || g->irow_ptr[V] != A) return nullptr;
+    parallel_chunks(V, V < (1u << 16) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        if (g->row_ptr[i] > g->row_ptr[i + 1] || g->irow_ptr[i] > g->irow_ptr[i + 1]) fail();
+        if (g->seg_line_off[i] >= T || g->seg_name_off[i] + g->seg_name_len[i] > T) fail();
+        if ((g->seg_len[i] >> 30) != 0) fail();
+      }
+    });
+    parallel_chunks(A, A < (1u << 16) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i)
+        if (g->col[i] >= V || g->icol[i] >= V || g->islot[i] >= A || g->slot_off[i] >= T) fail();
+    });
+    const size_t NT = g->names.table.size();
+    parallel_chunks(NT, NT < (1u << 16) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) { const uint32_t n = g->names.table[i]; if (n != NONE32 && n >= V) fail(); }
+    });
+    if (!ok.load()) return nullptr;
+  }
+  pt.lap("range checks");
   return g;
 }
 

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <thread>
 
 #include "augment.h"
@@ -330,12 +331,24 @@ void upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinne
   int k = 0;
   bool used[2] = {false, false};
   const unsigned threads = std::min<unsigned>(hw_threads(), 16);
+  std::atomic<size_t> first_lone_cr{SIZE_MAX};
   while (off < size) {
     const size_t len = std::min(STAGE, size - off);
     if (used[k]) HIP_OK(hipEventSynchronize(pinned_done[k]));
     char* dstp = static_cast<char*>(pinned[k]);
     const char* src = data + off;
-    parallel_chunks(len, len < (size_t(4) << 20) ? 1u : threads, [&](unsigned, size_t b, size_t e) { memcpy(dstp + b, src + b, e - b); });
+    parallel_chunks(len, len < (size_t(4) << 20) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+      memcpy(dstp + b, src + b, e - b);
+      // while the piece is in cache: a '\r' that no '\n' follows would be a line end to the reference (universal newlines)
+      // and is whitespace to the kernels -- refused rather than read differently (common.h lone_cr)
+      for (const char* q = dstp + b; q < dstp + e;) {
+        q = static_cast<const char*>(memchr(q, '\r', size_t(dstp + e - q)));
+        if (!q) break;
+        const size_t at = off + size_t(q - dstp);     // position in the text
+        if (at + 1 < size && data[at + 1] != '\n') { size_t none = SIZE_MAX; first_lone_cr.compare_exchange_strong(none, at); break; }
+        ++q;
+      }
+    });
     HIP_OK(hipMemcpyAsync(dst + off, pinned[k], len, hipMemcpyHostToDevice, stream));
     HIP_OK(hipEventRecord(pinned_done[k], stream));
     used[k] = true;
@@ -343,6 +356,9 @@ void upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinne
     k ^= 1;
   }
   HIP_OK(hipStreamSynchronize(stream));
+  if (first_lone_cr.load() != SIZE_MAX)
+    throw Error("Unsupported", "GAF text byte " + std::to_string(first_lone_cr.load()) + " of the batch: lone carriage return (Python's universal newlines end "
+                               "a line there; this engine splits at \\n only)");
 }
 
 // the kernels read whole tiles, and a line index entry may point one past the text: zero padding to a tile bound + one tile
@@ -579,7 +595,10 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   const uint32_t tot_nodes = uint32_t(n_nodes), tot_ops = uint32_t(n_ops);
   HIP_OK(hipMemcpyAsync(node_off0.as<uint32_t>() + n_rec, &tot_nodes, 4, hipMemcpyHostToDevice, s));
   HIP_OK(hipMemcpyAsync(op_off0.as<uint32_t>() + n_rec, &tot_ops, 4, hipMemcpyHostToDevice, s));
+  uint32_t first_rec_line = 0;
+  if (n_rec) HIP_OK(hipMemcpyAsync(&first_rec_line, &hdr0.as<LineHdr>()[0].line_id, 4, hipMemcpyDeviceToHost, s));   // file order here
   HIP_OK(hipStreamSynchronize(s));
+  if (n_rec) st.first_record_line = first_rec_line;
   tm.write_s = now() - t0;
   pt.lap("write records");
   text.release(); ls.release(); kept.release(); rec_of.release(); node_scan.release(); op_scan.release();

@@ -74,7 +74,11 @@ struct LineHdr {
   uint32_t flags;
 };
 
-enum : int { WALK_OK = 0, WALK_OPS_EXHAUSTED = 1, WALK_TILDE = 2 };
+// WALK_TILDE_FIRST: a '~' op is the first op the walk of a line reaches.  The reference never assigns a length for '~'
+// (:228-233) and reuses whatever the variable held: the length of the op in hand one iteration earlier.  Inside a line
+// that is reproduced (walk_line below); for the first op of a line the value leaks in from the PREVIOUS GAF line (or is
+// unbound on the first one: UnboundLocalError), which a line-parallel walk does not have -- such a line is refused.
+enum : int { WALK_OK = 0, WALK_OPS_EXHAUSTED = 1, WALK_TILDE_FIRST = 2 };
 
 enum : uint32_t { SIDE_IL = 0, SIDE_OL = 1 };
 
@@ -222,6 +226,8 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
   uint32_t oi = 0;          // index of the op in hand (or of the next one when !have)
   uint32_t cur_op = 0, cur_rem = 0;
   bool have = false;
+  uint32_t stale = 0;       // the reference's curr_cigar_len: length of the last op in hand that was not a '~' (:228-233)
+  bool have_stale = false;
   bool pending = false;
   KeptNode pend{};
   uint32_t kept = 0;        // kept nodes flushed or pending so far
@@ -243,7 +249,15 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
         cur_rem = w >> 3;
         have = true;
       }
-      if (cur_op == OP_TILDE) return WALK_TILDE;      // reference: stale/unbound length at :228-234
+      if (cur_op == OP_TILDE) {
+        // no branch of :228-233 assigns a length for '~': the op is laid out with the length of the op that was in hand
+        // one iteration earlier (its own length never matters), and what is written back as "left" is stale - room (:239)
+        if (!have_stale) return WALK_TILDE_FIRST;
+        cur_rem = stale;
+      } else {
+        stale = cur_rem;
+        have_stale = true;
+      }
       uint32_t take;
       const uint32_t op = cur_op;
       if (room <= int64_t(cur_rem)) {

@@ -40,17 +40,18 @@ class LibBackend:
         return b.value, e.value, n.value
 
     def load_shard(self, gaf_path, thr, begin, end, first_line):
-        if begin == end:
-            # an empty shard still needs a (zero-record) batch
-            self.batch = self.g.load_gaf_mem((C.addressof(C.create_string_buffer(1)), 0), thr, first_line)
-        else:
-            self.batch = self.g.load_gaf(gaf_path, thr, begin, end, first_line)
-        s = self.batch.stats
+        """Tokenises the shard batch by batch (a shard of any size: PANTAS_BATCH_BYTES of text per batch) and runs every
+        batch's rare-key kernel -- the first pass of a streamed run (pantas_augment_stream_rare)."""
+        self.empty = begin == end and begin != 0     # (begin == end == 0 is an empty FILE: end 0 means "to EOF")
+        if self.empty:                               # more ranks than lines: nothing to read, no batch, no kernel
+            self.rare_ms = 0.0
+            return dict(lines=0, rejected=0, del_path_nodes=0)
+        s, self.rare_ms = self.g.stream_rare(gaf_path, thr, begin, end, first_line)
         return dict(lines=s.lines, rejected=s.rejected, del_path_nodes=s.del_path_nodes)
 
-    def reserve(self, keys): self.g.reserve(keys)
-    def launch_rare(self): return self.g.launch_rare(self.batch)
-    def launch_main(self): return self.g.launch_main(self.batch)
+    def reserve(self, keys): self.g.reserve(keys)      # the key table grows in place when a later launch needs the room
+    def launch_rare(self): return self.rare_ms          # ran batch by batch inside load_shard
+    def launch_main(self): return 0.0 if self.empty else self.g.stream_main()
     def flags_export(self): return self.g.flags_export()
     def flags_import(self, codes): self.g.flags_import(codes)
 

@@ -76,11 +76,13 @@ int main(int argc, char** argv) {
     } else {
       g = load_graph(argv[2], threads);
     }
+    require_augmentable(*g);
     fprintf(stderr, "Augmentation by GAF alignments\n");
     MappedFile gaf;
     gaf.open(argv[1]);
     GafBatch b;
     tokenize_gaf(*g, gaf.data, gaf.size, thr, 0, threads, b);
+    const uint64_t first_record_line = b.first_record_line;
     if (getenv("HOSTSIM_BUCKET")) bucket_by_locus(b, threads);
     Tables t;
     t.word = g->seg_len;
@@ -100,7 +102,10 @@ int main(int argc, char** argv) {
         if (pass == 0) { RareSink s{t}; st = rare_walk(*g, t.word, h, nodes, k, ops, c, s); }
         else { MainSink s{t, *g}; st = main_walk(*g, t.word, h, nodes, k, ops, c, s); }
         if (st == WALK_OPS_EXHAUSTED) throw Error("IndexError", "GAF line " + std::to_string(h.line_id + 1) + ": cs ops exhausted before the path end");
-        if (st == WALK_TILDE) throw Error("Unsupported", "GAF line " + std::to_string(h.line_id + 1) + ": '~' op reached by the walk");
+        if (st == WALK_TILDE_FIRST) {
+          if (h.line_id == first_record_line) throw Error("UnboundLocalError", "GAF line " + std::to_string(h.line_id + 1) + ": '~' as the first op of the first walked line");
+          throw Error("Unsupported", "GAF line " + std::to_string(h.line_id + 1) + ": '~' as the first op the walk of a line reaches");
+        }
       }
     }
     AugmentResult r;

@@ -68,8 +68,7 @@ def test_crash_inputs(hostsim):
         else:
             r = run([hostsim["call"], *c["flags"], f"{cd}/{c['call_input']}", f"{cd}/{c['name']}.gtf"])
         assert r.returncode == 1, c["name"]
-        if c["name"] != "aug_tilde_first":
-            assert r.stderr.strip().splitlines()[-1].startswith(c["exception"]), (c["name"], r.stderr)
+        assert r.stderr.strip().splitlines()[-1].startswith(c["exception"]), (c["name"], r.stderr)
 
 
 @pytest.mark.parametrize("seed,genes,lines,kw,flags", [
@@ -196,6 +195,25 @@ def test_graph_cache_round_trip(hostsim, tmp_path):
         check(lib.pantas_graph_get_stats(h, C.byref(st)))
         assert used.value == want and st.segments > 100
         lib.pantas_graph_free(h)
+    # a damaged cache (same length, an index pushed out of range somewhere in its arrays) is parsed again, never trusted
+    good = open(cache, "rb").read()
+    for where in (0.3, 0.5, 0.7, 0.9):
+        bad = bytearray(good)
+        at = int(len(bad) * where) // 8 * 8
+        bad[at:at + 8] = b"\xff\xff\xff\x7f\xff\xff\xff\x7f"
+        open(cache, "wb").write(bad)
+        h, used = C.c_void_p(), C.c_int32()
+        check(lib.pantas_graph_load_cached(os.fsencode(pre + ".gfa"), os.fsencode(cache), 0, C.byref(h), C.byref(used)))
+        st = GraphStats()
+        check(lib.pantas_graph_get_stats(h, C.byref(st)))
+        assert st.segments > 100
+        lib.pantas_graph_free(h)
+        # (damage that lands in padding or in a sequence-length word is harmless and may be accepted: what must never
+        # happen is an index outside its array, which the loader checks -- a used cache therefore still gives the right graph)
+        if used.value:
+            r = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+            assert r.returncode == 0
+    open(cache, "wb").write(good)
     # a truncated cache is ignored
     with open(cache, "r+b") as f:
         f.truncate(os.path.getsize(cache) // 2)

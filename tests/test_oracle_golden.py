@@ -34,7 +34,9 @@ def check_rows(rows, golden_call):
     mine = collections.Counter(call_oracle.normalise_row(r) for r in rows)
     stable = collections.Counter(golden_call["stable"])
     variants = set(golden_call["variants"])
-    assert sum(mine.values()) == golden_call["n_rows"]
+    # (n_rows in the golden is what PYTHONHASHSEED=0 printed; a seed-dependent choice may add or drop a row, so the
+    # count is only bounded: every stable row, at most the alternatives on top)
+    assert sum(stable.values()) <= sum(mine.values()) <= sum(stable.values()) + len(variants)
     missing = stable - mine
     assert not missing, f"rows every reference run prints are missing: {list(missing)[:3]}"
     extra = mine - stable
@@ -75,5 +77,4 @@ def test_oracle_crashes_where_reference_crashes():
             with pytest.raises(augment_oracle.ReferenceCrash) as ei:
                 call_oracle.call(f"{cd}/{c['call_input']}", f"{cd}/{c['name']}.gtf", None,
                                  **_flags_to_opts(c["flags"]))
-        if c["name"] != "aug_tilde_first":
-            assert ei.value.kind == c["exception"], (c["name"], ei.value.kind, c["exception"])
+        assert ei.value.kind == c["exception"], (c["name"], ei.value.kind, c["exception"])
