@@ -23,9 +23,10 @@ struct NovelLink {
 };
 
 struct AugmentResult {
-  std::vector<uint32_t> nc;        // [V]
-  std::vector<uint32_t> rc;        // [A] per adjacency slot (first slot of a duplicated link gets the count)
-  std::vector<uint32_t> il0, oll;  // [V] IL[0] and OL[len] counts
+  // (RawVector: gigabytes at whole-genome scale, overwritten by a device-to-host copy right after they are sized)
+  RawVector<uint32_t> nc;          // [V]
+  RawVector<uint32_t> rc;          // [A] per adjacency slot (first slot of a duplicated link gets the count)
+  RawVector<uint32_t> il0, oll;    // [V] IL[0] and OL[len] counts
   std::vector<HistEntry> hist;     // sorted by (node, side, first)
   std::vector<NovelLink> novel;    // sorted by first
   uint64_t lines_total = 0, rejected = 0, skipped = 0, used = 0;
@@ -60,7 +61,7 @@ DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);
 // batch counters and a deferred tokeniser error, its arrays stay empty.  Needs a graph with dense (decimal) names.
 struct DeviceTokenizeTimes { double h2d_s = 0, index_s = 0, measure_s = 0, write_s = 0, bucket_s = 0, total_s = 0; };
 // text of whole lines already in HBM (zero-padded as the tokeniser's kernels need it): what a TextPrefetcher hands out
-struct DeviceText { uint8_t* dev = nullptr; size_t size = 0; };
+struct DeviceText { uint8_t* dev = nullptr; size_t size = 0; bool lone_cr = false; };   // lone_cr: see tokenize.hip upload_text
 // `resident`: the same bytes as [data, data + size), already on the device (data is still read for error wording)
 DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
                                    GafBatch& counts, DeviceTokenizeTimes* times = nullptr, const DeviceText* resident = nullptr);

@@ -1323,6 +1323,9 @@ void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   HIP_OK(hipSetDevice(d.device));
   const size_t V = d.V;
   r.nc.resize(V); r.il0.resize(V); r.oll.resize(V); r.rc.resize(d.A);
+  if (V > (1u << 22)) {   // fresh pages of gigabytes: touched from many threads instead of by the copy engine's single staging loop
+    prefault(r.nc.data(), V * 4); prefault(r.il0.data(), V * 4); prefault(r.oll.data(), V * 4); prefault(r.rc.data(), size_t(d.A) * 4);
+  }
   uint32_t* planar = nullptr;       // [nc V | il0 V | oll V | rc A]
   HIP_OK(hipMalloc(&planar, std::max<size_t>(1, 3 * V + d.A) * 4));
   if (d.A) HIP_OK(hipMemcpyAsync(planar + 3 * V, d.counters + 4 * V, size_t(d.A) * 4, hipMemcpyDeviceToDevice, d.stream));

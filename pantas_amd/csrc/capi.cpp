@@ -53,7 +53,7 @@ struct StreamState {
   std::vector<StreamBatch> batches;
   uint64_t max_batch_bytes = 0;
   uint64_t resident_bytes = 0, resident_budget = 0;
-  uint64_t retokenised = 0;
+  uint64_t retokenised = 0, kept_resident = 0;
   bool main_done = false;
   pantas_batch_stats total{};
 };
@@ -197,7 +197,9 @@ __attribute__((visibility("default"))) int pantas_graph_get_stats(const pantas_g
 __attribute__((visibility("default"))) int pantas_graph_to_device(pantas_graph* g, int device) {
   return guarded([&] {
     need(g && g->g, "null graph handle");
+    PhaseTimer pt("pantas_graph_to_device");
     if (!g->dev) g->dev = upload_graph(*g->g, device);
+    pt.lap("CSR + counters in HBM");
   });
 }
 
@@ -458,6 +460,7 @@ __attribute__((visibility("default"))) int pantas_counters_unpack(pantas_graph* 
 __attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g) {
   return guarded([&] {
     need_device(g);
+    PhaseTimer pt("pantas_augment_finish");
     check_device_status(*g->dev, g->first_record_line);      // a line that fails in the walk, before ...
     if (g->deferred) {                          // ... the line the tokeniser stopped at
       Error e = *g->deferred;
@@ -465,6 +468,7 @@ __attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g
       throw e;
     }
     download_result(*g->dev, *g->g, g->res);
+    pt.lap("counters + sparse tables to the host");
     g->res.lines_total = g->lines;
     g->res.rejected = g->rejected;
     g->res.skipped = g->skipped;
@@ -653,6 +657,7 @@ static void stream_rare_pass(pantas_graph* g, const char* gaf_path, int thr, uin
     if (st->resident_bytes + sb.device_bytes <= st->resident_budget) {
       st->resident_bytes += sb.device_bytes;
       sb.resident = std::move(b);
+      ++st->kept_resident;
     }
     ++n_loaded;
     if (g->deferred) break;    // the reference dies at this line: what follows it in the file is never read
@@ -728,10 +733,8 @@ __attribute__((visibility("default"))) int pantas_augment_stream_main(pantas_gra
 __attribute__((visibility("default"))) int pantas_augment_stream_info(const pantas_graph* g, uint64_t* batches, uint64_t* resident, uint64_t* retokenised) {
   return guarded([&] {
     need(g && g->stream, "no streamed run on this handle");
-    uint64_t r = 0;
-    for (const StreamBatch& sb : g->stream->batches) r += sb.resident ? 1 : 0;
     if (batches) *batches = g->stream->batches.size();
-    if (resident) *resident = r;
+    if (resident) *resident = g->stream->kept_resident;
     if (retokenised) *retokenised = g->stream->retokenised;
   });
 }

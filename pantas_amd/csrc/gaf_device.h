@@ -29,6 +29,7 @@ enum : uint32_t {
   TE_NO_NODE = 6,       // AssertionError (:197)
   TE_UNKNOWN_NODE = 7,  // KeyError: path node without S line (:212)
   TE_OFFSETS = 8,       // Unsupported: start / end offsets beyond 32 bits
+  TE_LONE_CR = 9,       // Unsupported: a '\r' inside the line (Python's universal newlines would end the line there)
 };
 
 // id - base -> node for graphs whose segment names are canonical decimals (graph.h NameIndex, dense form)
@@ -173,9 +174,15 @@ struct CsBytes {
 };
 
 // [b, e) = one line without its '\n'.
+// check_cr: the text is known to hold a '\r' that no '\n' follows (the copy to the device looked): find the line.
 template <class Out>
-PANTAS_HD void parse_gaf_line(const uint8_t* b, const uint8_t* e, int thr, const DenseNames& names, Out& out, LineSummary& r) {
+PANTAS_HD void parse_gaf_line(const uint8_t* b, const uint8_t* e, int thr, const DenseNames& names, Out& out, LineSummary& r, bool check_cr = true) {
   r.status = TOK_ERROR; r.err = TE_NONE; r.n_nodes = 0; r.n_ops = 0; r.flags = 0; r.start = 0; r.tail = 0;
+  if (check_cr) {
+    // [b, e) has no '\n': any '\r' before its last byte is a lone one (as its last byte it is the CR of a CRLF)
+    for (const uint8_t* q = b; q + 1 < e; ++q)
+      if (*q == '\r') { r.err = TE_LONE_CR; return; }
+  }
   // ---- columns 0..11 (str.split(): runs of whitespace, leading/trailing ignored)
   const uint8_t *p5b = b, *p5e = b, *p6b = b, *p6e = b, *p7b = b, *p7e = b, *p8b = b, *p8e = b, *p11b = b, *p11e = b;
   const uint8_t* p = b;

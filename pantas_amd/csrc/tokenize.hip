@@ -154,13 +154,13 @@ __device__ __forceinline__ void staged_lines(const uint8_t* text, const uint64_t
   }
 }
 
-__global__ void __launch_bounds__(LPB) measure_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr,
+__global__ void __launch_bounds__(LPB) measure_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                       DenseNames names, uint32_t* kept, uint32_t* cnt_nodes, uint32_t* cnt_ops, uint8_t* meta,
                                                       unsigned long long* err) {
   staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
     CountOnly co;
     LineSummary r;
-    parse_gaf_line(b, e, thr, names, co, r);
+    parse_gaf_line(b, e, thr, names, co, r, check_cr != 0u);
     kept[i] = r.status == TOK_KEEP ? 1u : 0u;
     cnt_nodes[i] = r.n_nodes;
     cnt_ops[i] = r.n_ops;
@@ -203,7 +203,7 @@ struct WriteOut {
   __device__ __forceinline__ void op(uint32_t i, uint32_t w) { ops[i] = w; }
 };
 
-__global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr,
+__global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                     DenseNames names, const uint32_t* kept, const uint32_t* rec_of, const uint32_t* node_scan,
                                                     const uint32_t* op_scan, uint32_t first_line, LineHdr* hdr, uint32_t* node_off,
                                                     uint32_t* op_off, uint32_t* nodes, uint32_t* ops) {
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const u
     const uint32_t rec = rec_of[i], no = node_scan[i], oo = op_scan[i];
     WriteOut wo{nodes + no, ops + oo};
     LineSummary r;
-    parse_gaf_line(b, e, thr, names, wo, r);
+    parse_gaf_line(b, e, thr, names, wo, r, check_cr != 0u);
     hdr[rec] = LineHdr{r.start, r.tail, first_line + i, r.flags};
     node_off[rec] = no;
     op_off[rec] = oo;
@@ -317,9 +317,12 @@ double now() { return now_s(); }
 
 // host text -> HBM through two pinned staging buffers (kept with the graph); several host threads fill one buffer while
 // the other is in flight
-void upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinned_bytes, const char* data, size_t size, uint8_t* dst, hipStream_t stream) {
+// returns true when the text holds a '\r' that no '\n' follows (looked for while each piece is in cache): the reference's
+// universal newlines end a line there, to the kernels it is whitespace -- the line that holds it is refused (gaf_device.h
+// TE_LONE_CR), which costs a scan of every line, so the kernels only do it when told that there is something to find
+bool upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinned_bytes, const char* data, size_t size, uint8_t* dst, hipStream_t stream) {
   constexpr size_t STAGE = size_t(32) << 20;
-  if (size == 0) return;
+  if (size == 0) return false;
   if (!pinned[0]) {
     for (int k = 0; k < 2; ++k) {
       HIP_OK(hipHostMalloc(&pinned[k], STAGE, hipHostMallocDefault));
@@ -339,8 +342,6 @@ void upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinne
     const char* src = data + off;
     parallel_chunks(len, len < (size_t(4) << 20) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
       memcpy(dstp + b, src + b, e - b);
-      // while the piece is in cache: a '\r' that no '\n' follows would be a line end to the reference (universal newlines)
-      // and is whitespace to the kernels -- refused rather than read differently (common.h lone_cr)
       for (const char* q = dstp + b; q < dstp + e;) {
         q = static_cast<const char*>(memchr(q, '\r', size_t(dstp + e - q)));
         if (!q) break;
@@ -356,9 +357,7 @@ void upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinne
     k ^= 1;
   }
   HIP_OK(hipStreamSynchronize(stream));
-  if (first_lone_cr.load() != SIZE_MAX)
-    throw Error("Unsupported", "GAF text byte " + std::to_string(first_lone_cr.load()) + " of the batch: lone carriage return (Python's universal newlines end "
-                               "a line there; this engine splits at \\n only)");
+  return first_lone_cr.load() != SIZE_MAX;
 }
 
 // the kernels read whole tiles, and a line index entry may point one past the text: zero padding to a tile bound + one tile
@@ -380,7 +379,7 @@ struct TextPrefetcher {
   size_t pinned_bytes = 0;
   uint8_t* buf[2] = {nullptr, nullptr};
   size_t cap = 0;                 // bytes of each device buffer
-  struct Job { std::thread th; std::shared_ptr<Error> err; size_t size = 0; double seconds = 0; };
+  struct Job { std::thread th; std::shared_ptr<Error> err; size_t size = 0; double seconds = 0; bool lone_cr = false; };
   Job job[2];
   unsigned head = 0, tail = 0;    // ranges started / handed out (slot = index & 1)
   double copy_seconds = 0;
@@ -425,7 +424,7 @@ void prefetch_start(TextPrefetcher& p, const char* data, size_t size) {
     try {
       HIP_OK(hipSetDevice(pp->device));
       HIP_OK(hipMemsetAsync(pp->buf[k] + size, 0, text_padded_bytes(size) - size, pp->stream));
-      upload_text(pp->pinned, pp->pinned_done, pp->pinned_bytes, data, size, pp->buf[k], pp->stream);
+      job.lone_cr = upload_text(pp->pinned, pp->pinned_done, pp->pinned_bytes, data, size, pp->buf[k], pp->stream);
       HIP_OK(hipStreamSynchronize(pp->stream));
     } catch (const Error& e) {
       job.err = std::make_shared<Error>(e);
@@ -445,7 +444,7 @@ DeviceText prefetch_get(TextPrefetcher& p) {
   ++p.tail;
   p.copy_seconds += j.seconds;
   if (j.err) throw *j.err;
-  return DeviceText{p.buf[k], j.size};
+  return DeviceText{p.buf[k], j.size, j.lone_cr};
 }
 
 double prefetch_copy_seconds(const TextPrefetcher& p) { return p.copy_seconds; }
@@ -471,14 +470,16 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   DevBuf text(pool);
   double t0 = now();
   const uint8_t* d_text;
+  uint32_t check_cr = 0;
   if (resident) {
     // the text is in HBM already (TextPrefetcher copied it while the batch before this one was being handled)
     if (resident->size != size || !resident->dev) throw Error("InternalError", "resident text does not match the range");
     d_text = resident->dev;
+    check_cr = resident->lone_cr ? 1u : 0u;
   } else {
     text.alloc(padded);
     HIP_OK(hipMemsetAsync(text.as<uint8_t>() + size, 0, padded - size, s));
-    upload_text(pool.pinned, pool.pinned_done, pool.pinned_bytes, data, size, text.as<uint8_t>(), s);
+    check_cr = upload_text(pool.pinned, pool.pinned_done, pool.pinned_bytes, data, size, text.as<uint8_t>(), s) ? 1u : 0u;
     d_text = text.as<uint8_t>();
   }
   const uint4* d_text4 = reinterpret_cast<const uint4*>(d_text);
@@ -537,7 +538,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   HIP_OK(hipMemsetAsync(small.as<uint8_t>() + 8, 0, 56, s));
   t0 = now();
   if (n_lines) {
-    hipLaunchKernelGGL(measure_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
+    hipLaunchKernelGGL(measure_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names,
                        kept.as<uint32_t>(), cnt_nodes.as<uint32_t>(), cnt_ops.as<uint32_t>(), meta.as<uint8_t>(), small.as<unsigned long long>());
     HIP_OK(hipGetLastError());
     hipLaunchKernelGGL(limit_and_totals_kernel, dim3(std::min<uint32_t>(blocks_for(n_lines), 2048)), dim3(TPB), 0, s, n_lines,
@@ -587,7 +588,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   nodes0.alloc((n_nodes + 1) * 4); ops0.alloc((n_ops + 1) * 4);
   t0 = now();
   if (n_lines) {
-    hipLaunchKernelGGL(write_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, names,
+    hipLaunchKernelGGL(write_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names,
                        kept.as<uint32_t>(), rec_of.as<uint32_t>(), node_scan.as<uint32_t>(), op_scan.as<uint32_t>(), uint32_t(first_line_id),
                        hdr0.as<LineHdr>(), node_off0.as<uint32_t>(), op_off0.as<uint32_t>(), nodes0.as<uint32_t>(), ops0.as<uint32_t>());
     HIP_OK(hipGetLastError());

@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
       }
     }
     AugmentResult r;
-    r.nc = t.nc; r.rc = t.rc; r.il0 = t.il0; r.oll = t.oll;
+    r.nc.assign(t.nc.begin(), t.nc.end()); r.rc.assign(t.rc.begin(), t.rc.end()); r.il0.assign(t.il0.begin(), t.il0.end()); r.oll.assign(t.oll.begin(), t.oll.end());
     for (auto& kv : t.rare)
       r.hist.push_back(HistEntry{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first, kv.second.second, false});
     for (auto& kv : t.common_first)

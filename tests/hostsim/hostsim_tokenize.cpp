@@ -26,7 +26,7 @@ static const char* kind_of(uint32_t te) {
   switch (te) {
     case TE_COLUMNS: return "IndexError";
     case TE_MAPQ: case TE_POSITIONS: case TE_NO_DV: return "ValueError";
-    case TE_OP_LEN: case TE_OFFSETS: return "Unsupported";
+    case TE_OP_LEN: case TE_OFFSETS: case TE_LONE_CR: return "Unsupported";
     case TE_NO_NODE: return "AssertionError";
     case TE_UNKNOWN_NODE: return "KeyError";
   }

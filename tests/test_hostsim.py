@@ -47,6 +47,16 @@ def test_walk_source_vs_reference_bytes(hostsim, case):
     assert r.returncode == 0, r.stderr
     assert r.stdout == open(f"{d}/expected.aug.gfa").read()
     assert r.stderr.splitlines() == json.load(open(f"{d}/expected.json"))["stderr"]
+    # stdout on a regular file (the `> out.gfa` of the command line): the writer's pieces go out concurrently with pwrite,
+    # behind whatever the file already holds
+    import tempfile
+    with tempfile.TemporaryFile() as f:
+        f.write(b"# already here\n")
+        f.flush()
+        r2 = subprocess.run([hostsim["augment"], f"{d}/in.gaf", f"{d}/in.gfa"], stdout=f, stderr=subprocess.PIPE)
+        assert r2.returncode == 0
+        f.seek(0)
+        assert f.read().decode() == "# already here\n" + r.stdout
 
 
 @pytest.mark.parametrize("case", CASES)
