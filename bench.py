@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the augment(+call) hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--scale s1|s2|s3|s4|auto]
+    python bench.py --gpus N --steps K --warmup W [--scale s1|s2|s3|s4|s5|auto]
 
-A "step" is one pass of the two augment kernels over one batch of tokenised GAF lines that is
-already resident in HBM (graph CSR and records are uploaded before the timed region).  With
-N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds a replica of the
-graph and its own batch of the same size (weak scaling: read shards), and the timed region ends
-with the ONE sum over the coverage arrays that a sharded replicate needs: the ranks all-gather a
-bitmap of the counter blocks they touched and all-reduce only the union's blocks (pantas_amd/csrc/exchange.hip).
-After the timed region rank 0 runs the call kernels on the accumulated coverage (fused path, no
-GFA text round trip) and reports events/s beside it.  Rank 0 prints one JSON line.
+A "step" is one pass of the augment kernels (rare-key kernel, then the main kernels) over the tokenised GAF records of
+one replicate share that are already resident in HBM (graph CSR and records are uploaded before the timed region).  With
+N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds a replica of the graph and its own block of
+the read stream of the same size (weak scaling: read shards), and the timed region ends with the ONE sum over the coverage
+arrays that a sharded replicate needs: the ranks all-gather a bitmap of the counter blocks they touched and
+all-reduce only the union's blocks (pantas_amd/csrc/exchange.hip).
 
-Workloads are synthetic (pantas_amd/csrc/synth.cpp, SURVEY.md 8-d recipe) at the BASELINE.json
-scales: s2 = Drosophila whole genome, s3 = human chr1, s4 = human whole genome (one replicate,
-50 M reads); they go through the product's own GFA / GAF / GTF parsers.
+`value` = records WALKED per second (lines the tokeniser filtered out -- low mapq, unmapped, high divergence -- never reach
+the kernels and are not counted).  Because a real batch is bucketed once and launched once, the line also carries, as
+first-class fields, the rate with the one-off locus bucketing inside the clock (`reads_per_s_incl_bucket`), the rate from
+GAF text in host memory to counters (`reads_per_s_text_to_counters`: PCIe copy, GPU tokeniser, bucketing, kernels) and, at
+N = 1, the END-TO-END wall time of the two command lines on the same workload written to disk (`e2e`: process start, GFA /
+GAF / GTF parsing, kernels, GFA and CSV writing, timed the way the reference's workflows time them,
+exps/3-homo-real/workflow/rules/pantas.smk:164,181), without and with the binary graph cache.
+
+After the timed region rank 0 runs the call kernels on the accumulated coverage (fused path, no GFA text round trip) and
+reports events/s beside it.  Rank 0 prints one JSON line.
+
+Workloads are synthetic (pantas_amd/csrc/synth.cpp, SURVEY.md 8-d recipe) at the BASELINE.json scales: s2 = Drosophila
+whole genome, s3 = human chr1, s4 = human whole genome (one replicate, 50 M reads), s5 = the same graph with 200 M reads
+(four resident batches of 50 M); they go through the product's own GFA / GAF / GTF parsers.
 """
 from __future__ import annotations
 
@@ -22,6 +31,8 @@ import argparse
 import collections
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -31,19 +42,23 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
+_HUMAN = dict(n_genes=62000, n_lines=50_000_000, base_id=10**9, intron_long_max=4780, n_chrom=24, zipf_a=1.0,
+              read_len=150, with_path=0)
 SCALES = {
-    # name: (description, synth parameters)
+    # name: (description, synth parameters [, blocks of n_lines reads per GPU])
     "s1": ("chr4-like plumbing case", dict(n_genes=114, n_lines=500, base_id=10**6)),
     "s2": ("Drosophila whole-genome scale (exps/1-dm-sim), 1M read pairs",
            dict(n_genes=18000, n_lines=2_000_000, base_id=10**7, intron_long_max=320, n_chrom=6, zipf_a=1.0)),
     "s3": ("human chr1 + 1000G scale, 10M GAF lines",
            dict(n_genes=5500, n_lines=10_000_000, base_id=10**8, intron_long_max=4280, n_chrom=1, zipf_a=1.0,
                 read_len=150, with_path=0)),
-    "s4": ("human whole-genome scale (exps/3-homo-real layout), one replicate of 50M GAF lines",
-           dict(n_genes=62000, n_lines=50_000_000, base_id=10**9, intron_long_max=4780, n_chrom=24, zipf_a=1.0,
-                read_len=150, with_path=0)),
+    "s4": ("human whole-genome scale (exps/3-homo-real layout), one replicate of 50M GAF lines", dict(_HUMAN)),
+    "s5": ("human whole-genome scale, annotated+novel search over 200M GAF lines (four resident batches of 50M)", dict(_HUMAN), 4),
 }
-CPU_SAMPLE = dict(n_genes=1500, n_lines=300_000, base_id=10**7, intron_long_max=320, n_chrom=2, zipf_a=1.0)
+# reference / port ratios measured in the build container on ONE input (profiles/r1_e2e_build_container_big.json: 6 000 genes,
+# 2 M lines, 48 483 junction links): what turns the port's rate on this box into an estimate for the reference on this box
+CALIBRATION = {"source": "profiles/r1_e2e_build_container_big.json", "augment_ref_over_port": 61.35 / 58.95,
+               "call_ref_seconds_per_J2": 1309.6 / 48483 ** 2, "call_flags": "--rca 3 --novel"}
 
 
 def host_ram_gb() -> float:
@@ -57,18 +72,23 @@ def host_ram_gb() -> float:
     return 0.0
 
 
-def cpu_baseline(sample_lines: int):
-    """The oracle (a Python port that keeps the reference's dict-based data structures) on a
-    bounded sample: a smaller instance of the same synthetic recipe, written to disk."""
+def cpu_baseline(scale_kw: dict, sample_lines: int, s4_lines: int, s4_junctions: int):
+    """The oracle (a Python port that keeps the reference's dict-based data structures) on a bounded sample of THE SAME
+    recipe as the GPU line: the scale's own parameters with fewer genes (a Python dict graph of the whole scale does not
+    fit a run of seconds) and `sample_lines` reads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import augment_oracle
     import call_oracle
     from pantas_amd.engine import Synth
     tmp = tempfile.mkdtemp(prefix="pantas_cpu_")
     pre = os.path.join(tmp, "sample")
-    kw = dict(CPU_SAMPLE)
+    kw = dict(scale_kw)
+    kw["n_genes"] = min(kw["n_genes"], 1500)
+    kw["n_chrom"] = min(kw.get("n_chrom", 1), 2)
     kw["n_lines"] = sample_lines
-    Synth(seed=11, **kw).write(pre)
+    kw["with_path"] = 1
+    syn = Synth(seed=11, **kw)
+    syn.write(pre)
     a = augment_oracle.Augmenter(20)
     a.load_gfa(pre + ".gfa")
     t0 = time.perf_counter()
@@ -79,12 +99,101 @@ def cpu_baseline(sample_lines: int):
     t1 = time.perf_counter()
     rows = call_oracle.call(pre + ".aug.gfa", pre + ".gtf", None, rca=3, novel=True)
     dc = time.perf_counter() - t1
-    return {"value": sample_lines / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_lines} GAF lines on a {kw['n_genes']}-gene instance of the same synthetic recipe, "
-                      f"{dt:.1f} s in oracle/augment_oracle.py (Python port of the reference's per-line loop)",
+    shutil.rmtree(tmp, ignore_errors=True)
+    port_rate = sample_lines / dt
+    ref_rate = port_rate / CALIBRATION["augment_ref_over_port"]
+    return {"value": port_rate, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_lines} GAF lines of the same synthetic recipe and parameters as the GPU line on a "
+                      f"{kw['n_genes']}-gene instance ({syn.stats.nodes} segments), {dt:.1f} s in oracle/augment_oracle.py "
+                      "(Python port of the reference's per-line loop; the rate does not depend on the graph size: dict lookups)",
             "call_events_per_s": len(rows) / dc,
-            "call_sample": f"{len(rows)} events in {dc:.1f} s, oracle/call_oracle.py incl. GFA/GTF parsing "
-                           "(indexed junction lookup: faster than the reference's O(J^2) scan)"}
+            "call_sample": f"{len(rows)} events from {syn.stats.junction_links} junction links in {dc:.1f} s, oracle/call_oracle.py incl. "
+                           "GFA/GTF parsing (indexed junction lookup: NOT the reference's O(J^2) scan)",
+            # the reference itself cannot run on this box; its speed here = the port's speed here x the ratio measured where both ran
+            "reference_estimate": {
+                "how": "port rate on this box x (reference / port) measured in the build container on one input; call: the "
+                       "reference's measured seconds per J^2 (its junction scan is quadratic, scripts/call.py:280-282)",
+                "calibration": CALIBRATION,
+                "augment_reads_per_s": ref_rate,
+                "augment_s_for_this_workload": s4_lines / ref_rate,
+                "call_s_for_this_workload": CALIBRATION["call_ref_seconds_per_J2"] * s4_junctions ** 2,
+                "note": "an extrapolation, not a measurement: the reference's Python dicts would not hold a whole-genome graph in memory"}}
+
+
+def e2e_leg(syns, scale, kw, flags="--rca 3 --novel", with_cache=True):
+    """`pantas augment` + `pantas call` as child processes on the workload written to disk, wall time of each."""
+    need = sum(s.stats.gaf_bytes for s in syns) * 1.0 + syns[0].stats.gfa_bytes * 3.3 + 2e9
+    where = None
+    for d in ("/dev/shm", os.environ.get("TMPDIR", "/tmp")):
+        try:
+            if shutil.disk_usage(d).free > need:
+                where = d
+                break
+        except OSError:
+            pass
+    if where is None:
+        return {"skipped": f"no place with {need / 1e9:.0f} GB free for the files"}
+    tmp = tempfile.mkdtemp(prefix="pantas_e2e_", dir=where)
+    pre = os.path.join(tmp, scale)
+    res = {"dir": where, "call_flags": flags,
+           "what": "wall time of `python -m pantas_amd.augment GAF GFA > aug.gfa` and `python -m pantas_amd.call FLAGS aug.gfa GTF > events.csv` "
+                   "as child processes on files in " + where + " (process start, parsing, kernels, writing: all inside)"}
+    try:
+        t0 = time.perf_counter()
+        syns[0].write(pre)
+        for b, s in enumerate(syns[1:], 1):
+            s.write(pre + f".b{b}")
+            with open(pre + ".gaf", "ab") as out, open(pre + f".b{b}.gaf", "rb") as src:
+                shutil.copyfileobj(src, out, 1 << 26)
+            for ext in (".gaf", ".gfa", ".gtf"):
+                try:
+                    os.unlink(pre + f".b{b}" + ext)
+                except OSError:
+                    pass
+        res["write_inputs_s"] = time.perf_counter() - t0
+        lines = sum(s.stats.gaf_lines for s in syns)
+        res["gaf_bytes"] = os.path.getsize(pre + ".gaf")
+        res["gfa_bytes"] = os.path.getsize(pre + ".gfa")
+        env = {**os.environ, "PANTAS_TIMING": "1"}
+        env.pop("PANTAS_GRAPH_CACHE", None)
+
+        def timed(cmd, out_path, env):
+            t0 = time.perf_counter()
+            with open(out_path, "wb") as f:
+                r = subprocess.run(cmd, stdout=f, stderr=subprocess.PIPE, env=env, cwd=ROOT)
+            dt = time.perf_counter() - t0
+            err = r.stderr.decode(errors="replace")
+            if r.returncode != 0:
+                raise RuntimeError(f"{cmd}: rc {r.returncode}: {err[-2000:]}")
+            return dt, [l[len("[timing]"):].strip() for l in err.splitlines() if l.startswith("[timing]")]
+        py = sys.executable
+        dt, ph = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], pre + ".aug.gfa", env)
+        res["augment"] = {"wall_s": dt, "reads_per_s": lines / dt, "out_bytes": os.path.getsize(pre + ".aug.gfa"), "phases": ph}
+        if with_cache:
+            env_c = {**env, "PANTAS_GRAPH_CACHE": "1"}
+            dt0, _ = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], pre + ".aug2.gfa", env_c)    # parses and writes the cache
+            dt1, ph1 = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], pre + ".aug2.gfa", env_c)
+            res["augment_graph_cache"] = {"wall_s": dt1, "reads_per_s": lines / dt1, "first_run_writing_the_cache_s": dt0, "phases": ph1,
+                                          "cache_bytes": os.path.getsize(pre + ".gfa.pgc")}
+            os.unlink(pre + ".aug2.gfa")
+            os.unlink(pre + ".gfa.pgc")
+        dt, ph = timed([py, "-m", "pantas_amd.call", *flags.split(), pre + ".aug.gfa", pre + ".gtf"], pre + ".csv", env)
+        rows = 0
+        with open(pre + ".csv", "rb") as f:
+            while True:
+                chunk = f.read(1 << 26)
+                if not chunk:
+                    break
+                rows += chunk.count(b"\n")
+        res["call"] = {"wall_s": dt, "events": rows - 1, "events_per_s": (rows - 1) / dt, "out_bytes": os.path.getsize(pre + ".csv"), "phases": ph}
+        res["total_s"] = res["augment"]["wall_s"] + res["call"]["wall_s"]
+        if with_cache:
+            res["total_graph_cache_s"] = res["augment_graph_cache"]["wall_s"] + res["call"]["wall_s"]
+    except Exception as e:   # the bench line must still be printed
+        res["error"] = str(e)[-1500:]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 def main():
@@ -93,11 +202,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scale", default=os.environ.get("PANTAS_BENCH_SCALE", "auto"))
-    ap.add_argument("--lines", type=int, default=0, help="override the scale's GAF lines per GPU")
+    ap.add_argument("--lines", type=int, default=0, help="override the scale's GAF lines per GPU (per batch)")
+    ap.add_argument("--blocks", type=int, default=0, help="override the number of resident batches per GPU")
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--del-hot", type=float, default=0.0,
+                    help="share of the deletion reads aimed at 1 000 fixed (node, position) sites: the skew of real indel variants")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-call", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-e2e-cache", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on cuda:0 with gloo carrying the device tensors: exercises the sharded path on a "
                          "one-GPU box; the number it prints is not a scaling measurement")
@@ -124,19 +238,37 @@ def main():
     scale = args.scale
     if scale == "auto":
         scale = "s4" if host_ram_gb() >= 400 else "s2"
-    desc, kw = SCALES[scale]
+    desc, kw, *rest = SCALES[scale]
+    blocks = args.blocks or (rest[0] if rest else 1)
     kw = dict(kw)
     if args.lines:
         kw["n_lines"] = args.lines
+    if args.del_hot:
+        kw["p_del_hot"] = args.del_hot
+    n_lines = kw["n_lines"]
     t_gen = time.perf_counter()
-    # every rank: the same graph (same seed), its own block of the read stream
-    syn = Synth(seed=args.seed, line_offset=rank * kw["n_lines"], **kw)
+    # every rank: the same graph (same seed), its own blocks of the read stream
+    first_line = rank * blocks * n_lines
+    syn = Synth(seed=args.seed, line_offset=first_line, **kw)
     t_gen = time.perf_counter() - t_gen
     g = Graph(text=syn.gfa).to_device(local_rank)
     gs = g.stats
     g.augment_reset()
-    batch = g.load_gaf_mem(syn.gaf, first_line=rank * kw["n_lines"])
-    bs = batch.stats
+    keep_for_e2e = rank == 0 and world == 1 and not args.no_e2e
+    syns = [syn]
+    batches = [g.load_gaf_mem(syn.gaf, first_line=first_line)]
+    for b in range(1, blocks):
+        more = Synth(seed=args.seed, line_offset=first_line + b * n_lines, gaf_only=1, **kw)
+        batches.append(g.load_gaf_mem(more.gaf, first_line=first_line + b * n_lines))
+        if keep_for_e2e:
+            syns.append(more)
+        else:
+            more.close()
+    stats = [b.stats for b in batches]
+
+    def tot(name):
+        return sum(getattr(s, name) for s in stats)
+    lines, records = tot("lines"), tot("records")
 
     class _Exchange:   # what pantas_amd.distributed.allreduce_counters drives (zero-copy views of the library's buffers)
         def counters_tensor(self): return g.counters_tensor(local_rank)
@@ -151,9 +283,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    warm_ms = []
-    for _ in range(args.warmup):
-        warm_ms.append(round(g.launch(batch).main_ms, 3))
+    def step():
+        """one pass over everything resident: (rare ms, main ms, short-walk ms)"""
+        if len(batches) == 1:
+            ls = g.launch(batches[0])      # returns after both kernels completed (HIP events on the launch stream)
+            return ls.rare_ms, ls.main_ms, ls.main_short_ms
+        # several batches: every rare-key kernel before the first main kernel (the library enforces it)
+        r = sum(g.launch_rare(b) for b in batches)
+        m = sum(g.launch_main(b) for b in batches)
+        return r, m, 0.0
+
+    warm_ms = [round(step()[1], 3) for _ in range(args.warmup)]
     if dist is not None:
         # warm-up of the two collectives of the counter exchange on buffers of their sizes (the library sets up channels and
         # protocols on first use); the counters themselves are not touched before the timed region
@@ -169,10 +309,10 @@ def main():
     main_ms, rare_ms, short_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ls = g.launch(batch)      # returns after both kernels completed (HIP events on the launch stream)
-        main_ms.append(ls.main_ms)
-        rare_ms.append(ls.rare_ms)
-        short_ms.append(ls.main_short_ms)
+        r, m, s = step()
+        rare_ms.append(r)
+        main_ms.append(m)
+        short_ms.append(s)
     allreduce_ms = 0.0
     if dist is not None:
         # the ONE sum over the coverage arrays that ends a read-sharded replicate: bitmap of touched blocks ->
@@ -184,10 +324,21 @@ def main():
         allreduce_ms = (time.perf_counter() - t1) * 1e3
     sync()
     elapsed = time.perf_counter() - t0
+    ranks = None
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # proof of who took part: what the process group itself reports, and every rank's device
+        mine = {"rank": dist.get_rank(), "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                "device_index": torch.cuda.current_device(), "records": records}
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        rec_t = torch.tensor([records, lines], dtype=torch.int64, device="cuda")
+        dist.all_reduce(rec_t)
+        records_all, lines_all = (int(x) for x in rec_t.tolist())
+    else:
+        records_all, lines_all = records, lines
     t_fin = time.perf_counter()
     g.finish()   # raises if a kernel flagged a line; downloads the counters
     t_fin = time.perf_counter() - t_fin
@@ -198,8 +349,8 @@ def main():
         g.call_prepare_fused(text=syn.gtf, device=local_rank)
         t_prep = time.perf_counter() - t1
         fd = os.open(os.devnull, os.O_WRONLY)
-        # coverage has accumulated over every launch of the same batch: scale the read-count threshold with it,
-        # so that the events are those of `--rca 3` on one pass over the batch
+        # coverage has accumulated over every launch of the same batches: scale the read-count threshold with it,
+        # so that the events are those of `--rca 3` on one pass over them
         rca = 3 * (args.steps + args.warmup)
         runs = []
         for _ in range(3):
@@ -217,23 +368,28 @@ def main():
                 "prepare_s": t_prep, "tag_parse_s": cs.parse_seconds, "render_s": cs.render_seconds}
 
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = bs.lines * world / (elapsed / args.steps)
+        step_s = elapsed / args.steps
+        ms_per_step = step_s * 1e3
+        value = records_all / step_s
         avg_main = sum(main_ms) / len(main_ms)
         avg_short = sum(short_ms) / len(short_ms)
+        alg_bytes, short_alg = tot("alg_bytes"), tot("short_alg_bytes")
         if avg_short > 0:
-            # two main kernels: the short-walk kernel takes ~93 % of the records and of the time -- the dominant one
-            dom_name, dom_ms, dom_bytes = "augment_main_agg_kernel<512,2048,10,10,7,8,packed,short-walk class,info gathers 2 ahead>", avg_short, bs.short_alg_bytes
+            # two main kernels: the short-walk kernel takes the records of its class -- the dominant one
+            dom_name, dom_ms, dom_bytes, dom_recs = "augment_main_agg_kernel<short-walk class>", avg_short, short_alg, tot("short_records")
         else:
-            dom_name, dom_ms, dom_bytes = "augment_main_agg_kernel<512,2048,10,10,7,8>", avg_main, bs.alg_bytes
+            dom_name, dom_ms, dom_bytes, dom_recs = "augment main kernels of all resident batches", avg_main, alg_bytes, records
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if scale in tj and not args.lines:
-                traffic = tj[scale]["traffic_bytes"]     # measured in a separate --pmc run of this workload
-        except (OSError, ValueError):
-            pass
+        for tf in ("r2_traffic.json", "r1_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if scale in tj and not args.lines and not args.del_hot:
+                    traffic = tj[scale]["traffic_bytes"]     # measured in a separate --pmc run of this workload
+                    break
+            except (OSError, ValueError):
+                pass
+        tok_s, up_s, bucket_s = tot("tokenize_seconds"), tot("upload_seconds"), tot("tok_bucket_seconds")
         out = collections.OrderedDict()
         out.update({
             "metric": "augment GAF reads/s (+ call events/s) on synthetic spliced pangenome",
@@ -241,10 +397,23 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{scale}: {desc}; {gs.segments} segments, {gs.link_slots} links, "
-                                   f"{kw['n_genes']} genes; {bs.lines} GAF lines per GPU per step "
-                                   f"({bs.records} walked, {bs.path_nodes / max(1, bs.records):.2f} nodes/line, "
-                                   f"{bs.cs_ops / max(1, bs.records):.2f} cs ops/line), gene expression Zipf a={kw.get('zipf_a', 1.2)}",
+                                   f"{kw['n_genes']} genes; {lines} GAF lines per GPU per step in {len(batches)} resident batch(es) "
+                                   f"({records} walked, {tot('path_nodes') / max(1, records):.2f} nodes/line, "
+                                   f"{tot('cs_ops') / max(1, records):.2f} cs ops/line), gene expression Zipf a={kw.get('zipf_a', 1.2)}"
+                                   + (f", {args.del_hot:.0%} of the deletion reads on 1000 fixed sites" if args.del_hot else ""),
                        "parallelism": f"read shards x{world}, graph replicated, one block-sparse all-reduce of the coverage counters per replicate"},
+            "value_counts": "records walked by the kernels per second, summed over ranks (GAF lines filtered out by the tokeniser are not counted)",
+            "walked_records_per_step": records_all, "gaf_lines_per_step": lines_all,
+            # first-class companions of `value`: what a batch that is bucketed once and launched once sees
+            "reads_per_s_kernels_only": records_all / step_s,
+            "reads_per_s_incl_bucket": records / (step_s + bucket_s) * world,
+            "reads_per_s_text_to_counters": lines / (tok_s + up_s + step_s) * world,
+            "reads_per_s_definitions": {
+                "reads_per_s_kernels_only": "= value: resident, bucketed records; rare-key + main kernels",
+                "reads_per_s_incl_bucket": "walked records / (step + the one-off locus bucketing and block ordering of the batch, "
+                                           f"{bucket_s * 1e3:.1f} ms): a batch is bucketed once and launched once",
+                "reads_per_s_text_to_counters": "GAF lines / (PCIe copy of the text + GPU tokeniser incl. bucketing + step): from text in host memory "
+                                                "to counters in HBM; never `value`"},
             "kernel_ms": {"augment_main": avg_main, "augment_main_short_walk": avg_short, "augment_main_general": avg_main - avg_short if avg_short else None,
                           "augment_rare": sum(rare_ms) / len(rare_ms),
                           "augment_main_min": min(main_ms), "augment_main_max": max(main_ms),
@@ -253,32 +422,34 @@ def main():
                           # graph, batch and counters); rocprofv3's per-kernel average includes it, the timed steps do not
                           "augment_main_warmup": warm_ms},
             "allreduce_ms": allreduce_ms, "allreduce": exchange,
-            "records_per_s_kernel_only": bs.records / (avg_main * 1e-3),
+            "ranks": {"world_size_seen_by_process_group": dist.get_world_size() if dist is not None else 1,
+                      "backend": dist.get_backend() if dist is not None else None, "per_rank": ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dom_name, "alg_bytes_per_launch": dom_bytes, "records_per_launch": bs.short_records if avg_short > 0 else bs.records,
-                         "whole_main_step": {"ms": avg_main, "alg_bytes": bs.alg_bytes, "achieved_GBps": bs.alg_bytes / (avg_main * 1e-3) / 1e9},
-                         "traffic_note": "HBM bytes per launch from profiles/r1_traffic.json (separate rocprofv3 --pmc passes "
+                         "kernel": dom_name, "alg_bytes_per_launch": dom_bytes, "records_per_launch": dom_recs,
+                         "whole_main_step": {"ms": avg_main, "alg_bytes": alg_bytes, "achieved_GBps": alg_bytes / (avg_main * 1e-3) / 1e9},
+                         "traffic_note": "HBM bytes per launch from profiles/r*_traffic.json (separate rocprofv3 --pmc passes "
                                          "of this workload), null when no profile of this scale is committed"},
             "call": call,
-            "host": {"generate_s": t_gen, "gfa_load_s": gs.load_seconds, "gaf_tokenize_s": bs.tokenize_seconds,
-                     "gaf_upload_s": bs.upload_seconds, "finish_download_s": t_fin,
-                     "gaf_text_bytes": bs.text_bytes, "gfa_text_bytes": gs.text_bytes,
-                     "tokenize_reads_per_s": bs.lines / bs.tokenize_seconds if bs.tokenize_seconds else None,
+            "host": {"generate_s": t_gen, "gfa_load_s": gs.load_seconds, "gaf_tokenize_s": tok_s,
+                     "gaf_upload_s": up_s, "finish_download_s": t_fin,
+                     "gaf_text_bytes": tot("text_bytes"), "gfa_text_bytes": gs.text_bytes,
+                     "tokenize_reads_per_s": lines / tok_s if tok_s else None,
                      "cores": os.cpu_count(), "ram_gb": host_ram_gb(),
                      "peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             # the step in front of the path: GAF text -> records; never part of `value`
-            "tokenizer": {"where": {1: "host threads (gaf.cpp)", 2: "GPU kernels (tokenize.hip)"}.get(bs.tokenizer),
-                          "text_to_hbm_s": bs.upload_seconds if bs.tokenizer == 2 else None,
-                          "line_index_s": bs.tok_index_seconds, "measure_and_scans_s": bs.tok_measure_seconds,
-                          "write_s": bs.tok_write_seconds, "bucket_s": bs.tok_bucket_seconds,
-                          "text_GBps_kernels": (bs.text_bytes / 1e9 / (bs.tok_index_seconds + bs.tok_measure_seconds +
-                                                                        bs.tok_write_seconds + bs.tok_bucket_seconds)
-                                                if bs.tokenizer == 2 else None),
-                          "pcie_inclusive_reads_per_s": bs.lines / (bs.tokenize_seconds + bs.upload_seconds + ms_per_step * 1e-3)},
+            "tokenizer": {"where": {1: "host threads (gaf.cpp)", 2: "GPU kernels (tokenize.hip)"}.get(stats[0].tokenizer),
+                          "text_to_hbm_s": up_s if stats[0].tokenizer == 2 else None,
+                          "line_index_s": tot("tok_index_seconds"), "measure_and_scans_s": tot("tok_measure_seconds"),
+                          "write_s": tot("tok_write_seconds"), "bucket_s": bucket_s,
+                          "text_GBps_kernels": (tot("text_bytes") / 1e9 / (tot("tok_index_seconds") + tot("tok_measure_seconds") +
+                                                                           tot("tok_write_seconds") + bucket_s)
+                                                if stats[0].tokenizer == 2 else None)},
         })
-        if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        if keep_for_e2e:
+            out["e2e"] = e2e_leg(syns, scale, kw, with_cache=not args.no_e2e_cache)
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, lines, syn.stats.junction_links)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

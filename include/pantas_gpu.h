@@ -242,6 +242,9 @@ typedef struct {
   double p_lowmapq, p_unmapped, p_sub, p_indel, p_highdv;
   double p_novel_skip, p_novel_ce, p_intron, p_novel_ss, p_clip;
   uint64_t line_offset;    /* lines [line_offset, line_offset + n_lines) of the read stream */
+  int32_t gaf_only;        /* 1: no GFA / GTF text (further blocks of the read stream of a graph generated before) */
+  uint32_t hot_sites;      /* with p_del_hot > 0: that share of the deletion reads is aimed at hot_sites fixed */
+  double p_del_hot;        /* (node, position) sites on the most expressed genes -- the skew of real indel variants */
 } pantas_synth_params;
 typedef struct {
   uint32_t struct_size, reserved0_;

@@ -78,7 +78,7 @@ class SynthParams(_Sized):
                 ("p_lowmapq", C.c_double), ("p_unmapped", C.c_double), ("p_sub", C.c_double), ("p_indel", C.c_double),
                 ("p_highdv", C.c_double), ("p_novel_skip", C.c_double), ("p_novel_ce", C.c_double),
                 ("p_intron", C.c_double), ("p_novel_ss", C.c_double), ("p_clip", C.c_double),
-                ("line_offset", C.c_uint64)]
+                ("line_offset", C.c_uint64), ("gaf_only", C.c_int32), ("hot_sites", C.c_uint32), ("p_del_hot", C.c_double)]
 
 
 class SynthStats(_Sized):

@@ -869,6 +869,7 @@ __attribute__((visibility("default"))) void pantas_synth_defaults(pantas_synth_p
   p->p_novel_skip = d.p_novel_skip; p->p_novel_ce = d.p_novel_ce; p->p_intron = d.p_intron; p->p_novel_ss = d.p_novel_ss;
   p->p_clip = d.p_clip;
   p->line_offset = 0;
+  p->gaf_only = d.gaf_only; p->hot_sites = d.hot_sites; p->p_del_hot = d.p_del_hot;
   (void)guarded([&] { put_out(out, v, "pantas_synth_params"); });   // a declaration without struct_size is left untouched
 }
 
@@ -887,6 +888,8 @@ __attribute__((visibility("default"))) int pantas_synth_generate(const pantas_sy
     d.p_novel_skip = p->p_novel_skip; d.p_novel_ce = p->p_novel_ce; d.p_intron = p->p_intron; d.p_novel_ss = p->p_novel_ss;
     d.p_clip = p->p_clip;
     d.line_offset = p->line_offset;
+    d.gaf_only = p->gaf_only; d.p_del_hot = p->p_del_hot;
+    if (p->hot_sites) d.hot_sites = p->hot_sites;
     auto h = std::make_unique<pantas_synth>();
     double t0 = now_s();
     synth_generate(d, h->out);

@@ -333,12 +333,22 @@ void emit_gaf_line(const Model& m, const std::vector<double>& cdf, const std::ve
     out += '\n';
     return;
   }
+  // deletion skew (p_del_hot): decided from a stream of its own so that p_del_hot = 0 leaves every other draw as it was
+  bool hot = false, cool_del = false;
+  uint32_t hot_id = 0;
+  if (p.p_del_hot > 0) {
+    Rng h(p.seed * 7919ull + li * 0x9E3779B97F4A7C15ull + 101);
+    hot = h.prob() < p.p_indel * 0.5 * p.p_del_hot;
+    cool_del = h.prob() < p.p_del_hot;        // a random-position deletion of this read becomes an insertion
+    hot_id = uint32_t(h.next() % std::max<uint32_t>(1, p.hot_sites));
+  }
   const double x = r.prob() * cdf.back();
-  const uint32_t gi = perm[size_t(std::lower_bound(cdf.begin(), cdf.end(), x) - cdf.begin())];
+  uint32_t gi = perm[size_t(std::lower_bound(cdf.begin(), cdf.end(), x) - cdf.begin())];
+  if (hot) gi = perm[hot_id % p.n_genes];          // perm[0], perm[1], ... = the most expressed genes
   const Gene& g = m.genes[gi];
-  std::vector<Range> ex = g.txs[size_t(r.next() % g.txs.size())];
-  const int hap = int(r.next() & 1);
-  const double kx = r.prob();
+  std::vector<Range> ex = g.txs[hot ? 0 : size_t(r.next() % g.txs.size())];
+  const int hap = hot ? 0 : int(r.next() & 1);
+  const double kx = hot ? 1.0 : r.prob();
   int kind = 0;   // 0 plain, 1 skip, 2 cassette, 3 intron, 4 splice-site shift
   double acc = 0;
   const double pk[4] = {p.p_novel_skip, p.p_novel_ce, p.p_intron, p.p_novel_ss};
@@ -385,7 +395,26 @@ void emit_gaf_line(const Model& m, const std::vector<double>& cdf, const std::ve
   for (uint32_t l : lens) total += l;
   const uint32_t span = uint32_t(std::min<uint64_t>(p.read_len, total));
   uint64_t off;
-  if (kind == 0) off = uint64_t(r.range(0, int64_t(total - span)));
+  uint32_t hot_c = 0, hot_n = 0;     // the hot deletion starts hot_c path bases into the window and is hot_n long
+  if (hot && span >= 24) {
+    hot_n = 1 + (hot_id * 2654435761u >> 30);                                       // 1 .. 4, fixed per site
+    // the site = the first base of a path node (fixed per site): the '-' is then the first op the reads lay on that node,
+    // which is what makes a deletion an IL/OL key at all (:282, :322) -- every covering read bumps the same key
+    uint64_t site = 3;
+    {
+      const size_t nn = lens.size();
+      const size_t j = nn > 2 ? 1 + size_t((uint64_t(hot_id) * 0x9E3779B1ull + gi) % (nn - 1)) : 0;
+      uint64_t pre = 0;
+      for (size_t i = 0; i < j; ++i) pre += lens[i];
+      site = std::min<uint64_t>(std::max<uint64_t>(pre, 3), total > 12 + hot_n ? total - 9 - hot_n : 3);
+    }
+    // windows that hold the site with the margins cs_for_span keeps (3 before, 8 behind)
+    const int64_t lo = std::max<int64_t>(0, int64_t(site) - (int64_t(span) - 8 - hot_n));
+    const int64_t hi = std::min<int64_t>(int64_t(total - span), int64_t(site) - 3);
+    if (lo <= hi) { off = uint64_t(r.range(lo, hi)); hot_c = uint32_t(site - off); }
+    else { hot = false; off = uint64_t(r.range(0, int64_t(total - span))); }
+  } else if (hot) { hot = false; off = uint64_t(r.range(0, int64_t(total - span))); }
+  else if (kind == 0) off = uint64_t(r.range(0, int64_t(total - span)));
   else {
     uint64_t before = 0;
     for (size_t i = 0; i < jpos && i < lens.size(); ++i) before += lens[i];
@@ -403,9 +432,29 @@ void emit_gaf_line(const Model& m, const std::vector<double>& cdf, const std::ve
   uint64_t plen = 0;
   for (size_t i = i0; i <= i1; ++i) plen += lens[i];
   const bool rev = r.next() & 1;
-  const int mapq = r.prob() < p.p_lowmapq ? int(r.range(0, 19)) : 60;
+  const int mapq = (r.prob() < p.p_lowmapq && !hot) ? int(r.range(0, 19)) : 60;
   cs_for_span(r, p, span, cs);
-  if (r.prob() < p.p_clip && span > 20) {
+  if (hot) {
+    // the deletion in READ order: a reverse read runs down the path, so the site is met from the other end
+    const uint32_t c = rev ? span - hot_c - hot_n : hot_c;
+    cs.clear();
+    cs += ':'; put_u(cs, c);
+    cs += '-';
+    for (uint32_t i = 0; i < hot_n; ++i) cs += 'a';
+    cs += ':'; put_u(cs, span - c - hot_n);
+  } else if (cool_del) {
+    const size_t d = cs.find('-');
+    if (d != std::string::npos) {       // ":c-xyz:rest" -> ":c+xyz:(rest + n)": the ops must still cover the window
+      size_t e = d + 1;
+      while (e < cs.size() && cs[e] >= 'a' && cs[e] <= 'z') ++e;
+      const uint64_t n = e - d - 1;
+      const uint64_t rest = strtoull(cs.c_str() + e + 1, nullptr, 10);
+      std::string t = cs.substr(0, d) + "+" + cs.substr(d + 1, n) + ":";
+      put_u(t, rest + n);
+      cs = t;
+    }
+  }
+  if (!hot && r.prob() < p.p_clip && span > 20) {
     uint32_t n = uint32_t(r.range(1, 6));
     std::string ins;
     static const char B[4] = {'a', 'c', 'g', 't'};
@@ -467,6 +516,7 @@ void synth_generate(const SynthParams& p, SynthOutput& out, unsigned threads) {
     if (wa != wb) throw Error("ArgumentError", "base_id too small: node ids would change width");
   }
   // ---- GFA ----------------------------------------------------------------------------------
+  if (!p.gaf_only) {
   std::vector<std::string> s_parts(R), l_parts(R), gtf_parts(R);
   std::vector<uint64_t> nl(R, 0), nj(R, 0);
   parallel_chunks(R, tg, [&](unsigned, size_t b, size_t e) {
@@ -519,6 +569,7 @@ void synth_generate(const SynthParams& p, SynthOutput& out, unsigned threads) {
   memcpy(dst + p_off, paths.data(), paths.size());
   out.gtf = "#!synthetic annotation\n";
   for (auto& s : gtf_parts) out.gtf += s;
+  }
   // ---- GAF ----------------------------------------------------------------------------------
   std::vector<uint32_t> perm(p.n_genes);
   for (uint32_t i = 0; i < p.n_genes; ++i) perm[i] = i;

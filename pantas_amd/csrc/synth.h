@@ -25,6 +25,13 @@ struct SynthParams {
   double p_novel_skip = 0.04, p_novel_ce = 0.02, p_intron = 0.06, p_novel_ss = 0.04, p_clip = 0.03;
   uint32_t n_chrom = 1;             // genes are dealt to chromosomes in contiguous blocks
   int with_path = 1;                // P line per chromosome
+  int gaf_only = 0;                 // 1: no GFA / GTF text (further blocks of the read stream of a graph generated before)
+  // Deletion skew of real data: a true indel variant is ONE (node, position) key that every read covering it increments,
+  // while the plain recipe drops deletions at random positions.  With p_del_hot > 0 that share of the deletion reads is
+  // aimed at `hot_sites` fixed sites on the first transcripts of the most expressed genes (and the rest of the deletion
+  // reads stay random).
+  double p_del_hot = 0.0;
+  uint32_t hot_sites = 1000;
 };
 
 // text buffer without the zero-fill of std::string::resize (the GFA is ~12 GB at the human scale)

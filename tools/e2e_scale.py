@@ -57,7 +57,9 @@ def main():
     ap.add_argument("--seed", type=int, default=7)
     a = ap.parse_args()
     from pantas_amd.engine import Synth
-    desc, kw = bench.SCALES[a.scale]
+    desc, kw, *rest = bench.SCALES[a.scale]
+    if rest and a.blocks == 1:
+        a.blocks = rest[0]
     kw = dict(kw)
     if a.lines:
         kw["n_lines"] = a.lines
