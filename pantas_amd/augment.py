@@ -8,8 +8,16 @@ from __future__ import annotations
 
 import os
 import sys
+import time
 
-from .engine import Graph, PantasError, graph_cache_path
+_T0 = time.perf_counter()
+
+from .engine import Graph, PantasError, graph_cache_path  # noqa: E402
+
+
+def _lap(what: str) -> None:
+    if os.environ.get("PANTAS_TIMING"):
+        print(f"[timing] cli augment: {what:<28} at {time.perf_counter() - _T0:8.3f} s since interpreter start of the module", file=sys.stderr)
 
 
 def main(argv) -> int:
@@ -19,14 +27,18 @@ def main(argv) -> int:
     device = int(os.environ.get("PANTAS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     print("Read GFA", file=sys.stderr)
     try:
+        _lap("imports done")
         g = Graph(gfa_file, cache=graph_cache_path(gfa_file))   # PANTAS_GRAPH_CACHE: the graph is shared by all replicates
+        _lap("graph loaded")
         g.to_device(device)
         print("Augmentation by GAF alignments", file=sys.stderr)
         bs, _ = g.augment(gaf_file, thr, fd_out=-1)
+        _lap("reads walked, counters on host")
         print(f"Rejected alignments: {bs.rejected}", file=sys.stderr)
         print("Annotating GFA", file=sys.stderr)
         sys.stdout.flush()
         g.write_gfa(sys.stdout.fileno())
+        _lap("GFA written")
     except PantasError as e:
         # the reference dies with a traceback and exit status 1, stdout still empty
         print(f"{e.kind}: {e}", file=sys.stderr)
@@ -35,4 +47,8 @@ def main(argv) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1:]))
+    rc = main(sys.argv[1:])
+    sys.stdout.flush()
+    sys.stderr.flush()
+    # the output is complete: leave without tearing down 60 GB of graph arrays page by page (seconds at whole-genome scale)
+    os._exit(rc)

@@ -11,8 +11,16 @@ import argparse
 import datetime
 import os
 import sys
+import time
 
-from .engine import Graph, PantasError
+_T0 = time.perf_counter()
+
+from .engine import Graph, PantasError  # noqa: E402
+
+
+def _lap(what: str) -> None:
+    if os.environ.get("PANTAS_TIMING"):
+        print(f"[timing] cli call: {what:<28} at {time.perf_counter() - _T0:8.3f} s since interpreter start of the module", file=sys.stderr)
 
 CSV_HEADER = ("event_type,annotated/novel,chrom,gene,strand,transcripts1,transcripts2,transcripts3,"
               "nodes1,coverage1,nodes2,coverage2,nodes3,coverage3")      # scripts/call.py:218-234
@@ -49,14 +57,18 @@ def run(args) -> int:
     device = int(os.environ.get("PANTAS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     try:
         _stamp("Parsing GFA..")
+        _lap("imports done")
         g = Graph(args.GFA)
+        _lap("graph loaded")
         _stamp("Parsing GTF..")
         g.call_prepare(args.GTF, device)
+        _lap("tables built and uploaded")
         sys.stdout.flush()
         sys.stderr.flush()
         g.call(sys.stdout.fileno(), sys.stderr.fileno(), rca=args.rca, novel=args.novel,
                no_annotated=args.annotated, events=args.events, isw=args.isw,
                minintronsize=args.minintronsize, junction=args.junction)
+        _lap("events written")
     except PantasError as e:
         print(f"{e.kind}: {e}", file=sys.stderr)
         return 1
@@ -68,4 +80,7 @@ def main(argv=None) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    rc = main()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc)      # (see augment.py: no page-by-page teardown of the graph arrays)

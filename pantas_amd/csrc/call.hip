@@ -180,8 +180,8 @@ static void exclusive_scan(DeviceCall& d, const uint32_t* a, uint32_t* out, uint
   hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1), 0, d.stream, a, out, n);
 }
 
-template <class T>
-static const T* up(DeviceCall& d, const std::vector<T>& v) {
+template <class T, class A>
+static const T* up(DeviceCall& d, const std::vector<T, A>& v) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
   d.allocs.push_back(p);

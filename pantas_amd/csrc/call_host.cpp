@@ -42,8 +42,9 @@ const char* call_error_text(uint32_t code) {
 
 namespace {
 
-struct SegAttr { uint64_t ex_off = 0; uint32_t ex_len = 0; bool has_ex = false; };
-struct LinkAttr { uint64_t jn_off = 0; uint32_t jn_len = 0; bool has_jn = false, has_id = false, has_rc = false; int32_t rc = 0; };
+// (trivial on purpose: arrays of 2.5e8 of them are sized without a constructor pass and every element is set by the tag scan)
+struct SegAttr { uint64_t ex_off; uint32_t ex_len; bool has_ex; };
+struct LinkAttr { uint64_t jn_off; uint32_t jn_len; bool has_jn, has_id, has_rc; int32_t rc; };
 
 [[noreturn]] void bad_tag(uint64_t off, Span f) {
   throw Error("ValueError", "GFA byte " + std::to_string(off) + ": tag '" + std::string(f.b, f.size()) +
@@ -289,11 +290,14 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
 
   pt.lap("gtf + link layout");
   // ---- phase A (parallel): locate the tags of every S line and every link slot -----------------
-  std::vector<SegAttr> sa(V);
-  t.nc.assign(V, 0);
-  t.nflags.assign(V, 0);
+  RawVector<SegAttr> sa(V);
+  t.nc.resize(V);
+  t.nflags.resize(V);
   parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
     for (size_t n = b; n < e; ++n) {
+      sa[n] = SegAttr{0, 0, false};
+      t.nc[n] = 0;
+      t.nflags[n] = 0;
       const uint64_t off = g.seg_line_off[n];
       const char* le = static_cast<const char*>(memchr(base + off, '\n', g.text.size - off));
       Span st = strip(Span{base + off, le ? le : base + g.text.size});
@@ -315,12 +319,13 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       }
     }
   });
-  std::vector<LinkAttr> la(A);
+  RawVector<LinkAttr> la(A);
   t.src.resize(A);
   parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
     for (size_t u = b; u < e; ++u)
       for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s) {
         t.src[s] = uint32_t(u);
+        la[s] = LinkAttr{0, 0, false, false, false, 0};
         const uint32_t gs = graph_slot(s);
         if (gs == NONE32) continue;      // a link added by the reads: filled in below
         const uint64_t off = g.slot_off[gs];
@@ -362,9 +367,9 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   pt.lap("tag scan (parallel)");
   // ---- canonical slots: first slot of each (u, v); attributes of the LAST duplicate (dict overwrite, :173)
   t.first_slot.resize(A);
-  t.lflags.assign(A, 0);
-  t.rc.assign(A, 0);
-  std::vector<uint32_t> attr_slot(A);
+  par_assign(t.lflags, A, 0u, threads);
+  par_assign(t.rc, A, int32_t(0), threads);
+  RawVector<uint32_t> attr_slot(A);
   parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t ub, size_t ue) {
     for (size_t u = ub; u < ue; ++u) {
       const uint32_t b = t.row_ptr[u], e = t.row_ptr[u + 1];
@@ -406,54 +411,126 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     t.tx_gene.push_back(gi == gtf.tx_gene.end() ? CNONE : gi->second);
     return id;
   };
-  std::unordered_map<std::string_view, uint32_t> ex_ids;
+  // EX tags (:86-121), ids in first-appearance order (rule R2 picks "the tag that appears first").  At whole-genome scale
+  // there are ~4e7 tag occurrences on 2.5e8 segments but only a few million distinct tags, local to their genes: every
+  // thread interns the occurrences of its node range in a map of its own (no locks), the maps are merged in chunk order
+  // -- which IS first-appearance order -- touching each distinct tag once, and the per-node lists are written in parallel.
   std::vector<uint32_t> extag_tx;
-  t.ex_ptr.assign(size_t(V) + 1, 0);
-  std::vector<uint32_t> tmp;
-  for (uint32_t n = 0; n < V; ++n) {
-    t.ex_ptr[n] = uint32_t(t.ex_tag.size());
-    if (!sa[n].has_ex) continue;
-    tmp.clear();
-    const char* p = base + sa[n].ex_off;
-    const char* e = p + sa[n].ex_len;
-    for (;;) {
-      const char* c = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
-      Span tag{p, c ? c : e};
-      auto it = ex_ids.find(tag.sv());
-      uint32_t id;
-      if (it == ex_ids.end()) {
-        id = uint32_t(t.extag_span.size());
-        ex_ids.emplace(tag.sv(), id);
-        t.extag_span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
-        extag_tx.push_back(tx_id(tx_of_exon(tag)));
-      } else id = it->second;
-      tmp.push_back(id);
-      if (!c) break;
-      p = c + 1;
+  par_assign(t.ex_ptr, size_t(V) + 1, 0u, threads);
+  {
+    struct ExChunk {
+      size_t nb = 0, ne = 0;
+      std::unordered_map<std::string_view, uint32_t> ids;   // tag -> local id (order of first appearance in the chunk)
+      std::vector<StrRef> span;                             // local id -> tag text
+      std::vector<uint32_t> occ;                            // per node, its distinct local ids (concatenated)
+      std::vector<uint32_t> to_global;
+      uint64_t out_base = 0;
+    };
+    const unsigned C = V < 4096 ? 1u : threads;
+    std::vector<ExChunk> ck(C);
+    parallel_chunks(V, C, [&](unsigned c, size_t nb, size_t ne) {
+      ExChunk& k = ck[c];
+      k.nb = nb; k.ne = ne;
+      std::vector<uint32_t> tmp;
+      for (size_t n = nb; n < ne; ++n) {
+        if (!sa[n].has_ex) continue;
+        tmp.clear();
+        const char* p = base + sa[n].ex_off;
+        const char* e = p + sa[n].ex_len;
+        for (;;) {
+          const char* cm = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
+          Span tag{p, cm ? cm : e};
+          auto ins = k.ids.emplace(tag.sv(), uint32_t(k.span.size()));
+          if (ins.second) k.span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
+          tmp.push_back(ins.first->second);
+          if (!cm) break;
+          p = cm + 1;
+        }
+        sort_unique(tmp);
+        t.ex_ptr[n] = uint32_t(tmp.size());        // count for now, offset after the scan below
+        k.occ.insert(k.occ.end(), tmp.begin(), tmp.end());
+      }
+    });
+    // merge in chunk order = first-appearance order over the whole file
+    std::unordered_map<std::string_view, uint32_t> ex_ids;
+    {
+      size_t distinct = 0;
+      for (const ExChunk& k : ck) distinct += k.span.size();
+      ex_ids.reserve(distinct);
     }
-    sort_unique(tmp);
-    for (uint32_t id : tmp) {
-      t.ex_tag.push_back(id);
-      t.ex_tx.push_back(extag_tx[id]);
-      t.ex_gene.push_back(t.tx_gene[extag_tx[id]]);
+    uint64_t total = 0;
+    for (ExChunk& k : ck) {
+      k.to_global.resize(k.span.size());
+      for (size_t i = 0; i < k.span.size(); ++i) {
+        const Span tag{base + k.span[i].off, base + k.span[i].off + k.span[i].len};
+        auto ins = ex_ids.emplace(tag.sv(), uint32_t(t.extag_span.size()));
+        if (ins.second) {
+          t.extag_span.push_back(k.span[i]);
+          extag_tx.push_back(tx_id(tx_of_exon(tag)));
+        }
+        k.to_global[i] = ins.first->second;
+      }
+      k.out_base = total;
+      total += k.occ.size();
+      std::unordered_map<std::string_view, uint32_t>().swap(k.ids);
     }
+    if (total >= uint64_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 EX tag entries");
+    // counts -> offsets (per chunk: its nodes' entries are contiguous behind out_base)
+    parallel_chunks(C, C, [&](unsigned, size_t cb, size_t ce) {
+      for (size_t c = cb; c < ce; ++c) {
+        uint64_t at = ck[c].out_base;
+        for (size_t n = ck[c].nb; n < ck[c].ne; ++n) { const uint32_t cnt = t.ex_ptr[n]; t.ex_ptr[n] = uint32_t(at); at += cnt; }
+      }
+    });
+    t.ex_ptr[V] = uint32_t(total);
+    t.ex_tag.resize(total); t.ex_tx.resize(total); t.ex_gene.resize(total);
+    parallel_chunks(C, C, [&](unsigned, size_t cb, size_t ce) {
+      std::vector<uint32_t> tmp;
+      for (size_t c = cb; c < ce; ++c) {
+        const ExChunk& k = ck[c];
+        size_t in = 0;
+        for (size_t n = k.nb; n < k.ne; ++n) {
+          const uint32_t lo = t.ex_ptr[n], cnt = t.ex_ptr[n + 1] - lo;      // (ex_ptr[n + 1] of the chunk's last node belongs to the next chunk: already final)
+          if (!cnt) continue;
+          tmp.assign(k.occ.begin() + long(in), k.occ.begin() + long(in + cnt));
+          in += cnt;
+          for (uint32_t& x : tmp) x = k.to_global[x];
+          std::sort(tmp.begin(), tmp.end());
+          for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t id = tmp[j];
+            t.ex_tag[lo + j] = id;
+            t.ex_tx[lo + j] = extag_tx[id];
+            t.ex_gene[lo + j] = t.tx_gene[extag_tx[id]];
+          }
+        }
+      }
+    });
   }
-  t.ex_ptr[V] = uint32_t(t.ex_tag.size());
 
-  pt.lap("intern EX (sequential)");
+  pt.lap("intern EX (parallel scan, merge of distinct tags)");
+  // JN tags: only junction links carry them (5e5 of 2.6e8 slots): the tags are interned in slot order by one thread, the
+  // four per-slot offset arrays -- constant between two junction slots -- are filled by all of them
   std::unordered_map<std::string_view, uint32_t> jn_ids;
-  t.jn_ptr.assign(A + 1, 0);
-  t.jt_ptr.assign(A + 1, 0);
-  t.jx_ptr.assign(A + 1, 0);
-  t.jg_ptr.assign(A + 1, 0);
+  std::vector<uint32_t> jslot;                      // junction slots (first slot of their pair), ascending
+  {
+    const unsigned C = A < 65536 ? 1u : threads;
+    std::vector<std::vector<uint32_t>> part(C);
+    parallel_chunks(A, C, [&](unsigned c, size_t sb, size_t se) {
+      for (size_t s2 = sb; s2 < se; ++s2)
+        if (t.first_slot[s2] == s2 && (t.lflags[s2] & L_JUNC)) part[c].push_back(uint32_t(s2));
+    });
+    for (auto& v : part) jslot.insert(jslot.end(), v.begin(), v.end());
+  }
+  const size_t NJ = jslot.size();
+  std::vector<uint32_t> o_jn(NJ + 1, 0), o_jt(NJ + 1, 0), o_jx(NJ + 1, 0), o_jg(NJ + 1, 0);
   std::vector<uint32_t> tags, txs, genes;
-  for (size_t s = 0; s < A; ++s) {
-    t.jn_ptr[s] = uint32_t(t.jn_ftx.size());
-    t.jt_ptr[s] = uint32_t(t.jt.size());
-    t.jx_ptr[s] = uint32_t(t.jx.size());
-    t.jg_ptr[s] = uint32_t(t.jg.size());
-    if (t.first_slot[s] != s || !(t.lflags[s] & L_JUNC)) continue;
-    const LinkAttr& a = la[attr_slot[s]];
+  for (size_t j = 0; j < NJ; ++j) {
+    const size_t sl = jslot[j];
+    o_jn[j] = uint32_t(t.jn_ftx.size());
+    o_jt[j] = uint32_t(t.jt.size());
+    o_jx[j] = uint32_t(t.jx.size());
+    o_jg[j] = uint32_t(t.jg.size());
+    const LinkAttr& a = la[attr_slot[sl]];
     tags.clear(); txs.clear(); genes.clear();
     const char* p = base + a.jn_off;
     const char* e = p + a.jn_len;
@@ -475,14 +552,24 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     t.jt.insert(t.jt.end(), tags.begin(), tags.end());
     t.jx.insert(t.jx.end(), txs.begin(), txs.end());
     t.jg.insert(t.jg.end(), genes.begin(), genes.end());
-    if (keyerr) t.lflags[s] |= L_GENE_KEYERR;
+    if (keyerr) t.lflags[sl] |= L_GENE_KEYERR;
   }
-  t.jn_ptr[A] = uint32_t(t.jn_ftx.size());
-  t.jt_ptr[A] = uint32_t(t.jt.size());
-  t.jx_ptr[A] = uint32_t(t.jx.size());
-  t.jg_ptr[A] = uint32_t(t.jg.size());
+  o_jn[NJ] = uint32_t(t.jn_ftx.size());
+  o_jt[NJ] = uint32_t(t.jt.size());
+  o_jx[NJ] = uint32_t(t.jx.size());
+  o_jg[NJ] = uint32_t(t.jg.size());
+  // ptr[s] = offset of the first junction at or behind slot s (a junction slot's own entries start there, every other
+  // slot's range is empty), ptr[A] = the totals
+  t.jn_ptr.resize(A + 1); t.jt_ptr.resize(A + 1); t.jx_ptr.resize(A + 1); t.jg_ptr.resize(A + 1);
+  parallel_chunks(A + 1, A < 65536 ? 1u : threads, [&](unsigned, size_t sb, size_t se) {
+    size_t j = size_t(std::lower_bound(jslot.begin(), jslot.end(), uint32_t(sb)) - jslot.begin());
+    for (size_t s2 = sb; s2 < se; ++s2) {
+      while (j < NJ && jslot[j] < s2) ++j;
+      t.jn_ptr[s2] = o_jn[j]; t.jt_ptr[s2] = o_jt[j]; t.jx_ptr[s2] = o_jx[j]; t.jg_ptr[s2] = o_jg[j];
+    }
+  });
 
-  pt.lap("intern JN (sequential)");
+  pt.lap("intern JN (junction slots only, parallel fill)");
   // ---- lexicographic rank of segment names ------------------------------------------------------------
   t.rank.resize(V);
   bool fixed_width = g.names.dense && V > 0;

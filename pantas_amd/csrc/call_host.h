@@ -36,11 +36,14 @@ struct CallTables {
   std::vector<uint32_t> x_row_ptr, x_col, x_irow_ptr, x_icol, x_islot;
   std::vector<uint64_t> x_order;
   // ---- mirrored to the device -----------------------------------------------------------
-  std::vector<uint32_t> first_slot, src, lflags;
-  std::vector<int32_t> rc, nc;
-  std::vector<uint32_t> nflags, rank;
-  std::vector<uint32_t> ex_ptr, ex_tag, ex_tx, ex_gene;
-  std::vector<uint32_t> jn_ptr, jn_ftx, jt_ptr, jt, jx_ptr, jx, jg_ptr, jg;
+  // (RawVector: [V] / [A] arrays, gigabytes at whole-genome scale -- huge pages, filled by many threads)
+  RawVector<uint32_t> first_slot, src, lflags;
+  RawVector<int32_t> rc, nc;
+  RawVector<uint32_t> nflags, rank;
+  RawVector<uint32_t> ex_ptr;
+  std::vector<uint32_t> ex_tag, ex_tx, ex_gene;
+  RawVector<uint32_t> jn_ptr, jt_ptr, jx_ptr, jg_ptr;
+  std::vector<uint32_t> jn_ftx, jt, jx, jg;
   std::vector<uint32_t> tx_gene;
   std::vector<uint32_t> junctions, novels;   // canonical slots in file order
   std::vector<uint32_t> probe, probe_ok;

@@ -6,7 +6,9 @@
 #include <unistd.h>
 #include <chrono>
 #include <cerrno>
+#include <cstdlib>
 #include <exception>
+#include <new>
 #include <mutex>
 
 namespace pantas {
@@ -34,6 +36,25 @@ void MappedFile::close() {
   data = nullptr;
   size = 0;
   fd = -1;
+}
+
+void* big_alloc(size_t bytes) {
+  constexpr size_t HUGE = size_t(2) << 20;
+  if (bytes < 4 * HUGE) {
+    void* p = ::operator new(bytes ? bytes : 1);
+    return p;
+  }
+  const size_t rounded = (bytes + HUGE - 1) / HUGE * HUGE;
+  void* p = aligned_alloc(HUGE, rounded);
+  if (!p) throw std::bad_alloc();
+  (void)madvise(p, rounded, MADV_HUGEPAGE);      // advice only: without transparent huge pages this is an ordinary block
+  return p;
+}
+
+void big_free(void* p, size_t bytes) {
+  constexpr size_t HUGE = size_t(2) << 20;
+  if (bytes < 4 * HUGE) ::operator delete(p);
+  else free(p);
 }
 
 unsigned hw_threads() {
@@ -101,9 +122,10 @@ void PhaseTimer::lap(const char* phase) {
 }
 
 // parallel LSD radix sort of (key, idx) pairs, 16-bit digits
-void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads) {
+template <class Vec>
+static void radix_sort_pairs_impl(Vec& key, Vec& idx, unsigned threads) {
   const size_t n = key.size();
-  std::vector<uint32_t> key2(n), idx2(n);
+  Vec key2(n), idx2(n);
   const unsigned T = n < (1u << 16) ? 1 : threads;
   uint32_t maxk = 0;
   for (uint32_t k : key) maxk = std::max(maxk, k);
@@ -131,6 +153,9 @@ void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, un
   }
 }
 
+
+void radix_sort_pairs(RawVector<uint32_t>& key, RawVector<uint32_t>& idx, unsigned threads) { radix_sort_pairs_impl(key, idx, threads); }
+void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads) { radix_sort_pairs_impl(key, idx, threads); }
 
 double now_s() {
   using namespace std::chrono;

@@ -127,17 +127,27 @@ inline bool parse_py_int(Span t, int64_t& v, bool saturate = false) {
 unsigned hw_threads();
 
 // std::vector whose resize() leaves trivially constructible elements uninitialised: for buffers of gigabytes that are
-// about to be overwritten (a device-to-host copy), where the value-initialising fill would be a serial pass over fresh pages
+// about to be overwritten (a device-to-host copy, a parallel fill), where the value-initialising fill would be a serial pass
+// over fresh pages.  Blocks of 8 MB and more are 2 MB-aligned and marked MADV_HUGEPAGE: the first touch of 4 GB of fresh
+// 4 KB pages costs 0.3 s on 64 threads, of transparent huge pages 0.014 s (profiles/r2_hostio_probe.txt) -- the graph
+// arrays of a whole-genome GFA are 14 GB, the loader's temporaries another 20.
+void* big_alloc(size_t bytes);
+void big_free(void* p, size_t bytes);
 template <class T>
-struct NoInitAlloc : std::allocator<T> {
+struct NoInitAlloc {
+  using value_type = T;
   template <class U> struct rebind { using other = NoInitAlloc<U>; };
   NoInitAlloc() = default;
   template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(big_alloc(n * sizeof(T))); }
+  void deallocate(T* p, size_t n) { big_free(p, n * sizeof(T)); }
   template <class U, class... A>
   void construct(U* p, A&&... a) {
     if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
     else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
   }
+  template <class U> bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
 };
 template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 // touches every page of [p, p + bytes) from several threads (first-touch page faults are the cost of a fresh buffer)
@@ -146,10 +156,21 @@ void prefault(void* p, size_t bytes);
 // Runs fn(chunk_index, begin, end) over [0, n) split into `chunks` contiguous ranges.
 void parallel_chunks(size_t n, unsigned chunks, const std::function<void(unsigned, size_t, size_t)>& fn);
 
+// v = n copies of value, written by many threads (RawVector::assign would be one thread's pass over fresh pages)
+template <class T>
+void par_assign(RawVector<T>& v, size_t n, T value, unsigned threads = 0) {
+  v.resize(n);
+  T* p = v.data();
+  parallel_chunks(n, n < (size_t(1) << 20) ? 1u : (threads ? threads : hw_threads()), [&](unsigned, size_t b, size_t e) {
+    for (size_t i = b; i < e; ++i) p[i] = value;
+  });
+}
+
 // Splits a text buffer into `want` byte ranges that end on '\n' boundaries.
 std::vector<std::pair<size_t, size_t>> split_at_newlines(const char* data, size_t size, unsigned want);
 
 // stable parallel LSD radix sort of (key, idx) pairs by key (16-bit digits)
+void radix_sort_pairs(RawVector<uint32_t>& key, RawVector<uint32_t>& idx, unsigned threads);
 void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads);
 
 double now_s();

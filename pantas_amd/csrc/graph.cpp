@@ -10,8 +10,8 @@ struct SRec { uint64_t line_off, name_off; uint32_t name_len, seq_len; bool defi
 struct LRec { uint64_t line_off, u_off, v_off; uint32_t u_len, v_len; uint8_t ntok; };
 
 struct ChunkOut {
-  std::vector<SRec> s;
-  std::vector<LRec> l;
+  RawVector<SRec> s;      // (18 GB of records at whole-genome scale: huge pages)
+  RawVector<LRec> l;
   uint64_t lines = 0, p_lines = 0;
   uint64_t bad_p = UINT64_MAX;
 };
@@ -120,7 +120,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   if (all_num && hi - lo < std::max<uint64_t>(uint64_t(ns) * 16, 1u << 20)) {
     ix.dense = true;
     ix.base = lo;
-    ix.table.assign(size_t(hi - lo + 1), NONE32);
+    par_assign(ix.table, size_t(hi - lo + 1), NONE32, threads);
   } else {
     ix.map.reserve(ns * 2);
   }
@@ -158,7 +158,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       fast_names = true;
     } else {
       // duplicates (or S lines behind leading whitespace): redo in file order
-      std::fill(ix.table.begin(), ix.table.end(), NONE32);
+      par_assign(ix.table, ix.table.size(), NONE32, threads);
       g->seg_len.clear(); g->seg_line_off.clear(); g->seg_name_off.clear(); g->seg_name_len.clear();
     }
   }
@@ -213,7 +213,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   // ---- resolve link ends (parallel) and build the out CSR in file order --------------------
   std::vector<size_t> lbase(outs.size() + 1, 0);
   for (size_t i = 0; i < outs.size(); ++i) lbase[i + 1] = lbase[i] + outs[i].l.size();
-  std::vector<uint32_t> lu(nl), lv(nl);
+  RawVector<uint32_t> lu(nl), lv(nl);
   parallel_chunks(outs.size(), unsigned(outs.size()), [&](unsigned, size_t b, size_t e) {
     for (size_t i = b; i < e; ++i) {
       size_t k = lbase[i];
@@ -279,8 +279,8 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   uint64_t A = c_valid[T];
   if (A >= NONE32) throw Error("Unsupported", "more than 2^32-2 links");
   g->A = A;
-  g->row_ptr.assign(size_t(g->V) + 1, 0);
-  g->irow_ptr.assign(size_t(g->V) + 1, 0);
+  par_assign(g->row_ptr, size_t(g->V) + 1, 0u, threads);
+  par_assign(g->irow_ptr, size_t(g->V) + 1, 0u, threads);
   g->col.resize(A);
   g->slot_off.resize(A);
   g->icol.resize(A);
@@ -288,7 +288,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   const bool fast_csr = sorted_by_source && A > (1u << 16) && !force_seq;
   if (fast_csr) {
     // links already grouped by source in node order (what vg / the annotator write): slot = rank among valid links
-    std::vector<uint32_t> ikey(A), iidx(A);
+    RawVector<uint32_t> ikey(A), iidx(A);
     parallel_chunks(T, T, [&](unsigned, size_t b, size_t e) {
       for (size_t i = b; i < e; ++i) {
         size_t k = lbase[i];
@@ -306,7 +306,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
     });
     // row_ptr[u] = first slot whose source is >= u.  Sources of slots: recover from the records again.
-    std::vector<uint32_t> src(A);
+    RawVector<uint32_t> src(A);
     parallel_chunks(T, T, [&](unsigned, size_t b, size_t e) {
       for (size_t i = b; i < e; ++i) {
         size_t k = lbase[i];
@@ -315,7 +315,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
           if (lu[k] != NONE32 && lv[k] != NONE32) src[p++] = lu[k];
       }
     });
-    auto fill_ptr = [&](const std::vector<uint32_t>& keys, std::vector<uint32_t>& ptr) {
+    auto fill_ptr = [&](const RawVector<uint32_t>& keys, RawVector<uint32_t>& ptr) {
       // keys are sorted: ptr[u] = lower_bound(keys, u)
       parallel_chunks(A, threads, [&](unsigned, size_t b, size_t e) {
         for (size_t p = b; p < e; ++p) {

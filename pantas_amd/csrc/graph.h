@@ -22,7 +22,7 @@ struct NameIndex {
   // dense table for canonical decimal names, else a string map
   bool dense = false;
   uint64_t base = 0;
-  std::vector<uint32_t> table;                           // id - base -> node, NONE32 = absent
+  RawVector<uint32_t> table;                             // id - base -> node, NONE32 = absent
   std::unordered_map<std::string_view, uint32_t> map;    // keys point into the mmap
   uint32_t find(Span name) const {
     if (dense) {
@@ -42,13 +42,14 @@ struct Graph {
   uint64_t A = 0;          // adjacency slots (L lines with both ends known)
   uint64_t n_lines = 0, n_s_lines = 0, n_l_lines = 0, n_p_lines = 0;
   NameIndex names;
-  std::vector<uint32_t> seg_len;       // [V]
-  std::vector<uint64_t> seg_line_off;  // [V] stripped-line offset of the defining (last) S line
-  std::vector<uint64_t> seg_name_off;  // [V] offset of the name token (first S line)
-  std::vector<uint16_t> seg_name_len;  // [V]
-  std::vector<uint32_t> row_ptr, col;  // out CSR
-  std::vector<uint64_t> slot_off;      // [A]
-  std::vector<uint32_t> irow_ptr, icol, islot;  // in CSR
+  // (RawVector: gigabytes each at whole-genome scale -- huge pages, no serial zero-fill; every element is written by the loader)
+  RawVector<uint32_t> seg_len;       // [V]
+  RawVector<uint64_t> seg_line_off;  // [V] stripped-line offset of the defining (last) S line
+  RawVector<uint64_t> seg_name_off;  // [V] offset of the name token (first S line)
+  RawVector<uint16_t> seg_name_len;  // [V]
+  RawVector<uint32_t> row_ptr, col;  // out CSR
+  RawVector<uint64_t> slot_off;      // [A]
+  RawVector<uint32_t> irow_ptr, icol, islot;  // in CSR
   // facts the two consumers validate differently
   bool dup_names = false;              // some name has more than one S line
   bool link_before_segment = false;    // an L line precedes the S line of one of its ends

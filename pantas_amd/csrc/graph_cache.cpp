@@ -54,7 +54,7 @@ uint64_t mtime_ns(const char* path) {
 
 struct Section { const void* p; size_t bytes; };
 
-template <class T> Section sec(const std::vector<T>& v) { return Section{v.data(), v.size() * sizeof(T)}; }
+template <class V> Section sec(const V& v) { return Section{v.data(), v.size() * sizeof(typename V::value_type)}; }
 
 }  // namespace
 

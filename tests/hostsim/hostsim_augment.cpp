@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     const uint64_t first_record_line = b.first_record_line;
     if (getenv("HOSTSIM_BUCKET")) bucket_by_locus(b, threads);
     Tables t;
-    t.word = g->seg_len;
+    t.word.assign(g->seg_len.begin(), g->seg_len.end());
     t.nc.assign(g->V, 0);
     t.il0.assign(g->V, 0);
     t.oll.assign(g->V, 0);

@@ -83,7 +83,7 @@ extern "C" {
 HS* hs_open(const char* gfa) {
   auto h = std::make_unique<HS>();
   try { h->g = load_graph(gfa, 2); } catch (...) { return nullptr; }
-  h->word = h->g->seg_len;
+  h->word.assign(h->g->seg_len.begin(), h->g->seg_len.end());
   h->counters.assign(3 * size_t(h->g->V) + h->g->A, 0);
   return h.release();
 }
