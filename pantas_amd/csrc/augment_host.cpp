@@ -100,30 +100,44 @@ void put_hist(std::string& s, const Graph& g, const AugmentResult& r, uint32_t n
   }
 }
 
-void format_range(const Graph& g, const AugmentResult& r, size_t b, size_t e, std::string& out) {
+// has_hist: one bit per node that owns explicit IL/OL entries (a few % of the nodes: the binary search below is for them only)
+void format_range(const Graph& g, const AugmentResult& r, const std::vector<uint64_t>& has_hist, size_t b, size_t e, std::string& out) {
   const char* base = g.text.data;
   const char* p = base + b;
   const char* end = base + e;
   out.reserve((e - b) + (e - b) / 4);
+  // Node indices follow the order of the S lines and, in a graph written by vg / the annotator, adjacency slots follow the
+  // order of the L lines: the node / slot of the NEXT S / L line is then the one after the last -- checked against the
+  // line offsets the loader kept, with the name lookup as the fallback.  That turns the three or four dependent random
+  // reads per line (name table, row bounds, slot offsets, counters: a cache miss each on a whole-genome graph) into
+  // sequential ones.
+  size_t n_exp = size_t(std::lower_bound(g.seg_line_off.begin(), g.seg_line_off.end(), uint64_t(b)) - g.seg_line_off.begin());
+  size_t s_exp = size_t(std::lower_bound(g.slot_off.begin(), g.slot_off.end(), uint64_t(b)) - g.slot_off.begin());
   while (p < end) {
     const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
     const char* le = nl ? nl : end;
     Span st = strip(Span{p, le});
     p = nl ? nl + 1 : end;
     if (st.size() && *st.b == 'S') {
-      Tokens tk(st);
-      Span t0, name;
-      tk.next(t0);
-      tk.next(name);
-      uint32_t n = g.names.find(name);
-      if (n == NONE32) throw Error("KeyError", "S line names an unknown segment");
+      uint32_t n;
+      if (n_exp < g.seg_line_off.size() && g.seg_line_off[n_exp] == uint64_t(st.b - base)) {
+        n = uint32_t(n_exp++);
+      } else {
+        Tokens tk(st);
+        Span t0, name;
+        tk.next(t0);
+        tk.next(name);
+        n = g.names.find(name);
+        if (n == NONE32) throw Error("KeyError", "S line names an unknown segment");
+        n_exp = size_t(n) + 1;
+      }
       out.append(st.b, st.size());
       out += "\tNC:i:";
       put_u64(out, r.nc[n]);
       // explicit entries of this node, if any
       const HistEntry* lo = nullptr;
       const HistEntry* hi = nullptr;
-      if (!r.hist.empty()) {
+      if ((has_hist[n >> 6] >> (n & 63u)) & 1u) {
         auto cmp = [](const HistEntry& a, uint32_t node) { return a.node < node; };
         const HistEntry* hb = r.hist.data();
         const HistEntry* he = hb + r.hist.size();
@@ -136,15 +150,19 @@ void format_range(const Graph& g, const AugmentResult& r, size_t b, size_t e, st
       out.push_back('\n');
     } else if (st.size() && *st.b == 'L') {
       if (st.size() == 1) continue;            // bare "L": dropped (:418-419)
-      Tokens tk(st);
-      Span t[4];
-      for (int i = 0; i < 4; ++i) tk.next(t[i]);
-      uint32_t u = g.names.find(t[1]), v = g.names.find(t[3]);
       uint32_t w = 0;
-      if (u != NONE32 && v != NONE32) {
-        const uint64_t off = uint64_t(st.b - base);
-        for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s)
-          if (g.slot_off[s] == off) { w = r.rc[s]; break; }
+      const uint64_t off = uint64_t(st.b - base);
+      if (s_exp < g.slot_off.size() && g.slot_off[s_exp] == off) {
+        w = r.rc[s_exp++];
+      } else {
+        Tokens tk(st);
+        Span t[4];
+        for (int i = 0; i < 4; ++i) tk.next(t[i]);
+        uint32_t u = g.names.find(t[1]), v = g.names.find(t[3]);
+        if (u != NONE32 && v != NONE32) {
+          for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s)
+            if (g.slot_off[s] == off) { w = r.rc[s]; s_exp = size_t(s) + 1; break; }
+        }
       }
       out.append(st.b, st.size());
       out += "\tRC:i:";
@@ -188,6 +206,8 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
     if (cut.back() != size) cut.push_back(size);
   }
   const size_t n_pieces = cut.size() - 1;
+  std::vector<uint64_t> has_hist((size_t(g.V) + 63) / 64 + 1, 0);
+  for (const HistEntry& h : r.hist) has_hist[h.node >> 6] |= uint64_t(1) << (h.node & 63u);
   off_t file_pos = -1;
   {
     struct stat st;
@@ -211,7 +231,7 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
       if (p >= n_pieces) break;
       try {
         buf.clear();
-        if (!failed.load(std::memory_order_relaxed)) format_range(g, r, cut[p], cut[p + 1], buf);
+        if (!failed.load(std::memory_order_relaxed)) format_range(g, r, has_hist, cut[p], cut[p + 1], buf);
       } catch (const Error& e) {
         std::lock_guard<std::mutex> lk(err_mu);
         if (!first_err) first_err = std::make_shared<Error>(e);

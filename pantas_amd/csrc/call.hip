@@ -223,6 +223,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.first_slot = up(*d, t.first_slot); c.src = up(*d, t.src); c.lflags = up(*d, t.lflags);
   c.rc = up(*d, t.rc); c.nc = up(*d, t.nc); c.nflags = up(*d, t.nflags); c.ln = up(*d, g.seg_len); c.rank = up(*d, t.rank);
   c.ex_ptr = up(*d, t.ex_ptr); c.ex_tag = up(*d, t.ex_tag); c.ex_tx = up(*d, t.ex_tx); c.ex_gene = up(*d, t.ex_gene);
+  c.jrow = up(*d, t.jrow);
   c.jn_ptr = up(*d, t.jn_ptr); c.jn_ftx = up(*d, t.jn_ftx);
   c.jt_ptr = up(*d, t.jt_ptr); c.jt = up(*d, t.jt);
   c.jx_ptr = up(*d, t.jx_ptr); c.jx = up(*d, t.jx);

@@ -71,7 +71,10 @@ struct CallView {
   const uint32_t* ln;           // [V] len(sequence)
   const uint32_t* rank;         // [V] lexicographic rank of the segment name
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
-  const uint32_t* jn_ptr; const uint32_t* jn_ftx;     // per canonical slot, FILE order: filter-transcript of each JN entry
+  // JN data hangs off the junction links only (5e5 of 2.6e8 slots at whole-genome scale): jrow[s] = ordinal of slot s
+  // among the junction slots or CNONE, the four offset arrays are per junction ordinal (+ 1)
+  const uint32_t* jrow;
+  const uint32_t* jn_ptr; const uint32_t* jn_ftx;     // per junction, FILE order: filter-transcript of each JN entry
   const uint32_t* jt_ptr; const uint32_t* jt;         // sorted unique JN tag ids
   const uint32_t* jx_ptr; const uint32_t* jx;         // sorted unique transcripts
   const uint32_t* jg_ptr; const uint32_t* jg;         // sorted unique genes
@@ -127,9 +130,16 @@ PANTAS_HD bool ex_has_gene(const Ex& s, uint32_t tag, uint32_t g) {
 }
 
 struct Set { const uint32_t* p; uint32_t n; };
-PANTAS_HD Set jx_of(const CallView& c, uint32_t s) { return Set{c.jx + c.jx_ptr[s], c.jx_ptr[s + 1] - c.jx_ptr[s]}; }
-PANTAS_HD Set jg_of(const CallView& c, uint32_t s) { return Set{c.jg + c.jg_ptr[s], c.jg_ptr[s + 1] - c.jg_ptr[s]}; }
-PANTAS_HD Set jt_of(const CallView& c, uint32_t s) { return Set{c.jt + c.jt_ptr[s], c.jt_ptr[s + 1] - c.jt_ptr[s]}; }
+// the range of slot s in one of the per-junction arrays (empty for a slot that is no junction)
+PANTAS_HD Set jrange(const CallView& c, const uint32_t* ptr, const uint32_t* data, uint32_t s) {
+  const uint32_t j = c.jrow[s];
+  if (j == CNONE) return Set{data, 0};
+  const uint32_t lo = ptr[j];
+  return Set{data + lo, ptr[j + 1] - lo};
+}
+PANTAS_HD Set jx_of(const CallView& c, uint32_t s) { return jrange(c, c.jx_ptr, c.jx, s); }
+PANTAS_HD Set jg_of(const CallView& c, uint32_t s) { return jrange(c, c.jg_ptr, c.jg, s); }
+PANTAS_HD Set jt_of(const CallView& c, uint32_t s) { return jrange(c, c.jt_ptr, c.jt, s); }
 PANTAS_HD bool set_has(const Set& s, uint32_t x) { return sorted_has(s.p, s.n, x); }
 
 // first slot of row u that leads to v, or CNONE
@@ -292,7 +302,8 @@ template <class Emit>
 PANTAS_HD void push_filtered(const CallView& c, uint32_t s, uint32_t a, uint32_t b, uint32_t minus, Emit& emit) {
   const Set xa = jx_of(c, a), xb = jx_of(c, b);
   const Set xm = minus == CNONE ? Set{nullptr, 0} : jx_of(c, minus);
-  const uint32_t lo = c.jn_ptr[s], hi = c.jn_ptr[s + 1];
+  const Set fl = jrange(c, c.jn_ptr, c.jn_ftx, s);
+  const uint32_t lo = uint32_t(fl.p - c.jn_ftx), hi = lo + fl.n;
   uint32_t cnt = 0;
   for (uint32_t i = lo; i < hi; ++i) {
     const uint32_t t = c.jn_ftx[i];

@@ -522,7 +522,9 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     for (auto& v : part) jslot.insert(jslot.end(), v.begin(), v.end());
   }
   const size_t NJ = jslot.size();
-  std::vector<uint32_t> o_jn(NJ + 1, 0), o_jt(NJ + 1, 0), o_jx(NJ + 1, 0), o_jg(NJ + 1, 0);
+  std::vector<uint32_t>& o_jn = t.jn_ptr; std::vector<uint32_t>& o_jt = t.jt_ptr;
+  std::vector<uint32_t>& o_jx = t.jx_ptr; std::vector<uint32_t>& o_jg = t.jg_ptr;
+  o_jn.assign(NJ + 1, 0); o_jt.assign(NJ + 1, 0); o_jx.assign(NJ + 1, 0); o_jg.assign(NJ + 1, 0);
   std::vector<uint32_t> tags, txs, genes;
   for (size_t j = 0; j < NJ; ++j) {
     const size_t sl = jslot[j];
@@ -558,16 +560,8 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   o_jt[NJ] = uint32_t(t.jt.size());
   o_jx[NJ] = uint32_t(t.jx.size());
   o_jg[NJ] = uint32_t(t.jg.size());
-  // ptr[s] = offset of the first junction at or behind slot s (a junction slot's own entries start there, every other
-  // slot's range is empty), ptr[A] = the totals
-  t.jn_ptr.resize(A + 1); t.jt_ptr.resize(A + 1); t.jx_ptr.resize(A + 1); t.jg_ptr.resize(A + 1);
-  parallel_chunks(A + 1, A < 65536 ? 1u : threads, [&](unsigned, size_t sb, size_t se) {
-    size_t j = size_t(std::lower_bound(jslot.begin(), jslot.end(), uint32_t(sb)) - jslot.begin());
-    for (size_t s2 = sb; s2 < se; ++s2) {
-      while (j < NJ && jslot[j] < s2) ++j;
-      t.jn_ptr[s2] = o_jn[j]; t.jt_ptr[s2] = o_jt[j]; t.jx_ptr[s2] = o_jx[j]; t.jg_ptr[s2] = o_jg[j];
-    }
-  });
+  par_assign(t.jrow, A, uint32_t(CNONE), threads);
+  for (size_t j = 0; j < NJ; ++j) t.jrow[jslot[j]] = uint32_t(j);
 
   pt.lap("intern JN (junction slots only, parallel fill)");
   // ---- lexicographic rank of segment names ------------------------------------------------------------
@@ -643,6 +637,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
   c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
   c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
+  c.jrow = t.jrow.data();
   c.jn_ptr = t.jn_ptr.data(); c.jn_ftx = t.jn_ftx.data();
   c.jt_ptr = t.jt_ptr.data(); c.jt = t.jt.data();
   c.jx_ptr = t.jx_ptr.data(); c.jx = t.jx.data();
@@ -720,9 +715,12 @@ struct Renderer {
   void name(uint32_t node) { Span n = g.name_of(node); out.append(n.b, n.size()); }
   void link_nodes(uint32_t s) { name(t.src[s]); out.push_back('>'); name(t.col[s]); }
   void link_rc(uint32_t s) { put_u(out, uint64_t(t.rc[s])); }
+  // (t.jn_ptr is per junction ordinal: a slot that is no junction has no JN entries)
+  uint32_t jn_lo(uint32_t s) const { const uint32_t j = t.jrow[s]; return j == CNONE ? 0u : t.jn_ptr[j]; }
+  uint32_t jn_hi(uint32_t s) const { const uint32_t j = t.jrow[s]; return j == CNONE ? 0u : t.jn_ptr[j + 1]; }
   void jn_all(uint32_t s) {
-    for (uint32_t i = t.jn_ptr[s]; i < t.jn_ptr[s + 1]; ++i) {
-      if (i != t.jn_ptr[s]) out.push_back('|');
+    for (uint32_t i = jn_lo(s); i < jn_hi(s); ++i) {
+      if (i != jn_lo(s)) out.push_back('|');
       out.append(base + t.jn_span[i].off, t.jn_span[i].len);
     }
   }
@@ -731,7 +729,7 @@ struct Renderer {
     uint32_t n = *p++;
     for (uint32_t i = 0; i < n; ++i) {
       if (i) out.push_back('|');
-      const StrRef& r = t.jn_span[t.jn_ptr[s] + p[i]];
+      const StrRef& r = t.jn_span[jn_lo(s) + p[i]];
       out.append(base + r.off, r.len);
     }
     return p + n;

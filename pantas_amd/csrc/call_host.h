@@ -42,7 +42,8 @@ struct CallTables {
   RawVector<uint32_t> nflags, rank;
   RawVector<uint32_t> ex_ptr;
   std::vector<uint32_t> ex_tag, ex_tx, ex_gene;
-  RawVector<uint32_t> jn_ptr, jt_ptr, jx_ptr, jg_ptr;
+  RawVector<uint32_t> jrow;                                // [A] junction ordinal of a slot or CNONE
+  std::vector<uint32_t> jn_ptr, jt_ptr, jx_ptr, jg_ptr;    // per junction ordinal (+ 1)
   std::vector<uint32_t> jn_ftx, jt, jx, jg;
   std::vector<uint32_t> tx_gene;
   std::vector<uint32_t> junctions, novels;   // canonical slots in file order

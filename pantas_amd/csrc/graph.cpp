@@ -338,6 +338,58 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
     });
     fill_ptr(ikey, g->irow_ptr);
+  } else if (A > (1u << 16) && !force_seq) {
+    // Links in any order (an augmented GFA carries the links the reads added behind its P lines): rows are the links of a
+    // source in FILE order, i.e. a stable sort of the file-order records by source -- parallel radix sort -- and the in-lists
+    // a stable sort by target of the same file-order records (call.py:174-175 appends to both lists line by line).
+    RawVector<uint32_t> fsrc(A), fdst(A), okey(A), oidx(A), ikey(A), iidx(A);
+    RawVector<uint64_t> foff(A);
+    parallel_chunks(T, T, [&](unsigned, size_t b2, size_t e2) {
+      for (size_t i = b2; i < e2; ++i) {
+        size_t k = lbase[i];
+        uint64_t p = c_valid[i];
+        for (auto& r : outs[i].l) {
+          if (lu[k] != NONE32 && lv[k] != NONE32) {
+            fsrc[p] = lu[k]; fdst[p] = lv[k]; foff[p] = r.line_off;
+            okey[p] = lu[k]; oidx[p] = uint32_t(p);
+            ikey[p] = lv[k]; iidx[p] = uint32_t(p);
+            ++p;
+          }
+          ++k;
+        }
+      }
+    });
+    auto fill_ptr = [&](const RawVector<uint32_t>& keys, RawVector<uint32_t>& ptr) {
+      parallel_chunks(A, threads, [&](unsigned, size_t b2, size_t e2) {
+        for (size_t p = b2; p < e2; ++p) {
+          const uint32_t cur = keys[p];
+          const uint32_t from = p == 0 ? 0u : keys[p - 1] + 1u;
+          if (p == 0 || keys[p - 1] != cur)
+            for (uint32_t u = from; u <= cur; ++u) ptr[u] = uint32_t(p);
+        }
+      });
+      const uint32_t last = A ? keys[A - 1] : 0u;
+      for (size_t u = size_t(A ? last + 1 : 0); u <= g->V; ++u) ptr[u] = uint32_t(A);
+    };
+    radix_sort_pairs(okey, oidx, threads);          // slot q holds file-order record oidx[q]
+    RawVector<uint32_t> slot_of(A);
+    parallel_chunks(A, threads, [&](unsigned, size_t b2, size_t e2) {
+      for (size_t q = b2; q < e2; ++q) {
+        const uint32_t p = oidx[q];
+        g->col[q] = fdst[p];
+        g->slot_off[q] = foff[p];
+        slot_of[p] = uint32_t(q);
+      }
+    });
+    fill_ptr(okey, g->row_ptr);
+    radix_sort_pairs(ikey, iidx, threads);
+    parallel_chunks(A, threads, [&](unsigned, size_t b2, size_t e2) {
+      for (size_t q = b2; q < e2; ++q) {
+        g->islot[q] = slot_of[iidx[q]];
+        g->icol[q] = fsrc[iidx[q]];
+      }
+    });
+    fill_ptr(ikey, g->irow_ptr);
   } else {
   {
     size_t k = 0;
@@ -369,7 +421,13 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
   }
   }
-  pt.lap(fast_csr ? "CSR build (parallel)" : "CSR fill (sequential)");
+  pt.lap(fast_csr ? "CSR build (parallel)" : (A > (1u << 16) && !force_seq) ? "CSR build (parallel, links in any order)" : "CSR fill (sequential)");
+  if (ns + nl > (size_t(1) << 24)) {
+    // the per-line records of a whole-genome graph are ~20 GB: giving them back to the kernel takes a second, which a
+    // thread of its own can spend while the caller goes on
+    auto* junk = new std::tuple<std::vector<ChunkOut>, RawVector<uint32_t>, RawVector<uint32_t>>(std::move(outs), std::move(lu), std::move(lv));
+    std::thread([junk] { delete junk; }).detach();
+  }
   return g;
 }
 

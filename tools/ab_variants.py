@@ -26,7 +26,7 @@ def main():
     from bench import SCALES
     from pantas_amd.engine import Graph, Synth
     import numpy as np
-    desc, kw = SCALES[args.scale]
+    desc, kw, *_ = SCALES[args.scale]
     kw = dict(kw)
     if args.lines:
         kw["n_lines"] = args.lines
