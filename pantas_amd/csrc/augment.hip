@@ -415,195 +415,51 @@ struct AggSink {
   }
 };
 
-// A kept node of the short walk waiting to learn whether it is the read's last kept node.
-struct SimplePend {
-  uint32_t node, word, row_lo, row_hi, col0;
-  bool has_colon;
-};
-
-template <class Sink>
-__device__ __forceinline__ uint32_t flush_simple(const SimplePend& p, uint32_t idx, bool is_last, const LineHdr& h, const Sink& sink) {
-  const bool rev = (h.flags & LINE_REV) != 0;
-  const bool is_first = idx == 0;
-  // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351)
-  const bool enter = p.has_colon && !is_first, leave = p.has_colon && !is_last;
-  const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
-  const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
-  const uint32_t slot = sink.bump_node(p.node, 1u, a_il, a_ol);
-  if (a_il && (p.word & FLAG_IL)) sink.order_min(p.node, SIDE_IL, event_order(h.line_id, idx, 1));
-  if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
-  return slot;
-}
-
-// Short walk for LINE_SIMPLE records.  Equivalent to walk_line on them: a node with room r > 0 at op-space
-// position P < T gets pieces that are all ':' or '*'; they compact to one ':' entry (plain = 1) unless all of
-// them are '*', in which case the node is kept (NC) but has no IL/OL entry.
-// The loads are software-pipelined: while node i is processed, the length word and CSR row bounds of node
-// i+1 and the first link target of node i are already in flight (the chain nodes[] -> word/row_ptr -> col[]
-// is what the kernel waits on).
-template <class Sink>
-__device__ __forceinline__ int walk_simple(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                           const uint32_t* ops, uint32_t nops, const Sink& sink) {
-  uint32_t T = 0, ns = 0;
-  uint32_t star[SIMPLE_MAX_STARS];
-#pragma unroll 1
-  for (uint32_t j = 0; j < nops; ++j) {
-    const uint32_t w = ops[j];
-    if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
-    T += w >> 3;
-  }
-  const bool rev = (h.flags & LINE_REV) != 0;
-  uint32_t P = 0, kept = 0;
-  bool pending = false;
-  SimplePend pend{};
-  // stage 0 of the pipeline: node 0
-  uint32_t nx_node = nodes[0];
-  uint32_t nx_word = g.word[nx_node];
-  uint32_t nx_lo = g.row_ptr[nx_node], nx_hi = g.row_ptr[nx_node + 1];
-#pragma unroll 1
-  for (uint32_t i = 0; i < k; ++i) {
-    const uint32_t node = nx_node, word = nx_word, row_lo = nx_lo, row_hi = nx_hi;
-    // first link target of this node (needed one iteration later on forward reads, now on reverse reads)
-    const uint32_t col0 = row_lo < row_hi ? g.col[row_lo] : 0u;
-    if (i + 1 < k) {
-      nx_node = nodes[i + 1];
-      nx_word = g.word[nx_node];
-      nx_lo = g.row_ptr[nx_node];
-      nx_hi = g.row_ptr[nx_node + 1];
-    }
-    int64_t room = int64_t(word & LEN_MASK);
-    if (i == 0) room -= h.start;
-    if (i == k - 1) room = room - h.tail + 1;
-    if (room <= 0) continue;
-    if (P >= T) return WALK_OPS_EXHAUSTED;
-    const uint32_t le = uint32_t(min(room, int64_t(T - P)));
-    uint32_t stars_in = 0;
-    for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
-    if (pending) {
-      const uint32_t hp = flush_simple(pend, kept - 1u, false, h, sink);
-      const uint64_t ord = event_order(h.line_id, kept - 1u, 0);
-      // one copy of the link code for both strands (a wave holds reads of both: two inlined calls would both run)
-      sink.link_pf(rev ? node : pend.node, rev ? LDS_EMPTY : hp, rev ? row_lo : pend.row_lo, rev ? row_hi : pend.row_hi,
-                   rev ? col0 : pend.col0, rev ? pend.node : node, ord);
-    }
-    pend = SimplePend{node, word, row_lo, row_hi, col0, stars_in < le};
-    pending = true;
-    ++kept;
-    P = (room >= int64_t(T - P)) ? T : P + uint32_t(room);
-  }
-  if (pending) flush_simple(pend, kept - 1u, true, h, sink);
-  return WALK_OK;
-}
-
-// The short walk over PACKED node entries: NC, IL[0], OL[len] and the count of the first out-slot of a kept node go
-// to LDS as one 64-bit add, issued when the next kept node is known.  On a forward read the link pend -> node is
-// pend's own first slot in the usual case; on a reverse read the link is node -> pend, i.e. the first slot of the
-// node just reached, which carries it until it is flushed itself.
-struct PackedPend {
-  uint32_t node, word, row_lo, row_hi, col0;
-  bool has_colon;
-  uint32_t r0;      // first-slot hits already owed to this node (reverse reads)
-};
-
-template <class Sink>
-__device__ __forceinline__ void flush_packed(const PackedPend& p, uint32_t idx, bool is_last, const LineHdr& h, const Sink& sink, uint32_t r0) {
-  const bool rev = (h.flags & LINE_REV) != 0;
-  const bool is_first = idx == 0;
-  const bool enter = p.has_colon && !is_first, leave = p.has_colon && !is_last;
-  const uint32_t a_il = rev ? (leave ? 1u : 0u) : (enter ? 1u : 0u);
-  const uint32_t a_ol = rev ? (enter ? 1u : 0u) : (leave ? 1u : 0u);
-  sink.bump_packed(p.node, p.row_lo, 1u, a_il, a_ol, r0);
-  if (a_il && (p.word & FLAG_IL)) sink.order_min(p.node, SIDE_IL, event_order(h.line_id, idx, 1));
-  if (a_ol && (p.word & FLAG_OL)) sink.order_min(p.node, SIDE_OL, event_order(h.line_id, idx, 1));
-}
-
 // The short walk itself lives in walk.h (walk_short: host + device source, so that the CPU harness runs the very same
 // code against the goldens); here are its two device-side views: the graph as g.info gathers, the sink as the packed LDS
 // entries of AggSink.
 template <class Agg>
 struct ShortSinkDev {
   const Agg& s;
+  // deferred links (walk.h DEFER): up to four per line as {path index of a, of b, kept index}, 5 bits each, two per word,
+  // in two LDS words of the thread (registers are what this kernel is short of: at 64 VGPRs two more spill)
+  uint32_t* dq = nullptr;
+  mutable uint32_t nq = 0;
   __device__ __forceinline__ void kept(uint32_t node, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t r0, uint64_t exact_order) const {
     s.bump_packed_flagged(node, word, line_id, a_il, a_ol, r0, exact_order);
   }
   __device__ __forceinline__ void link_rest(uint32_t a, uint32_t b, uint64_t order) const {
     s.link_rest(a, s.g.row_ptr[a], s.g.row_ptr[a + 1], b, order);
   }
+  __device__ __forceinline__ void defer(uint32_t ia, uint32_t ib, uint32_t kidx, uint32_t a, uint32_t b, uint32_t line_id) const {
+    if (nq < 4u) {
+      const uint32_t e = ia | (ib << 5) | (kidx << 10);     // a short-walk line has at most 31 path nodes
+      uint32_t* w = dq + (nq >> 1);
+      *w = (nq & 1u) ? (*w | (e << 15)) : e;
+      ++nq;
+    } else {
+      link_rest(a, b, event_order(line_id, kidx, 0));      // a fifth link off the first slots in one line: where it is met
+    }
+  }
+  __device__ __forceinline__ void drain(const uint32_t* nodes, uint32_t line_id) const {
+#pragma unroll 1
+    for (uint32_t j = 0; j < nq; ++j) {
+      const uint32_t e = (dq[j >> 1] >> ((j & 1u) * 15u)) & 0x7FFFu;
+      const uint32_t a = nodes[e & 31u], b = nodes[(e >> 5) & 31u];
+      link_rest(a, b, event_order(line_id, e >> 10, 0));
+    }
+  }
 };
-template <class Sink, int PF>
+template <class Sink, int PF, bool DEFER = false, bool LEAN = false>
 __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                               const uint32_t* ops, uint32_t nops, const Sink& sink, const uint32_t* first_ids) {
+                                               const uint32_t* ops, uint32_t nops, const Sink& sink, const uint32_t* first_ids, uint32_t* dq = nullptr) {
   const DevInfo ga{g};
-  const ShortSinkDev<Sink> ss{sink};
-  return walk_short<PF>(ga, h, nodes, k, ops, nops, ss, first_ids);
-}
-
-// INFO: the node's length word and first out-target come from g.info (one 8-byte gather, no dependent col[] load); the
-// CSR row bounds are only fetched for a link that is not its node's first out-slot.
-template <class Sink, bool INFO = false, int PF = 1>
-__device__ __forceinline__ int walk_simple_packed(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                                  const uint32_t* ops, uint32_t nops, const Sink& sink) {
-  if constexpr (INFO) {
-    uint32_t first_ids[PF + 1];
-    for (int j = 0; j <= PF; ++j) first_ids[j] = k ? nodes[uint32_t(j) < k - 1u ? uint32_t(j) : k - 1u] : 0u;
-    return walk_short_info<Sink, PF>(g, h, nodes, k, ops, nops, sink, first_ids);
-  }
-  uint32_t T = 0, ns = 0;
-  uint32_t star[SIMPLE_MAX_STARS];
-#pragma unroll 1
-  for (uint32_t j = 0; j < nops; ++j) {
-    const uint32_t w = ops[j];
-    if ((w & 7u) == OP_STAR && ns < SIMPLE_MAX_STARS) star[ns++] = T;
-    T += w >> 3;
-  }
-  const bool rev = (h.flags & LINE_REV) != 0;
-  const bool links = !(g.ablate & 4u);
-  uint32_t P = 0, kept = 0;
-  bool pending = false;
-  PackedPend pend{};
-  uint32_t nx_node = nodes[0];
-  uint32_t nx_word = g.word[nx_node];
-  uint32_t nx_lo = g.row_ptr[nx_node], nx_hi = g.row_ptr[nx_node + 1];
-#pragma unroll 1
-  for (uint32_t i = 0; i < k; ++i) {
-    const uint32_t node = nx_node, word = nx_word, row_lo = nx_lo, row_hi = nx_hi;
-    const uint32_t col0 = row_lo < row_hi ? g.col[row_lo] : 0u;
-    if (i + 1 < k) {
-      nx_node = nodes[i + 1];
-      nx_word = g.word[nx_node];
-      nx_lo = g.row_ptr[nx_node];
-      nx_hi = g.row_ptr[nx_node + 1];
-    }
-    int64_t room = int64_t(word & LEN_MASK);
-    if (i == 0) room -= h.start;
-    if (i == k - 1) room = room - h.tail + 1;
-    if (room <= 0) continue;
-    if (P >= T) return WALK_OPS_EXHAUSTED;
-    const uint32_t le = uint32_t(min(room, int64_t(T - P)));
-    uint32_t stars_in = 0;
-    for (uint32_t s = 0; s < ns; ++s) stars_in += (star[s] - P < le) ? 1u : 0u;
-    uint32_t r0_here = 0;
-    if (pending) {
-      const uint64_t ord = event_order(h.line_id, kept - 1u, 0);
-      // link a -> b, strand by select so that the code below exists once
-      const uint32_t a = rev ? node : pend.node, bnode = rev ? pend.node : node;
-      const uint32_t a_lo = rev ? row_lo : pend.row_lo, a_hi = rev ? row_hi : pend.row_hi, a_c0 = rev ? col0 : pend.col0;
-      const bool first_slot = links && a_lo < a_hi && a_c0 == bnode;
-      flush_packed(pend, kept - 1u, false, h, sink, rev ? pend.r0 : (first_slot ? 1u : 0u));
-      if (rev && first_slot) r0_here = 1u;
-      if (links && !first_slot) sink.link_rest(a, a_lo, a_hi, bnode, ord);
-    }
-    pend = PackedPend{node, word, row_lo, row_hi, col0, stars_in < le, r0_here};
-    pending = true;
-    ++kept;
-    P = (room >= int64_t(T - P)) ? T : P + uint32_t(room);
-  }
-  if (pending) flush_packed(pend, kept - 1u, true, h, sink, rev ? pend.r0 : 0u);
-  return WALK_OK;
+  const ShortSinkDev<Sink> ss{sink, dq};
+  return walk_short<PF, DEFER, LEAN>(ga, h, nodes, k, ops, nops, ss, first_ids);
 }
 
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          bool INFO = false, int PF = 1>
+          bool INFO = false, int PF = 1, bool DEFER = false, bool SPLIT_LEAN = false>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -621,6 +477,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   __shared__ uint32_t scnt[CS];
   __shared__ uint32_t fkey[CF];
   __shared__ uint32_t omin[INFO ? 2 * CN : 2];
+  __shared__ uint32_t defer_q[DEFER ? 2 * THREADS : 2];
   static_assert(!INFO || (PACKED && ONLY == 1), "the info walk exists for the short-walk class over packed entries");
   const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -644,23 +501,27 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
         const uint4 r = b.rec[2 * size_t(i)], r2 = b.rec[2 * size_t(i) + 1];
         const uint32_t first_ids[5] = {r.w, r2.x, r2.y, r2.z, r2.w};
         static_assert(PF <= 4, "rec holds the ids of the first five path nodes");
-        const int st = walk_short_info<Sink, PF>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids);
+        int st;
+        if constexpr (SPLIT_LEAN) {
+          // the records of a block are ordered with the one-indel lines last: nearly every wave holds LINE_SIMPLE lines
+          // only and takes the instance without the indel and exact-order code
+          if (__ballot((h.flags & LINE_ONE_INDEL) != 0u) == 0ull)
+            st = walk_short_info<Sink, PF, DEFER, true>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids, defer_q + 2u * threadIdx.x);
+          else
+            st = walk_short_info<Sink, PF, DEFER, false>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids, defer_q + 2u * threadIdx.x);
+        } else {
+          st = walk_short_info<Sink, PF, DEFER>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids, defer_q + 2u * threadIdx.x);
+        }
         if (st != WALK_OK) report_status(g, h.line_id, st);
         continue;
       }
       const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
       const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
       int st;
-      // ONLY == 1: the range holds short-walk records only (walk.h short_walk_class)
-      if (ONLY != 1 && PACKED && n1 - n0 > PACKED_MAX_PATH) {
+      if (PACKED && n1 - n0 > PACKED_MAX_PATH) {
         // a path this long could overflow a 16-bit field of the LDS entries: straight to memory
         MainSink direct{g};
         st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, direct);
-      } else if (ONLY == 1 || (ONLY == 0 && (h.flags & LINE_SIMPLE) && !(g.ablate & 16u))) {
-        // walk_short_info covers the whole short-walk class; the older short walks know ':' and '*' only
-        if (!INFO && !(h.flags & LINE_SIMPLE)) st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-        else if constexpr (PACKED) st = walk_simple_packed<Sink, INFO, PF>(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
-        else st = walk_simple(g, h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
       if (st != WALK_OK) report_status(g, h.line_id, st);
     }
@@ -1125,17 +986,16 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   d.last_short_ms = 0.f;
   if (b.n) {
-    // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = direct global atomics; 18 / 40 = ONE aggregating kernel over all
-    // records (32-bit / packed LDS entries); 60.. = the two record classes in their own kernels, the short-walk class
-    // [0, n_short) and the rest with the general kernel beside it on a second stream: 60 the mid-round short walk
-    // (three planar gathers per node), 72 / 73 (default) the walk over g.info with gathers one / two nodes ahead,
-    // 65 = 60 with the two kernels one after the other (each one's time alone).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 73;   // read per launch: tools/ab_variants.py switches it
+    // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
+    // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
+    // the rest with the general aggregating kernel beside it on a second stream: 73 = the round-1 short walk (gathers two
+    // nodes ahead), 80.. = this round's variants (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 80;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
-#define PANTAS_AGG_RANGE_ABL(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, PK, ON) \
-    do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, PK, ON, true>), \
+#define PANTAS_AGG_RANGE_ABL(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, PK, ON, INF, PFD) \
+    do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, PK, ON, true, INF, PFD>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
 #define PANTAS_AGG(ID, ...) case ID: PANTAS_AGG_RANGE(d.stream, 0u, b.n, __VA_ARGS__); break;
     // one after the other on the launch stream
@@ -1155,18 +1015,18 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     } else {
       if (g.ablate) {
         // timing experiments: the default pair of kernels with the ablation switches compiled in, one after the other
-        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1);
+        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2);
         HIP_OK(hipEventRecord(d.ev[3], d.stream));
         split = true;
-        PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 0);
+        PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
       } else switch (variant) {
-        PANTAS_AGG(18, 512, 2048, 10, 10, 7, 8)
-        PANTAS_AGG(40, 512, 2048, 10, 10, 7, 8, true)    // packed node entries, one kernel
-        PANTAS_SPLIT_SEQ(65, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        PANTAS_SPLIT(72, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))
-        PANTAS_SPLIT(60, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8))
-        default:   // 73: short walk over g.info, gathers two nodes ahead
-        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // ONLY 2: the general walk alone
+        // measured and dropped this round (profiles/r2_ab_s4_defer_lean_occupancy.txt): 7 or 6 waves per SIMD to give the
+        // variants registers (2.80 - 3.43 ms against 2.58: occupancy is worth more than anything it buys), a second, lean
+        // instance of the walk for waves without indel lines inside the same kernel (2.59: its registers add up)
+        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // round 1
+        PANTAS_SPLIT(81, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 1, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // 80 with gathers one node ahead
+        default:   // 80: gathers two nodes ahead, lookups of links off the first out-slot deferred to the end of the line
+        PANTAS_SPLIT(80, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // ONLY 2: the general walk alone
       }
     }
 #undef PANTAS_SPLIT_SEQ
@@ -1239,8 +1099,8 @@ void export_flags(DeviceGraph& d, std::vector<uint32_t>& codes) {
   uint32_t nk = 0;
   HIP_OK(hipMemcpy(&nk, d.small + 2, 4, hipMemcpyDeviceToHost));   // distinct rare keys bound the flag count
   const uint32_t cap = nk + 16;
-  uint32_t* out = nullptr;
-  HIP_OK(hipMalloc(&out, size_t(cap) * 4));
+  // (scratch pool of the graph: hipMalloc / hipFree cost milliseconds each, and this sits between the two kernels of a sharded run)
+  uint32_t* out = static_cast<uint32_t*>(scratch_pool(d).take(size_t(cap) * 4));
   HIP_OK(hipMemsetAsync(d.small + 6, 0, 4, d.stream));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(d.V) + 255) / 256, 4096));
   hipLaunchKernelGGL(collect_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.V, out, d.small + 6, cap);
@@ -1250,20 +1110,19 @@ void export_flags(DeviceGraph& d, std::vector<uint32_t>& codes) {
   n = std::min(n, cap);
   codes.resize(n);
   if (n) HIP_OK(hipMemcpy(codes.data(), out, size_t(n) * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(out);
+  scratch_pool(d).give(out);
   std::sort(codes.begin(), codes.end());
 }
 
 void import_flags(DeviceGraph& d, const uint32_t* codes, size_t n) {
   HIP_OK(hipSetDevice(d.device));
   if (!n) return;
-  uint32_t* in = nullptr;
-  HIP_OK(hipMalloc(&in, n * 4));
+  uint32_t* in = static_cast<uint32_t*>(scratch_pool(d).take(n * 4));
   HIP_OK(hipMemcpyAsync(in, codes, n * 4, hipMemcpyHostToDevice, d.stream));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((n + 255) / 256, 4096));
   hipLaunchKernelGGL(apply_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, in, uint32_t(n), d.V);
   HIP_OK(hipStreamSynchronize(d.stream));
-  (void)hipFree(in);
+  scratch_pool(d).give(in);
   d.imported_flags += n;
 }
 
@@ -1292,11 +1151,10 @@ static void download_table(DeviceGraph& d, Table& t, uint32_t n_keys, std::vecto
   cnt.resize(n_keys);
   first.resize(n_keys);
   if (!n_keys) return;
-  uint64_t *dk = nullptr, *df = nullptr;
-  uint32_t* dc = nullptr;
-  HIP_OK(hipMalloc(&dk, size_t(n_keys) * 8));
-  HIP_OK(hipMalloc(&df, size_t(n_keys) * 8));
-  HIP_OK(hipMalloc(&dc, size_t(n_keys) * 4));
+  ScratchPool& pool = scratch_pool(d);
+  uint64_t* dk = static_cast<uint64_t*>(pool.take(size_t(n_keys) * 8));
+  uint64_t* df = static_cast<uint64_t*>(pool.take(size_t(n_keys) * 8));
+  uint32_t* dc = static_cast<uint32_t*>(pool.take(size_t(n_keys) * 4));
   HIP_OK(hipMemsetAsync(d.small + 6, 0, 4, d.stream));
   const uint32_t blocks = std::min<uint32_t>((t.cap + 255) / 256, 8192);
   hipLaunchKernelGGL(compact_table_kernel, dim3(blocks), dim3(256), 0, d.stream, t.v, dk, dc, df, d.small + 6);
@@ -1305,7 +1163,7 @@ static void download_table(DeviceGraph& d, Table& t, uint32_t n_keys, std::vecto
   HIP_OK(hipMemcpyAsync(cnt.data(), dc, size_t(n_keys) * 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipMemcpyAsync(first.data(), df, size_t(n_keys) * 8, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
-  (void)hipFree(dk); (void)hipFree(df); (void)hipFree(dc);
+  pool.give(dk); pool.give(df); pool.give(dc);
 }
 
 // node-interleaved counters -> the planar arrays the host side works with: nc / il0 / oll [V], and rc [A] with the

@@ -50,6 +50,10 @@ constexpr uint32_t SIMPLE_MAX_STARS = 4;
 // < 65536), then the rest (general walk).
 constexpr uint32_t SHORT_MAX_PATH = 31;
 constexpr uint32_t SHORT_MAX_OPS = 1u << 24;    // the short-walk kernel reads a record's op count from 24 bits (':' runs may repeat)
+// The ops of a short-walk line add up to fewer than 2^16 bases (a line of at most 31 path nodes is a short read): positions
+// in op space then fit 16 bits, and the walk keeps the four '*' positions and the indel in three registers instead of
+// seven -- registers are what bounds the kernel (64 VGPRs = 8 waves per SIMD, and 7 waves cost 17 % of its speed).
+constexpr uint64_t SHORT_MAX_TOTAL = 1ull << 16;
 // A one-indel line can add 2 more IL / OL steps than it has path nodes (the node holding ':' '+' ':' counts three
 // entries), so it may have two path nodes fewer: 2048 x (29 + 2) < 65536 as well.
 constexpr uint32_t SHORT_MAX_PATH_INDEL = SHORT_MAX_PATH - 2;
@@ -63,7 +67,7 @@ PANTAS_HD uint32_t block_order_key(uint32_t flags, uint32_t path_nodes) {
 }
 // what the tokenisers set from a line's op statistics (both tokenisers call this: one definition of the classes)
 PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t indels, uint32_t others, bool slow, uint64_t total_len) {
-  if (n_ops == 0 || n_ops >= SHORT_MAX_OPS || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= (1ull << 31)) return 0u;
+  if (n_ops == 0 || n_ops >= SHORT_MAX_OPS || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= SHORT_MAX_TOTAL) return 0u;
   return indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u;
 }
 
@@ -95,50 +99,55 @@ PANTAS_HD uint64_t event_order(uint32_t line_id, uint32_t kept_idx, uint32_t pha
 // before the indel, the indel itself when it is a '+', a ':' run after it.  '*' pieces never make an entry of their own:
 // a leading one is swallowed by the next op, a later one merges into the entry before it.
 struct ShortOps {
-  uint32_t T = 0;                       // total op length
-  uint32_t ns = 0;                      // '*' ops, each one base long
-  uint32_t star[SIMPLE_MAX_STARS] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};   // their positions (unused: never inside an interval);
-                                        // only ever indexed by constants, so that the struct stays in registers on the GPU
-  uint32_t x_pos = 0, x_len = 0;        // the indel's interval (x_len == 0: none)
-  bool x_plus = false;
+  uint32_t T = 0;                       // total op length (< 2^16)
+  uint32_t ns = 0;                      // '*' ops, each one base long; bit 8: the indel is a '+'
+  uint32_t star01 = 0, star23 = 0;      // their positions, 16 bits each (only the first ns count)
+  uint32_t x = 0;                       // the indel's interval: position | length << 16 (length 0: none)
+  PANTAS_HD uint32_t n_stars() const { return ns & 0xFFu; }
+  PANTAS_HD bool x_plus() const { return (ns & 0x100u) != 0u; }
+  PANTAS_HD uint32_t x_pos() const { return x & 0xFFFFu; }
+  PANTAS_HD uint32_t x_len() const { return x >> 16; }
 };
 
 PANTAS_HD void short_ops_scan(const uint32_t* ops, uint32_t n_ops, ShortOps& so) {
+  uint32_t n = 0;
   for (uint32_t j = 0; j < n_ops; ++j) {
     const uint32_t w = ops[j], code = w & 7u;
     if (code == OP_STAR) {
-      if (so.ns == 0) so.star[0] = so.T;
-      else if (so.ns == 1) so.star[1] = so.T;
-      else if (so.ns == 2) so.star[2] = so.T;
-      else if (so.ns == 3) so.star[3] = so.T;
-      if (so.ns < SIMPLE_MAX_STARS) ++so.ns;
+      if (n == 0) so.star01 = so.T;
+      else if (n == 1) so.star01 |= so.T << 16;
+      else if (n == 2) so.star23 = so.T;
+      else if (n == 3) so.star23 |= so.T << 16;
+      if (n < SIMPLE_MAX_STARS) ++n;
     }
-    else if (code == OP_PLUS || code == OP_MINUS) { so.x_pos = so.T; so.x_len = w >> 3; so.x_plus = code == OP_PLUS; }
+    else if (code == OP_PLUS || code == OP_MINUS) { so.x = so.T | ((w >> 3) << 16); if (code == OP_PLUS) so.ns |= 0x100u; }
     so.T += w >> 3;
   }
+  so.ns |= n;
 }
 
 // true when [lo, hi) (non-empty) holds a base that is not a '*'
 PANTAS_HD bool short_has_colon(const ShortOps& so, uint32_t lo, uint32_t hi) {
-  const uint32_t len = hi - lo;
-  if (len > so.ns) return true;
+  const uint32_t len = hi - lo, ns = so.n_stars();
+  if (len > ns) return true;
   static_assert(SIMPLE_MAX_STARS == 4, "unrolled below");
-  const uint32_t stars_in = ((so.star[0] - lo < len) ? 1u : 0u) + ((so.star[1] - lo < len) ? 1u : 0u) + ((so.star[2] - lo < len) ? 1u : 0u) +
-                            ((so.star[3] - lo < len) ? 1u : 0u);       // len <= 4 here: an unused slot (2^32 - 1) is never inside
+  // len <= 4 here; star j counts when it exists (j < ns) and lies inside
+  const uint32_t stars_in = ((ns > 0u && (so.star01 & 0xFFFFu) - lo < len) ? 1u : 0u) + ((ns > 1u && (so.star01 >> 16) - lo < len) ? 1u : 0u) +
+                            ((ns > 2u && (so.star23 & 0xFFFFu) - lo < len) ? 1u : 0u) + ((ns > 3u && (so.star23 >> 16) - lo < len) ? 1u : 0u);
   return stars_in < len;
 }
 
 // the node that takes [P, P + le), le > 0: is it kept, and how many of its compacted entries are neither '-' nor '*'
 PANTAS_HD void short_node_summary(const ShortOps& so, uint32_t P, uint32_t le, bool& kept, uint32_t& plain) {
-  const uint32_t end = P + le, x_end = so.x_pos + so.x_len;
-  if (so.x_len == 0 || so.x_pos >= end || x_end <= P) {      // no piece of the indel here
+  const uint32_t end = P + le, x_pos = so.x_pos(), x_len = so.x_len(), x_end = x_pos + x_len;
+  if (x_len == 0 || x_pos >= end || x_end <= P) {      // no piece of the indel here
     kept = true;
     plain = short_has_colon(so, P, end) ? 1u : 0u;
     return;
   }
-  const bool before = so.x_pos > P, after = x_end < end;
+  const bool before = x_pos > P, after = x_end < end;
   kept = before || after;                                     // else the lone '+' / '-' piece (:101-102)
-  plain = (so.x_plus ? 1u : 0u) + ((before && short_has_colon(so, P, so.x_pos)) ? 1u : 0u) + ((after && short_has_colon(so, x_end, end)) ? 1u : 0u);
+  plain = (so.x_plus() ? 1u : 0u) + ((before && short_has_colon(so, P, x_pos)) ? 1u : 0u) + ((after && short_has_colon(so, x_end, end)) ? 1u : 0u);
 }
 
 struct KeptNode {
@@ -304,7 +313,15 @@ struct alignas(8) NodeInfo {
   uint32_t word, first;
 };
 
-template <int PF, class GraphAcc, class Sink>
+// DEFER: links that are not a first out-slot are not looked up where they are met -- about one lane in eight of a wave
+// meets one in any given pass of the node loop, and a wave pays for the whole lookup (row bounds, column scan, table
+// update) whenever ONE of its lanes needs it.  They are handed to the sink as path indices (sink.defer(ia, ib, kept_idx):
+// the link nodes[ia] -> nodes[ib] met behind kept node kept_idx) and looked up by sink.drain() after the node loop, when
+// most lanes of the wave have one or two of them to do at the same time.
+// LEAN: the line is LINE_SIMPLE (':' runs and at most four '*', no '+' / '-'): every node with room is kept, has one
+// compacted entry unless all its bases are '*', and no event of the line needs its exact within-line order -- the indel
+// and exact-order code is compiled out (the kernel takes this instance for a wave none of whose lines has an indel).
+template <int PF, bool DEFER = false, bool LEAN = false, class GraphAcc, class Sink>
 PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops, uint32_t nops,
                          const Sink& sink, const uint32_t* first_ids) {  // first_ids[j] = nodes[min(j, k - 1)], j = 0 .. PF: the caller may
                                                                          // already hold them (the GPU batch keeps them beside the offsets)
@@ -313,15 +330,18 @@ PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* n
   short_ops_scan(ops, nops, so);
   const uint32_t T = so.T;
   const bool rev = (h.flags & LINE_REV) != 0;
-  const bool exact = (h.flags & LINE_HAS_DEL) != 0;
+  const bool exact = !LEAN && (h.flags & LINE_HAS_DEL) != 0;
   uint32_t P = 0, kept = 0;
   bool pending = false;
-  uint32_t p_node = 0, p_word = 0, p_c0 = 0, p_r0 = 0, p_plain = 0;
+  // the pending kept node: id, first out-target, and in one word {plain entries (2 bits), first-slot hit owed (bit 2),
+  // path index (bits 8..12), the node's IL / OL flags (bits 30, 31 as in its length word)}
+  uint32_t p_node = 0, p_c0 = 0, p_meta = 0;
   // forward: IL[0] unless first, OL[len] unless last; reverse: IL[0] unless last, OL[len] unless first (:298-351), once per
   // compacted entry that is neither '-' nor '*' (p_plain of them)
   auto flush = [&](bool is_last, uint32_t r0) {
+    const uint32_t p_plain = p_meta & 3u;
     const bool enter = p_plain != 0u && kept != 1u, leave = p_plain != 0u && !is_last;      // the pending node is kept node number kept - 1
-    sink.kept(p_node, p_word, h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, r0,
+    sink.kept(p_node, p_meta & (FLAG_IL | FLAG_OL), h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, r0,
               exact ? event_order(h.line_id, kept - 1u, 1) : 0ull);
   };
   // Pipeline registers: at the top of pass i, nid[j] = id of node i+j (j = 0 .. PF) and inf[j] = info of node i+j
@@ -361,18 +381,24 @@ PANTAS_UNROLL
       const uint32_t le = room < left ? room : left;
       bool keep;
       uint32_t plain;
-      short_node_summary(so, P, le, keep, plain);
+      if constexpr (LEAN) { keep = true; plain = short_has_colon(so, P, P + le) ? 1u : 0u; }
+      else short_node_summary(so, P, le, keep, plain);
       P += le;                      // == T when the ops end inside this node
       if (keep) {
         uint32_t r0_here = 0;
         if (pending) {
           const uint32_t a = rev ? node : p_node, bnode = rev ? p_node : node;
           const bool first_slot = (rev ? col0 : p_c0) == bnode;          // NONE for a node without out-links
-          flush(false, rev ? p_r0 : (first_slot ? 1u : 0u));
+          flush(false, rev ? ((p_meta >> 2) & 1u) : (first_slot ? 1u : 0u));
           if (rev && first_slot) r0_here = 1u;
-          if (!first_slot) sink.link_rest(a, bnode, event_order(h.line_id, kept - 1u, 0));
+          if (!first_slot) {
+            const uint32_t p_i = (p_meta >> 8) & 31u;
+            if constexpr (DEFER) sink.defer(rev ? i : p_i, rev ? p_i : i, kept - 1u, a, bnode, h.line_id);
+            else sink.link_rest(a, bnode, event_order(h.line_id, kept - 1u, 0));
+          }
         }
-        p_node = node; p_word = word; p_c0 = col0; p_plain = plain; p_r0 = r0_here;
+        p_node = node; p_c0 = col0;
+        p_meta = plain | (r0_here << 2) | ((i & 31u) << 8) | (word & (FLAG_IL | FLAG_OL));
         pending = true;
         ++kept;
       }                             // else: the node holds the lone '+' / '-' piece and is dropped (:101-102)
@@ -385,7 +411,8 @@ PANTAS_UNROLL
     for (int j = 0; j + 1 < PF; ++j) inf[j] = inf[j + 1];
     inf[PF - 1] = new_inf;
   }
-  if (pending) flush(true, rev ? p_r0 : 0u);
+  if (pending) flush(true, rev ? ((p_meta >> 2) & 1u) : 0u);
+  if constexpr (DEFER) sink.drain(nodes, h.line_id);
   return WALK_OK;
 }
 
@@ -398,7 +425,7 @@ PANTAS_HD int walk_short_rare(const GraphAcc& ga, const LineHdr& h, const uint32
   if (k == 0) return WALK_OK;
   ShortOps so;
   short_ops_scan(ops, nops, so);
-  const uint32_t T = so.T, x_end = so.x_pos + so.x_len;
+  const uint32_t T = so.T, x_end = so.x_pos() + so.x_len();
   uint32_t P = 0, kept = 0;
   bool pending = false;
   KeptNode pend{};
@@ -423,7 +450,7 @@ PANTAS_HD int walk_short_rare(const GraphAcc& ga, const LineHdr& h, const uint32
     const uint32_t le = room < left ? room : left, end = P + le;
     KeptNode kn{node, word, 1u, OP_COLON, le, OP_COLON, le, 1u};      // a node without a piece of the indel: no rare key
     bool keep = true;
-    if (so.x_len != 0 && so.x_pos < end && x_end > P) {
+    if (so.x_len() != 0 && so.x_pos() < end && x_end > P) {
       PieceAcc acc;
       acc.begin(node, word);
       uint32_t q = 0;

@@ -1,6 +1,8 @@
 // TEST HARNESS ONLY.  Host-side views for the short walks of walk.h (walk_short, walk_short_rare), so that the CPU harness
 // walks every line the way the kernels do: short-walk class through walk_short, the rest through walk_line.
 #pragma once
+#include <vector>
+
 #include "graph.h"
 #include "walk.h"
 
@@ -29,6 +31,16 @@ struct ShortFromGeneral {
     for (uint32_t i = 0; i < r0; ++i) s.edge(node, g.col[g.row_ptr[node]], 0);      // the node's first out-slot
   }
   void link_rest(uint32_t a, uint32_t b, uint64_t order) const { s.edge(a, b, order); }
+  // walk_short<.., DEFER>: links off the first out-slot as path indices, looked up after the node loop (as the kernel does)
+  mutable std::vector<uint32_t> q;
+  void defer(uint32_t ia, uint32_t ib, uint32_t kidx, uint32_t a, uint32_t b, uint32_t line_id) const {
+    if (q.size() < 4) q.push_back(ia | (ib << 5) | (kidx << 10));
+    else link_rest(a, b, event_order(line_id, kidx, 0));
+  }
+  void drain(const uint32_t* nodes, uint32_t line_id) const {
+    for (uint32_t e : q) link_rest(nodes[e & 31u], nodes[(e >> 5) & 31u], event_order(line_id, e >> 10, 0));
+    q.clear();
+  }
 };
 
 // main pass over one line, as augment.hip dispatches it
@@ -40,7 +52,16 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
   const ShortFromGeneral<GenSink> ss{s, g};
   uint32_t first_ids[4] = {0, 0, 0, 0};
   for (uint32_t j = 0; j < 4 && k; ++j) first_ids[j] = nodes[j < k - 1 ? j : k - 1];
-  return (h.line_id & 1u) ? walk_short<2>(ga, h, nodes, k, ops, c, ss, first_ids) : walk_short<1>(ga, h, nodes, k, ops, c, ss, first_ids);
+  // every instance the kernels use takes its turn: gathers one / two nodes ahead, deferred link lookups, the lean
+  // instance for lines without an indel
+  switch (h.line_id & 3u) {
+    case 0: return walk_short<1>(ga, h, nodes, k, ops, c, ss, first_ids);
+    case 1: return walk_short<2>(ga, h, nodes, k, ops, c, ss, first_ids);
+    case 2: return walk_short<2, true>(ga, h, nodes, k, ops, c, ss, first_ids);
+    default:
+      if (h.flags & LINE_SIMPLE) return walk_short<2, true, true>(ga, h, nodes, k, ops, c, ss, first_ids);
+      return walk_short<1, true>(ga, h, nodes, k, ops, c, ss, first_ids);
+  }
 }
 
 // rare-key pass over one line with a '-'
