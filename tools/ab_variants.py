@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--lines", type=int, default=0)
     ap.add_argument("--env", default="", help="extra NAME=VALUE pairs applied to every variant, comma separated")
+    ap.add_argument("--del-hot", type=float, default=0.0, help="synthetic deletion skew (bench.py --del-hot)")
+    ap.add_argument("--hot-sites", type=int, default=1000)
+    ap.add_argument("--p-indel", type=float, default=0.0)
     args = ap.parse_args()
     from bench import SCALES
     from pantas_amd.engine import Graph, Synth
@@ -30,6 +33,11 @@ def main():
     kw = dict(kw)
     if args.lines:
         kw["n_lines"] = args.lines
+    if args.del_hot:
+        kw["p_del_hot"] = args.del_hot
+        kw["hot_sites"] = args.hot_sites
+    if args.p_indel:
+        kw["p_indel"] = args.p_indel
     syn = Synth(seed=7, **kw)
     g = Graph(text=syn.gfa).to_device(0)
     g.augment_reset()
@@ -40,7 +48,13 @@ def main():
         os.environ[k] = v
     ref = None
     for v in args.variants.split(","):
+        # "main" or "main:rare" (PANTAS_MAIN_KERNEL : PANTAS_RARE_KERNEL)
+        v, _, rv = v.partition(":")
         os.environ["PANTAS_MAIN_KERNEL"] = v
+        if rv:
+            os.environ["PANTAS_RARE_KERNEL"] = rv
+        else:
+            os.environ.pop("PANTAS_RARE_KERNEL", None)
         g.augment_reset()
         for _ in range(2):
             g.launch(batch)
@@ -60,7 +74,7 @@ def main():
         dig = h.hexdigest()[:16]
         ref = ref or dig
         avg_s = sum(short) / len(short)
-        print(json.dumps({"variant": int(v), "scale": args.scale, "main_ms": round(sum(ms) / len(ms), 4), "main_min": round(min(ms), 4),
+        print(json.dumps({"variant": int(v), "rare_variant": rv or "default", "del_hot": args.del_hot, "scale": args.scale, "main_ms": round(sum(ms) / len(ms), 4), "main_min": round(min(ms), 4),
                           "short_ms": round(avg_s, 4), "rare_ms": round(sum(rare) / len(rare), 4), "short_frac_of_8TBps": round(bs.short_alg_bytes / (avg_s * 1e-3) / 8e12, 4) if avg_s else None,
                           "whole_frac": round(bs.alg_bytes / (sum(ms) / len(ms) * 1e-3) / 8e12, 4),
                           "digest": dig, "same_as_first": dig == ref}), flush=True)
