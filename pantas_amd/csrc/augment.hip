@@ -19,6 +19,8 @@
 // needs a single (block-sparse, exchange.hip) all-reduce.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "augment.h"
 #include "device_batch.h"
 #include "walk.h"
@@ -754,6 +756,41 @@ void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   delete b;
 }
 
+void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  constexpr size_t STAGE = size_t(32) << 20;
+  if (bytes == 0) return;
+  if (bytes < 2 * STAGE) {
+    HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    return;
+  }
+  // process-wide staging buffers (one copy at a time; they live as long as the process)
+  static std::mutex mu;
+  static void* pinned[2] = {nullptr, nullptr};
+  static hipEvent_t done[2] = {nullptr, nullptr};
+  std::lock_guard<std::mutex> lk(mu);
+  if (!pinned[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIP_OK(hipHostMalloc(&pinned[k], STAGE, hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+    }
+  }
+  const unsigned threads = std::min<unsigned>(hw_threads(), 16);
+  bool used[2] = {false, false};
+  int k = 0;
+  for (size_t off = 0; off < bytes; off += STAGE, k ^= 1) {
+    const size_t len = std::min(STAGE, bytes - off);
+    if (used[k]) HIP_OK(hipEventSynchronize(done[k]));
+    char* stage = static_cast<char*>(pinned[k]);
+    const char* from = static_cast<const char*>(src) + off;
+    parallel_chunks(len, threads, [&](unsigned, size_t b, size_t e) { memcpy(stage + b, from + b, e - b); });
+    HIP_OK(hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, stream));
+    HIP_OK(hipEventRecord(done[k], stream));
+    used[k] = true;
+  }
+  HIP_OK(hipStreamSynchronize(stream));
+}
+
 int device_count() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -807,9 +844,9 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   }
   HIP_OK(hipMalloc(&d->small, 64));
   HIP_OK(hipMalloc(&d->slow_dev, sizeof(SlowTables)));
-  HIP_OK(hipMemcpyAsync(d->word, g.seg_len.data(), size_t(g.V) * 4, hipMemcpyHostToDevice, d->stream));
-  HIP_OK(hipMemcpyAsync(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, hipMemcpyHostToDevice, d->stream));
-  HIP_OK(hipMemcpyAsync(d->col, g.col.data(), size_t(g.A) * 4, hipMemcpyHostToDevice, d->stream));
+  h2d_staged(d->word, g.seg_len.data(), size_t(g.V) * 4, d->stream);
+  h2d_staged(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, d->stream);
+  h2d_staged(d->col, g.col.data(), size_t(g.A) * 4, d->stream);
   HIP_OK(hipMalloc(&d->info, std::max<size_t>(1, g.V) * 8));
   if (g.V) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(g.V) + 255) / 256, 1u << 16));

@@ -14,6 +14,7 @@
 
 #include "call_host.h"
 #include "call.h"
+#include "device_batch.h"
 
 namespace pantas {
 
@@ -185,7 +186,7 @@ static const T* up(DeviceCall& d, const std::vector<T, A>& v) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
   d.allocs.push_back(p);
-  if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, d.stream));
+  if (!v.empty()) h2d_staged(p, v.data(), v.size() * sizeof(T), d.stream);
   return static_cast<const T*>(p);
 }
 
@@ -194,7 +195,7 @@ static const T* up_raw(DeviceCall& d, const T* src, size_t n) {
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
   d.allocs.push_back(p);
-  if (n) HIP_OK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, d.stream));
+  if (n) h2d_staged(p, src, n * sizeof(T), d.stream);
   return static_cast<const T*>(p);
 }
 

@@ -85,6 +85,11 @@ struct ScratchPool {
   }
 };
 
+// Host array of gigabytes -> HBM: hipMemcpy from pageable memory stages through one runtime thread (~10 GB/s); this copies
+// through two pinned 32 MB buffers that several host threads fill (the text upload of tokenize.hip reaches 50 GB/s that
+// way).  Synchronous: returns when the bytes are on the device.  Small copies go straight through hipMemcpyAsync.
+void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
 // what tokenize.hip needs from a DeviceGraph without seeing its tables
 struct DeviceGraphInfo {
   int device;
