@@ -35,18 +35,6 @@ inline void put_i64(std::string& s, int64_t v) {
   if (v < 0) { s.push_back('-'); put_u64(s, uint64_t(-v)); } else put_u64(s, uint64_t(v));
 }
 
-void write_all(int fd, const char* p, size_t n) {
-  while (n) {
-    ssize_t w = ::write(fd, p, n);
-    if (w < 0) {
-      if (errno == EINTR) continue;
-      throw Error("OSError", std::string("write failed: ") + strerror(errno));
-    }
-    p += w;
-    n -= size_t(w);
-  }
-}
-
 struct KeyCount { int64_t key; uint64_t count; uint64_t first; };
 
 // one histogram tag (IL or OL) of node `n`; appends nothing when the histogram is empty
@@ -208,19 +196,24 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
   const size_t n_pieces = cut.size() - 1;
   std::vector<uint64_t> has_hist((size_t(g.V) + 63) / 64 + 1, 0);
   for (const HistEntry& h : r.hist) has_hist[h.node >> 6] |= uint64_t(1) << (h.node & 63u);
-  off_t file_pos = -1;
-  {
-    struct stat st;
-    const int fl = fcntl(fd, F_GETFL);
-    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl != -1 && !(fl & O_APPEND)) file_pos = lseek(fd, 0, SEEK_CUR);
+  // the novel-link tail is the last piece
+  std::string tail;
+  for (const NovelLink& nl : r.novel) {
+    tail += "L\t";
+    Span a = g.name_of(nl.u), b = g.name_of(nl.v);
+    tail.append(a.b, a.size());
+    tail += "\t+\t";
+    tail.append(b.b, b.size());
+    tail += "\t+\t*\tRC:i:";
+    put_u64(tail, nl.count);
+    tail += "\tID:Z:N\n";
   }
-  const bool positional = file_pos >= 0 && !getenv("PANTAS_WRITER_SEQUENTIAL");
+  // what the lines can grow by at most: NC (16), a common-only IL (18) and OL (27) per S line, RC (16) per L line, 24 per
+  // explicit histogram entry -- the (sparse) size the output file is mapped with; about a fifth more than the text is expected
+  const uint64_t bound = uint64_t(size) + 61ull * g.n_s_lines + 16ull * g.n_l_lines + 24ull * r.hist.size() + tail.size() + 4096;
+  OrderedOutput sink(fd, n_pieces + 1, uint64_t(size) + uint64_t(size) / 4 + tail.size(), bound);
   const unsigned T = unsigned(std::min<size_t>(std::max<size_t>(n_pieces, 1), threads));
   std::atomic<size_t> next{0};
-  // end_of[p] = output offset where piece p ends (positional) / flag that piece p has been written (stream); 0 = not yet
-  std::vector<std::atomic<uint64_t>> end_of(n_pieces + 1);
-  for (auto& x : end_of) x.store(UINT64_MAX, std::memory_order_relaxed);
-  end_of[0].store(0, std::memory_order_relaxed);      // "piece -1" ends at relative offset 0
   std::atomic<bool> failed{false};
   std::shared_ptr<Error> first_err;
   std::mutex err_mu;
@@ -238,36 +231,13 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
         failed.store(true);
         buf.clear();
       }
-      uint64_t start;
-      for (unsigned spins = 0; (start = end_of[p].load(std::memory_order_acquire)) == UINT64_MAX; ++spins) {
-        if (spins < 200) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(50));    // (a pipe: everyone behind the one writer)
-      }
-      if (positional) {
-        end_of[p + 1].store(start + buf.size(), std::memory_order_release);
-        const char* q = buf.data();
-        size_t n = buf.size();
-        off_t at = file_pos + off_t(start);
-        while (n && !failed.load(std::memory_order_relaxed)) {
-          const ssize_t w = ::pwrite(fd, q, n, at);
-          if (w < 0) {
-            if (errno == EINTR) continue;
-            std::lock_guard<std::mutex> lk(err_mu);
-            if (!first_err) first_err = std::make_shared<Error>("OSError", std::string("write failed: ") + strerror(errno));
-            failed.store(true);
-            break;
-          }
-          q += w; n -= size_t(w); at += w;
-        }
-      } else {
-        try {
-          if (!failed.load(std::memory_order_relaxed)) write_all(fd, buf.data(), buf.size());
-        } catch (const Error& e) {
-          std::lock_guard<std::mutex> lk(err_mu);
-          if (!first_err) first_err = std::make_shared<Error>(e);
-          failed.store(true);
-        }
-        end_of[p + 1].store(start + buf.size(), std::memory_order_release);
+      try {
+        if (failed.load(std::memory_order_relaxed)) buf.clear();
+        sink.put(p, buf.data(), buf.size());      // (an empty piece still hands the position on)
+      } catch (const Error& e) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (!first_err) first_err = std::make_shared<Error>(e);
+        failed.store(true);
       }
     }
   };
@@ -278,25 +248,10 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
     for (auto& x : th) x.join();
   }
   if (first_err) throw *first_err;
-  if (positional) {
-    const uint64_t total = end_of[n_pieces].load();
-    if (lseek(fd, file_pos + off_t(total), SEEK_SET) < 0) throw Error("OSError", "lseek failed on the output");
-  }
-  pt.lap(positional ? "format + pwrite (parallel)" : "format (parallel) + write (in order)");
   // links seen in reads but absent from the GFA, in first-seen order (:426-427)
-  std::string tail;
-  for (const NovelLink& nl : r.novel) {
-    tail += "L\t";
-    Span a = g.name_of(nl.u), b = g.name_of(nl.v);
-    tail.append(a.b, a.size());
-    tail += "\t+\t";
-    tail.append(b.b, b.size());
-    tail += "\t+\t*\tRC:i:";
-    put_u64(tail, nl.count);
-    tail += "\tID:Z:N\n";
-    if (tail.size() > (8u << 20)) { write_all(fd, tail.data(), tail.size()); tail.clear(); }
-  }
-  write_all(fd, tail.data(), tail.size());
+  sink.put(n_pieces, tail.data(), tail.size());
+  sink.finish();
+  pt.lap(sink.mode_name());
 }
 
 }  // namespace pantas

@@ -181,23 +181,25 @@ static void exclusive_scan(DeviceCall& d, const uint32_t* a, uint32_t* out, uint
   hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1), 0, d.stream, a, out, n);
 }
 
-template <class T, class A>
-static const T* up(DeviceCall& d, const std::vector<T, A>& v) {
-  void* p = nullptr;
-  HIP_OK(hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
-  d.allocs.push_back(p);
-  if (!v.empty()) h2d_staged(p, v.data(), v.size() * sizeof(T), d.stream);
-  return static_cast<const T*>(p);
-}
+static double g_up_malloc_s = 0, g_up_copy_s = 0;
+static uint64_t g_up_bytes = 0;
 
 template <class T>
 static const T* up_raw(DeviceCall& d, const T* src, size_t n) {
   void* p = nullptr;
+  const double t0 = now_s();
   HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
   d.allocs.push_back(p);
+  const double t1 = now_s();
   if (n) h2d_staged(p, src, n * sizeof(T), d.stream);
+  g_up_malloc_s += t1 - t0;
+  g_up_copy_s += now_s() - t1;
+  g_up_bytes += n * sizeof(T);
   return static_cast<const T*>(p);
 }
+
+template <class T, class A>
+static const T* up(DeviceCall& d, const std::vector<T, A>& v) { return up_raw(d, v.data(), v.size()); }
 
 template <class T>
 static T* dalloc(DeviceCall& d, size_t n) {
@@ -212,9 +214,13 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device)
     throw Error("NoDevice", "no HIP device " + std::to_string(device) + " (the call kernels have no CPU path)");
   HIP_OK(hipSetDevice(device));
+  PhaseTimer pt("upload_call");
+  g_up_malloc_s = g_up_copy_s = 0;
+  g_up_bytes = 0;
   DeviceCallPtr d(new DeviceCall());
   d->device = device;
   HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  pt.lap("device, stream");
   HIP_OK(hipEventCreate(&d->ev0));
   HIP_OK(hipEventCreate(&d->ev1));
   CallView& c = d->view;
@@ -235,6 +241,9 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   d->arena = dalloc<uint32_t>(*d, size_t(ARENA_SLOTS) * ARENA_CAP);
   d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
+  if (pt.on) fprintf(stderr, "[timing] upload_call: %.2f GB: hipMalloc %.3f s, copies %.3f s (%.1f GB/s)\n", g_up_bytes / 1e9, g_up_malloc_s, g_up_copy_s,
+                     g_up_copy_s > 0 ? g_up_bytes / 1e9 / g_up_copy_s : 0.0);
+  pt.lap("tables in HBM");
   return d;
 }
 

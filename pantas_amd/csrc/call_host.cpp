@@ -778,20 +778,12 @@ void render_events_to_fd(const Graph& g, const CallTables& t, const EventRec* re
   constexpr size_t BLOCK = 16384;
   const size_t nb = (n + BLOCK - 1) / BLOCK;
   const unsigned T = unsigned(std::max<size_t>(1, std::min<size_t>(n < 100000 ? 1 : hw_threads(), nb)));
-  // On a regular file (the `> events.csv` of the command line) the blocks are written concurrently with pwrite: a block's
-  // position is known as soon as the block before it has been RENDERED (the chain of block ends below); on a pipe the
-  // chain advances after each write.  (13 GB of rows through one writer were 3 of the 18 s of `pantas call` at S4.)
-  off_t file_pos = -1;
-  if (fd_csv >= 0) {
-    struct stat st;
-    const int fl = fcntl(fd_csv, F_GETFL);
-    if (fstat(fd_csv, &st) == 0 && S_ISREG(st.st_mode) && fl != -1 && !(fl & O_APPEND)) file_pos = lseek(fd_csv, 0, SEEK_CUR);
-  }
-  const bool positional = file_pos >= 0 && !getenv("PANTAS_WRITER_SEQUENTIAL");
+  // blocks of rows are rendered by a thread pool into buffers the threads keep and land in row order through
+  // OrderedOutput (common.h): on a regular file by many threads at once.  The bytes of a row are not known before it is
+  // rendered: ~200 per row are expected, and the file is mapped (sparse) with room for 16 times that -- a run that
+  // needs more finishes through pwrite.
+  OrderedOutput sink(fd_csv, nb, uint64_t(n) * 200, uint64_t(n) * 3200 + (uint64_t(1) << 30));
   std::atomic<size_t> next{0};
-  std::vector<std::atomic<uint64_t>> end_of(nb + 1);
-  for (auto& x : end_of) x.store(UINT64_MAX, std::memory_order_relaxed);
-  end_of[0].store(0, std::memory_order_relaxed);
   std::atomic<bool> failed{false};
   std::mutex mu;                 // first_error
   std::unique_ptr<Error> first_error;
@@ -808,27 +800,13 @@ void render_events_to_fd(const Graph& g, const CallTables& t, const EventRec* re
           render_range(g, t, recs, b * BLOCK, std::min(n, (b + 1) * BLOCK), side, tasks, paths, buf, err_parts[b]);
       } catch (const Error& x) {
         mine.reset(new Error(x));
-        buf.clear();
       }
-      uint64_t start;
-      for (unsigned spins = 0; (start = end_of[b].load(std::memory_order_acquire)) == UINT64_MAX; ++spins) {
-        if (spins < 200) std::this_thread::yield();
-        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+      if (mine || failed.load(std::memory_order_relaxed)) buf.clear();
+      try {
+        sink.put(b, buf.data(), buf.size());
+      } catch (const Error& x) {
+        if (!mine) mine.reset(new Error(x));
       }
-      if (positional) end_of[b + 1].store(start + buf.size(), std::memory_order_release);
-      if (!mine && fd_csv >= 0 && !failed.load(std::memory_order_relaxed)) {
-        const char* p = buf.data();
-        size_t left = buf.size();
-        off_t at = file_pos + off_t(start);
-        while (left) {
-          const ssize_t w = positional ? ::pwrite(fd_csv, p, left, at) : ::write(fd_csv, p, left);
-          if (w < 0) { if (errno == EINTR) continue; mine.reset(new Error("OSError", "write failed")); break; }
-          p += w;
-          left -= size_t(w);
-          at += w;
-        }
-      }
-      if (!positional) end_of[b + 1].store(start + buf.size(), std::memory_order_release);
       if (mine) {
         std::lock_guard<std::mutex> lk(mu);
         if (!first_error) first_error = std::move(mine);
@@ -843,7 +821,7 @@ void render_events_to_fd(const Graph& g, const CallTables& t, const EventRec* re
     for (auto& th : pool) th.join();
   }
   if (first_error) throw *first_error;
-  if (positional && lseek(fd_csv, file_pos + off_t(end_of[nb].load()), SEEK_SET) < 0) throw Error("OSError", "lseek failed on the output");
+  sink.finish();
   for (const std::string& e : err_parts) err += e;
 }
 

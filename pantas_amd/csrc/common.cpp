@@ -3,7 +3,9 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/statvfs.h>
 #include <unistd.h>
+#include <atomic>
 #include <chrono>
 #include <cerrno>
 #include <cstdlib>
@@ -156,6 +158,132 @@ static void radix_sort_pairs_impl(Vec& key, Vec& idx, unsigned threads) {
 
 void radix_sort_pairs(RawVector<uint32_t>& key, RawVector<uint32_t>& idx, unsigned threads) { radix_sort_pairs_impl(key, idx, threads); }
 void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, unsigned threads) { radix_sort_pairs_impl(key, idx, threads); }
+
+// ---- OrderedOutput ---------------------------------------------------------------------------------------------------
+struct OrderedOutput::Impl {
+  int fd;
+  int map_fd = -1;                  // descriptor the mapping and the truncations go through (fd itself or a read-write reopening)
+  bool own_map_fd = false;
+  int mode;                         // 0 stream, 1 pwrite, 2 mmap
+  off_t file_pos = 0;               // where the output starts in the file
+  std::vector<std::atomic<uint64_t>> end_of;
+  char* map = nullptr;              // maps [map_base, map_base + map_len) of the file
+  uint64_t map_base = 0, map_len = 0;
+  std::mutex grow_mu;
+  std::atomic<uint64_t> file_size{0};   // current (sparse) size of the file while mapped
+  uint64_t total = 0;
+  explicit Impl(size_t n) : end_of(n + 1) {}
+};
+
+OrderedOutput::OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, uint64_t bound_bytes) : im(new Impl(n_pieces)) {
+  im->fd = fd;
+  im->mode = 0;
+  for (auto& x : im->end_of) x.store(UINT64_MAX, std::memory_order_relaxed);
+  im->end_of[0].store(0, std::memory_order_relaxed);
+  if (fd < 0) return;
+  struct stat st;
+  const int fl = fcntl(fd, F_GETFL);
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || fl == -1 || (fl & O_APPEND) || getenv("PANTAS_WRITER_SEQUENTIAL")) return;
+  const off_t pos = lseek(fd, 0, SEEK_CUR);
+  if (pos < 0) return;
+  im->file_pos = pos;
+  im->mode = 1;
+  const char* e = getenv("PANTAS_OUTPUT_MMAP");
+  if (e && !strcmp(e, "0")) return;
+  im->map_fd = fd;
+  if ((fl & O_ACCMODE) != O_RDWR) {
+    // a shared writable mapping needs a descriptor opened for reading too, and the shell's `> file` is write-only:
+    // the same file once more through /proc (no /proc, no permission, another file: pwrite then)
+    const std::string link = "/proc/self/fd/" + std::to_string(fd);
+    const int fd2 = ::open(link.c_str(), O_RDWR);
+    if (fd2 < 0) return;
+    struct stat st2;
+    if (fstat(fd2, &st2) != 0 || st2.st_dev != st.st_dev || st2.st_ino != st.st_ino) { ::close(fd2); return; }
+    im->map_fd = fd2;
+    im->own_map_fd = true;
+  }
+  struct statvfs vs;
+  if (fstatvfs(fd, &vs) != 0 || uint64_t(vs.f_bavail) * vs.f_frsize < expected_bytes + expected_bytes / 8 + (uint64_t(1) << 30)) return;
+  const uint64_t page = 4096;
+  im->map_base = uint64_t(pos) / page * page;
+  im->map_len = (uint64_t(pos) - im->map_base + bound_bytes + page - 1) / page * page;
+  void* m = mmap(nullptr, im->map_len, PROT_READ | PROT_WRITE, MAP_SHARED, im->map_fd, off_t(im->map_base));
+  if (m == MAP_FAILED) return;
+  im->map = static_cast<char*>(m);
+  im->file_size.store(uint64_t(st.st_size));
+  im->mode = 2;
+}
+
+OrderedOutput::~OrderedOutput() {
+  if (im->map) munmap(im->map, im->map_len);
+  if (im->own_map_fd && im->map_fd >= 0) ::close(im->map_fd);
+  delete im;
+}
+
+const char* OrderedOutput::mode_name() const { return im->mode == 2 ? "shared mapping" : im->mode == 1 ? "pwrite" : "write in order"; }
+
+void OrderedOutput::put(size_t piece, const char* data, size_t n) {
+  uint64_t start;
+  for (unsigned spins = 0; (start = im->end_of[piece].load(std::memory_order_acquire)) == UINT64_MAX; ++spins) {
+    if (spins < 200) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+  auto fail = [&](const char* what) {
+    im->end_of[piece + 1].store(start + n, std::memory_order_release);     // nobody may wait for ever
+    throw Error("OSError", std::string(what) + ": " + strerror(errno));
+  };
+  if (im->mode == 0) {
+    if (im->fd >= 0) {
+      const char* p = data;
+      size_t left = n;
+      while (left) {
+        const ssize_t w = ::write(im->fd, p, left);
+        if (w < 0) { if (errno == EINTR) continue; fail("write failed"); }
+        p += w; left -= size_t(w);
+      }
+    }
+    im->end_of[piece + 1].store(start + n, std::memory_order_release);
+    return;
+  }
+  im->end_of[piece + 1].store(start + n, std::memory_order_release);
+  const uint64_t at = uint64_t(im->file_pos) + start;
+  if (im->mode == 2 && at - im->map_base + n <= im->map_len) {
+    // the file has to reach behind the piece before its pages may be touched (beyond the end of the file: SIGBUS)
+    const uint64_t need = at + n;
+    if (im->file_size.load(std::memory_order_acquire) < need) {
+      std::lock_guard<std::mutex> lk(im->grow_mu);
+      uint64_t cur = im->file_size.load(std::memory_order_relaxed);
+      if (cur < need) {
+        const uint64_t to = std::min<uint64_t>(im->map_base + im->map_len, std::max<uint64_t>(need + (uint64_t(2) << 30), cur + cur / 2));
+        if (ftruncate(im->map_fd, off_t(to)) != 0) throw Error("OSError", std::string("ftruncate failed: ") + strerror(errno));
+        im->file_size.store(to, std::memory_order_release);
+      }
+    }
+    memcpy(im->map + (at - im->map_base), data, n);
+    return;
+  }
+  const char* p = data;
+  size_t left = n;
+  off_t o = off_t(at);
+  while (left) {
+    const ssize_t w = ::pwrite(im->fd, p, left, o);
+    if (w < 0) { if (errno == EINTR) continue; throw Error("OSError", std::string("write failed: ") + strerror(errno)); }
+    p += w; left -= size_t(w); o += w;
+  }
+}
+
+void OrderedOutput::finish() {
+  const uint64_t total = im->end_of.back().load(std::memory_order_acquire);
+  if (total == UINT64_MAX) throw Error("InternalError", "OrderedOutput::finish before every piece was put");
+  if (im->mode == 0) return;
+  const off_t end = im->file_pos + off_t(total);
+  if (im->mode == 2) {
+    munmap(im->map, im->map_len);
+    im->map = nullptr;
+    if (ftruncate(im->map_fd, std::max<off_t>(end, 0)) != 0) throw Error("OSError", std::string("ftruncate failed: ") + strerror(errno));
+  }
+  if (lseek(im->fd, end, SEEK_SET) < 0) throw Error("OSError", "lseek failed on the output");
+}
 
 double now_s() {
   using namespace std::chrono;

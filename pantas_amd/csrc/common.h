@@ -175,6 +175,27 @@ void radix_sort_pairs(std::vector<uint32_t>& key, std::vector<uint32_t>& idx, un
 
 double now_s();
 
+// Output of pieces that are produced in parallel but must land in order (the augmented GFA, the events CSV).  Piece p may
+// be put once piece p - 1 has been put (its end is then known); what happens to the bytes depends on the descriptor:
+//   a regular file with room on its filesystem: the file is extended (sparse) and mapped, every thread copies its piece
+//     into the mapping -- page-cache pages are then allocated by many threads at once.  write() / pwrite() take the inode
+//     lock: 64 threads writing 23 GB into tmpfs measured 4.4 GB/s, the speed of ONE thread (profiles/r2_e2e_s4_cli_output_cost.json);
+//   a regular file otherwise (or PANTAS_OUTPUT_MMAP=0): pwrite at the piece's offset;
+//   anything else (pipe, terminal): write(), one piece after the other.
+// finish() sets the file size and position behind the last piece.  One put per piece index, any thread.
+struct OrderedOutput {
+  OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, uint64_t bound_bytes);
+  ~OrderedOutput();
+  OrderedOutput(const OrderedOutput&) = delete;
+  OrderedOutput& operator=(const OrderedOutput&) = delete;
+  void put(size_t piece, const char* data, size_t n);    // throws Error("OSError") on a failed write
+  void finish();
+  const char* mode_name() const;
+ private:
+  struct Impl;
+  Impl* im;
+};
+
 // phase timing to stderr when PANTAS_TIMING is set
 struct PhaseTimer {
   const char* what;

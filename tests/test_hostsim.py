@@ -57,6 +57,18 @@ def test_walk_source_vs_reference_bytes(hostsim, case):
         assert r2.returncode == 0
         f.seek(0)
         assert f.read().decode() == "# already here\n" + r.stdout
+    # the shell's `> out.gfa` is a write-only descriptor (the mapping goes through a read-write reopening of the same file),
+    # and the two fallbacks: pwrite at the piece offsets, write() in order
+    for env in ({}, {"PANTAS_OUTPUT_MMAP": "0"}, {"PANTAS_WRITER_SEQUENTIAL": "1"}):
+        with tempfile.NamedTemporaryFile(delete=False) as tf:
+            path = tf.name
+        try:
+            with open(path, "wb") as f:
+                r3 = subprocess.run([hostsim["augment"], f"{d}/in.gaf", f"{d}/in.gfa"], stdout=f, stderr=subprocess.PIPE, env={**os.environ, **env})
+            assert r3.returncode == 0, r3.stderr
+            assert open(path).read() == r.stdout, env
+        finally:
+            os.unlink(path)
 
 
 @pytest.mark.parametrize("case", CASES)

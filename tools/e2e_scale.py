@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--cache", action="store_true", help="second augment run with PANTAS_GRAPH_CACHE=1 (cache written by the first)")
     ap.add_argument("--flags", default="--rca 3 --novel")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--null-out", action="store_true", help="also time both stages with stdout on /dev/null (what the output file costs)")
     ap.add_argument("--seed", type=int, default=7)
     a = ap.parse_args()
     from pantas_amd.engine import Synth
@@ -114,6 +115,11 @@ def main():
         res["call"] = {"wall_s": dt, "events": rows - 1, "events_per_s": (rows - 1) / dt, "phases": phases(err), "peak_rss_gb": rss,
                        "out_bytes": os.path.getsize(pre + ".csv")}
         res["total_s"] = res["augment"]["wall_s"] + res["call"]["wall_s"]
+        if a.null_out:
+            dt, err, _ = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], "/dev/null", env)
+            res["augment_to_dev_null"] = {"wall_s": dt, "phases": [p for p in phases(err) if "tokenize_gaf_device" not in p]}
+            dt, err, _ = timed([py, "-m", "pantas_amd.call", *a.flags.split(), pre + ".aug.gfa", pre + ".gtf"], "/dev/null", env)
+            res["call_to_dev_null"] = {"wall_s": dt, "phases": phases(err)}
     finally:
         if not a.keep:
             for ext in (".gaf", ".gfa", ".gtf", ".aug.gfa", ".csv", ".gfa.pgc", ".aug2.gfa"):
