@@ -825,6 +825,7 @@ static void table_clear(Table& t, hipStream_t s) {
 DeviceGraphPtr upload_graph(const Graph& g, int device) {
   if (device_count() <= device) throw Error("NoDevice", "no HIP device " + std::to_string(device) + " (the augment kernels have no CPU path)");
   HIP_OK(hipSetDevice(device));
+  PhaseTimer pt("upload_graph");
   DeviceGraphPtr d(new DeviceGraph());
   d->device = device;
   d->V = g.V;
@@ -844,9 +845,11 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   }
   HIP_OK(hipMalloc(&d->small, 64));
   HIP_OK(hipMalloc(&d->slow_dev, sizeof(SlowTables)));
+  pt.lap("context, streams, hipMalloc");
   h2d_staged(d->word, g.seg_len.data(), size_t(g.V) * 4, d->stream);
   h2d_staged(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, d->stream);
   h2d_staged(d->col, g.col.data(), size_t(g.A) * 4, d->stream);
+  pt.lap("CSR to HBM");
   HIP_OK(hipMalloc(&d->info, std::max<size_t>(1, g.V) * 8));
   if (g.V) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(g.V) + 255) / 256, 1u << 16));
@@ -856,7 +859,9 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   table_alloc(d->hist, 1024, d->small + 2, d->small + 3);
   table_alloc(d->novel, 1024, d->small + 4, d->small + 5);
   HIP_OK(hipStreamSynchronize(d->stream));
+  pt.lap("node info records, tables");
   reset_counters(*d);
+  pt.lap("counters zeroed");
   return d;
 }
 

@@ -630,6 +630,11 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   }
   pt.lap("lists + probes");
   t.parse_s = now_s() - t0;
+  if (size_t(V) + A > (size_t(1) << 24)) {
+    // the per-line tag records of a whole-genome graph are ~13 GB: handed to a thread of its own to give back (a second)
+    auto* junk = new std::tuple<RawVector<SegAttr>, RawVector<LinkAttr>, RawVector<uint32_t>>(std::move(sa), std::move(la), std::move(attr_slot));
+    std::thread([junk] { delete junk; }).detach();
+  }
 }
 
 CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {

@@ -177,10 +177,11 @@ double now_s();
 
 // Output of pieces that are produced in parallel but must land in order (the augmented GFA, the events CSV).  Piece p may
 // be put once piece p - 1 has been put (its end is then known); what happens to the bytes depends on the descriptor:
-//   a regular file with room on its filesystem: the file is extended (sparse) and mapped, every thread copies its piece
-//     into the mapping -- page-cache pages are then allocated by many threads at once.  write() / pwrite() take the inode
-//     lock: 64 threads writing 23 GB into tmpfs measured 4.4 GB/s, the speed of ONE thread (profiles/r2_e2e_s4_cli_output_cost.json);
-//   a regular file otherwise (or PANTAS_OUTPUT_MMAP=0): pwrite at the piece's offset;
+//   a regular file: pwrite at the piece's offset, from the thread that made the piece.  (The kernel takes the inode lock
+//     for every write: 64 threads writing 23 GB into tmpfs measured 4.4 GB/s, the speed of ONE thread, and that is what
+//     `pantas augment` spends 5 of its 13 s on at whole-genome scale -- profiles/r2_e2e_s4_cli_output_cost.json.  With
+//     PANTAS_OUTPUT_MMAP=1 the file is extended (sparse), mapped, and the threads copy into the mapping instead: measured
+//     four times slower on the same tmpfs, kept as a switch for filesystems where it is not.);
 //   anything else (pipe, terminal): write(), one piece after the other.
 // finish() sets the file size and position behind the last piece.  One put per piece index, any thread.
 struct OrderedOutput {

@@ -57,9 +57,9 @@ def test_walk_source_vs_reference_bytes(hostsim, case):
         assert r2.returncode == 0
         f.seek(0)
         assert f.read().decode() == "# already here\n" + r.stdout
-    # the shell's `> out.gfa` is a write-only descriptor (the mapping goes through a read-write reopening of the same file),
-    # and the two fallbacks: pwrite at the piece offsets, write() in order
-    for env in ({}, {"PANTAS_OUTPUT_MMAP": "0"}, {"PANTAS_WRITER_SEQUENTIAL": "1"}):
+    # the shell's `> out.gfa` is a write-only descriptor: pwrite at the piece offsets (default), the opt-in shared mapping
+    # (through a read-write reopening of the same file), write() in order
+    for env in ({}, {"PANTAS_OUTPUT_MMAP": "1"}, {"PANTAS_WRITER_SEQUENTIAL": "1"}):
         with tempfile.NamedTemporaryFile(delete=False) as tf:
             path = tf.name
         try:
