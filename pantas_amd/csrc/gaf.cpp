@@ -203,7 +203,7 @@ void tokenize_range(const Graph& g, const char* data, size_t size, int thr, Chun
         else if (code != OP_COLON) ++others;
         total += out.ops[i] >> 3;
       }
-      flags |= line_class_flags(uint32_t(out.ops.size() - ops_before), stars, indels, others, (flags & LINE_SLOW) != 0, total);
+      flags |= line_class_flags(uint32_t(out.ops.size() - ops_before), stars, indels, others, (flags & LINE_SLOW) != 0, total, start, tail);
       if (has_del) {
         flags |= LINE_HAS_DEL;
         ++out.del_lines;

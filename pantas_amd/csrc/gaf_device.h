@@ -298,7 +298,7 @@ PANTAS_HD void parse_gaf_line(const uint8_t* b, const uint8_t* e, int thr, const
   if (start < -2147483648ll || start > 2147483647ll || tail < -2147483648ll || tail > 2147483647ll) { r.err = TE_OFFSETS; return; }
   uint32_t flags = rev ? LINE_REV : 0u;
   if (em.slow) flags |= LINE_SLOW;
-  flags |= line_class_flags(em.written, em.stars, em.indels, em.others, em.slow, em.total);
+  flags |= line_class_flags(em.written, em.stars, em.indels, em.others, em.slow, em.total, start, tail);
   if (em.has_del) flags |= LINE_HAS_DEL;
   r.status = TOK_KEEP;
   r.n_nodes = n_nodes;

@@ -66,7 +66,12 @@ PANTAS_HD uint32_t block_order_key(uint32_t flags, uint32_t path_nodes) {
   return ((flags & LINE_ONE_INDEL) ? 0x10000u : 0u) | (path_nodes < 0xFFFFu ? path_nodes : 0xFFFFu);
 }
 // what the tokenisers set from a line's op statistics (both tokenisers call this: one definition of the classes)
-PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t indels, uint32_t others, bool slow, uint64_t total_len) {
+// start / tail: the line's offsets on its first / last path node.  The short walk computes a node's room in 32 bits
+// (length < 2^30 minus the offsets): lines with offsets beyond +-2^29 -- none a mapper writes -- take the general walk.
+PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t indels, uint32_t others, bool slow, uint64_t total_len,
+                                    int64_t start, int64_t tail) {
+  constexpr int64_t OFF_MAX = int64_t(1) << 29;
+  if (start < -OFF_MAX || start > OFF_MAX || tail < -OFF_MAX || tail > OFF_MAX) return 0u;
   if (n_ops == 0 || n_ops >= SHORT_MAX_OPS || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= SHORT_MAX_TOTAL) return 0u;
   return indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u;
 }
@@ -364,17 +369,11 @@ PANTAS_UNROLL
     const uint32_t ahead = i + uint32_t(PF) + 1u;
     const uint32_t new_id = nodes[ahead < last ? ahead : last];
     const NodeInfo new_inf = ga.info(nid[PF]);
-    // room the node offers to the ops, as min(room, 2^32 - 1): every use compares it with T - P <= 2^32 - 1
-    const uint32_t len = word & LEN_MASK;
-    bool has_room = len != 0u;
-    uint32_t room = len;
-    if (i == 0 || i == k - 1) {
-      int64_t r = int64_t(len);
-      if (i == 0) r -= h.start;
-      if (i == k - 1) r = r - h.tail + 1;
-      has_room = r > 0;
-      room = r > int64_t(0xFFFFFFFFll) ? 0xFFFFFFFFu : uint32_t(r);
-    }
+    // room the node offers to the ops: its length, less the start offset on the first node, less tail - 1 on the last
+    // (:213-216).  32 bits hold it: lengths are below 2^30 and the class keeps both offsets within +-2^29.
+    const int32_t r = int32_t(word & LEN_MASK) - (i == 0 ? h.start : 0) - (i == last ? h.tail - 1 : 0);
+    const bool has_room = r > 0;
+    const uint32_t room = uint32_t(r);
     if (has_room) {
       if (P >= T) return WALK_OPS_EXHAUSTED;
       const uint32_t left = T - P;

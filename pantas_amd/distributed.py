@@ -219,12 +219,67 @@ def call_main(argv=None) -> int:
     return 0
 
 
+def replicates_main(argv=None) -> int:
+    """One replicate per GPU, no collective at all (the layout of exps/3-homo-real: six samples on one graph):
+
+        python -m torch.distributed.run --nproc-per-node N -m pantas_amd.distributed replicates \\
+            --out-dir DIR [--thr 20] [--gtf anno.gtf --call "--rca 3 --novel"] GFA GAF1 GAF2 ...
+
+    Rank r (LOCAL_RANK / RANK, WORLD_SIZE from the environment: under torchrun or any other launcher) parses the graph
+    once, keeps it in the HBM of GPU r, and runs `augment` for GAFs r, r + N, ...: DIR/<gaf name>.aug.gfa; with --gtf also
+    `call` on each result without the GFA text round trip: DIR/<gaf name>.events.csv.  No process group is created."""
+    import argparse
+    import sys
+    import time
+    from .call import CSV_HEADER  # noqa: F401  (the renderer writes it)
+    from .engine import Graph, graph_cache_path
+    ap = argparse.ArgumentParser(prog="pantas_amd.distributed replicates")
+    ap.add_argument("--out-dir", required=True)
+    ap.add_argument("--thr", type=int, default=20)
+    ap.add_argument("--gtf", default=None)
+    ap.add_argument("--call", default="", help="options of `pantas call` as one string, e.g. \"--rca 3 --novel\"")
+    ap.add_argument("GFA")
+    ap.add_argument("GAF", nargs="+")
+    a = ap.parse_args(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    mine = a.GAF[rank::world]
+    os.makedirs(a.out_dir, exist_ok=True)
+    if not mine:
+        return 0
+    t0 = time.perf_counter()
+    g = Graph(a.GFA, cache=graph_cache_path(a.GFA)).to_device(local)
+    call_opts = None
+    if a.gtf:
+        from .call import build_parser
+        call_opts = build_parser().parse_args(a.call.split() + ["-", "-"])
+    for gaf in mine:
+        base = os.path.join(a.out_dir, os.path.basename(gaf))
+        t1 = time.perf_counter()
+        with open(base + ".aug.gfa", "wb") as f:
+            bs, _ = g.augment(gaf, a.thr, f.fileno())
+        t2 = time.perf_counter()
+        msg = f"[rank {rank} gpu {local}] {gaf}: {bs.lines} lines, {bs.rejected} rejected, augment {t2 - t1:.2f} s"
+        if call_opts is not None:
+            g.call_prepare_fused(a.gtf, device=local)
+            with open(base + ".events.csv", "wb") as f:
+                cs = g.call(f.fileno(), 2, rca=call_opts.rca, novel=call_opts.novel, no_annotated=call_opts.annotated,
+                            events=call_opts.events, isw=call_opts.isw, minintronsize=call_opts.minintronsize, junction=call_opts.junction)
+            msg += f", call {time.perf_counter() - t2:.2f} s ({cs.events} events)"
+        print(msg, file=sys.stderr)
+    print(f"[rank {rank} gpu {local}] {len(mine)} replicate(s) in {time.perf_counter() - t0:.2f} s (graph parsed once)", file=sys.stderr)
+    return 0
+
+
 def main(argv=None) -> int:
     """torchrun entry:  python -m torch.distributed.run --nproc-per-node N -m pantas_amd.distributed GAF GFA [thr]"""
     import sys
+    argv = sys.argv[1:] if argv is None else argv
+    if argv and argv[0] == "replicates":
+        return replicates_main(argv[1:])
     import torch
     import torch.distributed as dist
-    argv = sys.argv[1:] if argv is None else argv
     if argv and argv[0] == "call":
         return call_main(argv[1:])
     gaf, gfa = argv[0], argv[1]

@@ -127,3 +127,35 @@ def test_stream_api_protocol(monkeypatch):
         g.augment(f"{d}/in.gaf", 20, f.fileno())
         f.seek(0)
         assert f.read().decode() == open(f"{d}/expected.aug.gfa").read()
+
+
+def test_replicate_per_gpu_launcher(tmp_path):
+    """`pantas_amd.distributed replicates`: rank r takes GAFs r, r + N, ... on its own GPU, no collective -- here two
+    ranks share the one GPU of the box (LOCAL_RANK 0 for both); augment bytes and fused call rows as the goldens have them."""
+    import collections
+    import call_oracle
+    d = os.path.join(GOLDEN, "synth_a")
+    gafs = []
+    for i in range(3):
+        p = tmp_path / f"rep{i}.gaf"
+        p.write_bytes(open(f"{d}/in.gaf", "rb").read())
+        gafs.append(str(p))
+    out = tmp_path / "out"
+    procs = []
+    for rank in range(2):
+        env = {**os.environ, "RANK": str(rank), "WORLD_SIZE": "2", "LOCAL_RANK": "0"}
+        procs.append(subprocess.Popen([sys.executable, "-m", "pantas_amd.distributed", "replicates", "--out-dir", str(out), "--gtf", f"{d}/in.gtf",
+                                       "--call", "--rca 3 --novel --minintronsize 25", f"{d}/in.gfa", *gafs], cwd=ROOT, env=env,
+                                      stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    exp = json.load(open(f"{d}/expected.json"))
+    gc = [c for c in exp["calls"] if c["flags"] == ["--rca", "3", "--novel", "--minintronsize", "25"]][0]
+    for i in range(3):
+        assert open(out / f"rep{i}.gaf.aug.gfa").read() == open(f"{d}/expected.aug.gfa").read()
+        rows = open(out / f"rep{i}.gaf.events.csv").read().splitlines()
+        assert rows[0] == call_oracle.HEADER
+        mine = collections.Counter(map(call_oracle.normalise_row, rows[1:]))
+        stable = collections.Counter(gc["stable"])
+        assert not (stable - mine) and all(r in set(gc["variants"]) for r in (mine - stable))

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 for e in "$@"; do export "$e"; done
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}/$name -- python3 bench.py --scale $scale --steps 4 --warmup 1 --no-cpu --no-call > gpurun_out/pmc_${tag}/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}/$name -- python3 bench.py --scale $scale --steps 4 --warmup 1 --no-cpu --no-call --no-e2e > gpurun_out/pmc_${tag}/$name.log 2>&1
 }
 mkdir -p gpurun_out/pmc_${tag}
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
