@@ -199,6 +199,8 @@ typedef struct {
   const char* junction;   /* --junction "u-v" or NULL */
   uint32_t shard_rank;    /* multi-GPU: evaluate every shard_world-th junction / novel link, starting at */
   uint32_t shard_world;   /* shard_rank (0 or 1 = everything); rows of all shards together = the full CSV */
+  int32_t debug;          /* --debug: the reference's "Checking ..." lines (call.py:254,317,...,1002) to fd_err */
+  int32_t reserved1_;
 } pantas_call_opts;
 
 typedef struct {

@@ -67,7 +67,7 @@ def run(args) -> int:
         sys.stderr.flush()
         g.call(sys.stdout.fileno(), sys.stderr.fileno(), rca=args.rca, novel=args.novel,
                no_annotated=args.annotated, events=args.events, isw=args.isw,
-               minintronsize=args.minintronsize, junction=args.junction)
+               minintronsize=args.minintronsize, junction=args.junction, debug=args.debug)
         _lap("events written")
     except PantasError as e:
         print(f"{e.kind}: {e}", file=sys.stderr)

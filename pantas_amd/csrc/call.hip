@@ -334,7 +334,7 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
 void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOptions& o, CallOutput& out, CallTimes& times) {
   HIP_OK(hipSetDevice(d.device));
   CallView c = d.view;
-  c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
+  c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events; c.debug = o.debug ? 1u : 0u;
   c.arena = d.arena; c.arena_next = d.arena_next; c.arena_slots = ARENA_SLOTS; c.arena_cap = ARENA_CAP;
   PhaseTimer pt("run_call");
   std::vector<uint32_t> ann, nov, around, around_j;

@@ -42,7 +42,11 @@ enum : uint32_t { EV_ES = 1, EV_SS = 2, EV_IR = 4 };
 // record types (EventRec.type)
 enum : uint32_t {
   T_ES_ANN = 0, T_SS_ANN_A = 1, T_SS_ANN_B = 2, T_IR_ANN = 3, T_ES_NOV = 4, T_SS1_NOV_A = 5, T_SS1_NOV_B = 6,
-  T_SS2_NOV = 7, T_IR1_NOV = 8, T_CE_NOV = 9, T_IR2_NOV = 10, T_SKIP_ES = 11, T_SKIP_SS = 12, T_SKIP_IR = 13
+  T_SS2_NOV = 7, T_IR1_NOV = 8, T_CE_NOV = 9, T_IR2_NOV = 10, T_SKIP_ES = 11, T_SKIP_SS = 12, T_SKIP_IR = 13,
+  // --debug (scripts/call.py:8-12, :1176-1177 turn eprint into print): one record per "Checking ..." line, in the place
+  // of the reference's eprint call; j0 = the junction
+  T_DBG_ANN_J = 14, T_DBG_ANN_ES = 15, T_DBG_ANN_SS = 16, T_DBG_ANN_IR = 17, T_DBG_NOV_J = 18, T_DBG_NOV_ES = 19,
+  T_DBG_NOV_SS1 = 20, T_DBG_NOV_SS2 = 21, T_DBG_NOV_IR1 = 22, T_DBG_NOV_CE = 23, T_DBG_NOV_IR2 = 24
 };
 
 // errors: where the reference raises (or this engine refuses)
@@ -83,6 +87,7 @@ struct CallView {
   const uint32_t* probe_ok;     // [nJ] bit 0: int(u) parses, bit 1: int(v) parses
   int32_t rca, isw, minintron;
   uint32_t events;
+  uint32_t debug;              // --debug: emit the T_DBG_* records
   // overflow space of the intronic search: slices of arena_cap words claimed with a counter
   uint32_t* arena;
   uint32_t* arena_next;
@@ -325,6 +330,8 @@ PANTAS_HD void gene_accumulate(const CallView& c, uint32_t tx, uint32_t& gene, F
   else if (gene != g) gene = GENE_MULTI;
 }
 
+#define PANTAS_DBG(TYPE, SLOT) do { if (c.debug) { emit.begin(TYPE, CNONE, SLOT, CNONE, CNONE); emit.end(0); } } while (0)
+
 // ---- pass 1: annotated junctions (:239-524) ----------------------------------------------------------------
 template <class Emit>
 PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
@@ -335,6 +342,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   const Set genes = jg_of(c, s);
   if (genes.n != 1) return;
   const uint32_t g = genes.p[0];
+  PANTAS_DBG(T_DBG_ANN_J, s);                       // :254
   const bool has_u = same_gene_exons(c, u, g, f);
   if (f.bad()) return;
   const bool has_v = same_gene_exons(c, v, g, f);
@@ -379,6 +387,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   };
 
   if (c.events & EV_ES) {
+    PANTAS_DBG(T_DBG_ANN_ES, s);                    // :317
     for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
       const uint32_t t1 = head_at(hi_);
       const Set x1 = jx_of(c, t1);
@@ -403,6 +412,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   }
 
   if (c.events & EV_SS) {
+    PANTAS_DBG(T_DBG_ANN_SS, s);                    // :378
     if (n_tails) {
       for (uint32_t t = ob; t < oe; ++t) {          // every out-link line of u, duplicates included
         const uint32_t n = c.col[t];
@@ -463,6 +473,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   }
 
   if (c.events & EV_IR) {
+    PANTAS_DBG(T_DBG_ANN_IR, s);                    // :466
     // exons (of gene g) that lie on both ends of the junction: only they can retain the intron.  Testing
     // this first, and per out-neighbour, keeps the out x in neighbour product of :473 off hub nodes.
     bool both_any = false;
@@ -507,6 +518,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
   if (c.rc[s] < c.rca) return;
   const Ex ex0 = ex_of(c, u), ex1 = ex_of(c, v);
   if (ex0.n == 0 && ex1.n == 0) return;
+  PANTAS_DBG(T_DBG_NOV_J, s);                       // :541
   const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
   // cap = transcripts with an exon on both ends
@@ -521,6 +533,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
     for (uint32_t k = 0; k < ex1.n && !cap_any; ++k) cap_any = ex0.tx[i] == ex1.tx[k];
 
   if (c.events & EV_ES) {
+    PANTAS_DBG(T_DBG_NOV_ES, s);                    // :551
     if (ex0.n && ex1.n) {
       uint32_t both = 0;
       for (uint32_t i = 0; i < ex0.n; ++i) both += ex_has(ex1, ex0.tag[i]) ? 1u : 0u;
@@ -550,6 +563,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
   }
 
   if (c.events & EV_SS) {
+    if (cap_any) PANTAS_DBG(T_DBG_NOV_SS1, s);      // :618
     if (cap_any) {
       // side 0: annotated junctions (u, n) into an exon that also covers v; side 1: (p, v) out of an exon covering u
       for (uint32_t side = 0; side < 2; ++side) {
@@ -578,6 +592,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
         }
       }
     }
+    PANTAS_DBG(T_DBG_NOV_SS2, s);                   // :728
     uint32_t j1 = CNONE;
     if (ex0.n && !ex1.n) {
       const uint32_t hit = frontier_search(c, v, u, 0, f);
@@ -597,6 +612,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
   }
 
   if ((c.events & EV_IR) && cap_any) {
+    PANTAS_DBG(T_DBG_NOV_IR1, s);                   // :839
     bool inside_any = false;
     for (uint32_t i = 0; i < ex0.n && !inside_any; ++i) inside_any = ex_has(ex1, ex0.tag[i]);
     if (inside_any) {
@@ -627,6 +643,7 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
   const Set genes = jg_of(c, s);
   if (genes.n != 1) return;
   const uint32_t g = genes.p[0];
+  PANTAS_DBG(T_DBG_ANN_J, s);                       // :911
   const bool has_u = same_gene_exons(c, u, g, f);
   if (f.bad()) return;
   const bool has_v = same_gene_exons(c, v, g, f);
@@ -637,6 +654,14 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
 
   // cassette exons (:954-984) are enumerated by cassette_item, one (junction, novel head link) per thread
+  if (c.debug && (c.events & EV_ES)) {
+    // :957 prints when a novel link leaves u and a novel link enters v (Js1, Js2: sets of (from, to) pairs, so a link
+    // listed twice counts once -- its first slot)
+    bool out_nov = false, in_nov = false;
+    for (uint32_t t = ob; t < oe && !out_nov; ++t) out_nov = c.first_slot[t] == t && t != s && (c.lflags[t] & L_NOVEL);
+    for (uint32_t q = ib; q < ie && !in_nov; ++q) { const uint32_t t = c.islot[q]; in_nov = c.first_slot[t] == t && t != s && (c.lflags[t] & L_NOVEL); }
+    if (out_nov && in_nov) PANTAS_DBG(T_DBG_NOV_CE, s);
+  }
 
   if (c.events & EV_IR) {
     if (!(c.probe_ok[jidx] & 1u)) { f.raise(CE_VALUE_INT); return; }   // int(u) fails
@@ -657,6 +682,7 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
       right |= c.rc[t] >= c.rca;
     }
     if (!right) return;
+    PANTAS_DBG(T_DBG_NOV_IR2, s);                   // :1002
     // exons of gene g that END at u (no out-neighbour carries them) and START at v
     auto ends_at_u = [&](uint32_t i) {
       if (exu.gene[i] != g) return false;

@@ -454,6 +454,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
         k.occ.insert(k.occ.end(), tmp.begin(), tmp.end());
       }
     });
+    pt.lap("intern EX: per-chunk maps (parallel)");
     // merge in chunk order = first-appearance order over the whole file
     std::unordered_map<std::string_view, uint32_t> ex_ids;
     {
@@ -477,6 +478,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       total += k.occ.size();
       std::unordered_map<std::string_view, uint32_t>().swap(k.ids);
     }
+    pt.lap("intern EX: merge of distinct tags (one thread)");
     if (total >= uint64_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 EX tag entries");
     // counts -> offsets (per chunk: its nodes' entries are contiguous behind out_base)
     parallel_chunks(C, C, [&](unsigned, size_t cb, size_t ce) {
@@ -510,7 +512,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     });
   }
 
-  pt.lap("intern EX (parallel scan, merge of distinct tags)");
+  pt.lap("intern EX: per-node lists (parallel)");
   // JN tags: only junction links carry them (5e5 of 2.6e8 slots): the tags are interned in slot order by one thread, the
   // four per-slot offset arrays -- constant between two junction slots -- are filled by all of them
   std::unordered_map<std::string_view, uint32_t> jn_ids;
@@ -524,6 +526,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     });
     for (auto& v : part) jslot.insert(jslot.end(), v.begin(), v.end());
   }
+  pt.lap("intern JN: junction slots (parallel)");
   const size_t NJ = jslot.size();
   std::vector<uint32_t>& o_jn = t.jn_ptr; std::vector<uint32_t>& o_jt = t.jt_ptr;
   std::vector<uint32_t>& o_jx = t.jx_ptr; std::vector<uint32_t>& o_jg = t.jg_ptr;
@@ -563,10 +566,11 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   o_jt[NJ] = uint32_t(t.jt.size());
   o_jx[NJ] = uint32_t(t.jx.size());
   o_jg[NJ] = uint32_t(t.jg.size());
+  pt.lap("intern JN: tags of the junctions (one thread)");
   par_assign(t.jrow, A, uint32_t(CNONE), threads);
   for (size_t j = 0; j < NJ; ++j) t.jrow[jslot[j]] = uint32_t(j);
 
-  pt.lap("intern JN (junction slots only, parallel fill)");
+  pt.lap("intern JN: slot -> junction map");
   // ---- lexicographic rank of segment names ------------------------------------------------------------
   t.rank.resize(V);
   bool fixed_width = g.names.dense && V > 0;
@@ -652,7 +656,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.jg_ptr = t.jg_ptr.data(); c.jg = t.jg.data();
   c.tx_gene = t.tx_gene.data();
   c.probe = t.probe.data(); c.probe_ok = t.probe_ok.data();
-  c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events;
+  c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events; c.debug = o.debug ? 1u : 0u;
   c.arena = nullptr; c.arena_next = nullptr; c.arena_slots = 0; c.arena_cap = 0;
   return c;
 }
@@ -931,6 +935,21 @@ static void render_range(const Graph& g, const CallTables& t, const EventRec* re
       case T_SKIP_ES: err += "Skipping ES due to multiple genes\n"; continue;
       case T_SKIP_SS: err += "Skipping SS due to multiple genes\n"; continue;
       case T_SKIP_IR: err += "Skipping novel IR due to multiple genes\n"; continue;
+      case T_DBG_ANN_J: case T_DBG_NOV_J: {
+        err += r.type == T_DBG_ANN_J ? "Checking annotated junction " : "Checking novel junction ";
+        Span a = g.name_of(t.src[r.j0]), b = g.name_of(t.col[r.j0]);
+        err.append(a.b, a.size()); err += " -> "; err.append(b.b, b.size()); err.push_back('\n');
+        continue;
+      }
+      case T_DBG_ANN_ES: err += "Checking annotated ES\n"; continue;
+      case T_DBG_ANN_SS: err += "Checking annotated SS\n"; continue;
+      case T_DBG_ANN_IR: err += "Checking annotated IR\n"; continue;
+      case T_DBG_NOV_ES: err += "Checking novel ES\n"; continue;
+      case T_DBG_NOV_SS1: err += "Checking novel SS (1)\n"; continue;
+      case T_DBG_NOV_SS2: err += "Checking novel SS (2)\n"; continue;
+      case T_DBG_NOV_IR1: err += "Checking novel IR (1)\n"; continue;
+      case T_DBG_NOV_CE: err += "Checking novel CE\n"; continue;
+      case T_DBG_NOV_IR2: err += "Checking novel IR (2)\n"; continue;
       default: throw Error("InternalError", "unknown event record type");
     }
     o.push_back('\n');

@@ -15,6 +15,7 @@ struct CallOptions {
   uint32_t events = EV_ES | EV_SS | EV_IR;   // --events
   bool novel = false;          // --novel
   bool no_annotated = false;   // --no-annotated
+  bool debug = false;          // --debug: the reference's "Checking ..." lines on stderr
   bool has_junction = false;   // --junction given
   std::string junction;        // "u-v"
   uint32_t shard_rank = 0, shard_world = 1;   // multi-GPU: this process evaluates every world-th junction / novel link

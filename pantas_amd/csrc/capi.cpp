@@ -802,6 +802,7 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     o.events = opts->events;
     o.novel = opts->novel != 0;
     o.no_annotated = opts->no_annotated != 0;
+    o.debug = opts->debug != 0;
     if (opts->junction) { o.has_junction = true; o.junction = opts->junction; }
     if (opts->shard_world > 1) {
       need(opts->shard_rank < opts->shard_world, "shard_rank out of range");

@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
   try {
     for (int i = 1; i < argc; ++i) {
       std::string a = argv[i];
-      if (a == "--rca") o.rca = atoi(argv[++i]);
+      if (a == "--debug") o.debug = true;
+      else if (a == "--rca") o.rca = atoi(argv[++i]);
       else if (a == "--isw") o.isw = atoi(argv[++i]);
       else if (a == "--minintronsize") o.minintron = atoi(argv[++i]);
       else if (a == "--novel") o.novel = true;

@@ -121,3 +121,41 @@ def test_engine_on_edge_inputs(c):
     else:
         got, _ = run()
         check_call_rows(got.splitlines()[1:], json.load(open(f"{EDGE}/{n}.expected")))
+
+
+DEBUG = json.load(open(os.path.join(EDGE, "debug_lines.json")))
+DEBUG_CASES = [(case, i) for case, sets in DEBUG.items() for i in range(len(sets))]
+
+
+@pytest.mark.parametrize("case,i", DEBUG_CASES)
+def test_device_sources_debug_lines(case, i):
+    """--debug: the reference's "Checking ..." / "Skipping ..." stderr lines (scripts/call.py:254 ... :1002) as a
+    multiset -- the reference visits junctions in the order of a Python set -- and rows unchanged by the option."""
+    from test_hostsim import BUILD
+    exe = os.path.join(BUILD, "hostsim_call")
+    if not os.path.exists(exe):
+        pytest.skip("hostsim not built (tests/test_hostsim.py builds it)")
+    d = os.path.join(GOLDEN, case)
+    want = DEBUG[case][i]
+    r = subprocess.run([exe, "--debug", *want["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = sorted(l for l in r.stderr.splitlines() if l.startswith(("Checking", "Skipping")))
+    assert got == want["stderr_sorted"]
+    plain = subprocess.run([exe, *want["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf"], capture_output=True, text=True)
+    assert plain.stdout == r.stdout and "Checking" not in plain.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,i", DEBUG_CASES)
+def test_engine_debug_lines(case, i):
+    import sys
+    d = os.path.join(GOLDEN, case)
+    want = DEBUG[case][i]
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.call", "--debug", *want["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    got = sorted(l for l in r.stderr.splitlines() if l.startswith(("Checking", "Skipping")))
+    assert got == want["stderr_sorted"]
+    plain = subprocess.run([sys.executable, "-m", "pantas_amd.call", *want["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf"],
+                           capture_output=True, text=True, cwd=ROOT)
+    assert plain.stdout == r.stdout and "Checking" not in plain.stderr

@@ -130,6 +130,22 @@ def main():
         meta.append(rec)
         print(f"{n}: rc {r.returncode} {rec['exception'] or ''}")
     json.dump(meta, open(f"{d}/cases.json", "w"), indent=1)
+    # ---- --debug: the "Checking ..." lines (scripts/call.py:254 ... :1002) as a sorted multiset (the order in which the
+    # reference visits junctions is that of a Python set), per golden case and flag set
+    dbg = {}
+    gold = os.path.join(ROOT, "tests", "golden")
+    for case, flag_sets in (("micro", [["--rca", "0", "--novel"], []]),
+                            ("synth_a", [["--rca", "3", "--novel", "--minintronsize", "25"], ["--events", "ES", "IR", "--rca", "1", "--novel", "--minintronsize", "1"]]),
+                            ("synth_b", [["--events", "SS", "--novel", "--isw", "8"], ["--rca", "5"]])):
+        for flags in flag_sets:
+            r = mg.run_ref(a.ref, "call.py", ["--debug", *flags, f"{gold}/{case}/expected.aug.gfa", f"{gold}/{case}/in.gtf"], seed=0)
+            assert r.returncode == 0, r.stderr
+            # with --debug the reference prints the lines with print(..., file=sys.stderr): all on stderr, between the
+            # two timestamped "Parsing" lines and the rows on stdout
+            lines = [l for l in r.stderr.splitlines() if l.startswith(("Checking", "Skipping"))]
+            dbg.setdefault(case, []).append({"flags": flags, "stderr_sorted": sorted(lines)})
+            print(f"debug {case} {' '.join(flags)}: {len(lines)} lines")
+    json.dump(dbg, open(f"{d}/debug_lines.json", "w"), indent=0)
 
 
 if __name__ == "__main__":
