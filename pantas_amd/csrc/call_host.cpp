@@ -225,7 +225,8 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   if (g.dup_names) throw Error("Unsupported", "duplicate S lines for one segment name (call)");
   const uint32_t V = g.V;
   // ---- link layout -------------------------------------------------------------------------------
-  std::vector<uint32_t> old_slot;   // fused: slot of the graph behind each slot of the layout (NONE32 = added link)
+  RawVector<uint32_t> old_slot;     // fused: slot of the graph behind each slot of the layout (NONE32 = added link)
+  std::vector<uint32_t> slot_of_added;   // fused: slot of the i-th added link (first-seen order) in the layout
   if (!aug || aug->novel.empty()) {
     t.A = g.A;
     t.row_ptr = g.row_ptr.data(); t.col = g.col.data();
@@ -235,44 +236,77 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     const size_t extra = aug->novel.size();
     const size_t An = g.A + extra;
     if (An >= NONE32) throw Error("Unsupported", "more than 2^32-2 links");
-    t.x_row_ptr.assign(size_t(V) + 1, 0);
-    t.x_irow_ptr.assign(size_t(V) + 1, 0);
-    for (uint32_t u = 0; u < V; ++u) {
-      t.x_row_ptr[u + 1] = g.row_ptr[u + 1] - g.row_ptr[u];
-      t.x_irow_ptr[u + 1] = g.irow_ptr[u + 1] - g.irow_ptr[u];
-    }
-    for (const NovelLink& nl : aug->novel) { ++t.x_row_ptr[nl.u + 1]; ++t.x_irow_ptr[nl.v + 1]; }
-    for (uint32_t u = 0; u < V; ++u) { t.x_row_ptr[u + 1] += t.x_row_ptr[u]; t.x_irow_ptr[u + 1] += t.x_irow_ptr[u]; }
+    // The layout = the graph's rows with the links the reads added appended to their rows, in the first-seen order the
+    // writer would print them in.  They are few (1.5e6 on 2.6e8 slots): row u moves up by the number of added links with a
+    // smaller source, found in a sorted copy of their sources; everything per node / per slot is done by all threads.
+    std::vector<uint32_t> by_u(extra), by_v(extra);
+    for (size_t i = 0; i < extra; ++i) by_u[i] = by_v[i] = uint32_t(i);
+    std::stable_sort(by_u.begin(), by_u.end(), [&](uint32_t a, uint32_t b2) { return aug->novel[a].u < aug->novel[b2].u; });
+    std::stable_sort(by_v.begin(), by_v.end(), [&](uint32_t a, uint32_t b2) { return aug->novel[a].v < aug->novel[b2].v; });
+    std::vector<uint32_t> src_sorted(extra), dst_sorted(extra);
+    for (size_t i = 0; i < extra; ++i) { src_sorted[i] = aug->novel[by_u[i]].u; dst_sorted[i] = aug->novel[by_v[i]].v; }
+    t.x_row_ptr.resize(size_t(V) + 1);
+    t.x_irow_ptr.resize(size_t(V) + 1);
     t.x_col.resize(An); t.x_order.resize(An); t.x_icol.resize(An); t.x_islot.resize(An);
-    old_slot.assign(An, NONE32);
-    std::vector<uint32_t> new_of_old(g.A);
-    std::vector<uint32_t> cur(V), icur(V);
-    for (uint32_t u = 0; u < V; ++u) {
-      uint32_t w = t.x_row_ptr[u];
-      for (uint32_t s = g.row_ptr[u]; s < g.row_ptr[u + 1]; ++s, ++w) {
-        t.x_col[w] = g.col[s];
-        t.x_order[w] = g.slot_off[s];
-        old_slot[w] = s;
-        new_of_old[s] = w;
+    old_slot.resize(An);
+    RawVector<uint32_t> new_of_old(g.A);
+    parallel_chunks(size_t(V) + 1, V < 4096 ? 1 : threads, [&](unsigned, size_t ub, size_t ue) {
+      size_t ku = size_t(std::lower_bound(src_sorted.begin(), src_sorted.end(), uint32_t(ub)) - src_sorted.begin());
+      size_t kv = size_t(std::lower_bound(dst_sorted.begin(), dst_sorted.end(), uint32_t(ub)) - dst_sorted.begin());
+      for (size_t u = ub; u < ue; ++u) {
+        while (ku < extra && src_sorted[ku] < u) ++ku;          // added links with a source below u
+        while (kv < extra && dst_sorted[kv] < u) ++kv;
+        t.x_row_ptr[u] = g.row_ptr[u] + uint32_t(ku);
+        t.x_irow_ptr[u] = g.irow_ptr[u] + uint32_t(kv);
       }
-      cur[u] = w;
-    }
-    for (uint32_t v = 0; v < V; ++v) {
-      uint32_t w = t.x_irow_ptr[v];
-      for (uint32_t q = g.irow_ptr[v]; q < g.irow_ptr[v + 1]; ++q, ++w) {
-        t.x_icol[w] = g.icol[q];
-        t.x_islot[w] = new_of_old[g.islot[q]];
+    });
+    parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t ub, size_t ue) {
+      for (size_t u = ub; u < ue; ++u) {
+        uint32_t w = t.x_row_ptr[u];
+        for (uint32_t s2 = g.row_ptr[u]; s2 < g.row_ptr[u + 1]; ++s2, ++w) {
+          t.x_col[w] = g.col[s2];
+          t.x_order[w] = g.slot_off[s2];
+          old_slot[w] = s2;
+          new_of_old[s2] = w;
+        }
       }
-      icur[v] = w;
+    });
+    // the added links behind the old ones of their row, in first-seen order (by_u is a stable sort of that order)
+    for (size_t k = 0; k < extra;) {
+      const uint32_t u = src_sorted[k];
+      uint32_t w = t.x_row_ptr[u] + (g.row_ptr[u + 1] - g.row_ptr[u]);
+      for (; k < extra && src_sorted[k] == u; ++k, ++w) {
+        const NovelLink& nl = aug->novel[by_u[k]];
+        t.x_col[w] = nl.v;
+        t.x_order[w] = uint64_t(g.text.size) + by_u[k];
+        old_slot[w] = NONE32;
+      }
     }
-    for (size_t i = 0; i < extra; ++i) {          // aug->novel is in first-seen order = file order of the appended lines
-      const NovelLink& nl = aug->novel[i];
-      const uint32_t w = cur[nl.u]++;
-      t.x_col[w] = nl.v;
-      t.x_order[w] = uint64_t(g.text.size) + i;
-      const uint32_t q = icur[nl.v]++;
-      t.x_icol[q] = nl.u;
-      t.x_islot[q] = w;
+    parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t vb, size_t ve) {
+      for (size_t v = vb; v < ve; ++v) {
+        uint32_t w = t.x_irow_ptr[v];
+        for (uint32_t q = g.irow_ptr[v]; q < g.irow_ptr[v + 1]; ++q, ++w) {
+          t.x_icol[w] = g.icol[q];
+          t.x_islot[w] = new_of_old[g.islot[q]];
+        }
+      }
+    });
+    {
+      // slot of added link i in the out layout: its row's old links, then its rank among the row's added links
+      slot_of_added.resize(extra);
+      for (size_t k = 0; k < extra;) {
+        const uint32_t u = src_sorted[k];
+        uint32_t w = t.x_row_ptr[u] + (g.row_ptr[u + 1] - g.row_ptr[u]);
+        for (; k < extra && src_sorted[k] == u; ++k, ++w) slot_of_added[by_u[k]] = w;
+      }
+      for (size_t k = 0; k < extra;) {
+        const uint32_t v = dst_sorted[k];
+        uint32_t q = t.x_irow_ptr[v] + (g.irow_ptr[v + 1] - g.irow_ptr[v]);
+        for (; k < extra && dst_sorted[k] == v; ++k, ++q) {
+          t.x_icol[q] = aug->novel[by_v[k]].u;
+          t.x_islot[q] = slot_of_added[by_v[k]];
+        }
+      }
     }
     t.A = An;
     t.row_ptr = t.x_row_ptr.data(); t.col = t.x_col.data();
@@ -356,10 +390,9 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   });
   if (aug && !old_slot.empty()) {
     // "L u + v + * RC:i:n ID:Z:N" lines the augment writer appends
-    std::vector<uint32_t> cur(V);
-    for (uint32_t u = 0; u < V; ++u) cur[u] = t.row_ptr[u] + (g.row_ptr[u + 1] - g.row_ptr[u]);
-    for (const NovelLink& nl : aug->novel) {
-      LinkAttr& a = la[cur[nl.u]++];
+    for (size_t i = 0; i < aug->novel.size(); ++i) {
+      const NovelLink& nl = aug->novel[i];
+      LinkAttr& a = la[slot_of_added[i]];
       if (nl.count > uint32_t(INT32_MAX)) throw Error("Unsupported", "link coverage beyond 2^31");
       a.rc = int32_t(nl.count);
       a.has_rc = true;

@@ -34,8 +34,8 @@ struct CallTables {
   const uint32_t* icol = nullptr;
   const uint32_t* islot = nullptr;
   const uint64_t* order = nullptr;           // file-order key of a slot (byte offset; novel links after the text)
-  std::vector<uint32_t> x_row_ptr, x_col, x_irow_ptr, x_icol, x_islot;
-  std::vector<uint64_t> x_order;
+  RawVector<uint32_t> x_row_ptr, x_col, x_irow_ptr, x_icol, x_islot;
+  RawVector<uint64_t> x_order;
   // ---- mirrored to the device -----------------------------------------------------------
   // (RawVector: [V] / [A] arrays, gigabytes at whole-genome scale -- huge pages, filled by many threads)
   RawVector<uint32_t> first_slot, src, lflags;
