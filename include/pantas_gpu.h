@@ -39,6 +39,9 @@ const char* pantas_last_error(void);
 const char* pantas_last_error_kind(void);
 const char* pantas_version(void);
 int pantas_device_count(void);
+/* optional: starts the HIP runtime and the context of `device` on a thread of its own and returns at once -- the second it takes
+ * on a cold process then runs beside the parsing of the GFA (the command lines call it first thing) */
+void pantas_device_warmup(int device);
 
 /* Structs cross this boundary by pointer and have grown between releases.  Every struct below therefore starts with
  * struct_size, which the CALLER sets to the sizeof() of the struct it was compiled (or, for a ctypes binding, declared)

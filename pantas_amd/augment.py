@@ -28,6 +28,8 @@ def main(argv) -> int:
     print("Read GFA", file=sys.stderr)
     try:
         _lap("imports done")
+        from ._lib import lib
+        lib.pantas_device_warmup(device)       # HIP runtime start-up beside the GFA parse
         g = Graph(gfa_file, cache=graph_cache_path(gfa_file))   # PANTAS_GRAPH_CACHE: the graph is shared by all replicates
         _lap("graph loaded")
         g.to_device(device)

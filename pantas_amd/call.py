@@ -58,6 +58,8 @@ def run(args) -> int:
     try:
         _stamp("Parsing GFA..")
         _lap("imports done")
+        from ._lib import lib
+        lib.pantas_device_warmup(device)       # HIP runtime start-up beside the GFA parse
         g = Graph(args.GFA)
         _lap("graph loaded")
         _stamp("Parsing GTF..")

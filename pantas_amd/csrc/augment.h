@@ -54,6 +54,9 @@ using DeviceGraphPtr = std::unique_ptr<DeviceGraph, DeviceGraphDeleter>;
 using DeviceBatchPtr = std::unique_ptr<DeviceBatch, DeviceBatchDeleter>;
 
 int device_count();                                   // 0 when no HIP device is usable
+// Starts the HIP runtime and the context of `device` on a thread of its own (about a second on a cold process) so that it
+// runs beside the parsing of the GFA instead of in front of the first upload.  Harmless without a device.
+void warm_up_device(int device);
 DeviceGraphPtr upload_graph(const Graph& g, int device);
 void reset_counters(DeviceGraph& dg);                 // zero NC/RC/IL/OL, clear flags and tables
 DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);

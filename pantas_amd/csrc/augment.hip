@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <thread>
 
 #include "augment.h"
 #include "device_batch.h"
@@ -789,6 +790,15 @@ void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     used[k] = true;
   }
   HIP_OK(hipStreamSynchronize(stream));
+}
+
+void warm_up_device(int device) {
+  std::thread([device] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return;
+    if (hipSetDevice(device) != hipSuccess) return;
+    (void)hipFree(nullptr);          // forces the context
+  }).detach();
 }
 
 int device_count() {

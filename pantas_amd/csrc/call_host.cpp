@@ -147,51 +147,84 @@ bool find_attr(Span s, const char* key, Span& out) {
   return false;
 }
 
-void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t) {
-  const char* p = f.data;
-  const char* end = f.data + f.size;
-  uint64_t lineno = 0;
+// :188-216.  The lines are split and matched by all threads (a whole-genome annotation is 180 MB: 1 s on one); the rows that
+// matter -- one per transcript -- are applied in file order by one, and the first line the reference would die on (in FILE
+// order, whatever chunk found it) is the error.
+void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t, unsigned threads = 0) {
+  struct Row { Span gid, tid, strand, chrom; };
+  struct Chunk { std::vector<Row> rows; uint64_t lines = 0; std::unique_ptr<Error> err; uint64_t err_line = 0; size_t rows_before_err = 0; };
+  if (threads == 0) threads = hw_threads();
+  const unsigned C = f.size < (size_t(4) << 20) ? 1u : threads;
+  const auto ranges = split_at_newlines(f.data, f.size, C);
+  std::vector<Chunk> ck(ranges.size());
   static const char* feats[] = {"mRNA", "transcript", "miRNA", "ncRNA", "pre_miRNA", "snoRNA", "pseudogene"};
-  while (p < end) {
-    const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
-    const char* le = nl ? nl : end;
-    ++lineno;
-    Span line{p, le};
-    p = nl ? nl + 1 : end;
-    if (lone_cr(line.b, line.e))
-      throw Error("Unsupported", "GTF line " + std::to_string(lineno) + ": lone carriage return (Python's universal newlines end a line there; this engine splits at \\n only)");
-    if (line.size() && *line.b == '#') continue;
-    // split on '\t' only (:194)
-    std::vector<Span> col;
-    const char* a = line.b;
-    for (;;) {
-      const char* tb = static_cast<const char*>(memchr(a, '\t', size_t(line.e - a)));
-      if (!tb) { col.push_back(Span{a, line.e}); break; }
-      col.push_back(Span{a, tb});
-      a = tb + 1;
+  parallel_chunks(ranges.size(), unsigned(ranges.size()), [&](unsigned, size_t cb, size_t ce) {
+    for (size_t c = cb; c < ce; ++c) {
+      Chunk& k = ck[c];
+      const char* p = f.data + ranges[c].first;
+      const char* end = f.data + ranges[c].second;
+      auto fail = [&](const char* kind, const std::string& what) {
+        k.err.reset(new Error(kind, what));
+        k.err_line = k.lines;
+        k.rows_before_err = k.rows.size();
+      };
+      std::vector<Span> col;
+      while (p < end && !k.err) {
+        const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
+        const char* le = nl ? nl : end;
+        ++k.lines;
+        Span line{p, le};
+        p = nl ? nl + 1 : end;
+        if (lone_cr(line.b, line.e)) { fail("Unsupported", ": lone carriage return (Python's universal newlines end a line there; this engine splits at \\n only)"); break; }
+        if (line.size() && *line.b == '#') continue;
+        // split on '\t' only (:194)
+        col.clear();
+        const char* a = line.b;
+        for (;;) {
+          const char* tb = static_cast<const char*>(memchr(a, '\t', size_t(line.e - a)));
+          if (!tb) { col.push_back(Span{a, line.e}); break; }
+          col.push_back(Span{a, tb});
+          a = tb + 1;
+        }
+        if (col.size() < 3) { fail("IndexError", ": fewer than 3 columns"); break; }
+        bool want = false;
+        for (const char* ft : feats) want |= col[2].sv() == ft;
+        if (!want) continue;
+        Span gid, tid;
+        if (!find_attr(col.back(), "gene_id", gid) || !find_attr(col.back(), "transcript_id", tid)) {
+          fail("AttributeError", ": 'NoneType' object has no attribute 'group' (gene_id/transcript_id \"[A-Za-z0-9_]+\";)");
+          break;
+        }
+        if (col.size() < 7) { fail("IndexError", ": fewer than 7 columns"); break; }
+        k.rows.push_back(Row{gid, tid, col[6], col[0]});
+      }
     }
-    if (col.size() < 3) throw Error("IndexError", "GTF line " + std::to_string(lineno) + ": fewer than 3 columns");
-    bool want = false;
-    for (const char* ft : feats) want |= col[2].sv() == ft;
-    if (!want) continue;
-    Span gid, tid;
-    if (!find_attr(col.back(), "gene_id", gid) || !find_attr(col.back(), "transcript_id", tid))
-      throw Error("AttributeError", "GTF line " + std::to_string(lineno) +
-                                        ": 'NoneType' object has no attribute 'group' (gene_id/transcript_id \"[A-Za-z0-9_]+\";)");
-    if (col.size() < 7) throw Error("IndexError", "GTF line " + std::to_string(lineno) + ": fewer than 7 columns");
-    std::string g(gid.b, gid.size());
-    auto it = gtf.gene_id.find(g);
-    uint32_t id;
-    if (it == gtf.gene_id.end()) {
-      id = uint32_t(t.gene_name.size());
-      gtf.gene_id.emplace(g, id);
-      t.gene_name.push_back(g);
-      t.gene_strand.emplace_back();
-      t.gene_chrom.emplace_back();
-    } else id = it->second;
-    t.gene_strand[id].assign(col[6].b, col[6].size());
-    t.gene_chrom[id].assign(col[0].b, col[0].size());
-    gtf.tx_gene[std::string(tid.b, tid.size())] = id;
+  });
+  uint64_t lines_before = 0;
+  for (Chunk& k : ck) {
+    const size_t n = k.err ? k.rows_before_err : k.rows.size();
+    for (size_t i = 0; i < n; ++i) {
+      const Row& r = k.rows[i];
+      std::string g(r.gid.b, r.gid.size());
+      auto it = gtf.gene_id.find(g);
+      uint32_t id;
+      if (it == gtf.gene_id.end()) {
+        id = uint32_t(t.gene_name.size());
+        gtf.gene_id.emplace(g, id);
+        t.gene_name.push_back(g);
+        t.gene_strand.emplace_back();
+        t.gene_chrom.emplace_back();
+      } else id = it->second;
+      t.gene_strand[id].assign(r.strand.b, r.strand.size());
+      t.gene_chrom[id].assign(r.chrom.b, r.chrom.size());
+      gtf.tx_gene[std::string(r.tid.b, r.tid.size())] = id;
+    }
+    if (k.err) {
+      const std::string msg = k.err->what();      // "Kind: <suffix>"
+      const size_t colon = msg.find(": ");
+      throw Error(k.err->kind, "GTF line " + std::to_string(lines_before + k.err_line) + (colon == std::string::npos ? msg : msg.substr(colon + 2)));
+    }
+    lines_before += k.lines;
   }
 }
 
@@ -629,10 +662,20 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
 
   pt.lap("name ranks");
   // ---- junction / novel lists in file order; IR-2 probes -----------------------------------------------
-  for (size_t s = 0; s < A; ++s) {
-    if (t.first_slot[s] != s) continue;
-    if (t.lflags[s] & L_JUNC) t.junctions.push_back(uint32_t(s));
-    if (t.lflags[s] & L_NOVEL) t.novels.push_back(uint32_t(s));
+  {
+    const unsigned C = A < 65536 ? 1u : threads;
+    std::vector<std::vector<uint32_t>> pj(C), pn(C);
+    parallel_chunks(A, C, [&](unsigned c, size_t sb, size_t se) {
+      for (size_t s2 = sb; s2 < se; ++s2) {
+        if (t.first_slot[s2] != s2) continue;
+        if (t.lflags[s2] & L_JUNC) pj[c].push_back(uint32_t(s2));
+        if (t.lflags[s2] & L_NOVEL) pn[c].push_back(uint32_t(s2));
+      }
+    });
+    for (unsigned c = 0; c < C; ++c) {
+      t.junctions.insert(t.junctions.end(), pj[c].begin(), pj[c].end());
+      t.novels.insert(t.novels.end(), pn[c].begin(), pn[c].end());
+    }
   }
   auto by_off = [&](uint32_t a, uint32_t b) { return t.order[a] < t.order[b]; };
   std::sort(t.junctions.begin(), t.junctions.end(), by_off);
@@ -643,28 +686,30 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s) if (t.col[s] == v) return s;
     return CNONE;
   };
-  for (size_t j = 0; j < t.junctions.size(); ++j) {
-    const uint32_t s = t.junctions[j];
-    const uint32_t u = t.src[s], v = t.col[s];
-    int64_t iu, iv;
-    char buf[32];
-    if (parse_py_int(g.name_of(u), iu)) {
-      t.probe_ok[j] |= 1u;
-      for (int d = 1; d <= 3; ++d) {
-        int n = snprintf(buf, sizeof buf, "%lld", (long long)(iu + d));
-        uint32_t x = g.names.find(Span{buf, buf + n});
-        if (x != CNONE) t.probe[j * 6 + size_t(d - 1)] = pair_slot(u, x);
+  parallel_chunks(t.junctions.size(), t.junctions.size() < 4096 ? 1 : threads, [&](unsigned, size_t jb, size_t je) {
+    for (size_t j = jb; j < je; ++j) {
+      const uint32_t s = t.junctions[j];
+      const uint32_t u = t.src[s], v = t.col[s];
+      int64_t iu, iv;
+      char buf[32];
+      if (parse_py_int(g.name_of(u), iu)) {
+        t.probe_ok[j] |= 1u;
+        for (int d = 1; d <= 3; ++d) {
+          int n = snprintf(buf, sizeof buf, "%lld", (long long)(iu + d));
+          uint32_t x = g.names.find(Span{buf, buf + n});
+          if (x != CNONE) t.probe[j * 6 + size_t(d - 1)] = pair_slot(u, x);
+        }
+      }
+      if (parse_py_int(g.name_of(v), iv)) {
+        t.probe_ok[j] |= 2u;
+        for (int d = 3; d >= 1; --d) {
+          int n = snprintf(buf, sizeof buf, "%lld", (long long)(iv - d));
+          uint32_t x = g.names.find(Span{buf, buf + n});
+          if (x != CNONE) t.probe[j * 6 + 3 + size_t(3 - d)] = pair_slot(x, v);
+        }
       }
     }
-    if (parse_py_int(g.name_of(v), iv)) {
-      t.probe_ok[j] |= 2u;
-      for (int d = 3; d >= 1; --d) {
-        int n = snprintf(buf, sizeof buf, "%lld", (long long)(iv - d));
-        uint32_t x = g.names.find(Span{buf, buf + n});
-        if (x != CNONE) t.probe[j * 6 + 3 + size_t(3 - d)] = pair_slot(x, v);
-      }
-    }
-  }
+  });
   pt.lap("lists + probes");
   t.parse_s = now_s() - t0;
   if (size_t(V) + A > (size_t(1) << 24)) {

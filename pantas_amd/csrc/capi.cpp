@@ -144,6 +144,7 @@ __attribute__((visibility("default"))) const char* pantas_last_error_kind(void) 
 __attribute__((visibility("default"))) const char* pantas_version(void) { return "pantas-mi355x 0.1 (gfx950)"; }
 __attribute__((visibility("default"))) int pantas_device_count(void) { return device_count(); }
 __attribute__((visibility("default"))) int pantas_abi_version(void) { return PANTAS_ABI_VERSION; }
+__attribute__((visibility("default"))) void pantas_device_warmup(int device) { try { warm_up_device(device); } catch (...) {} }
 
 __attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_path, pantas_graph** out) {
   return guarded([&] {
