@@ -45,6 +45,10 @@ const char* call_error_text(uint32_t code) {
 
 namespace {
 
+// sizes below which a step stays on one thread; PANTAS_TEST_SMALL_PARALLEL=1 (tests) makes every step take its parallel path
+// on the small inputs the test-suite has
+inline size_t par_min(size_t n) { static const bool small = getenv("PANTAS_TEST_SMALL_PARALLEL") != nullptr; return small ? 16 : n; }
+
 // (trivial on purpose: arrays of 2.5e8 of them are sized without a constructor pass and every element is set by the tag scan)
 struct SegAttr { uint64_t ex_off; uint32_t ex_len; bool has_ex; };
 struct LinkAttr { uint64_t jn_off; uint32_t jn_len; bool has_jn, has_id, has_rc; int32_t rc; };
@@ -154,7 +158,7 @@ void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t, unsigned threads = 
   struct Row { Span gid, tid, strand, chrom; };
   struct Chunk { std::vector<Row> rows; uint64_t lines = 0; std::unique_ptr<Error> err; uint64_t err_line = 0; size_t rows_before_err = 0; };
   if (threads == 0) threads = hw_threads();
-  const unsigned C = f.size < (size_t(4) << 20) ? 1u : threads;
+  const unsigned C = f.size < par_min(size_t(4) << 20) ? 1u : threads;
   const auto ranges = split_at_newlines(f.data, f.size, C);
   std::vector<Chunk> ck(ranges.size());
   static const char* feats[] = {"mRNA", "transcript", "miRNA", "ncRNA", "pre_miRNA", "snoRNA", "pseudogene"};
@@ -226,6 +230,89 @@ void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t, unsigned threads = 
     }
     lines_before += k.lines;
   }
+}
+
+// Strings interned per thread -> ids in order of FIRST APPEARANCE over all of them.  Every chunk lists its distinct strings
+// in the order it met them; chunks are in file order.  One pass per distinct string on one thread was 1.3 s for the 4e6 EX
+// tags of a whole-genome graph; here the strings are dealt to shards by hash, every shard (one thread each) walks the
+// chunks in order and keeps the first place it saw each of its strings, the places are sorted, and the rank is the id.
+struct InternChunk {
+  std::vector<StrRef> span;          // local id -> text (offsets into `base`), in local first-appearance order
+  std::vector<uint32_t> to_global;   // filled by merge_interned
+};
+std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& ck, unsigned threads) {
+  const size_t C = ck.size();
+  size_t total_local = 0;
+  for (const InternChunk& k : ck) total_local += k.span.size();
+  const unsigned S = total_local < par_min(size_t(1) << 16) ? 1u : std::max(1u, threads);
+  auto sv_of = [&](const StrRef& r) { return std::string_view(base + r.off, r.len); };
+  std::vector<std::vector<uint64_t>> hash(C);
+  parallel_chunks(C, unsigned(std::min<size_t>(C, threads ? threads : 1)), [&](unsigned, size_t cb, size_t ce) {
+    for (size_t c = cb; c < ce; ++c) {
+      hash[c].resize(ck[c].span.size());
+      for (size_t i = 0; i < ck[c].span.size(); ++i) hash[c][i] = std::hash<std::string_view>{}(sv_of(ck[c].span[i]));
+    }
+  });
+  struct Entry { StrRef span; uint64_t place; uint32_t id; };
+  std::vector<std::unordered_map<std::string_view, uint32_t>> maps(S);
+  std::vector<std::vector<Entry>> entries(S);
+  parallel_chunks(S, S, [&](unsigned, size_t sb, size_t se) {
+    for (size_t sh = sb; sh < se; ++sh) {
+      auto& m = maps[sh];
+      auto& ev = entries[sh];
+      for (size_t c = 0; c < C; ++c)
+        for (size_t i = 0; i < ck[c].span.size(); ++i) {
+          if (hash[c][i] % S != sh) continue;
+          auto ins = m.emplace(sv_of(ck[c].span[i]), uint32_t(ev.size()));
+          if (ins.second) ev.push_back(Entry{ck[c].span[i], (uint64_t(c) << 32) | uint64_t(i), 0u});
+        }
+    }
+  });
+  // distinct strings by the place they were first seen
+  std::vector<size_t> ebase(S + 1, 0);
+  for (unsigned sh = 0; sh < S; ++sh) ebase[sh + 1] = ebase[sh] + entries[sh].size();
+  const size_t D = ebase[S];
+  if (D >= size_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 distinct tags");
+  std::vector<std::pair<uint64_t, uint32_t>> order(D);      // (place, shard-major index)
+  parallel_chunks(S, S, [&](unsigned, size_t sb, size_t se) {
+    for (size_t sh = sb; sh < se; ++sh)
+      for (size_t k = 0; k < entries[sh].size(); ++k) order[ebase[sh] + k] = {entries[sh][k].place, uint32_t(ebase[sh] + k)};
+  });
+  {
+    // every shard's run is sorted already (chunks in order, local ids in order): sort runs in parallel, then merge pairwise
+    std::vector<size_t> cut(ebase);
+    while (cut.size() > 2) {
+      std::vector<size_t> next;
+      const size_t pairs = (cut.size() - 1) / 2;
+      parallel_chunks(pairs, unsigned(std::min<size_t>(pairs, threads ? threads : 1)), [&](unsigned, size_t pb, size_t pe) {
+        for (size_t q = pb; q < pe; ++q)
+          std::inplace_merge(order.begin() + long(cut[2 * q]), order.begin() + long(cut[2 * q + 1]), order.begin() + long(cut[2 * q + 2]));
+      });
+      for (size_t q = 0; q < cut.size(); q += 2) next.push_back(cut[q]);
+      if (next.back() != D) next.push_back(D);
+      cut.swap(next);
+    }
+  }
+  std::vector<StrRef> global(D);
+  parallel_chunks(D, D < par_min(65536) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+    for (size_t r = b; r < e; ++r) {
+      const uint32_t flat = order[r].second;
+      const size_t sh = size_t(std::upper_bound(ebase.begin(), ebase.end(), size_t(flat)) - ebase.begin()) - 1;
+      Entry& en = entries[sh][flat - ebase[sh]];
+      en.id = uint32_t(r);
+      global[r] = en.span;
+    }
+  });
+  parallel_chunks(C, unsigned(std::min<size_t>(C, threads ? threads : 1)), [&](unsigned, size_t cb, size_t ce) {
+    for (size_t c = cb; c < ce; ++c) {
+      ck[c].to_global.resize(ck[c].span.size());
+      for (size_t i = 0; i < ck[c].span.size(); ++i) {
+        const size_t sh = hash[c][i] % S;
+        ck[c].to_global[i] = entries[sh][maps[sh].find(sv_of(ck[c].span[i]))->second].id;
+      }
+    }
+  });
+  return global;
 }
 
 template <class T>
@@ -489,17 +576,17 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   {
     struct ExChunk {
       size_t nb = 0, ne = 0;
-      std::unordered_map<std::string_view, uint32_t> ids;   // tag -> local id (order of first appearance in the chunk)
-      std::vector<StrRef> span;                             // local id -> tag text
       std::vector<uint32_t> occ;                            // per node, its distinct local ids (concatenated)
-      std::vector<uint32_t> to_global;
       uint64_t out_base = 0;
     };
-    const unsigned C = V < 4096 ? 1u : threads;
+    const unsigned C = V < par_min(4096) ? 1u : threads;
     std::vector<ExChunk> ck(C);
+    std::vector<InternChunk> ick(C);
     parallel_chunks(V, C, [&](unsigned c, size_t nb, size_t ne) {
       ExChunk& k = ck[c];
+      InternChunk& ik = ick[c];
       k.nb = nb; k.ne = ne;
+      std::unordered_map<std::string_view, uint32_t> ids;   // tag -> local id (order of first appearance in the chunk)
       std::vector<uint32_t> tmp;
       for (size_t n = nb; n < ne; ++n) {
         if (!sa[n].has_ex) continue;
@@ -509,8 +596,8 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
         for (;;) {
           const char* cm = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
           Span tag{p, cm ? cm : e};
-          auto ins = k.ids.emplace(tag.sv(), uint32_t(k.span.size()));
-          if (ins.second) k.span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
+          auto ins = ids.emplace(tag.sv(), uint32_t(ik.span.size()));
+          if (ins.second) ik.span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
           tmp.push_back(ins.first->second);
           if (!cm) break;
           p = cm + 1;
@@ -521,30 +608,42 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       }
     });
     pt.lap("intern EX: per-chunk maps (parallel)");
-    // merge in chunk order = first-appearance order over the whole file
-    std::unordered_map<std::string_view, uint32_t> ex_ids;
+    t.extag_span = merge_interned(base, ick, threads);
+    const size_t D = t.extag_span.size();
+    // transcripts of the distinct tags, ids in first-appearance order again: the same merge over chunks of the tag list
     {
-      size_t distinct = 0;
-      for (const ExChunk& k : ck) distinct += k.span.size();
-      ex_ids.reserve(distinct);
+      const unsigned TC = D < par_min(65536) ? 1u : threads;
+      std::vector<InternChunk> tck(TC);
+      std::vector<std::vector<uint32_t>> local_tx(TC);
+      std::vector<size_t> tb(TC + 1, 0);
+      for (unsigned c = 0; c <= TC; ++c) tb[c] = D * c / TC;
+      parallel_chunks(TC, TC, [&](unsigned, size_t cb, size_t ce) {
+        for (size_t c = cb; c < ce; ++c) {
+          std::unordered_map<std::string_view, uint32_t> ids;
+          local_tx[c].resize(tb[c + 1] - tb[c]);
+          for (size_t i = tb[c]; i < tb[c + 1]; ++i) {
+            const StrRef& r = t.extag_span[i];
+            const Span tx = tx_of_exon(Span{base + r.off, base + r.off + r.len});
+            auto ins = ids.emplace(tx.sv(), uint32_t(tck[c].span.size()));
+            if (ins.second) tck[c].span.push_back(StrRef{uint64_t(tx.b - base), uint32_t(tx.size())});
+            local_tx[c][i - tb[c]] = ins.first->second;
+          }
+        }
+      });
+      const std::vector<StrRef> txs = merge_interned(base, tck, threads);
+      // (tx_ids is empty here: EX tags are interned first; JN tags below add the transcripts only they name)
+      tx_ids.reserve(txs.size() * 2);
+      t.tx_gene.reserve(txs.size());
+      for (const StrRef& r : txs) (void)tx_id(Span{base + r.off, base + r.off + r.len});
+      extag_tx.resize(D);
+      parallel_chunks(TC, TC, [&](unsigned, size_t cb, size_t ce) {
+        for (size_t c = cb; c < ce; ++c)
+          for (size_t i = tb[c]; i < tb[c + 1]; ++i) extag_tx[i] = tck[c].to_global[local_tx[c][i - tb[c]]];
+      });
     }
     uint64_t total = 0;
-    for (ExChunk& k : ck) {
-      k.to_global.resize(k.span.size());
-      for (size_t i = 0; i < k.span.size(); ++i) {
-        const Span tag{base + k.span[i].off, base + k.span[i].off + k.span[i].len};
-        auto ins = ex_ids.emplace(tag.sv(), uint32_t(t.extag_span.size()));
-        if (ins.second) {
-          t.extag_span.push_back(k.span[i]);
-          extag_tx.push_back(tx_id(tx_of_exon(tag)));
-        }
-        k.to_global[i] = ins.first->second;
-      }
-      k.out_base = total;
-      total += k.occ.size();
-      std::unordered_map<std::string_view, uint32_t>().swap(k.ids);
-    }
-    pt.lap("intern EX: merge of distinct tags (one thread)");
+    for (unsigned c = 0; c < C; ++c) { ck[c].out_base = total; total += ck[c].occ.size(); }
+    pt.lap("intern EX: merge of distinct tags and transcripts (sharded)");
     if (total >= uint64_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 EX tag entries");
     // counts -> offsets (per chunk: its nodes' entries are contiguous behind out_base)
     parallel_chunks(C, C, [&](unsigned, size_t cb, size_t ce) {
@@ -565,7 +664,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
           if (!cnt) continue;
           tmp.assign(k.occ.begin() + long(in), k.occ.begin() + long(in + cnt));
           in += cnt;
-          for (uint32_t& x : tmp) x = k.to_global[x];
+          for (uint32_t& x : tmp) x = ick[c].to_global[x];
           std::sort(tmp.begin(), tmp.end());
           for (uint32_t j = 0; j < cnt; ++j) {
             const uint32_t id = tmp[j];
@@ -581,7 +680,6 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   pt.lap("intern EX: per-node lists (parallel)");
   // JN tags: only junction links carry them (5e5 of 2.6e8 slots): the tags are interned in slot order by one thread, the
   // four per-slot offset arrays -- constant between two junction slots -- are filled by all of them
-  std::unordered_map<std::string_view, uint32_t> jn_ids;
   std::vector<uint32_t> jslot;                      // junction slots (first slot of their pair), ascending
   {
     const unsigned C = A < 65536 ? 1u : threads;
@@ -597,42 +695,112 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   std::vector<uint32_t>& o_jn = t.jn_ptr; std::vector<uint32_t>& o_jt = t.jt_ptr;
   std::vector<uint32_t>& o_jx = t.jx_ptr; std::vector<uint32_t>& o_jg = t.jg_ptr;
   o_jn.assign(NJ + 1, 0); o_jt.assign(NJ + 1, 0); o_jx.assign(NJ + 1, 0); o_jg.assign(NJ + 1, 0);
-  std::vector<uint32_t> tags, txs, genes;
-  for (size_t j = 0; j < NJ; ++j) {
-    const size_t sl = jslot[j];
-    o_jn[j] = uint32_t(t.jn_ftx.size());
-    o_jt[j] = uint32_t(t.jt.size());
-    o_jx[j] = uint32_t(t.jx.size());
-    o_jg[j] = uint32_t(t.jg.size());
-    const LinkAttr& a = la[attr_slot[sl]];
-    tags.clear(); txs.clear(); genes.clear();
-    const char* p = base + a.jn_off;
-    const char* e = p + a.jn_len;
-    bool keyerr = false;
-    for (;;) {
-      const char* c = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
-      Span tag{p, c ? c : e};
-      uint32_t id = jn_ids.emplace(tag.sv(), uint32_t(jn_ids.size())).first->second;
-      tags.push_back(id);
-      const uint32_t tx = tx_id(tx_of_junction(tag));
-      txs.push_back(tx);
-      if (t.tx_gene[tx] == CNONE) keyerr = true; else genes.push_back(t.tx_gene[tx]);
-      t.jn_ftx.push_back(tx_id(tx_for_filter(tag)));
-      t.jn_span.push_back(StrRef{uint64_t(tag.b - base), uint32_t(tag.size())});
-      if (!c) break;
-      p = c + 1;
+  {
+    // per thread: the tags of its junctions and the two transcript names each tag yields (:98-104 and :356 / :595), interned
+    // locally; merged to first-appearance ids (merge_interned); the transcripts only a JN tag names (none in a graph the
+    // annotator wrote) are added behind the EX ones in that order; the per-junction sets are then built by all threads
+    struct JEntry { uint32_t tag, tx, ftx; StrRef span; };
+    struct JnChunk {
+      size_t jb = 0, je = 0;
+      std::vector<JEntry> ent;              // entries of all its junctions, file order
+      std::vector<uint32_t> n_ent;          // per junction
+      std::vector<uint32_t> jt, jx, jg, ftx, cnt;     // outputs: concatenated per junction; cnt = {jt, jx, jg} sizes per junction
+      std::vector<StrRef> spans;
+      std::vector<uint8_t> keyerr;
+    };
+    const unsigned JC = NJ < par_min(4096) ? 1u : threads;
+    std::vector<JnChunk> jck(JC);
+    std::vector<InternChunk> tagck(JC), txck(JC);
+    parallel_chunks(NJ, JC, [&](unsigned c, size_t jb, size_t je) {
+      JnChunk& k = jck[c];
+      k.jb = jb; k.je = je;
+      std::unordered_map<std::string_view, uint32_t> tag_ids, txn_ids;
+      auto local = [&](std::unordered_map<std::string_view, uint32_t>& m, InternChunk& ic, Span sp) {
+        auto ins = m.emplace(sp.sv(), uint32_t(ic.span.size()));
+        if (ins.second) ic.span.push_back(StrRef{uint64_t(sp.b - base), uint32_t(sp.size())});
+        return ins.first->second;
+      };
+      for (size_t j = jb; j < je; ++j) {
+        const LinkAttr& a = la[attr_slot[jslot[j]]];
+        const char* p = base + a.jn_off;
+        const char* e = p + a.jn_len;
+        uint32_t n = 0;
+        for (;;) {
+          const char* cm = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
+          Span tag{p, cm ? cm : e};
+          JEntry en;
+          en.tag = local(tag_ids, tagck[c], tag);
+          en.tx = local(txn_ids, txck[c], tx_of_junction(tag));        // in this order: the order tx ids were handed out in
+          en.ftx = local(txn_ids, txck[c], tx_for_filter(tag));
+          en.span = StrRef{uint64_t(tag.b - base), uint32_t(tag.size())};
+          k.ent.push_back(en);
+          ++n;
+          if (!cm) break;
+          p = cm + 1;
+        }
+        k.n_ent.push_back(n);
+      }
+    });
+    (void)merge_interned(base, tagck, threads);      // only the numbering matters (disjointness of JN sets, :402)
+    const std::vector<StrRef> jtx = merge_interned(base, txck, threads);
+    std::vector<uint32_t> jtx_id(jtx.size());
+    for (size_t i = 0; i < jtx.size(); ++i) jtx_id[i] = tx_id(Span{base + jtx[i].off, base + jtx[i].off + jtx[i].len});
+    parallel_chunks(JC, JC, [&](unsigned, size_t cb, size_t ce) {
+      std::vector<uint32_t> tags, txs, genes;
+      for (size_t c = cb; c < ce; ++c) {
+        JnChunk& k = jck[c];
+        size_t at = 0;
+        for (size_t j = k.jb; j < k.je; ++j) {
+          const uint32_t n = k.n_ent[j - k.jb];
+          tags.clear(); txs.clear(); genes.clear();
+          bool keyerr = false;
+          for (uint32_t q = 0; q < n; ++q) {
+            const JEntry& en = k.ent[at + q];
+            tags.push_back(tagck[c].to_global[en.tag]);
+            const uint32_t tx = jtx_id[txck[c].to_global[en.tx]];
+            txs.push_back(tx);
+            if (t.tx_gene[tx] == CNONE) keyerr = true; else genes.push_back(t.tx_gene[tx]);
+            k.ftx.push_back(jtx_id[txck[c].to_global[en.ftx]]);
+            k.spans.push_back(en.span);
+          }
+          at += n;
+          sort_unique(tags); sort_unique(txs); sort_unique(genes);
+          k.jt.insert(k.jt.end(), tags.begin(), tags.end());
+          k.jx.insert(k.jx.end(), txs.begin(), txs.end());
+          k.jg.insert(k.jg.end(), genes.begin(), genes.end());
+          k.cnt.push_back(uint32_t(tags.size())); k.cnt.push_back(uint32_t(txs.size())); k.cnt.push_back(uint32_t(genes.size()));
+          k.keyerr.push_back(keyerr ? 1 : 0);
+        }
+      }
+    });
+    // chunk outputs one behind the other (they are in junction order)
+    std::vector<size_t> b_jn(JC + 1, 0), b_jt(JC + 1, 0), b_jx(JC + 1, 0), b_jg(JC + 1, 0);
+    for (unsigned c = 0; c < JC; ++c) {
+      b_jn[c + 1] = b_jn[c] + jck[c].ftx.size(); b_jt[c + 1] = b_jt[c] + jck[c].jt.size();
+      b_jx[c + 1] = b_jx[c] + jck[c].jx.size(); b_jg[c + 1] = b_jg[c] + jck[c].jg.size();
     }
-    sort_unique(tags); sort_unique(txs); sort_unique(genes);
-    t.jt.insert(t.jt.end(), tags.begin(), tags.end());
-    t.jx.insert(t.jx.end(), txs.begin(), txs.end());
-    t.jg.insert(t.jg.end(), genes.begin(), genes.end());
-    if (keyerr) t.lflags[sl] |= L_GENE_KEYERR;
+    if (b_jn[JC] >= size_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 JN tag entries");
+    t.jn_ftx.resize(b_jn[JC]); t.jn_span.resize(b_jn[JC]); t.jt.resize(b_jt[JC]); t.jx.resize(b_jx[JC]); t.jg.resize(b_jg[JC]);
+    parallel_chunks(JC, JC, [&](unsigned, size_t cb, size_t ce) {
+      for (size_t c = cb; c < ce; ++c) {
+        const JnChunk& k = jck[c];
+        std::copy(k.ftx.begin(), k.ftx.end(), t.jn_ftx.begin() + long(b_jn[c]));
+        std::copy(k.spans.begin(), k.spans.end(), t.jn_span.begin() + long(b_jn[c]));
+        std::copy(k.jt.begin(), k.jt.end(), t.jt.begin() + long(b_jt[c]));
+        std::copy(k.jx.begin(), k.jx.end(), t.jx.begin() + long(b_jx[c]));
+        std::copy(k.jg.begin(), k.jg.end(), t.jg.begin() + long(b_jg[c]));
+        size_t on = b_jn[c], ot = b_jt[c], ox = b_jx[c], og = b_jg[c];
+        for (size_t j = k.jb; j < k.je; ++j) {
+          o_jn[j] = uint32_t(on); o_jt[j] = uint32_t(ot); o_jx[j] = uint32_t(ox); o_jg[j] = uint32_t(og);
+          on += k.n_ent[j - k.jb];
+          ot += k.cnt[3 * (j - k.jb)]; ox += k.cnt[3 * (j - k.jb) + 1]; og += k.cnt[3 * (j - k.jb) + 2];
+          if (k.keyerr[j - k.jb]) t.lflags[jslot[j]] |= L_GENE_KEYERR;
+        }
+      }
+    });
+    o_jn[NJ] = uint32_t(b_jn[JC]); o_jt[NJ] = uint32_t(b_jt[JC]); o_jx[NJ] = uint32_t(b_jx[JC]); o_jg[NJ] = uint32_t(b_jg[JC]);
   }
-  o_jn[NJ] = uint32_t(t.jn_ftx.size());
-  o_jt[NJ] = uint32_t(t.jt.size());
-  o_jx[NJ] = uint32_t(t.jx.size());
-  o_jg[NJ] = uint32_t(t.jg.size());
-  pt.lap("intern JN: tags of the junctions (one thread)");
+  pt.lap("intern JN: tags of the junctions (sharded merge, parallel sets)");
   par_assign(t.jrow, A, uint32_t(CNONE), threads);
   for (size_t j = 0; j < NJ; ++j) t.jrow[jslot[j]] = uint32_t(j);
 

@@ -80,6 +80,12 @@ def test_call_source_vs_reference_rows(hostsim, case):
         rows = r.stdout.splitlines()
         assert rows[0] == call_oracle.HEADER
         check_rows(rows[1:], gc)
+        # the same with every host step of the table building on its parallel path (sharded tag interning, chunked GTF, ...),
+        # which inputs of this size would otherwise never take: identical rows in identical order
+        r2 = subprocess.run([hostsim["call"], *gc["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf"], capture_output=True, text=True,
+                            env={**os.environ, "PANTAS_TEST_SMALL_PARALLEL": "1"})
+        assert r2.returncode == 0, r2.stderr
+        assert r2.stdout == r.stdout
 
 
 def test_crash_inputs(hostsim):
