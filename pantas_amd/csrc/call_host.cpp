@@ -535,12 +535,18 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
         t.first_slot[s] = first;
         attr_slot[first] = s;   // the last duplicate wins
         if (first != s) {
-          // membership in `junctions` / `noveljunctions` is decided line by line; refuse the case where the
-          // lines of one pair disagree (the reference would then index a missing key or a stale set entry)
-          if (la[s].has_jn != la[first].has_jn || la[s].has_id != la[first].has_id)
-            throw Error("Unsupported", "duplicate L lines of one link disagree on JN/ID tags");
+          // Several L lines for one (from, to): gfaL keeps the attributes of the LAST line (dict overwrite, :173) while
+          // `junctions` / `noveljunctions` gain the pair whenever ANY of the lines carries JN / ID (:177-180).  la[first]
+          // is not read for attributes once a duplicate exists (they come from the last line): its flags collect "any".
+          la[first].has_jn = la[first].has_jn || la[s].has_jn;
+          la[first].has_id = la[first].has_id || la[s].has_id;
         }
       }
+      // a pair that is a junction through an earlier line only: the reference indexes gfaL[pair]["JN"] of the last line
+      // and dies with KeyError wherever it evaluates the junction -- refused here at load
+      for (uint32_t s = b; s < e; ++s)
+        if (t.first_slot[s] == s && attr_slot[s] != s && la[s].has_jn && !la[attr_slot[s]].has_jn)
+          throw Error("Unsupported", "duplicate L lines of one link: an earlier line carries a JN tag, the last one does not");
     }
   });
   parallel_chunks(A, A < 4096 ? 1 : threads, [&](unsigned, size_t sb, size_t se) {
@@ -548,8 +554,8 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       if (t.first_slot[s] != s) continue;
       const LinkAttr& a = la[attr_slot[s]];
       uint32_t fl = L_FIRST;
-      if (a.has_jn) fl |= L_JUNC;
-      if (a.has_id) fl |= L_NOVEL;
+      if (a.has_jn) fl |= L_JUNC;                       // (an earlier line's JN without the last one's was refused above)
+      if (a.has_id || la[s].has_id) fl |= L_NOVEL;      // any line with ID makes the pair a novel junction
       if (a.has_rc) { fl |= L_HAS_RC; t.rc[s] = a.rc; }
       t.lflags[s] = fl;
     }

@@ -58,7 +58,7 @@ def cases():
     out.append(dict(name="dup_s_call_annotated", stage="call_aug_dup_s", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="refuses"))
     # ---- duplicate L lines that disagree on JN ------------------------------------------------------------------
     out.append(dict(name="dup_l_jn_last", stage="call_aug_dup_l_last", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="refuses"))
-    out.append(dict(name="dup_l_jn_first", stage="call_aug_dup_l_first", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="refuses"))
+    out.append(dict(name="dup_l_jn_first", stage="call_aug_dup_l_first", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="same"))
     # ---- a lone carriage return: Python's universal newlines make it a line break --------------------------------
     cr_mid = [gaf[0], gaf[1].replace("\tcs:Z", "\r\tcs:Z"), gaf[2]]
     out.append(dict(name="cr_mid_line", stage="augment", gfa=gfa, gaf=cr_mid, gtf=gtf, flags=[], engine="refuses"))
