@@ -405,12 +405,13 @@ struct AggSink {
                                                       uint64_t exact_order) const {
     // a_il / a_ol: 0 .. 3 steps (a node holding a '+' between ':' runs counts each compacted entry); walk.h bounds what a
     // line can add to one field so that 2048 lines stay below 2^16
+    if (g.ablate & 8u) return;
     const bool f_il = a_il && (word & FLAG_IL), f_ol = a_ol && (word & FLAG_OL);
     const uint32_t h = probe<LOG_N>(nkey, n);
     if (h != LDS_EMPTY) {
       const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) |
                                      (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
-      atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
+      if (!(g.ablate & 16u)) atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
       if (exact_order == 0) {
         // a running minimum: read first (lanes reading one address do not conflict, lanes doing an atomic on it serialise)
         if (f_il | f_ol) {
@@ -1131,8 +1132,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
-#define PANTAS_AGG_RANGE_ABL(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, PK, ON, INF, PFD) \
-    do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, PK, ON, true, INF, PFD>), \
+#define PANTAS_AGG_RANGE_ABL(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, PK, ON, INF, PFD, ...) \
+    do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, PK, ON, true, INF, PFD, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
 #define PANTAS_AGG(ID, ...) case ID: PANTAS_AGG_RANGE(d.stream, 0u, b.n, __VA_ARGS__); break;
     // one after the other on the launch stream
@@ -1152,7 +1153,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     } else {
       if (g.ablate) {
         // timing experiments: the default pair of kernels with the ablation switches compiled in, one after the other
-        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2);
+        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2, true);
         HIP_OK(hipEventRecord(d.ev[3], d.stream));
         split = true;
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
