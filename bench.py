@@ -99,6 +99,10 @@ def cpu_baseline(scale_kw: dict, sample_lines: int, s4_lines: int, s4_junctions:
     t1 = time.perf_counter()
     rows = call_oracle.call(pre + ".aug.gfa", pre + ".gtf", None, rca=3, novel=True)
     dc = time.perf_counter() - t1
+    try:
+        cpp = cpp_baseline(kw, tmp)
+    except Exception as e:      # a reported baseline: its absence must not take the GPU line down
+        cpp = {"skipped": f"{type(e).__name__}: {e}"}
     shutil.rmtree(tmp, ignore_errors=True)
     port_rate = sample_lines / dt
     ref_rate = port_rate / CALIBRATION["augment_ref_over_port"]
@@ -106,6 +110,7 @@ def cpu_baseline(scale_kw: dict, sample_lines: int, s4_lines: int, s4_junctions:
             "sample": f"{sample_lines} GAF lines of the same synthetic recipe and parameters as the GPU line on a "
                       f"{kw['n_genes']}-gene instance ({syn.stats.nodes} segments), {dt:.1f} s in oracle/augment_oracle.py "
                       "(Python port of the reference's per-line loop; the rate does not depend on the graph size: dict lookups)",
+            "cpp": cpp,
             "call_events_per_s": len(rows) / dc,
             "call_sample": f"{len(rows)} events from {syn.stats.junction_links} junction links in {dc:.1f} s, oracle/call_oracle.py incl. "
                            "GFA/GTF parsing (indexed junction lookup: NOT the reference's O(J^2) scan)",
@@ -118,6 +123,38 @@ def cpu_baseline(scale_kw: dict, sample_lines: int, s4_lines: int, s4_junctions:
                 "augment_s_for_this_workload": s4_lines / ref_rate,
                 "call_s_for_this_workload": CALIBRATION["call_ref_seconds_per_J2"] * s4_junctions ** 2,
                 "note": "an extrapolation, not a measurement: the reference's Python dicts would not hold a whole-genome graph in memory"}}
+
+
+def cpp_baseline(kw: dict, tmp: str, lines: int = 6_000_000):
+    """the same algorithm in plain C++ (oracle/augment_oracle.cpp, pinned to the reference's goldens by
+    tests/test_oracle_cpp.py) on one core and on all of them.  The timed part is its per-line loop -- GAF text to counters in host
+    memory, what `value` and `reads_per_s_text_to_counters` cover on the GPU side -- not the GFA load or the output."""
+    import subprocess
+    from pantas_amd.engine import Synth
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    exe = os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp")
+    pre = os.path.join(tmp, "cpp_sample")
+    kw = dict(kw)
+    kw["n_lines"] = lines
+    syn = Synth(seed=12, **kw)
+    syn.write(pre)
+    cores = os.cpu_count() or 1
+    out = {"sample": f"{lines} GAF lines ({syn.stats.gaf_bytes / 1e9:.2f} GB of text) of the same recipe on the {kw['n_genes']}-gene instance "
+                     f"({syn.stats.nodes} segments: its tables stay in cache, a whole-genome graph's would not)",
+           "timed": "the per-line loop: GAF text -> parsed -> walked -> NC / IL / OL / RC tables in host memory (hash maps); GFA load, "
+                    "merge of the per-thread tables and the output are listed beside it",
+           "cores": cores}
+    for name, t in (("one_thread", 1), ("all_cores", cores)):
+        r = subprocess.run([exe, "--threads", str(t), "--no-out", pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, check=True)
+        st = json.loads(r.stderr.strip().splitlines()[-1])
+        out[name] = {"threads": t, "reads_per_s": st["lines"] / st["hot_loop_s"], "hot_loop_s": st["hot_loop_s"], "merge_s": st["merge_s"],
+                     "load_gfa_s": st["load_gfa_s"], "reads_per_s_incl_merge": st["lines"] / (st["hot_loop_s"] + st["merge_s"])}
+    for ext in (".gaf", ".gfa", ".gtf"):
+        try:
+            os.unlink(pre + ext)
+        except OSError:
+            pass
+    return out
 
 
 def e2e_leg(syns, scale, kw, flags="--rca 3 --novel", with_cache=True):

@@ -223,11 +223,12 @@ def replicates_main(argv=None) -> int:
     """One replicate per GPU, no collective at all (the layout of exps/3-homo-real: six samples on one graph):
 
         python -m torch.distributed.run --nproc-per-node N -m pantas_amd.distributed replicates \\
-            --out-dir DIR [--thr 20] [--gtf anno.gtf --call "--rca 3 --novel"] GFA GAF1 GAF2 ...
+            --out-dir DIR [--thr 20] [--gtf anno.gtf --call "--rca 3 --novel" [--no-aug-gfa]] GFA GAF1 GAF2 ...
 
     Rank r (LOCAL_RANK / RANK, WORLD_SIZE from the environment: under torchrun or any other launcher) parses the graph
     once, keeps it in the HBM of GPU r, and runs `augment` for GAFs r, r + N, ...: DIR/<gaf name>.aug.gfa; with --gtf also
-    `call` on each result without the GFA text round trip: DIR/<gaf name>.events.csv.  No process group is created."""
+    `call` on each result without the GFA text round trip: DIR/<gaf name>.events.csv (--no-aug-gfa: the events only, the
+    augmented GFA between the two stages is not written).  No process group is created."""
     import argparse
     import sys
     import time
@@ -238,9 +239,12 @@ def replicates_main(argv=None) -> int:
     ap.add_argument("--thr", type=int, default=20)
     ap.add_argument("--gtf", default=None)
     ap.add_argument("--call", default="", help="options of `pantas call` as one string, e.g. \"--rca 3 --novel\"")
+    ap.add_argument("--no-aug-gfa", action="store_true", help="with --gtf: do not write the augmented GFA, only the events")
     ap.add_argument("GFA")
     ap.add_argument("GAF", nargs="+")
     a = ap.parse_args(argv)
+    if a.no_aug_gfa and not a.gtf:
+        ap.error("--no-aug-gfa without --gtf would write nothing")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -257,8 +261,11 @@ def replicates_main(argv=None) -> int:
     for gaf in mine:
         base = os.path.join(a.out_dir, os.path.basename(gaf))
         t1 = time.perf_counter()
-        with open(base + ".aug.gfa", "wb") as f:
-            bs, _ = g.augment(gaf, a.thr, f.fileno())
+        if a.no_aug_gfa:
+            bs, _ = g.augment(gaf, a.thr, -1)
+        else:
+            with open(base + ".aug.gfa", "wb") as f:
+                bs, _ = g.augment(gaf, a.thr, f.fileno())
         t2 = time.perf_counter()
         msg = f"[rank {rank} gpu {local}] {gaf}: {bs.lines} lines, {bs.rejected} rejected, augment {t2 - t1:.2f} s"
         if call_opts is not None:

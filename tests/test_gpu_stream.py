@@ -159,3 +159,23 @@ def test_replicate_per_gpu_launcher(tmp_path):
         mine = collections.Counter(map(call_oracle.normalise_row, rows[1:]))
         stable = collections.Counter(gc["stable"])
         assert not (stable - mine) and all(r in set(gc["variants"]) for r in (mine - stable))
+
+
+def test_replicates_events_only(tmp_path):
+    """--no-aug-gfa: the same event rows without the augmented GFA between the two stages"""
+    d = os.path.join(GOLDEN, "synth_a")
+    gaf = tmp_path / "rep.gaf"
+    gaf.write_bytes(open(f"{d}/in.gaf", "rb").read())
+    outs = []
+    for extra in ([], ["--no-aug-gfa"]):
+        out = tmp_path / ("events_only" if extra else "both")
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.distributed", "replicates", "--out-dir", str(out), "--gtf", f"{d}/in.gtf",
+                            "--call", "--rca 3 --novel --minintronsize 25", *extra, f"{d}/in.gfa", str(gaf)], cwd=ROOT,
+                           env={**os.environ, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(out)
+    assert (outs[0] / "rep.gaf.aug.gfa").exists() and not (outs[1] / "rep.gaf.aug.gfa").exists()
+    assert (outs[0] / "rep.gaf.events.csv").read_bytes() == (outs[1] / "rep.gaf.events.csv").read_bytes()
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.distributed", "replicates", "--out-dir", str(tmp_path / "x"), "--no-aug-gfa", f"{d}/in.gfa", str(gaf)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2

@@ -1,0 +1,77 @@
+"""Pins the C++ form of the augment oracle (oracle/augment_oracle.cpp -- the `cpu_baseline` of bench.py: SURVEY.md 8-d rows
+2a / 2b) to the outputs of the real reference under tests/golden/: same bytes with one thread and with several, the
+reference's exception class where it dies."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import CASES, GOLDEN, ROOT
+
+EXE = os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp")
+EDGE = os.path.join(GOLDEN, "edge")
+# Python's universal newlines turn a lone '\r' into a line break; the C++ form cuts lines at '\n' only (stated in its header)
+LONE_CR = {"cr_mid_line", "cr_between_records"}
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return EXE
+
+
+def run(exe, gaf, gfa, threads):
+    return subprocess.run([exe, "--threads", str(threads), gaf, gfa], capture_output=True)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+@pytest.mark.parametrize("case", CASES)
+def test_golden_bytes(exe, case, threads):
+    d = os.path.join(GOLDEN, case)
+    r = run(exe, f"{d}/in.gaf", f"{d}/in.gfa", threads)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == open(f"{d}/expected.aug.gfa", "rb").read()
+    meta = json.load(open(f"{d}/expected.json"))
+    assert f"Rejected alignments: {meta['rejected']}\n".encode() in r.stderr
+
+
+def test_crashes_where_the_reference_crashes(exe):
+    crashes = [c for c in json.load(open(os.path.join(GOLDEN, "crashes.json"))) if c["stage"] == "augment"]
+    assert len(crashes) >= 5
+    cd = os.path.join(GOLDEN, "crashes")
+    for c in crashes:
+        for threads in ((1,) if "tilde" in c["name"] else (1, 4)):      # '~' first: one thread only (see the header)
+            r = run(exe, f"{cd}/{c['name']}.gaf", f"{cd}/{c['name']}.gfa", threads)
+            assert r.returncode == 1 and r.stdout == b"", (c["name"], r.stderr)
+            assert r.stderr.decode().strip().splitlines()[-1].startswith(c["exception"] + ":"), (c["name"], r.stderr, c["exception"])
+
+
+@pytest.mark.parametrize("c", [c for c in json.load(open(os.path.join(EDGE, "cases.json"))) if c["stage"] == "augment" and c["name"] not in LONE_CR],
+                         ids=lambda c: c["name"])
+def test_edge_inputs(exe, c):
+    n = c["name"]
+    # a '~' as the first op of a line takes its length from the line before: one thread only (the header says so)
+    for threads in ((1,) if n == "tilde_leak" else (1, 2)):
+        r = run(exe, f"{EDGE}/{n}.gaf", f"{EDGE}/{n}.gfa", threads)
+        if c["rc"]:
+            assert r.returncode == 1 and r.stderr.decode().strip().splitlines()[-1].startswith(c["exception"] + ":"), r.stderr
+        else:
+            assert r.returncode == 0, r.stderr.decode()
+            assert r.stdout == open(f"{EDGE}/{n}.expected", "rb").read()
+
+
+def test_equals_python_oracle_on_a_generated_workload(exe, tmp_path):
+    """40 000 lines of the bench recipe with indels and novel skips turned up: same bytes as oracle/augment_oracle.py, 1 and 8 threads"""
+    import io
+    import augment_oracle
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "w")
+    Synth(seed=77, n_genes=150, n_lines=40000, p_indel=0.25, p_novel_skip=0.05).write(pre)
+    out = io.StringIO()
+    augment_oracle.augment(pre + ".gaf", pre + ".gfa", out)
+    expected = out.getvalue().encode()
+    for threads in (1, 8):
+        r = run(exe, pre + ".gaf", pre + ".gfa", threads)
+        assert r.returncode == 0, r.stderr.decode()
+        assert r.stdout == expected

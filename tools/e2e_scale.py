@@ -43,6 +43,52 @@ def phases(stderr_text):
     return out
 
 
+def same_file(p, q):
+    if os.path.getsize(p) != os.path.getsize(q):
+        return False
+    with open(p, "rb") as f, open(q, "rb") as g:
+        while True:
+            x, y = f.read(1 << 26), g.read(1 << 26)
+            if x != y:
+                return False
+            if not x:
+                return True
+
+
+def replicates_leg(a, pre, env, py):
+    """N replicates in one process on one GPU: what the graph parse and the GFA text round trip cost per replicate."""
+    import shutil
+    d = pre + ".rep"
+    os.makedirs(d, exist_ok=True)
+    out = {"n": a.replicates}
+    try:
+        gafs = []
+        for i in range(a.replicates):
+            g = os.path.join(d, f"rep{i}.gaf")
+            os.link(pre + ".gaf", g)          # same reads under N names: the launcher works per file
+            gafs.append(g)
+        for mode, extra in (("with_aug_gfa", []), ("events_only", ["--no-aug-gfa"])):
+            t0 = time.perf_counter()
+            r = subprocess.run([py, "-m", "pantas_amd.distributed", "replicates", "--out-dir", d, "--gtf", pre + ".gtf", "--call", a.flags, *extra,
+                                pre + ".gfa", *gafs], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT)
+            dt = time.perf_counter() - t0
+            err = r.stderr.decode(errors="replace")
+            if r.returncode != 0:
+                raise RuntimeError(f"replicates: rc {r.returncode}: {err[-3000:]}")
+            o = {"wall_s": dt, "per_replicate_s": dt / a.replicates, "log": [l for l in err.splitlines() if l.startswith("[rank")]}
+            o["events_csv_equals_cli"] = all(same_file(g + ".events.csv", pre + ".csv") for g in gafs[:1])
+            if not extra:
+                o["aug_gfa_equals_cli"] = all(same_file(g + ".aug.gfa", pre + ".aug.gfa") for g in gafs[:1])
+            out[mode] = o
+            for g in gafs:
+                for ext in (".events.csv", ".aug.gfa"):
+                    if os.path.exists(g + ext):
+                        os.unlink(g + ext)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     import bench
     ap = argparse.ArgumentParser()
@@ -56,6 +102,9 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--null-out", action="store_true", help="also time both stages with stdout on /dev/null (what the output file costs)")
     ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--replicates", type=int, default=0,
+                    help="also time N replicates of the GAF through ONE `pantas_amd.distributed replicates` process (graph parsed once, "
+                         "call on the augment result without the GFA text round trip) and compare its files with the command lines'")
     a = ap.parse_args()
     from pantas_amd.engine import Synth
     desc, kw, *rest = bench.SCALES[a.scale]
@@ -115,6 +164,8 @@ def main():
         res["call"] = {"wall_s": dt, "events": rows - 1, "events_per_s": (rows - 1) / dt, "phases": phases(err), "peak_rss_gb": rss,
                        "out_bytes": os.path.getsize(pre + ".csv")}
         res["total_s"] = res["augment"]["wall_s"] + res["call"]["wall_s"]
+        if a.replicates:
+            res["replicates"] = replicates_leg(a, pre, env, py)
         if a.null_out:
             dt, err, _ = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], "/dev/null", env)
             res["augment_to_dev_null"] = {"wall_s": dt, "phases": [p for p in phases(err) if "tokenize_gaf_device" not in p]}
