@@ -20,7 +20,6 @@
 // Deviations from Python's text handling, none of which the goldens or the synthetic inputs contain: lines end at '\n'
 // only (no universal newlines), integers are [+-]?[0-9]+, lengths count bytes.
 #include <algorithm>
-#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -168,7 +167,8 @@ struct Augmenter {
   const Graph& g;
   long long thr;
   bool shared_carry;                 // single thread: the reference's curr_cigar_len lives across lines
-  std::vector<std::atomic<uint32_t>>* nc;   // shared, dense
+  std::unordered_map<uint32_t, uint32_t> nc;   // per thread (a shared dense array has every core fighting for the lines of the
+                                               // few highly expressed genes' nodes); added up in the merge
   Table hist, rc;                    // (node, side, pos) -> count; (u << 32 | v) -> count
   uint64_t rejected = 0, used = 0;
   bool have_carry = false;
@@ -181,7 +181,7 @@ struct Augmenter {
   std::vector<std::vector<Piece>> pieces;
   std::vector<uint32_t> placed_pos, kept_pos, node_of;
 
-  Augmenter(const Graph& g_, long long thr_, bool sc, std::vector<std::atomic<uint32_t>>* nc_) : g(g_), thr(thr_), shared_carry(sc), nc(nc_) {}
+  Augmenter(const Graph& g_, long long thr_, bool sc) : g(g_), thr(thr_), shared_carry(sc) {}
 
   void feed(sv raw, uint64_t lineno) {
     split(strip(raw), tok);
@@ -319,7 +319,7 @@ struct Augmenter {
       ++w;
     }
     const size_t F = kept_pos.size();
-    for (size_t i = 0; i < F; ++i) (*nc)[node_of[kept_pos[i]]].fetch_add(1, std::memory_order_relaxed);   // [:263-269]
+    for (size_t i = 0; i < F; ++i) ++nc[node_of[kept_pos[i]]];                // [:263-269]
     uint32_t seq = 0;
     for (size_t i = 0; i < F; ++i) {                                          // [:276-353]
       const uint32_t node = node_of[kept_pos[i]];
@@ -391,8 +391,7 @@ int main(int argc, char** argv) {
     const double t1 = now();
     Mapped gaf;
     gaf.open(pos[0]);
-    std::vector<std::atomic<uint32_t>> nc(g.name.size());
-    for (auto& x : nc) x.store(0, std::memory_order_relaxed);
+    std::vector<uint32_t> nc(g.name.size(), 0u);
     // byte ranges cut at line starts; the line number of a range's first line comes from counting newlines
     std::vector<size_t> cut(threads + 1, gaf.n);
     cut[0] = 0;
@@ -405,7 +404,7 @@ int main(int argc, char** argv) {
     std::vector<uint64_t> first_line(threads + 1, 0);
     std::vector<Augmenter> aug;
     aug.reserve(threads);
-    for (unsigned t = 0; t < threads; ++t) aug.emplace_back(g, thr, threads == 1, &nc);
+    for (unsigned t = 0; t < threads; ++t) aug.emplace_back(g, thr, threads == 1);
     std::vector<Crash> died(threads);
     std::vector<uint64_t> died_line(threads, UINT64_MAX);
     {
@@ -444,6 +443,8 @@ int main(int argc, char** argv) {
     // merge (T > 1): counts add up, the earliest appearance wins; then insertion order = order of first appearance
     Table hist = std::move(aug[0].hist), rc = std::move(aug[0].rc);
     uint64_t rejected = aug[0].rejected, used = aug[0].used;
+    for (unsigned t = 0; t < threads; ++t)
+      for (const auto& kv : aug[t].nc) nc[kv.first] += kv.second;
     for (unsigned t = 1; t < threads; ++t) {
       for (const Entry& e : aug[t].hist.e) hist.add(e.key, e.count, e.first);
       for (const Entry& e : aug[t].rc.e) rc.add(e.key, e.count, e.first);
@@ -483,7 +484,7 @@ int main(int argc, char** argv) {
         const uint32_t n = it->second;
         out.put(line);
         out.put("\tNC:i:");
-        out.put_int(nc[n].load(std::memory_order_relaxed));
+        out.put_int(nc[n]);
         for (uint64_t side = 0; side < 2; ++side) {
           bool any = false;
           for (uint32_t q = h_ptr[n]; q < h_ptr[n + 1]; ++q) {

@@ -327,6 +327,9 @@ struct AggSink {
   uint32_t* fkey; unsigned long long* fmin;
   unsigned long long* vkey; uint32_t* vcnt; unsigned long long* vmin;   // links absent from the graph (CF entries)
   uint32_t* omin = nullptr;   // INFO kernels: [CN][2] min line id that bumped IL[0] / OL[len] of a flagged node, by node-table slot
+  uint4* nvq = nullptr;       // NVQ kernels: links absent from the graph met by the short walk, queued for the end of the chunk
+  uint32_t* nvq_n = nullptr;
+  static constexpr uint32_t NVQ_CAP = 192;
 
   // link (a, b) that is not in the graph: aggregate in LDS, else straight to the global table
   __device__ __forceinline__ void novel(uint32_t a, uint32_t b, uint64_t order) const {
@@ -432,13 +435,24 @@ struct AggSink {
       if (f_ol) order_min(n, SIDE_OL, ord);
     }
   }
+  // A link the graph does not have is met by about one line in thirty, so nearly every wave has a lane or two that need the
+  // insertion into the novel-link table -- and a wave pays for that code (a 64-bit hash, a CAS loop, two atomics) whenever
+  // ONE lane takes it.  With a queue the lane leaves {a, b, order} in LDS (one counter atomic, one 16-byte store) and the
+  // workgroup does the insertions at the end of the chunk with all lanes busy.
+  __device__ __forceinline__ void novel_later(uint32_t a, uint32_t b, uint64_t order) const {
+    if (nvq) {
+      const uint32_t i = atomicAdd(nvq_n, 1u);
+      if (i < NVQ_CAP) { nvq[i] = make_uint4(a, b, uint32_t(order), uint32_t(order >> 32)); return; }
+    }
+    novel(a, b, order);
+  }
   // link (a -> b) that is not a's first out-slot: the other slots, else a link the graph does not have
   __device__ __forceinline__ void link_rest(uint32_t a, uint32_t lo, uint32_t hi, uint32_t b, uint64_t order) const {
     if (g.ablate & 4u) return;
     for (uint32_t s = lo + 1; s < hi; ++s) {
       if (g.col[s] == b) { bump_slot(s); return; }
     }
-    novel(a, b, order);
+    novel_later(a, b, order);
   }
   // returns the node's table slot (LDS_EMPTY when the increments went to memory)
   __device__ __forceinline__ uint32_t bump_node(uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol) const {
@@ -543,7 +557,7 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
 }
 
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          bool INFO = false, int PF = 1, bool DEFER = false>
+          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -562,6 +576,8 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   __shared__ uint32_t fkey[CF];
   __shared__ __attribute__((aligned(8))) uint32_t omin[INFO ? 2 * CN : 2];
   __shared__ uint32_t defer_q[DEFER ? 2 * THREADS : 2];
+  __shared__ uint4 nvq[NVQ ? Sink::NVQ_CAP : 1];
+  __shared__ uint32_t nvq_n;
   static_assert(!INFO || (PACKED && ONLY == 1), "the info walk exists for the short-walk class over packed entries");
   const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
   for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -573,8 +589,9 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
+    if (threadIdx.x == 0) nvq_n = 0u;
     __syncthreads();
-    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin};
+    const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin, NVQ ? nvq : nullptr, NVQ ? &nvq_n : nullptr};
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
@@ -601,6 +618,14 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       if (st != WALK_OK) report_status(g, h.line_id, st);
     }
     __syncthreads();
+    if constexpr (NVQ) {
+      const uint32_t m = min(nvq_n, Sink::NVQ_CAP);
+      for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
+        const uint4 e = nvq[i];
+        sink.novel(e.x, e.y, (static_cast<uint64_t>(e.w) << 32) | e.z);
+      }
+      __syncthreads();
+    }
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       const uint32_t n = nkey[i];
       if (n == LDS_EMPTY) continue;
@@ -1127,8 +1152,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
     // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
     // the rest with the general aggregating kernel beside it on a second stream: 73 = the round-1 short walk (gathers two
-    // nodes ahead), 80.. = this round's variants (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 80;   // read per launch: tools/ab_variants.py switches it
+    // nodes ahead), 80 / 85 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 85;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1153,7 +1178,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     } else {
       if (g.ablate) {
         // timing experiments: the default pair of kernels with the ablation switches compiled in, one after the other
-        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2, true);
+        PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2, true, true);
         HIP_OK(hipEventRecord(d.ev[3], d.stream));
         split = true;
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
@@ -1162,9 +1187,9 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         // variants registers (2.80 - 3.43 ms against 2.58: occupancy is worth more than anything it buys), a second, lean
         // instance of the walk for waves without indel lines inside the same kernel (2.59: its registers add up)
         PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // round 1
-        PANTAS_SPLIT(81, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 1, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // 80 with gathers one node ahead
-        default:   // 80: gathers two nodes ahead, lookups of links off the first out-slot deferred to the end of the line
-        PANTAS_SPLIT(80, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // ONLY 2: the general walk alone
+        PANTAS_SPLIT(80, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // mid round 2: deferred lookups of links off the first out-slot
+        default:   // 85: 80 + links absent from the graph queued per workgroup and inserted at the end of the chunk
+        PANTAS_SPLIT(85, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // ONLY 2: the general walk alone
       }
     }
 #undef PANTAS_SPLIT_SEQ

@@ -2,6 +2,11 @@
 
 * `test_e2e_command_lines_vs_oracle`: the 6 000-gene / 2 M-line workload through the two COMMAND LINES -- engine GFA bytes
   == oracle bytes, CSV rows == oracle rows as a multiset.
+* `test_whole_s3_vs_cpp_oracle`: ALL of S3 (human chr1 scale, 10 M lines) through `pantas augment` against the independent C++
+  form of the oracle (oracle/augment_oracle.cpp, pinned to the reference's goldens by tests/test_oracle_cpp.py) on the host
+  cores: the two augmented GFAs are the same file.  (The same check of ALL of S4 -- 50 M lines, 2.5e8 segments, 23 GB of output --
+  takes minutes of single-thread GFA indexing in the oracle and is run by `tools/e2e_scale.py --check-cpp-oracle`:
+  profiles/r2_e2e_s4_cpp_oracle.json.)
 * `test_full_graph_slice_vs_oracle[s3|s4]`: the FULL human-chr1 / human whole-genome graph (2.5e8 segments, ids in the
   1e9 range, the dense name table, counter offsets beyond 2^30 words) with a slice of the read stream spread over every
   chromosome.  The Python oracle cannot hold such a graph, and it does not have to: what it prints for a segment or a
@@ -51,6 +56,34 @@ def gfa_lines():
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "tools", "gfa_lines.cpp"), "-lpthread"])
     return exe
+
+
+def test_whole_s3_vs_cpp_oracle():
+    import bench
+    from pantas_amd.engine import Synth
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    tmp = workdir(12)
+    try:
+        pre = os.path.join(tmp, "s3")
+        Synth(seed=5, **bench.SCALES["s3"][1]).write(pre)
+        with open(pre + ".gpu.gfa", "wb") as f:
+            r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        with open(pre + ".or.gfa", "wb") as f:
+            o = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, 32)),
+                                pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
+        assert o.returncode == 0, o.stderr.decode()[-2000:]
+        assert os.path.getsize(pre + ".gpu.gfa") == os.path.getsize(pre + ".or.gfa") > 10**9
+        with open(pre + ".gpu.gfa", "rb") as x, open(pre + ".or.gfa", "rb") as y:
+            while True:
+                a, b = x.read(1 << 26), y.read(1 << 26)
+                assert a == b
+                if not a:
+                    break
+        rej = [l for l in o.stderr.decode().splitlines() if l.startswith("Rejected alignments:")]
+        assert rej and rej[0] in r.stderr.decode()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def test_e2e_command_lines_vs_oracle():
