@@ -297,6 +297,21 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
   HIP_OK(hipMemcpyAsync(&totals[1], word_off + n, 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipMemcpyAsync(&totals[2], task_off + n, 4, hipMemcpyDeviceToHost, d.stream));
   check_status();
+  if (getenv("PANTAS_CALL_HIST")) {
+    // how the records spread over the items of a pass (tuning aid): items and records by records-per-item bucket
+    std::vector<uint32_t> h(n);
+    HIP_OK(hipMemcpy(h.data(), nrec, size_t(n) * 4, hipMemcpyDeviceToHost));
+    const uint32_t edge[] = {0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 1024, 4096, 0xFFFFFFFFu};
+    uint64_t items[12] = {0}, recs[12] = {0};
+    for (uint32_t v : h) {
+      int k = 0;
+      while (k < 11 && v > edge[k]) ++k;
+      ++items[k]; recs[k] += v;
+    }
+    fprintf(stderr, "[call hist] pass %d: %u items, %u records\n", PASS, n, totals[0]);
+    for (int k = 0; k < 12; ++k)
+      if (items[k]) fprintf(stderr, "[call hist]   <= %10u records/item: %9llu items %11llu records\n", edge[k], (unsigned long long)items[k], (unsigned long long)recs[k]);
+  }
   HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
   EventRec* d_recs = static_cast<EventRec*>(dev(size_t(totals[0]) * sizeof(EventRec)));
   uint32_t* d_side = u32(totals[1]);

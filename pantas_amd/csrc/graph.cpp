@@ -286,6 +286,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   g->icol.resize(A);
   g->islot.resize(A);
   const bool fast_csr = sorted_by_source && A > (1u << 16) && !force_seq;
+  bool csr_merged = false;
   if (fast_csr) {
     // links already grouped by source in node order (what vg / the annotator write): slot = rank among valid links
     RawVector<uint32_t> ikey(A), iidx(A);
@@ -371,7 +372,48 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       const uint32_t last = A ? keys[A - 1] : 0u;
       for (size_t u = size_t(A ? last + 1 : 0); u <= g->V; ++u) ptr[u] = uint32_t(A);
     };
-    radix_sort_pairs(okey, oidx, threads);          // slot q holds file-order record oidx[q]
+    // The usual case of "any order" is an augmented GFA: the original links, grouped by source as vg wrote them, and behind them
+    // the few links the reads added.  Then the stable sort by source is a merge of the sorted head with the (sorted) tail: a head
+    // record moves up by the tail records with a SMALLER source, a tail record stands behind every head record with the same or a
+    // smaller source -- no second radix sort over 2.6e8 records.
+    size_t head = A;
+    csr_merged = false;
+    {
+      std::vector<size_t> first_drop(threads, A);
+      parallel_chunks(A, threads, [&](unsigned t, size_t b2, size_t e2) {
+        for (size_t p2 = std::max<size_t>(b2, 1); p2 < e2; ++p2)
+          if (fsrc[p2] < fsrc[p2 - 1]) { first_drop[t] = p2; break; }
+      });
+      for (size_t v : first_drop) head = std::min(head, v);
+    }
+    if (A - head <= A / 8 && !getenv("PANTAS_CSR_NO_MERGE")) {
+      csr_merged = true;
+      const size_t tn = A - head;
+      std::vector<uint32_t> tidx(tn);
+      for (size_t j = 0; j < tn; ++j) tidx[j] = uint32_t(head + j);
+      std::stable_sort(tidx.begin(), tidx.end(), [&](uint32_t a, uint32_t b2) { return fsrc[a] < fsrc[b2]; });
+      std::vector<uint32_t> tsrc(tn);
+      for (size_t j = 0; j < tn; ++j) tsrc[j] = fsrc[tidx[j]];
+      parallel_chunks(head, threads, [&](unsigned, size_t b2, size_t e2) {
+        if (b2 >= e2) return;
+        size_t kt = size_t(std::lower_bound(tsrc.begin(), tsrc.end(), fsrc[b2]) - tsrc.begin());
+        for (size_t p2 = b2; p2 < e2; ++p2) {
+          while (kt < tn && tsrc[kt] < fsrc[p2]) ++kt;
+          okey[p2 + kt] = fsrc[p2];
+          oidx[p2 + kt] = uint32_t(p2);
+        }
+      });
+      const uint32_t* hb = fsrc.data();
+      parallel_chunks(tn, tn < 4096 ? 1 : threads, [&](unsigned, size_t b2, size_t e2) {
+        for (size_t j = b2; j < e2; ++j) {
+          const size_t q = size_t(std::upper_bound(hb, hb + head, tsrc[j]) - hb) + j;
+          okey[q] = tsrc[j];
+          oidx[q] = tidx[j];
+        }
+      });
+    } else {
+      radix_sort_pairs(okey, oidx, threads);        // slot q holds file-order record oidx[q]
+    }
     RawVector<uint32_t> slot_of(A);
     parallel_chunks(A, threads, [&](unsigned, size_t b2, size_t e2) {
       for (size_t q = b2; q < e2; ++q) {
@@ -421,7 +463,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
       }
   }
   }
-  pt.lap(fast_csr ? "CSR build (parallel)" : (A > (1u << 16) && !force_seq) ? "CSR build (parallel, links in any order)" : "CSR fill (sequential)");
+  pt.lap(fast_csr ? "CSR build (parallel)" : (A > (1u << 16) && !force_seq) ? (csr_merged ? "CSR build (parallel, sorted links + a tail in any order)" : "CSR build (parallel, links in any order)") : "CSR fill (sequential)");
   if (ns + nl > (size_t(1) << 24)) {
     // the per-line records of a whole-genome graph are ~20 GB: giving them back to the kernel takes a second, which a
     // thread of its own can spend while the caller goes on

@@ -145,7 +145,9 @@ def test_parallel_loader_equals_sequential(hostsim, tmp_path):
     pre = str(tmp_path / "w")
     Synth(seed=31, n_genes=700, n_lines=40000, base_id=10**7, intron_long_max=200).write(pre)
     outs = []
-    for env in ({}, {"PANTAS_LOADER_SEQUENTIAL": "1"}):
+    # (the augmented GFA carries the added links behind everything else: its CSR is the sorted head merged with that tail,
+    # or, PANTAS_CSR_NO_MERGE, a radix sort of all links)
+    for env in ({}, {"PANTAS_LOADER_SEQUENTIAL": "1"}, {"PANTAS_CSR_NO_MERGE": "1"}):
         e = {**os.environ, **env, "HOSTSIM_THREADS": "4"}
         a = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=e)
         assert a.returncode == 0, a.stderr
@@ -154,7 +156,7 @@ def test_parallel_loader_equals_sequential(hostsim, tmp_path):
         assert c.returncode == 0, c.stderr
         outs.append((a.stdout, c.stdout))
     assert outs[0][0].count("\n") > 150000
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
 
 
 def test_call_source_parameter_sweep(hostsim, tmp_path):
