@@ -139,6 +139,7 @@ struct Graph {
   std::vector<long long> len;
   void load(const char* path) {                    // [:121-126]
     text.open(path);
+    id.reserve(text.n / 64);          // (S and L lines of a spliced pangenome average ~75 bytes: about one segment per 150)
     std::vector<sv> tok;
     size_t i = 0;
     while (i < text.n) {

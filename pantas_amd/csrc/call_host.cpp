@@ -51,7 +51,6 @@ inline size_t par_min(size_t n) { static const bool small = getenv("PANTAS_TEST_
 
 // (trivial on purpose: arrays of 2.5e8 of them are sized without a constructor pass and every element is set by the tag scan)
 struct SegAttr { uint64_t ex_off; uint32_t ex_len; bool has_ex; };
-struct LinkAttr { uint64_t jn_off; uint32_t jn_len; bool has_jn, has_id, has_rc; int32_t rc; };
 
 [[noreturn]] void bad_tag(uint64_t off, Span f) {
   throw Error("ValueError", "GFA byte " + std::to_string(off) + ": tag '" + std::string(f.b, f.size()) +
@@ -329,12 +328,33 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
   build_call_tables_mem(g, f.data, f.size, t, threads);
 }
 
+// 64-bit mix over the bytes of the GTF: "the same GTF" for CallTables::Reusable
+static uint64_t bytes_hash(const char* p, size_t n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+  }
+  for (; i < n; ++i) h = (h ^ uint8_t(p[i])) * 0x100000001B3ull;
+  return h;
+}
+
 void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size, CallTables& t, unsigned threads,
-                           const AugmentResult* aug) {
+                           const AugmentResult* aug, CallTables* previous) {
   const double t0 = now_s();
   PhaseTimer pt("call_tables");
   if (threads == 0) threads = hw_threads();
   const char* base = g.text.data;
+  const uint64_t gtf_hash = aug ? bytes_hash(gtf_data, gtf_size) : 0;
+  // the graph-and-GTF-only part of an earlier fused build on this graph
+  const bool reuse = aug && previous && previous->reuse.valid && previous->reuse.text == static_cast<const void*>(base) &&
+                     previous->reuse.V == g.V && previous->reuse.graph_A == g.A && previous->reuse.gtf_size == gtf_size &&
+                     previous->reuse.gtf_hash == gtf_hash && !getenv("PANTAS_CALL_NO_REUSE");
+  t.reused_previous = reuse;
+  if (pt.on && reuse) fprintf(stderr, "[timing] call_tables: graph-and-GTF-only part taken over from the previous build on this handle\n");
   // inputs the reference's GFA loop dies on (call.py:145-181)
   if (g.first_bad_p_off != UINT64_MAX)
     throw Error("ValueError", "GFA byte " + std::to_string(g.first_bad_p_off) + ": P line does not have exactly 4 fields");
@@ -439,7 +459,9 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   (void)next_novel;
 
   Gtf gtf;
-  {
+  if (reuse) {
+    t.gene_name = std::move(previous->gene_name); t.gene_strand = std::move(previous->gene_strand); t.gene_chrom = std::move(previous->gene_chrom);
+  } else {
     MappedFile f;
     f.attach(gtf_data, gtf_size);
     parse_gtf(f, gtf, t);
@@ -447,9 +469,19 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
 
   pt.lap("gtf + link layout");
   // ---- phase A (parallel): locate the tags of every S line and every link slot -----------------
-  RawVector<SegAttr> sa(V);
+  RawVector<SegAttr> sa(reuse ? 0 : V);
   t.nc.resize(V);
   t.nflags.resize(V);
+  if (reuse) {
+    // the S lines were read (and their tags checked) by the build whose tables are taken over: only the counters are new
+    parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t n = b; n < e; ++n) {
+        if (aug->nc[n] > uint32_t(INT32_MAX)) throw Error("Unsupported", "node coverage beyond 2^31");
+        t.nc[n] = int32_t(aug->nc[n]);
+        t.nflags[n] = N_HAS_NC;
+      }
+    });
+  } else
   parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
     for (size_t n = b; n < e; ++n) {
       sa[n] = SegAttr{0, 0, false};
@@ -476,22 +508,21 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       }
     }
   });
-  RawVector<LinkAttr> la(A);
-  t.src.resize(A);
-  parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
-    for (size_t u = b; u < e; ++u)
-      for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s) {
-        t.src[s] = uint32_t(u);
-        la[s] = LinkAttr{0, 0, false, false, false, 0};
-        const uint32_t gs = graph_slot(s);
-        if (gs == NONE32) continue;      // a link added by the reads: filled in below
+  // tag records of the GRAPH's L lines, by graph slot: read from the text, or taken over from the previous build
+  RawVector<LinkAttr> la_graph;
+  if (reuse) la_graph = std::move(previous->reuse.la_graph);
+  else {
+    la_graph.resize(g.A);
+    parallel_chunks(g.A, g.A < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t gs = b; gs < e; ++gs) {
+        LinkAttr& a = la_graph[gs];
+        a = LinkAttr{0, 0, false, false, false, 0};
         const uint64_t off = g.slot_off[gs];
         const char* le = static_cast<const char*>(memchr(base + off, '\n', g.text.size - off));
         Span st = strip(Span{base + off, le ? le : base + g.text.size});
         Tokens tk(st);
         Span f;
         for (int i = 0; i < 6; ++i) tk.next(f);
-        LinkAttr& a = la[s];
         while (tk.next(f)) {
           Span name, value;
           if (!split_tag(f, name, value)) bad_tag(off, f);
@@ -501,6 +532,22 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
           else if (name_is(name, "JN")) { a.jn_off = uint64_t(value.b - base); a.jn_len = uint32_t(value.size()); a.has_jn = true; }
           else if (name_is(name, "ID")) a.has_id = true;
         }
+      }
+    });
+  }
+  RawVector<LinkAttr> la;
+  t.src.resize(A);
+  const bool la_is_graph = !aug;              // the command line on a GFA text: the layout is the graph, nothing to keep
+  if (la_is_graph) la = std::move(la_graph); else la.resize(A);
+  parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+    for (size_t u = b; u < e; ++u)
+      for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s) {
+        t.src[s] = uint32_t(u);
+        if (la_is_graph) continue;
+        const uint32_t gs = graph_slot(s);
+        if (gs == NONE32) { la[s] = LinkAttr{0, 0, false, false, false, 0}; continue; }      // a link added by the reads: filled in below
+        LinkAttr& a = la[s];
+        a = la_graph[gs];
         if (aug) {
           if (aug->rc[gs] > uint32_t(INT32_MAX)) throw Error("Unsupported", "link coverage beyond 2^31");
           a.rc = int32_t(aug->rc[gs]);
@@ -578,6 +625,12 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   // thread interns the occurrences of its node range in a map of its own (no locks), the maps are merged in chunk order
   // -- which IS first-appearance order -- touching each distinct tag once, and the per-node lists are written in parallel.
   std::vector<uint32_t> extag_tx;
+  if (reuse) {
+    // node-indexed and tag-indexed: nothing in them depends on a run
+    t.ex_ptr = std::move(previous->ex_ptr); t.ex_tag = std::move(previous->ex_tag); t.ex_tx = std::move(previous->ex_tx);
+    t.ex_gene = std::move(previous->ex_gene); t.extag_span = std::move(previous->extag_span);
+    t.tx_gene = std::move(previous->tx_gene);         // complete: the JN tags of the earlier build added theirs
+  } else {
   par_assign(t.ex_ptr, size_t(V) + 1, 0u, threads);
   {
     struct ExChunk {
@@ -682,6 +735,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       }
     });
   }
+  }
 
   pt.lap("intern EX: per-node lists (parallel)");
   // JN tags: only junction links carry them (5e5 of 2.6e8 slots): the tags are interned in slot order by one thread, the
@@ -700,6 +754,17 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   const size_t NJ = jslot.size();
   std::vector<uint32_t>& o_jn = t.jn_ptr; std::vector<uint32_t>& o_jt = t.jt_ptr;
   std::vector<uint32_t>& o_jx = t.jx_ptr; std::vector<uint32_t>& o_jg = t.jg_ptr;
+  std::vector<uint8_t> j_keyerr(NJ, 0);
+  if (reuse) {
+    // The junction links are links of the GRAPH (the reads add links with ID, never with JN) and a junction's ordinal is its
+    // rank among them in slot order, which the added links do not disturb: everything per junction ordinal carries over.
+    if (previous->reuse.n_junctions != NJ) throw Error("InternalError", "junction count changed between two builds on one graph");
+    o_jn = std::move(previous->jn_ptr); o_jt = std::move(previous->jt_ptr); o_jx = std::move(previous->jx_ptr); o_jg = std::move(previous->jg_ptr);
+    t.jn_ftx = std::move(previous->jn_ftx); t.jn_span = std::move(previous->jn_span);
+    t.jt = std::move(previous->jt); t.jx = std::move(previous->jx); t.jg = std::move(previous->jg);
+    j_keyerr = std::move(previous->reuse.j_keyerr);
+    for (size_t j = 0; j < NJ; ++j) if (j_keyerr[j]) t.lflags[jslot[j]] |= L_GENE_KEYERR;
+  } else {
   o_jn.assign(NJ + 1, 0); o_jt.assign(NJ + 1, 0); o_jx.assign(NJ + 1, 0); o_jg.assign(NJ + 1, 0);
   {
     // per thread: the tags of its junctions and the two transcript names each tag yields (:98-104 and :356 / :595), interned
@@ -800,11 +865,12 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
           o_jn[j] = uint32_t(on); o_jt[j] = uint32_t(ot); o_jx[j] = uint32_t(ox); o_jg[j] = uint32_t(og);
           on += k.n_ent[j - k.jb];
           ot += k.cnt[3 * (j - k.jb)]; ox += k.cnt[3 * (j - k.jb) + 1]; og += k.cnt[3 * (j - k.jb) + 2];
-          if (k.keyerr[j - k.jb]) t.lflags[jslot[j]] |= L_GENE_KEYERR;
+          if (k.keyerr[j - k.jb]) { t.lflags[jslot[j]] |= L_GENE_KEYERR; j_keyerr[j] = 1; }
         }
       }
     });
     o_jn[NJ] = uint32_t(b_jn[JC]); o_jt[NJ] = uint32_t(b_jt[JC]); o_jx[NJ] = uint32_t(b_jx[JC]); o_jg[NJ] = uint32_t(b_jg[JC]);
+  }
   }
   pt.lap("intern JN: tags of the junctions (sharded merge, parallel sets)");
   par_assign(t.jrow, A, uint32_t(CNONE), threads);
@@ -812,6 +878,8 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
 
   pt.lap("intern JN: slot -> junction map");
   // ---- lexicographic rank of segment names ------------------------------------------------------------
+  if (reuse) t.rank = std::move(previous->rank);
+  else {
   t.rank.resize(V);
   bool fixed_width = g.names.dense && V > 0;
   if (fixed_width) {
@@ -832,6 +900,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     for (uint32_t n = 0; n < V; ++n) order[n] = n;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return g.name_of(a).sv() < g.name_of(b).sv(); });
     for (uint32_t i = 0; i < V; ++i) t.rank[order[i]] = i;
+  }
   }
 
   pt.lap("name ranks");
@@ -886,6 +955,15 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   });
   pt.lap("lists + probes");
   t.parse_s = now_s() - t0;
+  if (previous) previous->reuse.valid = false;      // whatever was taken out of it, it is not a set of tables any more
+  if (aug) {
+    // what the next build on this graph may take over (the handle keeps these tables until then)
+    CallTables::Reusable& r = t.reuse;
+    r.gtf_hash = gtf_hash; r.gtf_size = gtf_size; r.graph_A = g.A; r.V = g.V; r.text = base; r.n_junctions = NJ;
+    r.la_graph = std::move(la_graph);
+    r.j_keyerr = std::move(j_keyerr);
+    r.valid = true;
+  }
   if (size_t(V) + A > (size_t(1) << 24)) {
     // the per-line tag records of a whole-genome graph are ~13 GB: handed to a thread of its own to give back (a second)
     auto* junk = new std::tuple<RawVector<SegAttr>, RawVector<LinkAttr>, RawVector<uint32_t>>(std::move(sa), std::move(la), std::move(attr_slot));

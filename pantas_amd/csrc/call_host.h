@@ -23,6 +23,9 @@ struct CallOptions {
 
 struct StrRef { uint64_t off; uint32_t len; };
 
+// tag record of one L line (call_host.cpp fills it; kept per graph slot between builds on the same graph, see CallTables::Reusable)
+struct LinkAttr { uint64_t jn_off; uint32_t jn_len; bool has_jn, has_id, has_rc; int32_t rc; };
+
 struct CallTables {
   // ---- link layout the call path works on: the graph's CSR, or (fused augment -> call) a copy
   //      extended by the links the reads added, which the reference appends after the GFA's
@@ -54,6 +57,19 @@ struct CallTables {
   std::vector<StrRef> extag_span;            // per EX tag id
   std::vector<std::string> gene_name, gene_strand, gene_chrom;
   double parse_s = 0;
+  // ---- what a later build on the SAME graph and GTF takes over instead of computing it again (replicates: the tags of the graph
+  //      and the GTF do not change between augment runs; counters, added links and everything indexed by slot do).  Filled by a
+  //      fused build (`aug` given); a build that is handed these tables as `previous` MOVES the arrays out of them.
+  struct Reusable {
+    bool valid = false;
+    uint64_t gtf_hash = 0;
+    size_t gtf_size = 0, graph_A = 0, n_junctions = 0;
+    uint32_t V = 0;
+    const void* text = nullptr;           // the graph's mapped text: spans point into it
+    RawVector<LinkAttr> la_graph;         // tag record of every slot of the GRAPH (before the counters of a run replace RC)
+    std::vector<uint8_t> j_keyerr;        // per junction ordinal: a transcript of its JN tags is missing from the GTF
+  } reuse;
+  bool reused_previous = false;           // this build took the previous tables' static part
 };
 
 // Parses the tags of an (augmented) GFA already loaded as `g` plus the GTF.  Throws Error where
@@ -62,8 +78,11 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
 // `aug` (optional): results of an augment run on the same graph.  NC / RC then come from its
 // counters and its novel links join the layout, exactly as if the augmented GFA text had been
 // written and parsed again.
+// `previous` (optional, fused builds): the tables of an earlier fused build on this graph; when its GTF was the same bytes, the
+// graph-and-GTF-only part (tag records, EX / JN interning, name ranks, gene table) is moved over from it instead of recomputed.
+// `previous` is left unusable either way.
 void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size, CallTables& t, unsigned threads = 0,
-                           const AugmentResult* aug = nullptr);
+                           const AugmentResult* aug = nullptr, CallTables* previous = nullptr);
 
 // A CallView over the host arrays (used by the CPU test harness; the product builds one over
 // device copies in call.hip).

@@ -986,7 +986,12 @@ __attribute__((visibility("default"))) int pantas_call_prepare_fused(pantas_grap
     auto t = std::make_unique<CallTables>();
     MappedFile f;
     if (gtf_text) f.attach(gtf_text, size_t(size)); else f.open(gtf_path);
-    build_call_tables_mem(*g->g, f.data, f.size, *t, 0, &g->res);
+    // a second replicate on this handle: the tables of the first hand their graph-and-GTF-only part over (and are gutted by it,
+    // so they and their device copy go first)
+    std::unique_ptr<CallTables> previous = std::move(g->call_tables);
+    g->call_dev.reset();
+    build_call_tables_mem(*g->g, f.data, f.size, *t, 0, &g->res, previous.get());
+    previous.reset();
     double t0 = now_s();
     g->call_dev = upload_call(*g->g, *t, device);
     g->call_upload_s = now_s() - t0;

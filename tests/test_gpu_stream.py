@@ -179,3 +179,36 @@ def test_replicates_events_only(tmp_path):
     r = subprocess.run([sys.executable, "-m", "pantas_amd.distributed", "replicates", "--out-dir", str(tmp_path / "x"), "--no-aug-gfa", f"{d}/in.gfa", str(gaf)],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 2
+
+
+def test_replicates_take_over_the_static_call_tables(tmp_path):
+    """Second and later replicates of one process reuse the graph-and-GTF-only part of the call tables (tag records, EX / JN
+    interning, name ranks, gene table): three DIFFERENT read sets on one graph give the files a process without the reuse
+    writes, and the files of the two command lines."""
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "w")
+    kw = dict(seed=13, n_genes=300, n_lines=30000, p_novel_skip=0.04, p_indel=0.05)
+    Synth(**kw).write(pre)
+    gafs = [pre + ".gaf"]
+    for b in (1, 2):
+        Synth(line_offset=b * 30000, **kw).write(f"{pre}.b{b}")
+        assert open(f"{pre}.b{b}.gfa", "rb").read() == open(pre + ".gfa", "rb").read()
+        gafs.append(f"{pre}.b{b}.gaf")
+    assert len({open(g, "rb").read() for g in gafs}) == 3
+    outs = {}
+    for mode, env in (("reuse", {}), ("fresh", {"PANTAS_CALL_NO_REUSE": "1"})):
+        out = tmp_path / mode
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.distributed", "replicates", "--out-dir", str(out), "--gtf", pre + ".gtf",
+                            "--call", "--rca 2 --novel", "--no-aug-gfa", pre + ".gfa", *gafs], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                           env={**os.environ, **env, "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "PANTAS_TIMING": "1"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        taken = r.stderr.count("taken over from the previous build")
+        assert taken == (2 if mode == "reuse" else 0), r.stderr[-3000:]
+        outs[mode] = [(out / (os.path.basename(g) + ".events.csv")).read_bytes() for g in gafs]
+    assert outs["reuse"] == outs["fresh"]
+    assert len(set(outs["reuse"])) == 3 and all(o.count(b"\n") > 100 for o in outs["reuse"])
+    # and the command lines on the third read set
+    with open(pre + ".cli.gfa", "wb") as f:
+        subprocess.run([sys.executable, "-m", "pantas_amd.augment", gafs[2], pre + ".gfa"], stdout=f, cwd=ROOT, check=True, stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.call", "--rca", "2", "--novel", pre + ".cli.gfa", pre + ".gtf"], cwd=ROOT, capture_output=True, timeout=600)
+    assert r.returncode == 0 and r.stdout == outs["reuse"][2]

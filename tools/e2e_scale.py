@@ -108,7 +108,18 @@ def main():
     ap.add_argument("--check-cpp-oracle", action="store_true",
                     help="run oracle/augment_oracle.cpp (the independent C++ restatement, all cores) on the same files and compare the "
                          "augmented GFA byte for byte")
+    ap.add_argument("--heartbeat", default=None, help="append a line to this file every 30 s (gpurun takes 7 silent minutes for a hang)")
     a = ap.parse_args()
+    if a.heartbeat:
+        import threading
+
+        def beat():
+            t0 = time.perf_counter()
+            while True:
+                with open(a.heartbeat, "a") as f:
+                    f.write(f"{time.perf_counter() - t0:.0f} s\n")
+                time.sleep(30)
+        threading.Thread(target=beat, daemon=True).start()
     from pantas_amd.engine import Synth
     desc, kw, *rest = bench.SCALES[a.scale]
     if rest and a.blocks == 1:
