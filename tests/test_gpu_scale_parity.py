@@ -5,7 +5,7 @@
 * `test_whole_s3_vs_cpp_oracle`: ALL of S3 (human chr1 scale, 10 M lines) through `pantas augment` against the independent C++
   form of the oracle (oracle/augment_oracle.cpp, pinned to the reference's goldens by tests/test_oracle_cpp.py) on the host
   cores: the two augmented GFAs are the same file.  (The same check of ALL of S4 -- 50 M lines, 2.5e8 segments, 23 GB of output --
-  takes minutes of single-thread GFA indexing in the oracle and is run by `tools/e2e_scale.py --check-cpp-oracle`:
+  takes minutes of single-thread GFA indexing in the oracle: `test_whole_s4_vs_cpp_oracle`, run with PANTAS_WHOLE_S4=1 once per round:
   profiles/r2_e2e_s4_cpp_oracle.json.)
 * `test_full_graph_slice_vs_oracle[s3|s4]`: the FULL human-chr1 / human whole-genome graph (2.5e8 segments, ids in the
   1e9 range, the dense name table, counter offsets beyond 2^30 words) with a slice of the read stream spread over every
@@ -58,22 +58,39 @@ def gfa_lines():
     return exe
 
 
-def test_whole_s3_vs_cpp_oracle():
+def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads):
+    """`pantas augment` on the whole workload of a BASELINE scale against oracle/augment_oracle.cpp on the host cores: one file."""
+    import json
+    import threading
+    import time
     import bench
     from pantas_amd.engine import Synth
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    tmp = workdir(12)
+    tmp = workdir(need_gb)
+    beat = os.path.join(ROOT, "gpurun_out", "heartbeat.txt")       # (a silent GPU-box command is taken for hung after 7 minutes)
+    stop = threading.Event()
+
+    def heartbeat():
+        while not stop.wait(30):
+            if os.path.isdir(os.path.dirname(beat)):
+                with open(beat, "a") as f:
+                    f.write(f"{scale} parity {time.strftime('%H:%M:%S')}\n")
+    threading.Thread(target=heartbeat, daemon=True).start()
     try:
-        pre = os.path.join(tmp, "s3")
-        Synth(seed=5, **bench.SCALES["s3"][1]).write(pre)
+        pre = os.path.join(tmp, scale)
+        Synth(seed=5, **bench.SCALES[scale][1]).write(pre)
+        t0 = time.perf_counter()
         with open(pre + ".gpu.gfa", "wb") as f:
             r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
+        t1 = time.perf_counter()
         with open(pre + ".or.gfa", "wb") as f:
-            o = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, 32)),
+            o = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, oracle_threads)),
                                 pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
         assert o.returncode == 0, o.stderr.decode()[-2000:]
-        assert os.path.getsize(pre + ".gpu.gfa") == os.path.getsize(pre + ".or.gfa") > 10**9
+        t2 = time.perf_counter()
+        size = os.path.getsize(pre + ".gpu.gfa")
+        assert size == os.path.getsize(pre + ".or.gfa") > 10**9
         with open(pre + ".gpu.gfa", "rb") as x, open(pre + ".or.gfa", "rb") as y:
             while True:
                 a, b = x.read(1 << 26), y.read(1 << 26)
@@ -82,8 +99,25 @@ def test_whole_s3_vs_cpp_oracle():
                     break
         rej = [l for l in o.stderr.decode().splitlines() if l.startswith("Rejected alignments:")]
         assert rej and rej[0] in r.stderr.decode()
+        if os.environ.get("PANTAS_PARITY_JSON"):
+            json.dump({"scale": scale, "workload": bench.SCALES[scale][0], "aug_gfa_equals_cpp_oracle": True, "bytes": size,
+                       "engine_augment_wall_s": t1 - t0, "cpp_oracle_wall_s": t2 - t1,
+                       "cpp_oracle_stats": json.loads(o.stderr.decode().strip().splitlines()[-1])},
+                      open(os.environ["PANTAS_PARITY_JSON"], "w"), indent=1)
     finally:
+        stop.set()
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_whole_s3_vs_cpp_oracle():
+    _whole_workload_vs_cpp_oracle("s3", 12, 32)
+
+
+@pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S4"),
+                    reason="11 minutes (the oracle hashes 2.5e8 segment names on one thread and prints 23 GB on one): PANTAS_WHOLE_S4=1; "
+                           "the round's run is profiles/r2_e2e_s4_cpp_oracle.json")
+def test_whole_s4_vs_cpp_oracle():
+    _whole_workload_vs_cpp_oracle("s4", 80, 64)
 
 
 def test_e2e_command_lines_vs_oracle():

@@ -105,9 +105,6 @@ def main():
     ap.add_argument("--replicates", type=int, default=0,
                     help="also time N replicates of the GAF through ONE `pantas_amd.distributed replicates` process (graph parsed once, "
                          "call on the augment result without the GFA text round trip) and compare its files with the command lines'")
-    ap.add_argument("--check-cpp-oracle", action="store_true",
-                    help="run oracle/augment_oracle.cpp (the independent C++ restatement, all cores) on the same files and compare the "
-                         "augmented GFA byte for byte")
     ap.add_argument("--heartbeat", default=None, help="append a line to this file every 30 s (gpurun takes 7 silent minutes for a hang)")
     a = ap.parse_args()
     if a.heartbeat:
@@ -178,18 +175,6 @@ def main():
         res["call"] = {"wall_s": dt, "events": rows - 1, "events_per_s": (rows - 1) / dt, "phases": phases(err), "peak_rss_gb": rss,
                        "out_bytes": os.path.getsize(pre + ".csv")}
         res["total_s"] = res["augment"]["wall_s"] + res["call"]["wall_s"]
-        if a.check_cpp_oracle:
-            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-            t0 = time.perf_counter()
-            with open(pre + ".oracle.gfa", "wb") as f:
-                r = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, 64)),
-                                    pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
-            if r.returncode != 0:
-                raise RuntimeError("augment_oracle_cpp: " + r.stderr.decode(errors="replace")[-2000:])
-            res["cpp_oracle"] = {"wall_s": time.perf_counter() - t0, "stats": json.loads(r.stderr.decode().strip().splitlines()[-1]),
-                                 "aug_gfa_equals_cpp_oracle": same_file(pre + ".aug.gfa", pre + ".oracle.gfa"),
-                                 "bytes": os.path.getsize(pre + ".oracle.gfa")}
-            os.unlink(pre + ".oracle.gfa")
         if a.replicates:
             res["replicates"] = replicates_leg(a, pre, env, py)
         if a.null_out:
@@ -199,7 +184,7 @@ def main():
             res["call_to_dev_null"] = {"wall_s": dt, "phases": phases(err)}
     finally:
         if not a.keep:
-            for ext in (".gaf", ".gfa", ".gtf", ".aug.gfa", ".csv", ".gfa.pgc", ".aug2.gfa", ".oracle.gfa"):
+            for ext in (".gaf", ".gfa", ".gtf", ".aug.gfa", ".csv", ".gfa.pgc", ".aug2.gfa"):
                 try:
                     os.unlink(pre + ext)
                 except OSError:
