@@ -814,12 +814,29 @@ void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   HIP_OK(hipStreamSynchronize(stream));
 }
 
+__global__ void warm_augment_kernel() {}
+void warm_up_call_module(hipStream_t s);        // call.hip
+void warm_up_tokenize_module(hipStream_t s);    // tokenize.hip
+
+// What the first HIP calls of a process pay for -- the context, the queues behind the first stream, the first allocation, the
+// code objects of this library (one per .hip file, loaded at the first launch of one of its kernels): about a second, spent here on
+// a thread of its own while the graph is parsed.
 void warm_up_device(int device) {
   std::thread([device] {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return;
     if (hipSetDevice(device) != hipSuccess) return;
     (void)hipFree(nullptr);          // forces the context
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+    void* p = nullptr;
+    if (hipMalloc(&p, 1 << 20) == hipSuccess) (void)hipFree(p);
+    hipLaunchKernelGGL(warm_augment_kernel, dim3(1), dim3(64), 0, s);
+    warm_up_call_module(s);
+    warm_up_tokenize_module(s);
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
   }).detach();
 }
 
@@ -1141,8 +1158,11 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   if (std::find(d.rare_done.begin(), d.rare_done.end(), b.id) == d.rare_done.end())
     throw Error("ProtocolError", "main kernel of a batch whose rare-key kernel has not run");
   d.main_started = true;
+  PhaseTimer pt("launch_main");
   if (std::find(d.main_done.begin(), d.main_done.end(), b.id) == d.main_done.end()) { register_batch_main(d, b); d.main_done.push_back(b.id); }
+  pt.lap("register batch");
   ensure_tables(d);
+  pt.lap("tables sized");
   d.sync_slow();
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
@@ -1207,6 +1227,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   }
   float m = 0;
   HIP_OK(hipEventElapsedTime(&m, d.ev[1], d.ev[2]));
+  pt.lap("kernels + wait");
   return m;
 }
 
