@@ -42,6 +42,10 @@ int pantas_device_count(void);
 /* optional: starts the HIP runtime and the context of `device` on a thread of its own and returns at once -- the second it takes
  * on a cold process then runs beside the parsing of the GFA (the command lines call it first thing) */
 void pantas_device_warmup(int device);
+/* the same start-up on the calling thread, returning when it is done.  For a caller whose next seconds are a graph parse on every
+ * core: the parse's page faults hold the address-space lock the runtime's start-up needs, and the background thread was measured to
+ * take longer than the parse (0.9 s left over when the graph went to the device) where the same calls take 0.25 s up front. */
+void pantas_device_init(int device);
 
 /* Structs cross this boundary by pointer and have grown between releases.  Every struct below therefore starts with
  * struct_size, which the CALLER sets to the sizeof() of the struct it was compiled (or, for a ctypes binding, declared)

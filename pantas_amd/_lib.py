@@ -101,6 +101,7 @@ def _load():
         "pantas_device_count": (i32, []),
         "pantas_abi_version": (i32, []),
         "pantas_device_warmup": (None, [i32]),
+        "pantas_device_init": (None, [i32]),
         "pantas_graph_load": (i32, [C.c_char_p, P(vp)]),
         "pantas_graph_free": (None, [vp]),
         "pantas_graph_get_stats": (i32, [vp, P(GraphStats)]),

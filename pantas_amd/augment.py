@@ -29,7 +29,9 @@ def main(argv) -> int:
     try:
         _lap("imports done")
         from ._lib import lib
-        lib.pantas_device_warmup(device)       # HIP runtime start-up beside the GFA parse
+        # HIP runtime start-up before the GFA parse (0.25 s): on a thread beside it, it was starved by the parse's page faults and
+        # left 0.9 s for the moment the graph goes to the device; `call` has its table build between parse and upload and keeps the thread
+        lib.pantas_device_init(device)
         g = Graph(gfa_file, cache=graph_cache_path(gfa_file))   # PANTAS_GRAPH_CACHE: the graph is shared by all replicates
         _lap("graph loaded")
         g.to_device(device)

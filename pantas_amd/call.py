@@ -59,7 +59,7 @@ def run(args) -> int:
         _stamp("Parsing GFA..")
         _lap("imports done")
         from ._lib import lib
-        lib.pantas_device_warmup(device)       # HIP runtime start-up beside the GFA parse
+        lib.pantas_device_init(device)         # HIP runtime start-up and the streams of the run, while the process is small
         g = Graph(args.GFA)
         _lap("graph loaded")
         _stamp("Parsing GTF..")

@@ -57,6 +57,7 @@ int device_count();                                   // 0 when no HIP device is
 // Starts the HIP runtime and the context of `device` on a thread of its own (about a second on a cold process) so that it
 // runs beside the parsing of the GFA instead of in front of the first upload.  Harmless without a device.
 void warm_up_device(int device);
+void init_device(int device);     // the same on the calling thread
 DeviceGraphPtr upload_graph(const Graph& g, int device);
 void reset_counters(DeviceGraph& dg);                 // zero NC/RC/IL/OL, clear flags and tables
 DeviceBatchPtr upload_batch(DeviceGraph& dg, const GafBatch& b);

@@ -821,24 +821,52 @@ void warm_up_tokenize_module(hipStream_t s);    // tokenize.hip
 // What the first HIP calls of a process pay for -- the context, the queues behind the first stream, the first allocation, the
 // code objects of this library (one per .hip file, loaded at the first launch of one of its kernels): about a second, spent here on
 // a thread of its own while the graph is parsed.
-void warm_up_device(int device) {
-  std::thread([device] {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return;
-    if (hipSetDevice(device) != hipSuccess) return;
-    (void)hipFree(nullptr);          // forces the context
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
-    void* p = nullptr;
-    if (hipMalloc(&p, 1 << 20) == hipSuccess) (void)hipFree(p);
-    hipLaunchKernelGGL(warm_augment_kernel, dim3(1), dim3(64), 0, s);
-    warm_up_call_module(s);
-    warm_up_tokenize_module(s);
-    (void)hipGetLastError();
-    (void)hipStreamSynchronize(s);
-    (void)hipStreamDestroy(s);
-  }).detach();
+static std::mutex g_spare_mu;
+static std::vector<std::pair<int, hipStream_t>> g_spare_streams;      // made by device start-up, handed out by take_stream
+constexpr int SPARE_STREAMS = 4;      // the graph's two, the call tables' one, the text prefetcher's one
+
+hipStream_t take_stream(int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    for (size_t i = 0; i < g_spare_streams.size(); ++i)
+      if (g_spare_streams[i].first == device) {
+        hipStream_t s = g_spare_streams[i].second;
+        g_spare_streams.erase(g_spare_streams.begin() + long(i));
+        return s;
+      }
+  }
+  hipStream_t s = nullptr;
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return s;
 }
+
+static void warm_up_body(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return;
+  if (hipSetDevice(device) != hipSuccess) return;
+  (void)hipFree(nullptr);          // forces the context
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return;
+  void* p = nullptr;
+  if (hipMalloc(&p, 1 << 20) == hipSuccess) (void)hipFree(p);
+  hipLaunchKernelGGL(warm_augment_kernel, dim3(1), dim3(64), 0, s);
+  warm_up_call_module(s);
+  warm_up_tokenize_module(s);
+  (void)hipGetLastError();
+  (void)hipStreamSynchronize(s);
+  // streams for later: made now, while the process is small
+  std::vector<hipStream_t> made{s};
+  for (int i = 1; i < SPARE_STREAMS; ++i) {
+    hipStream_t x = nullptr;
+    if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) break;
+    made.push_back(x);
+  }
+  std::lock_guard<std::mutex> lk(g_spare_mu);
+  for (hipStream_t x : made) g_spare_streams.emplace_back(device, x);
+}
+void warm_up_device(int device) { std::thread([device] { warm_up_body(device); }).detach(); }
+void init_device(int device) { warm_up_body(device); }
 
 int device_count() {
   int n = 0;
@@ -879,9 +907,11 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   d->device = device;
   d->V = g.V;
   d->A = g.A;
-  HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
+  d->stream = take_stream(device);
+  d->stream2 = take_stream(device);
+  pt.lap("streams");
   for (auto& e : d->ev) HIP_OK(hipEventCreate(&e));
+  pt.lap("events");
   HIP_OK(hipMalloc(&d->word, std::max<size_t>(1, g.V) * 4));
   HIP_OK(hipMalloc(&d->row_ptr, (size_t(g.V) + 1) * 4));
   HIP_OK(hipMalloc(&d->col, std::max<size_t>(1, g.A) * 4));
@@ -894,7 +924,7 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   }
   HIP_OK(hipMalloc(&d->small, 64));
   HIP_OK(hipMalloc(&d->slow_dev, sizeof(SlowTables)));
-  pt.lap("context, streams, hipMalloc");
+  pt.lap("hipMalloc of the graph arrays and counters");
   h2d_staged(d->word, g.seg_len.data(), size_t(g.V) * 4, d->stream);
   h2d_staged(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, d->stream);
   h2d_staged(d->col, g.col.data(), size_t(g.A) * 4, d->stream);

@@ -219,7 +219,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   g_up_bytes = 0;
   DeviceCallPtr d(new DeviceCall());
   d->device = device;
-  HIP_OK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+  d->stream = take_stream(device);
   pt.lap("device, stream");
   HIP_OK(hipEventCreate(&d->ev0));
   HIP_OK(hipEventCreate(&d->ev1));

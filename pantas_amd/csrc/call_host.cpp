@@ -346,6 +346,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
                            const AugmentResult* aug, CallTables* previous) {
   const double t0 = now_s();
   PhaseTimer pt("call_tables");
+  release_deferred();      // host-only work from here to the upload: the parse's temporaries are freed beside it
   if (threads == 0) threads = hw_threads();
   const char* base = g.text.data;
   const uint64_t gtf_hash = aug ? bytes_hash(gtf_data, gtf_size) : 0;
@@ -967,7 +968,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   if (size_t(V) + A > (size_t(1) << 24)) {
     // the per-line tag records of a whole-genome graph are ~13 GB: handed to a thread of its own to give back (a second)
     auto* junk = new std::tuple<RawVector<SegAttr>, RawVector<LinkAttr>, RawVector<uint32_t>>(std::move(sa), std::move(la), std::move(attr_slot));
-    std::thread([junk] { delete junk; }).detach();
+    defer_free(size_t(V) * sizeof(SegAttr) + A * (sizeof(LinkAttr) + 4), [junk] { delete junk; });      // (common.h: when the output is being written)
   }
 }
 

@@ -145,6 +145,7 @@ __attribute__((visibility("default"))) const char* pantas_version(void) { return
 __attribute__((visibility("default"))) int pantas_device_count(void) { return device_count(); }
 __attribute__((visibility("default"))) int pantas_abi_version(void) { return PANTAS_ABI_VERSION; }
 __attribute__((visibility("default"))) void pantas_device_warmup(int device) { try { warm_up_device(device); } catch (...) {} }
+__attribute__((visibility("default"))) void pantas_device_init(int device) { try { init_device(device); } catch (...) {} }
 
 __attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_path, pantas_graph** out) {
   return guarded([&] {
@@ -174,7 +175,10 @@ __attribute__((visibility("default"))) int pantas_graph_load_cached(const char* 
   });
 }
 
-__attribute__((visibility("default"))) void pantas_graph_free(pantas_graph* g) { delete g; }
+__attribute__((visibility("default"))) void pantas_graph_free(pantas_graph* g) {
+  release_deferred();      // nothing parked outlives the handle it came from
+  delete g;
+}
 
 __attribute__((visibility("default"))) int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out) {
   return guarded([&] {
@@ -474,6 +478,7 @@ __attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g
     g->res.rejected = g->rejected;
     g->res.skipped = g->skipped;
     g->have_result = true;
+    release_deferred();      // the device work of the run is over: what the parse left behind is freed beside whatever comes next
   });
 }
 
@@ -820,6 +825,7 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     // raised it) -- so the rows can go to the descriptor block by block instead of through one 10 GB string
     std::string err;
     if (fd_csv >= 0) write_fd(fd_csv, std::string(CALL_CSV_HEADER) + "\n");
+    release_deferred();      // (common.h) the tag records of the table build are freed beside the rendering
     render_events_to_fd(*g->g, *g->call_tables, recs.data(), recs.size(), co.side.data(), co.tasks.data(), co.paths.data(), fd_csv, err);
     double t1 = now_s();
     if (fd_err >= 0) write_fd(fd_err, err);

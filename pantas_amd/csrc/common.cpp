@@ -1,4 +1,6 @@
 #include "common.h"
+#include <cstdio>
+#include <thread>
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -290,6 +292,45 @@ void OrderedOutput::finish() {
 double now_s() {
   using namespace std::chrono;
   return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+namespace {
+std::mutex g_deferred_mu;
+std::vector<std::function<void()>> g_deferred;
+
+size_t mem_available_bytes() {
+  FILE* f = fopen("/proc/meminfo", "r");
+  if (!f) return SIZE_MAX;
+  char line[256];
+  size_t kb = SIZE_MAX;
+  while (fgets(line, sizeof line, f)) {
+    unsigned long long v = 0;
+    if (sscanf(line, "MemAvailable: %llu kB", &v) == 1) { kb = size_t(v); break; }
+  }
+  fclose(f);
+  return kb == SIZE_MAX ? SIZE_MAX : kb * 1024;
+}
+}  // namespace
+
+void defer_free(size_t bytes, std::function<void()> fn) {
+  if (getenv("PANTAS_KEEP_TEMPORARIES")) return;            // experiment switch: leak them
+  const size_t avail = mem_available_bytes();
+  if (getenv("PANTAS_FREE_AT_ONCE") || avail / 4 < bytes) {
+    std::thread(std::move(fn)).detach();
+    return;
+  }
+  std::lock_guard<std::mutex> lk(g_deferred_mu);
+  g_deferred.push_back(std::move(fn));
+}
+
+void release_deferred() {
+  std::vector<std::function<void()>> todo;
+  {
+    std::lock_guard<std::mutex> lk(g_deferred_mu);
+    todo.swap(g_deferred);
+  }
+  if (todo.empty()) return;
+  std::thread([todo = std::move(todo)] { for (const auto& fn : todo) fn(); }).detach();
 }
 
 }  // namespace pantas

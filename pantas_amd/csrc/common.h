@@ -150,6 +150,14 @@ struct NoInitAlloc {
   template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
 };
 template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
+// Giving tens of GB of temporaries back to the kernel takes seconds (50 - 85 ms per GB on the GPU box, huge pages or not) and holds
+// the address-space lock in long stretches: a free on a thread of its own right after the parse made the NEXT call that maps memory
+// -- the first hipMalloc / stream / pinned buffer -- wait for it (0.9 s at whole-genome scale).  So the big frees are parked
+// (defer_free) and started (release_deferred: one detached thread) when the run turns to writing its output file, which waits on
+// the file system, not on memory.  With less than four times `bytes` of memory available the free happens at once.
+void defer_free(size_t bytes, std::function<void()> fn);
+void release_deferred();
+
 // touches every page of [p, p + bytes) from several threads (first-touch page faults are the cost of a fresh buffer)
 void prefault(void* p, size_t bytes);
 

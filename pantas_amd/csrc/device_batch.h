@@ -19,6 +19,11 @@ namespace pantas {
       throw Error("HipError", std::string(#expr) + ": " + hipGetErrorString(e__));                     \
   } while (0)
 
+// A non-blocking stream on `device`: one of those device start-up made while the process was small, else a new one.  (A stream made
+// after a whole-genome graph was parsed -- 35 GB resident -- took 0.3 - 0.5 s on the GPU box, 9 ms in a fresh process: its queue is
+// mapped against the process as it is then.)  augment.hip
+hipStream_t take_stream(int device);
+
 // identity of a resident batch for the rare-before-main protocol of a run (an address can be reused after a free)
 inline uint64_t next_batch_id() {
   static std::atomic<uint64_t> n{1};

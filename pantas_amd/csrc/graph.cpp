@@ -468,7 +468,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
     // the per-line records of a whole-genome graph are ~20 GB: giving them back to the kernel takes a second, which a
     // thread of its own can spend while the caller goes on
     auto* junk = new std::tuple<std::vector<ChunkOut>, RawVector<uint32_t>, RawVector<uint32_t>>(std::move(outs), std::move(lu), std::move(lv));
-    std::thread([junk] { delete junk; }).detach();
+    defer_free((ns * sizeof(SRec) + nl * (sizeof(LRec) + 8)) * 3 / 2, [junk] { delete junk; });      // (common.h: when the output is being written)
   }
   return g;
 }

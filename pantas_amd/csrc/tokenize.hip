@@ -404,7 +404,7 @@ TextPrefetcherPtr make_text_prefetcher(DeviceGraph& dg, size_t max_bytes) {
   TextPrefetcherPtr p(new TextPrefetcher());
   p->device = gi.device;
   p->cap = text_padded_bytes(max_bytes);
-  HIP_OK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  p->stream = take_stream(gi.device);
   for (int k = 0; k < 2; ++k) HIP_OK(hipMalloc(&p->buf[k], p->cap));
   return p;
 }
