@@ -6,8 +6,26 @@ namespace pantas {
 
 namespace {
 
-struct SRec { uint64_t line_off, name_off; uint32_t name_len, seq_len; bool defines; };
-struct LRec { uint64_t line_off, u_off, v_off; uint32_t u_len, v_len; uint8_t ntok; };
+// One record per S / L line between the scan and the arrays of the graph: 2.5e8 + 2.6e8 of them at whole-genome scale, written once,
+// read twice and given back -- their size is load time (16 and 24 bytes: field positions as offsets from the line start, 10 GB
+// instead of 18).
+struct SRec {
+  uint64_t line_off;
+  uint32_t seq_len_def;                 // len(sequence) (< 2^30) | bit 31: the line starts with 'S' itself (no whitespace before it)
+  uint16_t name_delta, name_len;
+  uint64_t name_off() const { return line_off + name_delta; }
+  uint32_t seq_len() const { return seq_len_def & 0x7FFFFFFFu; }
+  bool defines() const { return (seq_len_def >> 31) != 0; }
+};
+struct LRec {
+  uint64_t line_off;
+  uint32_t v_delta;
+  uint16_t u_delta, u_len, v_len;
+  uint8_t ntok;
+  uint64_t u_off() const { return line_off + u_delta; }
+  uint64_t v_off() const { return line_off + v_delta; }
+};
+static_assert(sizeof(SRec) == 16 && sizeof(LRec) == 24, "loader records");
 
 struct ChunkOut {
   RawVector<SRec> s;      // (18 GB of records at whole-genome scale: huge pages)
@@ -36,8 +54,8 @@ void scan_chunk(const char* base, size_t b, size_t e, ChunkOut& out) {
           throw Error("IndexError", "GFA byte " + std::to_string(st.b - base) + ": S line with fewer than 3 fields");
         if (name.size() > 65535) throw Error("Unsupported", "segment name longer than 65535 bytes");
         if (seq.size() >= (size_t(1) << 30)) throw Error("Unsupported", "segment longer than 2^30-1 bases");
-        out.s.push_back(SRec{uint64_t(st.b - base), uint64_t(name.b - base), uint32_t(name.size()),
-                             uint32_t(seq.size()), *raw.b == 'S'});
+        if (name.b - st.b > 65535) throw Error("Unsupported", "GFA byte " + std::to_string(st.b - base) + ": more than 65535 bytes between the line start and the segment name");
+        out.s.push_back(SRec{uint64_t(st.b - base), uint32_t(seq.size()) | (*raw.b == 'S' ? 0x80000000u : 0u), uint16_t(name.b - st.b), uint16_t(name.size())});
       } else if (c == 'L') {
         if (st.size() > 1) {
           Tokens tk(st);
@@ -46,8 +64,10 @@ void scan_chunk(const char* base, size_t b, size_t e, ChunkOut& out) {
           while (n < 6 && tk.next(t[n])) ++n;
           if (n < 4)
             throw Error("IndexError", "GFA byte " + std::to_string(st.b - base) + ": L line with fewer than 4 fields");
-          out.l.push_back(LRec{uint64_t(st.b - base), uint64_t(t[1].b - base), uint64_t(t[3].b - base),
-                               uint32_t(t[1].size()), uint32_t(t[3].size()), n});
+          if (t[1].size() > 65535 || t[3].size() > 65535) throw Error("Unsupported", "segment name longer than 65535 bytes");
+          if (t[1].b - st.b > 65535 || uint64_t(t[3].b - st.b) > 0xFFFFFFFFull)
+            throw Error("Unsupported", "GFA byte " + std::to_string(st.b - base) + ": an L line with its fields too far apart");
+          out.l.push_back(LRec{uint64_t(st.b - base), uint32_t(t[3].b - st.b), uint16_t(t[1].b - st.b), uint16_t(t[1].size()), uint16_t(t[3].size()), n});
         }
       } else if (c == 'P') {
         ++out.p_lines;
@@ -110,7 +130,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   for (auto& o : outs) {
     for (auto& s : o.s) {
       uint64_t id;
-      if (!parse_canonical_u64(Span{base + s.name_off, base + s.name_off + s.name_len}, id)) { all_num = false; break; }
+      if (!parse_canonical_u64(Span{base + s.name_off(), base + s.name_off() + s.name_len}, id)) { all_num = false; break; }
       lo = std::min(lo, id);
       hi = std::max(hi, id);
     }
@@ -141,14 +161,14 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
         size_t k = sbase[i];
         for (auto& s : outs[i].s) {
           uint64_t id = 0;
-          parse_canonical_u64(Span{base + s.name_off, base + s.name_off + s.name_len}, id);
+          parse_canonical_u64(Span{base + s.name_off(), base + s.name_off() + s.name_len}, id);
           uint32_t expect = NONE32;
           if (!__atomic_compare_exchange_n(&ix.table[size_t(id - lo)], &expect, uint32_t(k), false, __ATOMIC_RELAXED, __ATOMIC_RELAXED))
             dup.store(true, std::memory_order_relaxed);
-          if (!s.defines) undefined.store(true, std::memory_order_relaxed);
-          g->seg_len[k] = s.seq_len;
+          if (!s.defines()) undefined.store(true, std::memory_order_relaxed);
+          g->seg_len[k] = s.seq_len();
           g->seg_line_off[k] = s.line_off;
-          g->seg_name_off[k] = s.name_off;
+          g->seg_name_off[k] = s.name_off();
           g->seg_name_len[k] = uint16_t(s.name_len);
           ++k;
         }
@@ -169,7 +189,7 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   g->seg_name_len.reserve(ns);
   for (auto& o : outs) {
     for (auto& s : o.s) {
-      Span nm{base + s.name_off, base + s.name_off + s.name_len};
+      Span nm{base + s.name_off(), base + s.name_off() + s.name_len};
       uint32_t* slot;
       if (ix.dense) {
         uint64_t id = 0;
@@ -182,16 +202,16 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
         // an S line behind leading whitespace that no plain S line backs: call.py strips the line before it looks at its
         // first byte (:146-147) and takes it; the augment script misses it in its first pass (:123) and dies with a
         // KeyError in the second (:387) -- the segment exists, and pantas_augment_reset refuses the graph
-        if (!s.defines && g->ws_only_seg_off == UINT64_MAX) g->ws_only_seg_off = s.line_off;
+        if (!s.defines() && g->ws_only_seg_off == UINT64_MAX) g->ws_only_seg_off = s.line_off;
         *slot = uint32_t(g->seg_len.size());
-        g->seg_len.push_back(s.seq_len);
+        g->seg_len.push_back(s.seq_len());
         g->seg_line_off.push_back(s.line_off);
-        g->seg_name_off.push_back(s.name_off);
+        g->seg_name_off.push_back(s.name_off());
         g->seg_name_len.push_back(uint16_t(s.name_len));
       } else {
         g->dup_names = true;
-        if (s.defines) {
-          g->seg_len[*slot] = s.seq_len;
+        if (s.defines()) {
+          g->seg_len[*slot] = s.seq_len();
           g->seg_line_off[*slot] = s.line_off;
         }
       }
@@ -218,8 +238,8 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
     for (size_t i = b; i < e; ++i) {
       size_t k = lbase[i];
       for (auto& r : outs[i].l) {
-        lu[k] = ix.find(Span{base + r.u_off, base + r.u_off + r.u_len});
-        lv[k] = ix.find(Span{base + r.v_off, base + r.v_off + r.v_len});
+        lu[k] = ix.find(Span{base + r.u_off(), base + r.u_off() + r.u_len});
+        lv[k] = ix.find(Span{base + r.v_off(), base + r.v_off() + r.v_len});
         ++k;
       }
     }
