@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--env", default="", help="extra NAME=VALUE pairs applied to every variant, comma separated")
     ap.add_argument("--del-hot", type=float, default=0.0, help="synthetic deletion skew (bench.py --del-hot)")
     ap.add_argument("--hot-sites", type=int, default=1000)
-    ap.add_argument("--p-indel", type=float, default=0.0)
+    ap.add_argument("--p-indel", type=float, default=-1.0, help="indel rate of the synthetic reads (default: the scale's own, 0.05)")
     args = ap.parse_args()
     from bench import SCALES
     from pantas_amd.engine import Graph, Synth
@@ -36,7 +36,7 @@ def main():
     if args.del_hot:
         kw["p_del_hot"] = args.del_hot
         kw["hot_sites"] = args.hot_sites
-    if args.p_indel:
+    if args.p_indel >= 0:
         kw["p_indel"] = args.p_indel
     syn = Synth(seed=7, **kw)
     g = Graph(text=syn.gfa).to_device(0)
