@@ -17,8 +17,8 @@
 // counts and keeps the earliest appearance, so the output is the single-thread output.  What cannot be cut that way is
 // the reference's `curr_cigar_len` leaking from one line into the next (a '~' as the first op a line reaches): with
 // T > 1 such a line is an error.
-// Deviations from Python's text handling, none of which the goldens or the synthetic inputs contain: lines end at '\n'
-// only (no universal newlines), integers are [+-]?[0-9]+, lengths count bytes.
+// Deviations from Python's text handling, none of which the goldens or the synthetic inputs contain: integers are
+// [+-]?[0-9]+, lengths count bytes.  (Universal newlines are applied when a file is mapped.)
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -54,8 +54,12 @@ struct Mapped {
     fstat(fd, &st);
     n = size_t(st.st_size);
     if (n) {
-      p = static_cast<const char*>(mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0));
-      if (p == MAP_FAILED) { perror("mmap"); exit(2); }
+      // a private, writable mapping: Python's universal newlines are applied in place -- a '\r' that no '\n' follows ends its line
+      char* w = static_cast<char*>(mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0));
+      if (w == MAP_FAILED) { perror("mmap"); exit(2); }
+      for (char* q = w; (q = static_cast<char*>(memchr(q, '\r', size_t(w + n - q)))) != nullptr; ++q)
+        if (q + 1 < w + n && q[1] != '\n') *q = '\n';
+      p = w;
     }
     close(fd);
   }

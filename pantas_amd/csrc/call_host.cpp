@@ -347,6 +347,12 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   const double t0 = now_s();
   PhaseTimer pt("call_tables");
   release_deferred();      // host-only work from here to the upload: the parse's temporaries are freed beside it
+  // a GTF with a '\r' that no '\n' follows: read the way Python does (common.h lone_cr), from a copy
+  RawVector<char> gtf_universal;
+  if (has_lone_cr(gtf_data, gtf_size)) {
+    universal_newlines_copy(gtf_data, gtf_size, gtf_universal);
+    gtf_data = gtf_universal.data();
+  }
   if (threads == 0) threads = hw_threads();
   const char* base = g.text.data;
   const uint64_t gtf_hash = aug ? bytes_hash(gtf_data, gtf_size) : 0;

@@ -48,6 +48,7 @@ struct StreamBatch {
   uint64_t device_bytes = 0;
 };
 struct StreamState {
+  RawVector<char> text_copy;          // universal newlines applied (stream_rare_pass): `file` then points here
   MappedFile file;
   int thr = 20;
   std::vector<StreamBatch> batches;
@@ -613,9 +614,15 @@ static uint64_t batch_device_bytes(const pantas_batch_stats& s) {
 }
 
 static void stream_rare_pass(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end, uint64_t first_line,
-                             pantas_batch_stats* stats, float* rare_ms) {
+                             pantas_batch_stats* stats, float* rare_ms, bool universal_newlines = false) {
   auto st = std::make_unique<StreamState>();
   st->file.open(gaf_path);
+  if (universal_newlines) {
+    // a '\r' that no '\n' follows ends its line, as it does for the reference (common.h lone_cr): the run reads a copy of the text
+    // with those bytes turned into '\n' -- cut into batches, counted in lines and tokenised like any other text
+    universal_newlines_copy(st->file.data, st->file.size, st->text_copy);
+    st->file.attach(st->text_copy.data(), st->text_copy.size());
+  }
   st->thr = thr;
   if (end == 0 || end > st->file.size) end = st->file.size;
   need(begin <= end, "bad byte range");
@@ -726,6 +733,12 @@ __attribute__((visibility("default"))) int pantas_augment_stream_rare(pantas_gra
     need(gaf_path != nullptr, "null argument");
     if (g->stream) throw Error("ProtocolError", "one streamed byte range per run: pantas_augment_reset first");
     stream_rare_pass(g, gaf_path, thr, begin, end, first_line, stats, rare_ms);
+    if (g->deferred && is_lone_cr_error(*g->deferred) && begin == 0 && (end == 0 || end >= g->stream->file.size)) {
+      // the whole file is this run's: read it again the way Python does (a byte range of a file shared between ranks keeps the
+      // refusal: where its lines start and how they are numbered is the caller's arithmetic)
+      if (pantas_augment_reset(g) != PANTAS_OK) throw Error(g_kind.c_str(), g_err);
+      stream_rare_pass(g, gaf_path, thr, 0, 0, first_line, stats, rare_ms, true);
+    }
   });
 }
 

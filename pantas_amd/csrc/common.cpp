@@ -1,4 +1,5 @@
 #include "common.h"
+#include <cstring>
 #include <cstdio>
 #include <thread>
 
@@ -331,6 +332,35 @@ void release_deferred() {
   }
   if (todo.empty()) return;
   std::thread([todo = std::move(todo)] { for (const auto& fn : todo) fn(); }).detach();
+}
+
+bool is_lone_cr_error(const std::exception& e) { return strstr(e.what(), LONE_CR_MARK) != nullptr; }
+
+bool has_lone_cr(const char* p, size_t n) {
+  const char* q = p;
+  const char* end = p + n;
+  while (q < end) {
+    q = static_cast<const char*>(memchr(q, '\r', size_t(end - q)));
+    if (!q) return false;
+    if (q + 1 < end && q[1] != '\n') return true;
+    ++q;
+  }
+  return false;
+}
+
+void universal_newlines_copy(const char* p, size_t n, RawVector<char>& out) {
+  out.resize(n);
+  char* o = out.data();
+  parallel_chunks(n, n < (size_t(1) << 22) ? 1u : hw_threads(), [&](unsigned, size_t b, size_t e) {
+    memcpy(o + b, p + b, e - b);
+    for (size_t i = b; i < e;) {
+      const char* q = static_cast<const char*>(memchr(o + i, '\r', e - i));
+      if (!q) break;
+      const size_t at = size_t(q - o);
+      if (at + 1 < n && p[at + 1] != '\n') o[at] = '\n';      // (p, not o: the next byte may belong to another thread's chunk)
+      i = at + 1;
+    }
+  });
 }
 
 }  // namespace pantas

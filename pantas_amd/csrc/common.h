@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <thread>
 #include <vector>
+#include <exception>
 #include <functional>
 #include <algorithm>
 
@@ -59,7 +60,9 @@ inline Span strip(Span s) {
 
 // Python reads text files with universal newlines: a '\r' that is not followed by '\n' ends a line too.  This engine splits
 // at '\n' only ('\r' is whitespace to it), so a text with such a byte would silently be read differently: every reader
-// refuses it instead.  [b, e) = one line without its '\n' (a '\r' as its last byte is the CR of a CRLF).  Returns the
+// stops at it (an Error whose text holds LONE_CR_MARK), and the callers that own the text read a COPY with every such byte turned
+// into '\n' instead (universal_newlines_copy: same size, same offsets, the reference's lines) -- a slow path nothing a mapper
+// or vg writes ever takes.  [b, e) = one line without its '\n' (a '\r' as its last byte is the CR of a CRLF).  Returns the
 // offending byte or nullptr.
 inline const char* lone_cr(const char* b, const char* e) {
   const char* p = b;
@@ -71,6 +74,10 @@ inline const char* lone_cr(const char* b, const char* e) {
   }
   return nullptr;
 }
+
+constexpr const char* LONE_CR_MARK = "lone carriage return";
+bool is_lone_cr_error(const std::exception& e);
+bool has_lone_cr(const char* p, size_t n);
 
 // Iterates whitespace-separated tokens of a (stripped or not) line.
 struct Tokens {
@@ -150,6 +157,8 @@ struct NoInitAlloc {
   template <class U> bool operator!=(const NoInitAlloc<U>&) const { return false; }
 };
 template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
+// out = [p, p + n) with every '\r' that no '\n' follows replaced by '\n' (universal newlines, see lone_cr above); many threads
+void universal_newlines_copy(const char* p, size_t n, RawVector<char>& out);
 // Giving tens of GB of temporaries back to the kernel takes seconds (50 - 85 ms per GB on the GPU box, huge pages or not) and holds
 // the address-space lock in long stretches: a free on a thread of its own right after the parse made the NEXT call that maps memory
 // -- the first hipMalloc / stream / pinned buffer -- wait for it (0.9 s at whole-genome scale).  So the big frees are parked

@@ -42,7 +42,7 @@ void scan_chunk(const char* base, size_t b, size_t e, ChunkOut& out) {
     const char* le = nl ? nl : end;
     Span raw{p, le};
     if (const char* cr = lone_cr(p, le))
-      throw Error("Unsupported", "GFA byte " + std::to_string(cr - base) + ": lone carriage return (Python's universal newlines end a line there; this engine splits at \\n only)");
+      throw Error("Unsupported", "GFA byte " + std::to_string(cr - base) + ": " + LONE_CR_MARK + " (Python's universal newlines end a line there; the loader reads a copy with them applied)");
     Span st = strip(raw);
     ++out.lines;
     if (st.size() > 0) {
@@ -86,18 +86,43 @@ void scan_chunk(const char* base, size_t b, size_t e, ChunkOut& out) {
 
 static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned threads);
 
-std::unique_ptr<Graph> load_graph(const char* path, unsigned threads) {
+// the graph over a copy of the text in which a '\r' that no '\n' follows ends its line, as it does for the reference
+static std::unique_ptr<Graph> parse_with_universal_newlines(const char* path, const char* data, size_t size, unsigned threads) {
   auto g = std::make_unique<Graph>();
   g->path = path;
-  g->text.open(path);
+  universal_newlines_copy(data, size, g->text_owned);
+  g->text.attach(g->text_owned.data(), g->text_owned.size());
   return parse_graph(std::move(g), threads);
 }
 
+std::unique_ptr<Graph> load_graph(const char* path, unsigned threads) {
+  {
+    auto g = std::make_unique<Graph>();
+    g->path = path;
+    g->text.open(path);
+    try {
+      return parse_graph(std::move(g), threads);
+    } catch (const Error& e) {
+      if (!is_lone_cr_error(e)) throw;
+    }
+  }
+  MappedFile f;
+  f.open(path);
+  return parse_with_universal_newlines(path, f.data, f.size, threads);
+}
+
 std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads) {
-  auto g = std::make_unique<Graph>();
-  g->path = "<memory>";
-  g->text.attach(data, size);
-  return parse_graph(std::move(g), threads);
+  {
+    auto g = std::make_unique<Graph>();
+    g->path = "<memory>";
+    g->text.attach(data, size);
+    try {
+      return parse_graph(std::move(g), threads);
+    } catch (const Error& e) {
+      if (!is_lone_cr_error(e)) throw;
+    }
+  }
+  return parse_with_universal_newlines("<memory>", data, size, threads);
 }
 
 static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned threads) {

@@ -37,6 +37,8 @@ struct NameIndex {
 
 struct Graph {
   MappedFile text;
+  RawVector<char> text_owned;      // the text with universal newlines applied (common.h lone_cr): `text` then points here, not at the file
+
   std::string path;
   uint32_t V = 0;          // distinct segment names
   uint64_t A = 0;          // adjacency slots (L lines with both ends known)

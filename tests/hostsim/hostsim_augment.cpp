@@ -82,6 +82,12 @@ int main(int argc, char** argv) {
     gaf.open(argv[1]);
     GafBatch b;
     tokenize_gaf(*g, gaf.data, gaf.size, thr, 0, threads, b);
+    RawVector<char> universal;
+    if (b.deferred && is_lone_cr_error(*b.deferred)) {      // as pantas_augment_stream_rare: the text again, with universal newlines applied
+      universal_newlines_copy(gaf.data, gaf.size, universal);
+      b = GafBatch();
+      tokenize_gaf(*g, universal.data(), universal.size(), thr, 0, threads, b);
+    }
     const uint64_t first_record_line = b.first_record_line;
     if (getenv("HOSTSIM_BUCKET")) bucket_by_locus(b, threads);
     Tables t;

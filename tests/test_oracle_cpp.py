@@ -11,8 +11,7 @@ from conftest import CASES, GOLDEN, ROOT
 
 EXE = os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp")
 EDGE = os.path.join(GOLDEN, "edge")
-# Python's universal newlines turn a lone '\r' into a line break; the C++ form cuts lines at '\n' only (stated in its header)
-LONE_CR = {"cr_mid_line", "cr_between_records"}
+LONE_CR = set()      # (the C++ form applies universal newlines when it maps a file)
 
 
 @pytest.fixture(scope="module")

@@ -61,9 +61,16 @@ def cases():
     out.append(dict(name="dup_l_jn_first", stage="call_aug_dup_l_first", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="same"))
     # ---- a lone carriage return: Python's universal newlines make it a line break --------------------------------
     cr_mid = [gaf[0], gaf[1].replace("\tcs:Z", "\r\tcs:Z"), gaf[2]]
-    out.append(dict(name="cr_mid_line", stage="augment", gfa=gfa, gaf=cr_mid, gtf=gtf, flags=[], engine="refuses"))
+    out.append(dict(name="cr_mid_line", stage="augment", gfa=gfa, gaf=cr_mid, gtf=gtf, flags=[], engine="same"))
     cr_sep = [gaf[0] + "\r" + gaf[1], gaf[2]]
-    out.append(dict(name="cr_between_records", stage="augment", gfa=gfa, gaf=cr_sep, gtf=gtf, flags=[], engine="refuses"))
+    out.append(dict(name="cr_between_records", stage="augment", gfa=gfa, gaf=cr_sep, gtf=gtf, flags=[], engine="same"))
+    # the same in the other two inputs: two S lines of the GFA / two rows of the GTF with a lone '\r' between them
+    k3 = [k for k, l in enumerate(gfa) if l.startswith("S\t1003")][0]
+    gfa_cr = gfa[:k3] + [gfa[k3] + "\r" + gfa[k3 + 1]] + gfa[k3 + 2:]
+    out.append(dict(name="cr_in_gfa", stage="augment", gfa=gfa_cr, gaf=gaf, gtf=gtf, flags=[], engine="same"))
+    out.append(dict(name="cr_in_gfa_call", stage="call_aug_cr", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0", "--novel"], engine="same"))
+    gtf_cr = [gtf[0] + "\r" + gtf[1]] + gtf[2:]
+    out.append(dict(name="cr_in_gtf", stage="call_aug_plain", gfa=gfa, gaf=gaf, gtf=gtf_cr, flags=["--rca", "0", "--novel"], engine="same"))
     crlf = [l + "\r" for l in gaf]
     out.append(dict(name="crlf_gaf", stage="augment", gfa=[l + "\r" for l in gfa], gaf=crlf, gtf=gtf, flags=[], engine="same"))
     return out
@@ -101,6 +108,9 @@ def main():
                 i = [k for k, l in enumerate(lines) if l.startswith("L\t1002\t+\t1004")][0]
                 s1002 = [l for l in lines if l.startswith("S\t1002")][0]
                 lines.insert(i + 1, s1002)            # a second S line for 1002 after some of its links
+            elif kind == "call_aug_cr":
+                i = [k for k, l in enumerate(lines) if l.startswith("S\t1003")][0]
+                lines[i:i + 2] = [lines[i] + "\r" + lines[i + 1]]      # a lone '\r' between two S lines of the augmented graph
             elif kind in ("call_aug_dup_l_last", "call_aug_dup_l_first"):
                 i = [k for k, l in enumerate(lines) if l.startswith("L\t1002\t+\t1004")][0]
                 plain = "L\t1002\t+\t1004\t+\t*\tRC:i:2"
