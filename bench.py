@@ -61,6 +61,25 @@ CALIBRATION = {"source": "profiles/r1_e2e_build_container_big.json", "augment_re
                "call_ref_seconds_per_J2": 1309.6 / 48483 ** 2, "call_flags": "--rca 3 --novel"}
 
 
+def cpu_quota_cores():
+    """cores the cgroup lets this process use at a time (cpu.max: quota / period), None when unlimited or unknown.  The GPU box shows
+    256 cores and grants 16: every host-side rate of this file is a 16-core rate there."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] == "max":
+                    return None
+                return float(txt[0]) / float(txt[1])
+            q = float(txt[0])
+            if q <= 0:
+                return None
+            return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError, IndexError):
+            pass
+    return None
+
+
 def host_ram_gb() -> float:
     try:
         with open("/proc/meminfo") as f:
@@ -139,12 +158,14 @@ def cpp_baseline(kw: dict, tmp: str, lines: int = 6_000_000):
     syn = Synth(seed=12, **kw)
     syn.write(pre)
     cores = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    many = cores if quota is None else max(1, min(cores, int(round(quota * 2))))      # two threads per granted core
     out = {"sample": f"{lines} GAF lines ({syn.stats.gaf_bytes / 1e9:.2f} GB of text) of the same recipe on the {kw['n_genes']}-gene instance "
                      f"({syn.stats.nodes} segments: its tables stay in cache, a whole-genome graph's would not)",
            "timed": "the per-line loop: GAF text -> parsed -> walked -> NC / IL / OL / RC tables in host memory (hash maps); GFA load, "
                     "merge of the per-thread tables and the output are listed beside it",
-           "cores": cores}
-    for name, t in (("one_thread", 1), ("all_cores", cores)):
+           "cores": cores, "cpu_quota_cores": quota}
+    for name, t in (("one_thread", 1), ("all_cores", many)):
         r = subprocess.run([exe, "--threads", str(t), "--no-out", pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, check=True)
         st = json.loads(r.stderr.strip().splitlines()[-1])
         out[name] = {"threads": t, "reads_per_s": st["lines"] / st["hot_loop_s"], "hot_loop_s": st["hot_loop_s"], "merge_s": st["merge_s"],
@@ -472,7 +493,7 @@ def main():
                      "gaf_upload_s": up_s, "finish_download_s": t_fin,
                      "gaf_text_bytes": tot("text_bytes"), "gfa_text_bytes": gs.text_bytes,
                      "tokenize_reads_per_s": lines / tok_s if tok_s else None,
-                     "cores": os.cpu_count(), "ram_gb": host_ram_gb(),
+                     "cores": os.cpu_count(), "cpu_quota_cores": cpu_quota_cores(), "ram_gb": host_ram_gb(),
                      "peak_rss_gb": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6},
             # the step in front of the path: GAF text -> records; never part of `value`
             "tokenizer": {"where": {1: "host threads (gaf.cpp)", 2: "GPU kernels (tokenize.hip)"}.get(stats[0].tokenizer),
