@@ -172,7 +172,7 @@ void format_range(const Graph& g, const AugmentResult& r, const std::vector<uint
 // rounds and writing them from one thread took 10 of the 22 s of `pantas augment` at whole-genome scale.)
 void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigned threads) {
   PhaseTimer pt("write_augmented_gfa");
-  if (threads == 0) threads = hw_threads();
+  if (threads == 0) threads = writer_threads();
   const size_t size = g.text.size;
   const char* base = g.text.data;
   constexpr size_t PIECE = size_t(4) << 20;

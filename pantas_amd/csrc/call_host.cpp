@@ -1123,7 +1123,7 @@ void render_events_to_fd(const Graph& g, const CallTables& t, const EventRec* re
                          const TaskOut* tasks, const uint32_t* paths, int fd_csv, std::string& err) {
   constexpr size_t BLOCK = 16384;
   const size_t nb = (n + BLOCK - 1) / BLOCK;
-  const unsigned T = unsigned(std::max<size_t>(1, std::min<size_t>(n < 100000 ? 1 : hw_threads(), nb)));
+  const unsigned T = unsigned(std::max<size_t>(1, std::min<size_t>(n < 100000 ? 1 : writer_threads(), nb)));
   // blocks of rows are rendered by a thread pool into buffers the threads keep and land in row order through
   // OrderedOutput (common.h): on a regular file by many threads at once.  The bytes of a row are not known before it is
   // rendered: ~200 per row are expected, and the file is mapped (sparse) with room for 16 times that -- a run that

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <exception>
 #include <new>
+#include <condition_variable>
 #include <mutex>
 
 namespace pantas {
@@ -69,6 +70,15 @@ unsigned hw_threads() {
     unsigned h = std::thread::hardware_concurrency();
     if (h == 0) h = 1;
     return std::min(h, 64u);
+  }();
+  return n;
+}
+
+unsigned writer_threads() {
+  static unsigned n = [] {
+    const char* e = getenv("PANTAS_WRITER_THREADS");
+    if (e && atoi(e) > 0) return unsigned(atoi(e));
+    return hw_threads();
   }();
   return n;
 }
@@ -167,7 +177,16 @@ struct OrderedOutput::Impl {
   int fd;
   int map_fd = -1;                  // descriptor the mapping and the truncations go through (fd itself or a read-write reopening)
   bool own_map_fd = false;
-  int mode;                         // 0 stream, 1 pwrite, 2 mmap
+  int mode;                         // 0 stream (every piece written by the thread that made it, in turn), 1 pwrite, 2 mmap, 3 one writer thread
+  // mode 3
+  struct Slot { const char* p = nullptr; size_t n = 0; bool ready = false, done = false; };
+  std::vector<Slot> slots;
+  std::mutex mu;
+  static constexpr size_t DONE_CVS = 128;      // a maker waits on the variable of its piece's residue: a finished write wakes one thread,
+  std::condition_variable cv_ready, cv_done[DONE_CVS];      // not every maker that is waiting
+  std::thread writer;
+  bool failed = false;
+  std::string failure;
   off_t file_pos = 0;               // where the output starts in the file
   std::vector<std::atomic<uint64_t>> end_of;
   char* map = nullptr;              // maps [map_base, map_base + map_len) of the file
@@ -184,9 +203,53 @@ OrderedOutput::OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, u
   for (auto& x : im->end_of) x.store(UINT64_MAX, std::memory_order_relaxed);
   im->end_of[0].store(0, std::memory_order_relaxed);
   if (fd < 0) return;
+  if (getenv("PANTAS_WRITER_SEQUENTIAL")) return;
   struct stat st;
   const int fl = fcntl(fd, F_GETFL);
-  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || fl == -1 || (fl & O_APPEND) || getenv("PANTAS_WRITER_SEQUENTIAL")) return;
+  const char* pw = getenv("PANTAS_OUTPUT_PWRITE");
+  const char* mm = getenv("PANTAS_OUTPUT_MMAP");
+  const bool positional = ((pw && !strcmp(pw, "1")) || (mm && !strcmp(mm, "1"))) && fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && fl != -1 && !(fl & O_APPEND);
+  if (!positional) {
+    // One thread does every write, in piece order, back to back.  Many threads writing one file queue for the file's lock: on the
+    // GPU box's tmpfs (16 cores of CPU quota) 2 - 64 threads pwrite at 3 - 4 GB/s, now and then 9; ONE thread does 9 GB/s every time
+    // (profiles/r2_pwrite_probe.txt), and threads that wait on a condition variable instead of a lock or a spin leave the quota to
+    // the formatting.  The makers of the pieces block in put() until their piece is written (their buffers are the queue).
+    im->mode = 3;
+    im->slots.resize(n_pieces);
+    Impl* q = im;
+    im->writer = std::thread([q] {
+      for (size_t k = 0; k < q->slots.size(); ++k) {
+        const char* p;
+        size_t left;
+        {
+          std::unique_lock<std::mutex> lk(q->mu);
+          q->cv_ready.wait(lk, [&] { return q->slots[k].ready || q->failed; });
+          if (q->failed) break;
+          p = q->slots[k].p;
+          left = q->slots[k].n;
+        }
+        while (left) {
+          const ssize_t w = ::write(q->fd, p, left);
+          if (w < 0) {
+            if (errno == EINTR) continue;
+            std::lock_guard<std::mutex> lk(q->mu);
+            q->failed = true;
+            q->failure = std::string("write failed: ") + strerror(errno);
+            break;
+          }
+          p += w; left -= size_t(w);
+        }
+        std::lock_guard<std::mutex> lk(q->mu);
+        if (q->failed) break;
+        q->total += q->slots[k].n;
+        q->slots[k].done = true;
+        q->cv_done[k % Impl::DONE_CVS].notify_all();
+      }
+      std::lock_guard<std::mutex> lk(q->mu);
+      for (auto& cv : q->cv_done) cv.notify_all();
+    });
+    return;
+  }
   const off_t pos = lseek(fd, 0, SEEK_CUR);
   if (pos < 0) return;
   im->file_pos = pos;
@@ -220,14 +283,30 @@ OrderedOutput::OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, u
 }
 
 OrderedOutput::~OrderedOutput() {
+  if (im->writer.joinable()) {
+    { std::lock_guard<std::mutex> lk(im->mu); im->failed = true; }      // (a maker threw: nobody will bring the missing pieces)
+    im->cv_ready.notify_all();
+    im->writer.join();
+  }
   if (im->map) munmap(im->map, im->map_len);
   if (im->own_map_fd && im->map_fd >= 0) ::close(im->map_fd);
   delete im;
 }
 
-const char* OrderedOutput::mode_name() const { return im->mode == 2 ? "shared mapping" : im->mode == 1 ? "pwrite" : "write in order"; }
+const char* OrderedOutput::mode_name() const {
+  return im->mode == 3 ? "one writer thread" : im->mode == 2 ? "shared mapping" : im->mode == 1 ? "pwrite" : "write in order";
+}
 
 void OrderedOutput::put(size_t piece, const char* data, size_t n) {
+  if (im->mode == 3) {
+    std::unique_lock<std::mutex> lk(im->mu);
+    Impl::Slot& sl = im->slots[piece];
+    sl.p = data; sl.n = n; sl.ready = true;
+    im->cv_ready.notify_one();
+    im->cv_done[piece % Impl::DONE_CVS].wait(lk, [&] { return sl.done || im->failed; });
+    if (im->failed) throw Error("OSError", im->failure.empty() ? std::string("output abandoned") : im->failure);
+    return;
+  }
   uint64_t start;
   for (unsigned spins = 0; (start = im->end_of[piece].load(std::memory_order_acquire)) == UINT64_MAX; ++spins) {
     if (spins < 200) std::this_thread::yield();
@@ -278,6 +357,13 @@ void OrderedOutput::put(size_t piece, const char* data, size_t n) {
 }
 
 void OrderedOutput::finish() {
+  if (im->mode == 3) {
+    if (im->writer.joinable()) im->writer.join();
+    if (im->failed) throw Error("OSError", im->failure.empty() ? std::string("output abandoned") : im->failure);
+    for (const Impl::Slot& sl : im->slots)
+      if (!sl.done) throw Error("InternalError", "OrderedOutput::finish before every piece was put");
+    return;
+  }
   const uint64_t total = im->end_of.back().load(std::memory_order_acquire);
   if (total == UINT64_MAX) throw Error("InternalError", "OrderedOutput::finish before every piece was put");
   if (im->mode == 0) return;

@@ -159,6 +159,10 @@ struct NoInitAlloc {
 template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 // out = [p, p + n) with every '\r' that no '\n' follows replaced by '\n' (universal newlines, see lone_cr above); many threads
 void universal_newlines_copy(const char* p, size_t n, RawVector<char>& out);
+// threads of the two output writers (PANTAS_WRITER_THREADS, default hw_threads()): they format pieces and queue for the output
+// file's lock, so the best count is not the parsers'
+unsigned writer_threads();
+
 // Giving tens of GB of temporaries back to the kernel takes seconds (50 - 85 ms per GB on the GPU box, huge pages or not) and holds
 // the address-space lock in long stretches: a free on a thread of its own right after the parse made the NEXT call that maps memory
 // -- the first hipMalloc / stream / pinned buffer -- wait for it (0.9 s at whole-genome scale).  So the big frees are parked
