@@ -56,6 +56,7 @@ using DeviceBatchPtr = std::unique_ptr<DeviceBatch, DeviceBatchDeleter>;
 int device_count();                                   // 0 when no HIP device is usable
 // Starts the HIP runtime and the context of `device` on a thread of its own (about a second on a cold process) so that it
 // runs beside the parsing of the GFA instead of in front of the first upload.  Harmless without a device.
+void set_tilde_table(DeviceGraph& d, const std::vector<TildeEntry>& tab);   // walk.h TildeCarry of the runs to come
 void warm_up_device(int device);
 void init_device(int device);     // the same on the calling thread
 DeviceGraphPtr upload_graph(const Graph& g, int device);

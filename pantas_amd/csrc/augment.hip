@@ -45,6 +45,7 @@ struct TableView {
 struct SlowTables {
   TableView hist, novel;
   unsigned long long* status; // min over failing lines of (line_id << 8 | code)
+  TildeCarry tilde;           // lengths that leak into lines whose first op is '~' (walk.h); empty unless the run found such lines
 };
 
 struct GraphView {
@@ -197,7 +198,7 @@ __device__ __forceinline__ void run_line(const GraphView& g, const BatchView& b,
   const uint32_t n0 = b.node_off[i], n1 = b.node_off[i + 1];
   const uint32_t o0 = b.op_off[i], o1 = b.op_off[i + 1];
   Sink sink{g};
-  const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+  const int st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink, &g.slow->tilde);
   if (st != WALK_OK) report_status(g, h.line_id, st);
 }
 
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(RARE_THREADS) void augment_rare_agg_kernel(GraphVie
         const DevInfo ga{g};
         st = walk_short_rare(ga, h, b.nodes + n0, k, b.ops + o0, c_ops, sink);
       } else {
-        st = walk_line(h, b.nodes + n0, k, b.ops + o0, c_ops, sink);
+        st = walk_line(h, b.nodes + n0, k, b.ops + o0, c_ops, sink, &g.slow->tilde);
       }
       if (st != WALK_OK) report_status(g, h.line_id, st);
     }
@@ -613,8 +614,8 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       if (PACKED && n1 - n0 > PACKED_MAX_PATH) {
         // a path this long could overflow a 16-bit field of the LDS entries: straight to memory
         MainSink direct{g};
-        st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, direct);
-      } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink);
+        st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, direct, &g.slow->tilde);
+      } else st = walk_line(h, b.nodes + n0, n1 - n0, b.ops + o0, o1 - o0, sink, &g.slow->tilde);
       if (st != WALK_OK) report_status(g, h.line_id, st);
     }
     __syncthreads();
@@ -723,8 +724,10 @@ struct DeviceGraph {
   SlowTables* slow_dev = nullptr;   // device copy of {hist, novel, status}
   SlowTables slow_host{};           // what slow_dev holds
   // brings the device copy up to date (table pointers change when a table grows); ordered on `stream`
+  TildeEntry* tilde_dev = nullptr;  // walk.h TildeCarry of the run (set_tilde_table), kept until the next one
+  uint32_t tilde_n = 0;
   void sync_slow() {
-    SlowTables t{hist.v, novel.v, reinterpret_cast<unsigned long long*>(small)};
+    SlowTables t{hist.v, novel.v, reinterpret_cast<unsigned long long*>(small), TildeCarry{tilde_dev, tilde_n}};
     if (memcmp(&t, &slow_host, sizeof t) != 0) {
       slow_host = t;
       HIP_OK(hipMemcpyAsync(slow_dev, &slow_host, sizeof t, hipMemcpyHostToDevice, stream));
@@ -761,7 +764,7 @@ uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
 void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->slow_dev})
+  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->slow_dev, (void*)d->tilde_dev})
     if (p) (void)hipFree(p);
   d->scratch.reset();
   d->hist.free_all();
@@ -942,6 +945,18 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   reset_counters(*d);
   pt.lap("counters zeroed");
   return d;
+}
+
+// lengths that leak into lines whose first op is '~' (walk.h TildeCarry), sorted by line id; stays until replaced
+void set_tilde_table(DeviceGraph& d, const std::vector<TildeEntry>& tab) {
+  HIP_OK(hipSetDevice(d.device));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  if (d.tilde_dev) { (void)hipFree(d.tilde_dev); d.tilde_dev = nullptr; }
+  d.tilde_n = uint32_t(tab.size());
+  if (!tab.empty()) {
+    HIP_OK(hipMalloc(&d.tilde_dev, tab.size() * sizeof(TildeEntry)));
+    HIP_OK(hipMemcpy(d.tilde_dev, tab.data(), tab.size() * sizeof(TildeEntry), hipMemcpyHostToDevice));
+  }
 }
 
 void reset_counters(DeviceGraph& d) {
@@ -1352,8 +1367,9 @@ void check_device_status(DeviceGraph& d, uint64_t first_record_line) {
       throw Error("IndexError", "GAF line " + std::to_string(line) + ": cs ops exhausted before the path end");
     if (line - 1 == first_record_line)
       throw Error("UnboundLocalError", "GAF line " + std::to_string(line) + ": '~' is the first cs op the walk reaches and no line before it left a length behind");
-    throw Error("Unsupported", "GAF line " + std::to_string(line) + ": '~' is the first cs op the walk of this line reaches; the reference lays it out with a length "
-                               "left over from the GAF line before (alignments_augmentation_from_gaf.py:228-233), which a line-parallel walk does not have");
+    throw Error("Unsupported", "GAF line " + std::to_string(line) + ": " + TILDE_FIRST_MARK + "; the reference lays it out with a length "
+                               "left over from the GAF line before (alignments_augmentation_from_gaf.py:228-233): pantas_augment_run works those out "
+                               "for a whole file, a byte range or a batch on its own cannot");
   }
   if (s[3]) throw Error("TableOverflow", "hist");
   if (s[5]) throw Error("TableOverflow", "novel");

@@ -25,6 +25,8 @@ struct pantas_graph {
   int tokenizer = PANTAS_TOKENIZER_AUTO;
   double load_s = 0;
   std::unique_ptr<struct StreamState> stream;   // a run over a GAF byte range in several batches (pantas_augment_stream_*)
+  std::vector<TildeEntry> tilde_tab;   // walk.h TildeCarry of the file pantas_augment_run is on (computed when a run stops at such a line)
+  bool tilde_tried = false;
   // call
   std::unique_ptr<CallTables> call_tables;
   DeviceCallPtr call_dev;
@@ -209,10 +211,19 @@ __attribute__((visibility("default"))) int pantas_graph_to_device(pantas_graph* 
   });
 }
 
-__attribute__((visibility("default"))) int pantas_augment_reset(pantas_graph* g) {
+static int reset_run(pantas_graph* g, bool keep_tilde);
+__attribute__((visibility("default"))) int pantas_augment_reset(pantas_graph* g) { return reset_run(g, false); }
+
+static int reset_run(pantas_graph* g, bool keep_tilde) {
   return guarded([&] {
     need_device(g);
     require_augmentable(*g->g);
+    if (!keep_tilde && (g->tilde_tried || !g->tilde_tab.empty())) {
+      // the lengths worked out for the lines of one file (walk.h TildeCarry) say nothing about the next
+      g->tilde_tab.clear();
+      g->tilde_tried = false;
+      set_tilde_table(*g->dev, g->tilde_tab);
+    }
     reset_counters(*g->dev);
     g->have_result = false;
     g->res = AugmentResult();
@@ -736,7 +747,7 @@ __attribute__((visibility("default"))) int pantas_augment_stream_rare(pantas_gra
     if (g->deferred && is_lone_cr_error(*g->deferred) && begin == 0 && (end == 0 || end >= g->stream->file.size)) {
       // the whole file is this run's: read it again the way Python does (a byte range of a file shared between ranks keeps the
       // refusal: where its lines start and how they are numbered is the caller's arithmetic)
-      if (pantas_augment_reset(g) != PANTAS_OK) throw Error(g_kind.c_str(), g_err);
+      if (reset_run(g, true) != PANTAS_OK) throw Error(g_kind.c_str(), g_err);
       stream_rare_pass(g, gaf_path, thr, 0, 0, first_line, stats, rare_ms, true);
     }
   });
@@ -761,8 +772,8 @@ __attribute__((visibility("default"))) int pantas_augment_stream_info(const pant
 __attribute__((visibility("default"))) int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
                        pantas_launch_stats* launch) {
   int rc = PANTAS_OK;
-  for (int attempt = 0; attempt < 6; ++attempt) {
-    rc = pantas_augment_reset(g);
+  for (int attempt = 0; attempt < 7; ++attempt) {
+    rc = reset_run(g, attempt > 0);
     if (rc) return rc;
     float rare = 0, mainms = 0;
     rc = pantas_augment_stream_rare(g, gaf_path, thr, 0, 0, 0, stats, &rare);
@@ -776,6 +787,25 @@ __attribute__((visibility("default"))) int pantas_augment_run(pantas_graph* g, c
       if (r2) return r2;
     }
     rc = pantas_augment_finish(g);
+    if (rc != PANTAS_OK && g_kind == "Unsupported" && g_err.find(TILDE_FIRST_MARK) != std::string::npos && g->stream) {
+      if (!g->tilde_tried) {
+        // a line whose first cs op is '~' takes its length from the line in front of it (walk.h TildeCarry): work those lengths out on the
+        // host, once, and run again with them
+        g->tilde_tried = true;
+        const int r2 = guarded([&] {
+          g->tilde_tab = tilde_carries(*g->g, g->stream->file.data, g->stream->file.size, thr, 0);
+          set_tilde_table(*g->dev, g->tilde_tab);
+        });
+        if (r2) return r2;
+        continue;
+      }
+      // still stopped at such a line: the table says nothing in front of it took an op in hand
+      const size_t at = g_err.find("GAF line ");
+      const uint64_t line = at == std::string::npos ? 0 : strtoull(g_err.c_str() + at + 9, nullptr, 10);
+      for (const TildeEntry& e : g->tilde_tab)
+        if (uint64_t(e.line_id) + 1 == line && e.carry == TILDE_UNBOUND)
+          return fail(Error("UnboundLocalError", "GAF line " + std::to_string(line) + ": '~' is the first cs op the walk reaches and no line before it left a length behind"));
+    }
     if (rc == PANTAS_E_INTERNAL && g_kind == "TableOverflow") {
       // a table sized from a guess was too small: enlarge it and redo the run from the text (every batch is tokenised
       // again, so a deferred tokeniser error comes back with it)

@@ -387,4 +387,79 @@ void bucket_by_locus(GafBatch& b, unsigned threads) {
   b.ops.swap(ops);
 }
 
+namespace {
+// walk_line's sink with nothing behind it: only the lengths of the nodes matter to what a line leaves in `curr_cigar_len`
+struct LengthOnlySink {
+  const Graph& g;
+  uint32_t node_word(uint32_t n) const { return g.seg_len[n]; }
+  void nc(uint32_t) const {}
+  void common(uint32_t, uint32_t, uint32_t, uint32_t, uint64_t) const {}
+  void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
+  void edge(uint32_t, uint32_t, uint64_t) const {}
+};
+}  // namespace
+
+std::vector<TildeEntry> tilde_carries(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id) {
+  // candidates: lines with a cs tag that starts with '~' (start offset and 0-based line number inside the text)
+  struct Cand { size_t off; uint64_t line; };
+  std::vector<Cand> cand;
+  {
+    const unsigned T = size < (size_t(1) << 24) ? 1u : hw_threads();
+    auto ranges = split_at_newlines(data, size, T);
+    std::vector<std::vector<Cand>> part(ranges.size());
+    std::vector<uint64_t> lines_in(ranges.size(), 0);
+    parallel_chunks(ranges.size(), unsigned(ranges.size()), [&](unsigned, size_t rb, size_t re) {
+      for (size_t r = rb; r < re; ++r) {
+        const char* p = data + ranges[r].first;
+        const char* end = data + ranges[r].second;
+        uint64_t ln = 0;
+        while (p < end) {
+          const char* nl = static_cast<const char*>(memchr(p, '\n', size_t(end - p)));
+          const char* le = nl ? nl : end;
+          static const char key[] = "cs:Z:~";
+          if (le - p >= 6 && memmem(p, size_t(le - p), key, 6)) part[r].push_back(Cand{size_t(p - data), ln});
+          ++ln;
+          p = nl ? nl + 1 : end;
+        }
+        lines_in[r] = ln;
+      }
+    });
+    uint64_t base = 0;
+    for (size_t r = 0; r < ranges.size(); ++r) {
+      for (const Cand& c : part[r]) cand.push_back(Cand{c.off, base + c.line});
+      base += lines_in[r];
+    }
+  }
+  std::vector<TildeEntry> out;
+  out.reserve(cand.size());
+  const LengthOnlySink sink{g};
+  for (const Cand& c : cand) {
+    uint32_t carry = TILDE_UNBOUND;
+    size_t at = c.off;            // start of the line under the cursor
+    uint64_t line = c.line;
+    while (at > 0) {
+      // the line in front
+      const char* prev_end = data + at - 1;                                  // its '\n'
+      const char* q = static_cast<const char*>(memrchr(data, '\n', size_t(prev_end - data)));
+      const size_t lb = q ? size_t(q - data) + 1 : 0;
+      --line;
+      GafBatch one;
+      tokenize_gaf(g, data + lb, size_t(prev_end - (data + lb)), thr, first_line_id + line, 1, one);
+      at = lb;
+      if (one.deferred) break;                     // the reference dies there: nothing behind that line is ever read
+      if (one.size() == 0) continue;               // rejected, unmapped or beyond the dv threshold: the walk never saw it
+      const TildeCarry tc{out.data(), uint32_t(out.size())};
+      uint32_t left = TILDE_UNBOUND;
+      LengthOnlySink s2 = sink;
+      const int st = walk_line(one.hdr[0], one.nodes.data(), uint32_t(one.nodes.size()), one.ops.data(), uint32_t(one.ops.size()), s2, &tc, &left);
+      if (st != WALK_OK) break;                    // that line dies in the reference (or is itself unbound)
+      if (left != TILDE_UNBOUND) { carry = left; break; }
+      // (no op came into hand on that line -- no room on any of its nodes: `curr_cigar_len` is what it was before it)
+    }
+    if (first_line_id + c.line > 0xFFFFFFFFull) throw Error("Unsupported", "more than 2^32-1 GAF lines in one run");
+    out.push_back(TildeEntry{uint32_t(first_line_id + c.line), carry});
+  }
+  return out;
+}
+
 }  // namespace pantas

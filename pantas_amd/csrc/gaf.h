@@ -45,4 +45,11 @@ void bucket_by_locus(GafBatch& b, unsigned threads = 0);
 void tokenize_gaf(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
                   unsigned threads, GafBatch& out);
 
+// The lengths that leak into the lines whose cs starts with a '~' op (walk.h TildeCarry; the reference's `curr_cigar_len` is a variable
+// of main() that outlives its line): for every such line of [data, data + size), whose first line has id first_line_id, the length the
+// last line in front of it that took an op in hand left behind -- found by walking backwards from the line, one line at a time, with the
+// host tokeniser and walk_line.  Sorted by line id; TILDE_UNBOUND where no such line exists (the reference: UnboundLocalError).  A
+// slow, sequential look that only a file with such lines pays for.
+std::vector<TildeEntry> tilde_carries(const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id);
+
 }  // namespace pantas

@@ -86,8 +86,31 @@ struct LineHdr {
 // WALK_TILDE_FIRST: a '~' op is the first op the walk of a line reaches.  The reference never assigns a length for '~'
 // (:228-233) and reuses whatever the variable held: the length of the op in hand one iteration earlier.  Inside a line
 // that is reproduced (walk_line below); for the first op of a line the value leaks in from the PREVIOUS GAF line (or is
-// unbound on the first one: UnboundLocalError), which a line-parallel walk does not have -- such a line is refused.
+// unbound when no line before it took an op in hand: UnboundLocalError), which a line-parallel walk does not have.  Such
+// lines get the value from a table the host computes for them (TildeCarry: a sequential look at the lines in front of each,
+// done only for a file that has such lines -- no mapper writes a cs that starts inside an intron); without an entry the
+// walk stops with this code.
 enum : int { WALK_OK = 0, WALK_OPS_EXHAUSTED = 1, WALK_TILDE_FIRST = 2 };
+
+constexpr const char* TILDE_FIRST_MARK = "'~' is the first cs op the walk of this line reaches";      // in the text of the refusal
+// {line id, length that leaks into the line} sorted by line id; TILDE_UNBOUND: no line in front took an op in hand
+constexpr uint32_t TILDE_UNBOUND = 0xFFFFFFFFu;
+struct TildeEntry { uint32_t line_id, carry; };
+struct TildeCarry {
+  const TildeEntry* tab = nullptr;
+  uint32_t n = 0;
+};
+PANTAS_HD bool tilde_lookup(const TildeCarry* t, uint32_t line_id, uint32_t& carry) {
+  if (!t || t->n == 0) return false;
+  uint32_t lo = 0, hi = t->n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (t->tab[mid].line_id < line_id) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= t->n || t->tab[lo].line_id != line_id || t->tab[lo].carry == TILDE_UNBOUND) return false;
+  carry = t->tab[lo].carry;
+  return true;
+}
 
 enum : uint32_t { SIDE_IL = 0, SIDE_OL = 1 };
 
@@ -234,9 +257,11 @@ PANTAS_HD void flush_kept(const KeptNode& kn, uint32_t idx, bool is_last, const 
   }
 }
 
+// tc: lengths that leak into lines whose first op is '~' (may be null).  out_stale: where the length the NEXT line would inherit
+// goes when this line took an op in hand (host use: the computation of such a table).
 template <class Sink>
 PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_nodes, const uint32_t* ops,
-                        uint32_t n_ops, Sink& sink) {
+                        uint32_t n_ops, Sink& sink, const TildeCarry* tc = nullptr, uint32_t* out_stale = nullptr) {
   uint32_t oi = 0;          // index of the op in hand (or of the next one when !have)
   uint32_t cur_op = 0, cur_rem = 0;
   bool have = false;
@@ -266,7 +291,10 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
       if (cur_op == OP_TILDE) {
         // no branch of :228-233 assigns a length for '~': the op is laid out with the length of the op that was in hand
         // one iteration earlier (its own length never matters), and what is written back as "left" is stale - room (:239)
-        if (!have_stale) return WALK_TILDE_FIRST;
+        if (!have_stale) {
+          if (!tilde_lookup(tc, h.line_id, stale)) return WALK_TILDE_FIRST;
+          have_stale = true;
+        }
         cur_rem = stale;
       } else {
         stale = cur_rem;
@@ -300,6 +328,7 @@ PANTAS_HD int walk_line(const LineHdr& h, const uint32_t* nodes, uint32_t n_node
     ++kept;
   }
   if (pending) flush_kept(pend, kept - 1, true, h, sink);
+  if (out_stale && have_stale) *out_stale = stale;      // what `curr_cigar_len` holds behind this line
   return WALK_OK;
 }
 

@@ -89,6 +89,10 @@ int main(int argc, char** argv) {
       tokenize_gaf(*g, universal.data(), universal.size(), thr, 0, threads, b);
     }
     const uint64_t first_record_line = b.first_record_line;
+    // lines whose first cs op is '~' inherit a length from the line in front (walk.h TildeCarry): as pantas_augment_run, from the text
+    const char* text = universal.empty() ? gaf.data : universal.data();
+    const std::vector<TildeEntry> tilde = tilde_carries(*g, text, gaf.size, thr, 0);
+    const TildeCarry tc{tilde.data(), uint32_t(tilde.size())};
     if (getenv("HOSTSIM_BUCKET")) bucket_by_locus(b, threads);
     Tables t;
     t.word.assign(g->seg_len.begin(), g->seg_len.end());
@@ -105,12 +109,12 @@ int main(int argc, char** argv) {
         const uint32_t* ops = b.ops.data() + b.op_off[i];
         uint32_t k = b.node_off[i + 1] - b.node_off[i], c = b.op_off[i + 1] - b.op_off[i];
         // as the kernels dispatch: short-walk class through walk.h's short walks, the rest through walk_line
-        if (pass == 0) { RareSink s{t}; st = rare_walk(*g, t.word, h, nodes, k, ops, c, s); }
-        else { MainSink s{t, *g}; st = main_walk(*g, t.word, h, nodes, k, ops, c, s); }
+        if (pass == 0) { RareSink s{t}; st = rare_walk(*g, t.word, h, nodes, k, ops, c, s, &tc); }
+        else { MainSink s{t, *g}; st = main_walk(*g, t.word, h, nodes, k, ops, c, s, &tc); }
         if (st == WALK_OPS_EXHAUSTED) throw Error("IndexError", "GAF line " + std::to_string(h.line_id + 1) + ": cs ops exhausted before the path end");
         if (st == WALK_TILDE_FIRST) {
-          if (h.line_id == first_record_line) throw Error("UnboundLocalError", "GAF line " + std::to_string(h.line_id + 1) + ": '~' as the first op of the first walked line");
-          throw Error("Unsupported", "GAF line " + std::to_string(h.line_id + 1) + ": '~' as the first op the walk of a line reaches");
+          (void)first_record_line;
+          throw Error("UnboundLocalError", "GAF line " + std::to_string(h.line_id + 1) + ": '~' as the first op the walk reaches and no line before it left a length behind");
         }
       }
     }

@@ -46,8 +46,8 @@ struct ShortFromGeneral {
 // main pass over one line, as augment.hip dispatches it
 template <class GenSink>
 int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops,
-              uint32_t c, GenSink& s) {
-  if (!short_walk_class(h.flags, k) || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s);
+              uint32_t c, GenSink& s, const TildeCarry* tc = nullptr) {
+  if (!short_walk_class(h.flags, k) || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s, tc);
   const HostInfo ga{g, word};
   const ShortFromGeneral<GenSink> ss{s, g};
   uint32_t first_ids[4] = {0, 0, 0, 0};
@@ -67,8 +67,8 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
 // rare-key pass over one line with a '-'
 template <class GenSink>
 int rare_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops,
-              uint32_t c, GenSink& s) {
-  if (!(h.flags & LINE_ONE_INDEL) || k == 0 || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s);
+              uint32_t c, GenSink& s, const TildeCarry* tc = nullptr) {
+  if (!(h.flags & LINE_ONE_INDEL) || k == 0 || getenv("HOSTSIM_GENERAL_WALK")) return walk_line(h, nodes, k, ops, c, s, tc);
   // the rare sink sets flags in `word` while it walks: the short walk only reads lengths from it
   const HostInfo ga{g, word};
   return walk_short_rare(ga, h, nodes, k, ops, c, s);

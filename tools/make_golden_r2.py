@@ -48,7 +48,7 @@ def cases():
             mg.gaf_line("x_first_op", [1001, 1002], L, 0, 15, "~ac5gt:10"),                # length leaks in from the line before
             mg.gaf_line("rejected", [1001, 1002], L, 0, 15, ":7", mapq=3),
             mg.gaf_line("y_first_op", [1002, 1004], L, 4, 20, "~ac5gt:30")]
-    out.append(dict(name="tilde_leak", stage="augment", gfa=gfa, gaf=leak, gtf=gtf, flags=[], engine="refuses"))
+    out.append(dict(name="tilde_leak", stage="augment", gfa=gfa, gaf=leak, gtf=gtf, flags=[], engine="same"))
     # ---- S line behind leading whitespace --------------------------------------------------------------------
     ws = [("  " + l if l.startswith("S\t1003") else l) for l in gfa]
     out.append(dict(name="ws_s_augment", stage="augment", gfa=ws, gaf=gaf, gtf=gtf, flags=[], engine="same"))
