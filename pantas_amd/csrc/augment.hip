@@ -558,7 +558,7 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
 }
 
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false>
+          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false, uint32_t XCD = 0>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -581,7 +581,17 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   __shared__ uint32_t nvq_n;
   static_assert(!INFO || (PACKED && ONLY == 1), "the info walk exists for the short-walk class over packed entries");
   const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
-  for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+  // XCD: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each XCD has its own L2): workgroup b takes
+  // chunk (b % 8) * n/8 + b / 8, so that an XCD walks ONE contiguous eighth of the locus-ordered chunks -- the chunks in flight on it are
+  // neighbours, and neighbours share graph nodes (an expressed gene's reads fill dozens of consecutive chunks)
+  // XCD = 1: eighths; XCD = G > 1: runs of G consecutive chunks per XCD, the XCDs advancing through the loci together
+  const uint32_t per_xcd = (n_chunks + 7u) / 8u;
+  const uint32_t n_slots = XCD == 0 ? n_chunks : XCD == 1 ? 8u * per_xcd : (n_chunks + 8u * XCD - 1u) / (8u * XCD) * (8u * XCD);
+  for (uint32_t c0 = blockIdx.x; c0 < n_slots; c0 += gridDim.x) {
+    uint32_t c = c0;
+    if constexpr (XCD == 1) c = (c0 & 7u) * per_xcd + (c0 >> 3);
+    else if constexpr (XCD > 1) { const uint32_t j = c0 >> 3; c = (j / XCD) * (8u * XCD) + (c0 & 7u) * XCD + j % XCD; }
+    if (XCD && c >= n_chunks) continue;
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       if constexpr (INFO) { omin[i] = ~0u; omin[CN + i] = ~0u; }
       nkey[i] = LDS_EMPTY;
@@ -1217,8 +1227,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
     // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
     // the rest with the general aggregating kernel beside it on a second stream: 73 = the round-1 short walk (gathers two
-    // nodes ahead), 80 / 85 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 85;   // read per launch: tools/ab_variants.py switches it
+    // nodes ahead), 80 / 85 / 97 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 97;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1237,6 +1247,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; \
       HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0)); break;
     bool split = false;
+    const uint32_t n_ch = (b.n_short + 2047u) / 2048u;      // chunks of the short-walk class
+    (void)n_ch;
     if (variant == 0) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
@@ -1253,8 +1265,19 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         // instance of the walk for waves without indel lines inside the same kernel (2.59: its registers add up)
         PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // round 1
         PANTAS_SPLIT(80, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // mid round 2: deferred lookups of links off the first out-slot
-        default:   // 85: 80 + links absent from the graph queued per workgroup and inserted at the end of the chunk
-        PANTAS_SPLIT(85, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // ONLY 2: the general walk alone
+        PANTAS_SPLIT(85, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // 80 + links absent from the graph queued per workgroup and inserted at the end of the chunk
+        default:
+          // 97: 85 with the chunks dealt to the XCDs in contiguous eighths of the locus order (workgroups are dealt round-robin over the 8
+          // XCDs, each with an L2 of its own: neighbouring chunks, which share the nodes of an expressed gene, now meet in ONE L2).
+          // Runs of 16 or 64 chunks per XCD instead of eighths measured in between (profiles/r2_ab_s4_xcd.txt).
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
+          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1>),
+                                            dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
+          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          break;
       }
     }
 #undef PANTAS_SPLIT_SEQ
