@@ -29,6 +29,7 @@
 namespace pantas {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr uint32_t REC_QUADS = 3;      // BatchView::rec: three 16-byte words per record
 constexpr uint32_t REC_OPS_MAX = SHORT_MAX_OPS - 1u;     // BatchView::rec holds the op count in 24 bits (saturated; only short-walk records are read through it)
 constexpr uint32_t COMMON_POS = 0x7FFFFFFFu;
 
@@ -551,14 +552,15 @@ struct ShortSinkDev {
 };
 template <class Sink, int PF, bool DEFER = false, bool LEAN = false>
 __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr& h, const uint32_t* nodes, uint32_t k,
-                                               const uint32_t* ops, uint32_t nops, const Sink& sink, const uint32_t* first_ids, uint32_t* dq = nullptr) {
+                                               const uint32_t* ops, uint32_t nops, const Sink& sink, const uint32_t* first_ids, uint32_t* dq = nullptr,
+                                               const ShortOps* pre = nullptr) {
   const DevInfo ga{g};
   const ShortSinkDev<Sink> ss{sink, dq};
-  return walk_short<PF, DEFER, LEAN>(ga, h, nodes, k, ops, nops, ss, first_ids);
+  return walk_short<PF, DEFER, LEAN>(ga, h, nodes, k, ops, nops, ss, first_ids, pre);
 }
 
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false, uint32_t XCD = 0>
+          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false, uint32_t XCD = 0, bool PRE = false>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -610,10 +612,16 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       if constexpr (INFO) {
         // the record's offsets, sizes and first node id in one 16-byte load beside the header
         // (a line of the short-walk class has at most 31 path nodes and fewer than SHORT_MAX_OPS ops: both fit)
-        const uint4 r = b.rec[2 * size_t(i)], r2 = b.rec[2 * size_t(i) + 1];
+        const uint4 r = b.rec[REC_QUADS * size_t(i)], r2 = b.rec[REC_QUADS * size_t(i) + 1];
         const uint32_t first_ids[5] = {r.w, r2.x, r2.y, r2.z, r2.w};
         static_assert(PF <= 4, "rec holds the ids of the first five path nodes");
         int st;
+        if constexpr (PRE) {
+          const uint4 r3 = b.rec[REC_QUADS * size_t(i) + 2];
+          ShortOps so;
+          so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
+          st = walk_short_info<Sink, PF, DEFER>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids, defer_q + 2u * threadIdx.x, &so);
+        } else
         st = walk_short_info<Sink, PF, DEFER>(g, h, b.nodes + r.x, r.z & 0xFFu, b.ops + r.y, r.z >> 8, sink, first_ids, defer_q + 2u * threadIdx.x);
         if (st != WALK_OK) report_status(g, h.line_id, st);
         continue;
@@ -1028,23 +1036,28 @@ static void table_grow(DeviceGraph& d, Table& t, uint32_t cap, uint32_t* n_keys,
   t = big;
 }
 
-__global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, uint4* rec) {
+__global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, const uint32_t* ops, uint4* rec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t n0 = node_off[i], k = node_off[i + 1] - n0, o0 = op_off[i], c = op_off[i + 1] - o0;
     const uint32_t last = k ? k - 1u : 0u;
     auto id = [&](uint32_t j) { return k ? nodes[n0 + (j < last ? j : last)] : 0u; };
-    rec[2 * size_t(i)] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
-    rec[2 * size_t(i) + 1] = make_uint4(id(1), id(2), id(3), id(4));
+    rec[REC_QUADS * size_t(i)] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
+    rec[REC_QUADS * size_t(i) + 1] = make_uint4(id(1), id(2), id(3), id(4));
+    // the short walk's view of the cs (walk.h ShortOps), so that the dominant kernel neither reads ops[] nor scans it; only read for
+    // records of the short-walk class (fewer than SHORT_MAX_OPS ops, total below 2^16)
+    ShortOps so;
+    if (c < SHORT_MAX_OPS) short_ops_scan(ops + o0, c, so);
+    rec[REC_QUADS * size_t(i) + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
   }
 }
 
 void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
   if (b.rec) { (void)hipFree(b.rec); b.rec = nullptr; }
-  HIP_OK(hipMalloc(&b.rec, std::max<size_t>(1, b.n) * 2 * sizeof(uint4)));
+  HIP_OK(hipMalloc(&b.rec, std::max<size_t>(1, b.n) * REC_QUADS * sizeof(uint4)));
   if (b.n) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 16));
-    hipLaunchKernelGGL(build_rec_kernel, dim3(blocks), dim3(256), 0, d.stream, b.n, b.node_off, b.op_off, b.nodes, b.rec);
+    hipLaunchKernelGGL(build_rec_kernel, dim3(blocks), dim3(256), 0, d.stream, b.n, b.node_off, b.op_off, b.nodes, b.ops, b.rec);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
@@ -1227,8 +1240,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
     // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
     // the rest with the general aggregating kernel beside it on a second stream: 73 = the round-1 short walk (gathers two
-    // nodes ahead), 80 / 85 / 97 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 97;   // read per launch: tools/ab_variants.py switches it
+    // nodes ahead), 80 / 85 / 97 / 100 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 100;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1266,14 +1279,24 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // round 1
         PANTAS_SPLIT(80, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // mid round 2: deferred lookups of links off the first out-slot
         PANTAS_SPLIT(85, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // 80 + links absent from the graph queued per workgroup and inserted at the end of the chunk
-        default:
-          // 97: 85 with the chunks dealt to the XCDs in contiguous eighths of the locus order (workgroups are dealt round-robin over the 8
-          // XCDs, each with an L2 of its own: neighbouring chunks, which share the nodes of an expressed gene, now meet in ONE L2).
-          // Runs of 16 or 64 chunks per XCD instead of eighths measured in between (profiles/r2_ab_s4_xcd.txt).
+        case 97:   // 85 with the chunks dealt to the XCDs in contiguous eighths of the locus order
           HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.ev[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1>),
+                                            dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
+          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          break;
+        default:
+          // 100: workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: workgroup b takes chunk (b % 8) * n/8 + b/8,
+          // so that neighbouring chunks, which share the nodes of an expressed gene, meet in ONE L2 (97; runs of 16 or 64 chunks per XCD
+          // instead of eighths measured in between, profiles/r2_ab_s4_xcd.txt) -- and the line's ShortOps comes with the record (third
+          // 16-byte word, made when the batch comes to be) instead of being scanned from ops[] by every launch.
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
+          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true>),
                                             dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));

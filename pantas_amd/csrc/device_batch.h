@@ -34,10 +34,11 @@ struct DeviceBatch {
   uint64_t id = next_batch_id();
   LineHdr* hdr = nullptr;
   uint32_t *node_off = nullptr, *op_off = nullptr, *nodes = nullptr, *ops = nullptr, *del_idx = nullptr;
-  uint4* rec = nullptr;          // derived per record, 32 bytes: {node_off, op_off, path nodes (8 bits, saturated) | cs ops << 8, id of
-                                 // node 0} {ids of nodes 1 .. 4, clamped to the path} -- with hdr[] everything the short-walk kernel
-                                 // needs to start a record AND its gather pipeline, in three 16-byte loads (instead of hdr, two
-                                 // offset pairs, then nodes[0..2]: two dependent load levels less per record)
+  uint4* rec = nullptr;          // derived per record, 48 bytes: {node_off, op_off, path nodes (8 bits, saturated) | cs ops << 8, id of
+                                 // node 0} {ids of nodes 1 .. 4, clamped to the path} {the line's ShortOps (walk.h): total | stars << 16,
+                                 // star positions, the indel} -- with hdr[] everything the short-walk kernel needs to start a record
+                                 // AND its gather pipeline, in four 16-byte loads (instead of hdr, two offset pairs, nodes[0..2], then
+                                 // ops[] and a scan of it: three dependent load levels and a loop less per record)
   uint32_t n = 0, n_del = 0;
   uint32_t n_short = 0;          // records [0, n_short) are the short-walk class (walk.h), bucketed apart from the rest
   uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;

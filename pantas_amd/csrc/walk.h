@@ -355,13 +355,15 @@ struct alignas(8) NodeInfo {
 // LEAN: the line is LINE_SIMPLE (':' runs and at most four '*', no '+' / '-'): every node with room is kept, has one
 // compacted entry unless all its bases are '*', and no event of the line needs its exact within-line order -- the indel
 // and exact-order code is compiled out (the kernel takes this instance for a wave none of whose lines has an indel).
+// pre: the line's ShortOps when the caller already holds it (the GPU batch keeps it beside the record: `ops` is then not read)
 template <int PF, bool DEFER = false, bool LEAN = false, class GraphAcc, class Sink>
 PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops, uint32_t nops,
-                         const Sink& sink, const uint32_t* first_ids) {  // first_ids[j] = nodes[min(j, k - 1)], j = 0 .. PF: the caller may
-                                                                         // already hold them (the GPU batch keeps them beside the offsets)
+                         const Sink& sink, const uint32_t* first_ids,   // first_ids[j] = nodes[min(j, k - 1)], j = 0 .. PF: the caller may
+                                                                        // already hold them (the GPU batch keeps them beside the offsets)
+                         const ShortOps* pre = nullptr) {
   if (k == 0) return WALK_OK;
   ShortOps so;
-  short_ops_scan(ops, nops, so);
+  if (pre) so = *pre; else short_ops_scan(ops, nops, so);
   const uint32_t T = so.T;
   const bool rev = (h.flags & LINE_REV) != 0;
   const bool exact = !LEAN && (h.flags & LINE_HAS_DEL) != 0;

@@ -56,7 +56,11 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
   // instance for lines without an indel
   switch (h.line_id & 3u) {
     case 0: return walk_short<1>(ga, h, nodes, k, ops, c, ss, first_ids);
-    case 1: return walk_short<2>(ga, h, nodes, k, ops, c, ss, first_ids);
+    case 1: {      // with the line's ShortOps handed in (the GPU batch keeps it beside the record) and ops[] out of reach
+      ShortOps so;
+      short_ops_scan(ops, c, so);
+      return walk_short<2>(ga, h, nodes, k, nullptr, c, ss, first_ids, &so);
+    }
     case 2: return walk_short<2, true>(ga, h, nodes, k, ops, c, ss, first_ids);
     default:
       if (h.flags & LINE_SIMPLE) return walk_short<2, true, true>(ga, h, nodes, k, ops, c, ss, first_ids);
