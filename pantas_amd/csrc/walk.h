@@ -43,6 +43,7 @@ constexpr uint32_t LINE_REV = 1u;       // path written with '<'
 constexpr uint32_t LINE_HAS_DEL = 2u;   // cs string holds a '-' op
 constexpr uint32_t LINE_SLOW = 4u;      // cs holds a zero-length or '~' op: walked by the scalar code only
 constexpr uint32_t LINE_SIMPLE = 8u;    // cs holds only ':' and at most 4 '*' ops (no zero lengths): eligible for the short walk
+constexpr uint32_t LINE_STARS = 32u;      // a short-walk line with at least one '*' op (set beside LINE_SIMPLE / LINE_ONE_INDEL)
 constexpr uint32_t LINE_ONE_INDEL = 16u;  // cs holds ':' ops, at most 4 '*' ops and exactly ONE '+' or '-' op (no zero lengths): short walk too
 constexpr uint32_t SIMPLE_MAX_STARS = 4;
 // Records of a batch come in two classes, each bucketed by locus: first the ones the short-walk kernel takes
@@ -62,8 +63,10 @@ PANTAS_HD bool short_walk_class(uint32_t flags, uint32_t path_nodes) {
 }
 // order of the records inside a block of 2048 of a class (stable): by path length, so that the lanes of a wave loop
 // alike, with the one-indel lines behind the others -- a wave pays for the indel code whenever ONE of its lanes needs it
+// ... and, in front of those, the lines with a '*' behind the plain ones: a wave whose lines are all ':' runs skips the per-node
+// look at the star positions
 PANTAS_HD uint32_t block_order_key(uint32_t flags, uint32_t path_nodes) {
-  return ((flags & LINE_ONE_INDEL) ? 0x10000u : 0u) | (path_nodes < 0xFFFFu ? path_nodes : 0xFFFFu);
+  return ((flags & LINE_ONE_INDEL) ? 0x20000u : 0u) | ((flags & LINE_STARS) ? 0x10000u : 0u) | (path_nodes < 0xFFFFu ? path_nodes : 0xFFFFu);
 }
 // what the tokenisers set from a line's op statistics (both tokenisers call this: one definition of the classes)
 // start / tail: the line's offsets on its first / last path node.  The short walk computes a node's room in 32 bits
@@ -73,7 +76,7 @@ PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t ind
   constexpr int64_t OFF_MAX = int64_t(1) << 29;
   if (start < -OFF_MAX || start > OFF_MAX || tail < -OFF_MAX || tail > OFF_MAX) return 0u;
   if (n_ops == 0 || n_ops >= SHORT_MAX_OPS || others != 0 || slow || stars > SIMPLE_MAX_STARS || total_len >= SHORT_MAX_TOTAL) return 0u;
-  return indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u;
+  return (indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u) | (indels <= 1 && stars ? LINE_STARS : 0u);
 }
 
 struct LineHdr {
@@ -367,6 +370,7 @@ PANTAS_HD int walk_short(const GraphAcc& ga, const LineHdr& h, const uint32_t* n
   const uint32_t T = so.T;
   const bool rev = (h.flags & LINE_REV) != 0;
   const bool exact = !LEAN && (h.flags & LINE_HAS_DEL) != 0;
+  const bool all_colon = (so.ns | so.x) == 0u;      // no '*', no indel (the tokenisers order such lines first inside a block)
   uint32_t P = 0, kept = 0;
   bool pending = false;
   // the pending kept node: id, first out-target, and in one word {plain entries (2 bits), first-slot hit owed (bit 2),
@@ -412,6 +416,7 @@ PANTAS_UNROLL
       bool keep;
       uint32_t plain;
       if constexpr (LEAN) { keep = true; plain = short_has_colon(so, P, P + le) ? 1u : 0u; }
+      else if (all_colon) { keep = true; plain = 1u; }      // one ':' run after another: every node with room is kept with one plain entry
       else short_node_summary(so, P, le, keep, plain);
       P += le;                      // == T when the ops end inside this node
       if (keep) {
