@@ -30,6 +30,19 @@ def coverage(text: str) -> float:
     return float(text) if text != "." else -1
 
 
+def _int_mean(vals: list) -> int:
+    """int(statistics.mean(vals)) -- coverages are whole numbers held in floats: their sum is exact as an int, and the true division of
+    two ints is correctly rounded like float(Fraction(sum, n)), so the Fraction arithmetic of statistics.mean (more than half of the
+    run time of this script) is only needed for anything else"""
+    try:
+        ints = [int(v) for v in vals]
+        if all(i == v for i, v in zip(ints, vals)):
+            return int(sum(ints) / len(ints))
+    except (OverflowError, ValueError):
+        pass
+    return int(mean(vals))
+
+
 class Event:
     """One row of a call CSV with its junctions sorted into 'event' and 'canonical' (quantify.py:65-160)."""
     __slots__ = ("etype", "annotation_type", "chrom", "gene", "strand", "event_cov", "canonic_cov", "key",
@@ -96,7 +109,7 @@ class Event:
         return mean(vals) if vals else -1
 
     def weights(self) -> str:
-        return f"{int(mean([r[1] for r in self.replicates]))}/{int(mean([r[0] for r in self.replicates]))}"
+        return f"{_int_mean([r[1] for r in self.replicates])}/{_int_mean([r[0] for r in self.replicates])}"
 
     def prefix(self) -> str:
         return ",".join([self.etype, self.annotation_type, self.chrom, self.gene, self.strand,
