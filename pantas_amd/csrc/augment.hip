@@ -1494,11 +1494,13 @@ __global__ void planar_nodes_kernel(const uint4* __restrict__ cnt4, const uint32
 
 void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   HIP_OK(hipSetDevice(d.device));
+  PhaseTimer pt("download_result");
   const size_t V = d.V;
   r.nc.resize(V); r.il0.resize(V); r.oll.resize(V); r.rc.resize(d.A);
   if (V > (1u << 22)) {   // fresh pages of gigabytes: touched from many threads instead of by the copy engine's single staging loop
     prefault(r.nc.data(), V * 4); prefault(r.il0.data(), V * 4); prefault(r.oll.data(), V * 4); prefault(r.rc.data(), size_t(d.A) * 4);
   }
+  pt.lap("host arrays");
   uint32_t* planar = nullptr;       // [nc V | il0 V | oll V | rc A]
   HIP_OK(hipMalloc(&planar, std::max<size_t>(1, 3 * V + d.A) * 4));
   if (d.A) HIP_OK(hipMemcpyAsync(planar + 3 * V, d.counters + 4 * V, size_t(d.A) * 4, hipMemcpyDeviceToDevice, d.stream));
@@ -1516,6 +1518,7 @@ void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   HIP_OK(hipMemcpyAsync(s, d.small, 32, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
   (void)hipFree(planar);
+  pt.lap("planar counters to the host");
   std::vector<uint64_t> keys, first;
   std::vector<uint32_t> cnt;
   download_table(d, d.hist, s[2], keys, cnt, first);
@@ -1534,7 +1537,9 @@ void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   for (size_t i = 0; i < keys.size(); ++i)
     r.novel.push_back(NovelLink{uint32_t(keys[i] >> 32), uint32_t(keys[i]), cnt[i], first[i]});
   (void)g;
+  pt.lap("sparse tables to the host");
   finalize_result(r);
+  pt.lap("first-seen order of the sparse entries");
 }
 
 CounterPtrs counter_ptrs(DeviceGraph& d) {

@@ -14,12 +14,13 @@
 namespace pantas {
 
 void finalize_result(AugmentResult& r) {
-  std::sort(r.hist.begin(), r.hist.end(), [](const HistEntry& a, const HistEntry& b) {
+  // (first-seen orders are unique: no ties for the order of equal keys to matter)
+  par_sort(r.hist.begin(), r.hist.end(), [](const HistEntry& a, const HistEntry& b) {
     if (a.node != b.node) return a.node < b.node;
     if (a.side != b.side) return a.side < b.side;
     return a.first < b.first;
   });
-  std::sort(r.novel.begin(), r.novel.end(), [](const NovelLink& a, const NovelLink& b) { return a.first < b.first; });
+  par_sort(r.novel.begin(), r.novel.end(), [](const NovelLink& a, const NovelLink& b) { return a.first < b.first; });
 }
 
 namespace {

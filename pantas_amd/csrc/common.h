@@ -177,6 +177,29 @@ void prefault(void* p, size_t bytes);
 // Runs fn(chunk_index, begin, end) over [0, n) split into `chunks` contiguous ranges.
 void parallel_chunks(size_t n, unsigned chunks, const std::function<void(unsigned, size_t, size_t)>& fn);
 
+// std::sort by several threads: chunks sorted side by side, then merged pairwise (rounds of std::inplace_merge, each round's merges
+// side by side); the same result as std::sort for a strict weak order whose ties are equal elements
+template <class It, class Cmp>
+void par_sort(It b, It e, Cmp cmp, unsigned threads = 0) {
+  const size_t n = size_t(e - b);
+  if (threads == 0) threads = hw_threads();
+  unsigned c = 1;
+  while (c * 2 <= threads && c < 16 && n / (c * 2) >= (size_t(1) << 16)) c *= 2;
+  if (c == 1) { std::sort(b, e, cmp); return; }
+  std::vector<size_t> cut(c + 1);
+  for (unsigned i = 0; i <= c; ++i) cut[i] = n * i / c;
+  parallel_chunks(c, c, [&](unsigned, size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) std::sort(b + long(cut[i]), b + long(cut[i + 1]), cmp); });
+  for (unsigned w = 1; w < c; w *= 2) {
+    const unsigned pairs = c / (2 * w);
+    parallel_chunks(pairs, pairs, [&](unsigned, size_t lo, size_t hi) {
+      for (size_t p = lo; p < hi; ++p) {
+        const size_t a = cut[p * 2 * w], m = cut[p * 2 * w + w], z = cut[p * 2 * w + 2 * w];
+        std::inplace_merge(b + long(a), b + long(m), b + long(z), cmp);
+      }
+    });
+  }
+}
+
 // v = n copies of value, written by many threads (RawVector::assign would be one thread's pass over fresh pages)
 template <class T>
 void par_assign(RawVector<T>& v, size_t n, T value, unsigned threads = 0) {
