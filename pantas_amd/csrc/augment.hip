@@ -560,7 +560,7 @@ __device__ __forceinline__ int walk_short_info(const GraphView& g, const LineHdr
 }
 
 template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, uint32_t MINW = 1, bool PACKED = false, int ONLY = 0, bool ABL = false,
-          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false, uint32_t XCD = 0, bool PRE = false>
+          bool INFO = false, int PF = 1, bool DEFER = false, bool NVQ = false, uint32_t XCD = 0, bool PRE = false, bool SNAKE = false>
 __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   // the timing-only ablation switches (PANTAS_ABLATE) exist in the ABL instantiations only; elsewhere the tests fold away
   GraphView g = g_in;
@@ -607,7 +607,11 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     const Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin, NVQ ? nvq : nullptr, NVQ ? &nvq_n : nullptr};
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+    for (uint32_t r0 = lo, round = 0; r0 < hi; r0 += THREADS, ++round) {
+      // a block is ordered by cost (plain lines by path length, then lines with a '*', then the one-indel lines): taken the same way round
+      // in every round, the last wave of the workgroup would get the dearest 64 lines of every round -- odd rounds run the other way
+      const uint32_t i = r0 + ((SNAKE && (round & 1u)) ? THREADS - 1u - threadIdx.x : threadIdx.x);
+      if (i >= hi) continue;
       const LineHdr h = b.hdr[i];
       if constexpr (INFO) {
         // the record's offsets, sizes and first node id in one 16-byte load beside the header
@@ -1279,8 +1283,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
     // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
     // the rest with the general aggregating kernel beside it on a second stream: 73 = the round-1 short walk (gathers two
-    // nodes ahead), 80 / 85 / 97 / 100 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 100;   // read per launch: tools/ab_variants.py switches it
+    // nodes ahead), 80 / 85 / 97 / 100 / 101 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 101;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1327,15 +1331,25 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
-        default:
-          // 100: workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: workgroup b takes chunk (b % 8) * n/8 + b/8,
-          // so that neighbouring chunks, which share the nodes of an expressed gene, meet in ONE L2 (97; runs of 16 or 64 chunks per XCD
-          // instead of eighths measured in between, profiles/r2_ab_s4_xcd.txt) -- and the line's ShortOps comes with the record (third
-          // 16-byte word, made when the batch comes to be) instead of being scanned from ops[] by every launch.
+        case 100:   // 97 with the line's ShortOps read from the record instead of scanned from ops[]
           HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.ev[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true>),
+                                            dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
+          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          break;
+        default:
+          // 101: workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: workgroup b takes chunk (b % 8) * n/8 + b/8,
+          // so that neighbouring chunks, which share the nodes of an expressed gene, meet in ONE L2 (97; runs of 16 or 64 chunks per XCD
+          // instead of eighths measured in between, profiles/r2_ab_s4_xcd.txt); the line's ShortOps comes with the record (third 16-byte
+          // word, made when the batch comes to be) instead of being scanned from ops[] by every launch (100); odd rounds of a chunk run
+          // the other way round, so that no wave gets the dearest lines of every round (101).
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
+          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true, true>),
                                             dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));

@@ -106,6 +106,7 @@ def test_kernel_variants_and_record_order_give_identical_gfa():
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "80"}) == base      # deferred link lookups without the novel-link queue
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "85"}) == base      # ... with it, chunks in launch order (the default deals them to the XCDs in eighths)
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "97"}) == base      # ... XCD-aware, the op summary scanned from ops[] (the default reads it from the record)
+    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "100"}) == base     # ... the summary from the record, every round taken the same way round
     assert _augmented_sha({"PANTAS_NO_BUCKET": "1"}) == base
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0", "PANTAS_NO_BUCKET": "1", "PANTAS_THREADS": "3"}) == base
 
