@@ -122,6 +122,10 @@ def cpu_baseline(scale_kw: dict, sample_lines: int, s4_lines: int, s4_junctions:
         cpp = cpp_baseline(kw, tmp)
     except Exception as e:      # a reported baseline: its absence must not take the GPU line down
         cpp = {"skipped": f"{type(e).__name__}: {e}"}
+    try:
+        cpp_call = cpp_call_baseline(scale_kw, tmp)
+    except Exception as e:
+        cpp_call = {"skipped": f"{type(e).__name__}: {e}"}
     shutil.rmtree(tmp, ignore_errors=True)
     port_rate = sample_lines / dt
     ref_rate = port_rate / CALIBRATION["augment_ref_over_port"]
@@ -130,6 +134,7 @@ def cpu_baseline(scale_kw: dict, sample_lines: int, s4_lines: int, s4_junctions:
                       f"{kw['n_genes']}-gene instance ({syn.stats.nodes} segments), {dt:.1f} s in oracle/augment_oracle.py "
                       "(Python port of the reference's per-line loop; the rate does not depend on the graph size: dict lookups)",
             "cpp": cpp,
+            "cpp_call": cpp_call,
             "call_events_per_s": len(rows) / dc,
             "call_sample": f"{len(rows)} events from {syn.stats.junction_links} junction links in {dc:.1f} s, oracle/call_oracle.py incl. "
                            "GFA/GTF parsing (indexed junction lookup: NOT the reference's O(J^2) scan)",
@@ -171,6 +176,44 @@ def cpp_baseline(kw: dict, tmp: str, lines: int = 6_000_000):
         out[name] = {"threads": t, "reads_per_s": st["lines"] / st["hot_loop_s"], "hot_loop_s": st["hot_loop_s"], "merge_s": st["merge_s"],
                      "load_gfa_s": st["load_gfa_s"], "reads_per_s_incl_merge": st["lines"] / (st["hot_loop_s"] + st["merge_s"])}
     for ext in (".gaf", ".gfa", ".gtf"):
+        try:
+            os.unlink(pre + ext)
+        except OSError:
+            pass
+    return out
+
+
+def cpp_call_baseline(scale_kw: dict, tmp: str, genes: int = 6000, lines: int = 2_000_000, flags=("--rca", "3", "--novel")):
+    """SURVEY.md 8-d rows 2a / 2b for `call`: oracle/call_oracle.cpp (pinned to the reference's goldens by tests/test_oracle_cpp.py)
+    on one core and on all of them, on an augmented GFA of the same recipe (made by the C++ augment oracle).  Two rates each:
+    the three passes alone (what the call kernels do on the GPU) and the whole program incl. GFA / GTF parsing."""
+    import subprocess
+    from pantas_amd.engine import Synth
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    pre = os.path.join(tmp, "cpp_call_sample")
+    kw = dict(scale_kw)
+    kw["n_genes"] = min(kw["n_genes"], genes)
+    kw["n_chrom"] = min(kw.get("n_chrom", 1), 2)
+    kw["n_lines"] = lines
+    kw["with_path"] = 1
+    syn = Synth(seed=13, **kw)
+    syn.write(pre)
+    cores = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    many = cores if quota is None else max(1, min(cores, int(round(quota * 2))))
+    with open(pre + ".aug.gfa", "wb") as f:
+        subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(many), pre + ".gaf", pre + ".gfa"],
+                       stdout=f, stderr=subprocess.DEVNULL, check=True)
+    exe = os.path.join(ROOT, "oracle", "bin", "call_oracle_cpp")
+    out = {"sample": f"`call {' '.join(flags)}` on a {kw['n_genes']}-gene instance of the same recipe ({syn.stats.nodes} segments, "
+                     f"{syn.stats.junction_links} junction links) augmented with {lines} reads",
+           "cores": cores, "cpu_quota_cores": quota}
+    for name, t in (("one_thread", 1), ("all_cores", many)):
+        r = subprocess.run([exe, "--threads", str(t), "--no-out", *flags, pre + ".aug.gfa", pre + ".gtf"], capture_output=True, text=True, check=True)
+        st = json.loads(r.stderr.strip().splitlines()[-1])
+        out[name] = {"threads": t, "events": st["rows"], "events_per_s_passes": st["rows"] / max(st["passes_s"], 1e-9),
+                     "events_per_s_whole_program": st["rows"] / st["total_s"], "passes_s": st["passes_s"], "gfa_s": st["gfa_s"], "total_s": st["total_s"]}
+    for ext in (".gaf", ".gfa", ".gtf", ".aug.gfa"):
         try:
             os.unlink(pre + ext)
         except OSError:

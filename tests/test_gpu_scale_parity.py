@@ -4,7 +4,8 @@
   == oracle bytes, CSV rows == oracle rows as a multiset.
 * `test_whole_s3_vs_cpp_oracle`: ALL of S3 (human chr1 scale, 10 M lines) through `pantas augment` against the independent C++
   form of the oracle (oracle/augment_oracle.cpp, pinned to the reference's goldens by tests/test_oracle_cpp.py) on the host
-  cores: the two augmented GFAs are the same file.  (The same check of ALL of S4 -- 50 M lines, 2.5e8 segments, 23 GB of output --
+  cores: the two augmented GFAs are the same file; then `pantas call --rca 3 --novel` on that file against
+  oracle/call_oracle.cpp: the same rows (round 3).  (The same check of ALL of S4 -- 50 M lines, 2.5e8 segments, 23 GB of output --
   takes minutes of single-thread GFA indexing in the oracle: `test_whole_s4_vs_cpp_oracle`, run with PANTAS_WHOLE_S4=1 once per round:
   profiles/r2_e2e_s4_cpp_oracle.json.)
 * `test_full_graph_slice_vs_oracle[s3|s4]`: the FULL human-chr1 / human whole-genome graph (2.5e8 segments, ids in the
@@ -58,8 +59,9 @@ def gfa_lines():
     return exe
 
 
-def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads):
-    """`pantas augment` on the whole workload of a BASELINE scale against oracle/augment_oracle.cpp on the host cores: one file."""
+def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads, check_augment=True):
+    """`pantas augment` on the whole workload of a BASELINE scale against oracle/augment_oracle.cpp on the host cores: one file;
+    then `pantas call --rca 3 --novel` on it against oracle/call_oracle.cpp: the same rows."""
     import json
     import threading
     import time
@@ -78,35 +80,90 @@ def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads):
     threading.Thread(target=heartbeat, daemon=True).start()
     try:
         pre = os.path.join(tmp, scale)
-        Synth(seed=5, **bench.SCALES[scale][1]).write(pre)
+        desc, kw, *rest = bench.SCALES[scale]
+        Synth(seed=5, **kw).write(pre)
+        for b in range(1, rest[0] if rest else 1):          # (s5: four blocks of the read stream in ONE GAF file)
+            Synth(seed=5, line_offset=b * kw["n_lines"], gaf_only=1, **kw).write(pre + f".b{b}")
+            with open(pre + ".gaf", "ab") as out, open(pre + f".b{b}.gaf", "rb") as src:
+                shutil.copyfileobj(src, out, 1 << 26)
+            for ext in (".gaf", ".gfa", ".gtf"):
+                if os.path.exists(pre + f".b{b}" + ext):
+                    os.unlink(pre + f".b{b}" + ext)
         t0 = time.perf_counter()
         with open(pre + ".gpu.gfa", "wb") as f:
             r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         t1 = time.perf_counter()
-        with open(pre + ".or.gfa", "wb") as f:
-            o = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, oracle_threads)),
-                                pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
-        assert o.returncode == 0, o.stderr.decode()[-2000:]
-        t2 = time.perf_counter()
-        size = os.path.getsize(pre + ".gpu.gfa")
-        assert size == os.path.getsize(pre + ".or.gfa") > 10**9
-        with open(pre + ".gpu.gfa", "rb") as x, open(pre + ".or.gfa", "rb") as y:
-            while True:
-                a, b = x.read(1 << 26), y.read(1 << 26)
-                assert a == b
-                if not a:
-                    break
-        rej = [l for l in o.stderr.decode().splitlines() if l.startswith("Rejected alignments:")]
-        assert rej and rej[0] in r.stderr.decode()
+        res = {"scale": scale, "workload": desc, "gaf_bytes": os.path.getsize(pre + ".gaf"), "engine_augment_wall_s": t1 - t0}
+        if check_augment:
+            with open(pre + ".or.gfa", "wb") as f:
+                o = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, oracle_threads)),
+                                    pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
+            assert o.returncode == 0, o.stderr.decode()[-2000:]
+            t2 = time.perf_counter()
+            size = os.path.getsize(pre + ".gpu.gfa")
+            assert size == os.path.getsize(pre + ".or.gfa") > 10**9
+            with open(pre + ".gpu.gfa", "rb") as x, open(pre + ".or.gfa", "rb") as y:
+                while True:
+                    a, b = x.read(1 << 26), y.read(1 << 26)
+                    assert a == b
+                    if not a:
+                        break
+            rej = [l for l in o.stderr.decode().splitlines() if l.startswith("Rejected alignments:")]
+            assert rej and rej[0] in r.stderr.decode()
+            res.update({"aug_gfa_equals_cpp_oracle": True, "bytes": size, "cpp_oracle_wall_s": t2 - t1,
+                        "cpp_oracle_stats": json.loads(o.stderr.decode().strip().splitlines()[-1])})
+            os.unlink(pre + ".or.gfa")
+        os.unlink(pre + ".gaf")
+        res["call"] = _call_vs_cpp_oracle(pre, pre + ".gpu.gfa", oracle_threads)
         if os.environ.get("PANTAS_PARITY_JSON"):
-            json.dump({"scale": scale, "workload": bench.SCALES[scale][0], "aug_gfa_equals_cpp_oracle": True, "bytes": size,
-                       "engine_augment_wall_s": t1 - t0, "cpp_oracle_wall_s": t2 - t1,
-                       "cpp_oracle_stats": json.loads(o.stderr.decode().strip().splitlines()[-1])},
-                      open(os.environ["PANTAS_PARITY_JSON"], "w"), indent=1)
+            json.dump(res, open(os.environ["PANTAS_PARITY_JSON"], "w"), indent=1)
     finally:
         stop.set()
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+CALL_FLAGS = ["--rca", "3", "--novel"]
+
+
+def _call_vs_cpp_oracle(pre, aug_gfa, oracle_threads, flags=CALL_FLAGS):
+    """`pantas call` on an augmented GFA against oracle/call_oracle.cpp (pinned to the reference's goldens by
+    tests/test_oracle_cpp.py) on the host cores: the two CSVs hold the same rows -- compared as multisets through the oracle's
+    128-bit order-independent digest of the normalised rows, and line by line after sorting while the files
+    are small enough to sort in Python."""
+    import json
+    import time
+    exe = os.path.join(ROOT, "oracle", "bin", "call_oracle_cpp")
+    threads = str(min(os.cpu_count() or 1, oracle_threads))
+    t0 = time.perf_counter()
+    with open(pre + ".gpu.csv", "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.call", *flags, aug_gfa, pre + ".gtf"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    t1 = time.perf_counter()
+    small = os.path.getsize(pre + ".gpu.csv") < 1.5e9
+    with open(pre + ".or.csv" if small else os.devnull, "wb") as f:
+        o = subprocess.run([exe, "--threads", threads, "--digest", *([] if small else ["--no-out"]), *flags, aug_gfa, pre + ".gtf"],
+                           stdout=f, stderr=subprocess.PIPE)
+    assert o.returncode == 0, o.stderr.decode()[-2000:]
+    t2 = time.perf_counter()
+    want = json.loads(o.stderr.decode().strip().splitlines()[-1])
+    got = json.loads(subprocess.run([exe, "--threads", threads, "--digest-csv", pre + ".gpu.csv"], capture_output=True, check=True).stdout)
+    keys = ("rows", "s1", "s2", "x")
+    assert want["rows"] > 100_000
+    assert {k: got[k] for k in keys} == {k: want[k] for k in keys}, (got, want)
+    if small:
+        mine, ref = open(pre + ".gpu.csv").read().splitlines(), open(pre + ".or.csv").read().splitlines()
+        assert mine[0] == ref[0] == call_oracle.HEADER
+        norm = call_oracle.normalise_row
+        assert sorted(map(norm, mine[1:])) == sorted(map(norm, ref[1:]))
+        kinds = {tuple(l.split(",", 2)[:2]) for l in ref[1:]}
+        assert {("ES", "annotated"), ("IR", "annotated"), ("ES", "novel"), ("CE", "novel"), ("IR", "novel")} <= kinds, kinds
+        os.unlink(pre + ".or.csv")
+    res = {"flags": " ".join(flags), "events_csv_equals_cpp_oracle_as_row_multiset": True, "sorted_lines_compared": small, "rows": want["rows"],
+           "csv_bytes": os.path.getsize(pre + ".gpu.csv"), "digest": {k: want[k] for k in keys},
+           "engine_call_wall_s": t1 - t0, "cpp_oracle_call_wall_s": t2 - t1, "cpp_oracle_stats": want}
+    os.unlink(pre + ".gpu.csv")
+    return res
 
 
 def test_whole_s3_vs_cpp_oracle():
@@ -114,10 +171,25 @@ def test_whole_s3_vs_cpp_oracle():
 
 
 @pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S4"),
-                    reason="11 minutes (the oracle hashes 2.5e8 segment names on one thread and prints 23 GB on one): PANTAS_WHOLE_S4=1; "
-                           "the round's run is profiles/r2_e2e_s4_cpp_oracle.json")
+                    reason="11 minutes (the augment oracle hashes 2.5e8 segment names on one thread and prints 23 GB on one): PANTAS_WHOLE_S4=1; "
+                           "the round's run is profiles/r3_parity_s4_cpp_oracles.json")
 def test_whole_s4_vs_cpp_oracle():
-    _whole_workload_vs_cpp_oracle("s4", 80, 64)
+    _whole_workload_vs_cpp_oracle("s4", 120, 64)
+
+
+@pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S4_CALL"),
+                    reason="the call half of the S4 check alone (68 M rows; minutes): PANTAS_WHOLE_S4_CALL=1; profiles/r3_parity_s4_call.json")
+def test_whole_s4_call_vs_cpp_oracle():
+    _whole_workload_vs_cpp_oracle("s4", 120, 64, check_augment=False)
+
+
+@pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S5"),
+                    reason="200 M reads, annotated + novel search, 276 M rows / 52 GB of CSV: PANTAS_WHOLE_S5=1; the round's run is "
+                           "profiles/r3_parity_s5_call.json")
+def test_whole_s5_call_vs_cpp_oracle():
+    """BASELINE.json configs[4] at its size: `pantas augment` over 200 M reads, `pantas call --rca 3 --novel` on the result against
+    oracle/call_oracle.cpp (the augment half at this graph size is test_whole_s4_vs_cpp_oracle's)"""
+    _whole_workload_vs_cpp_oracle("s5", 220, 64, check_augment=False)
 
 
 def test_e2e_command_lines_vs_oracle():
@@ -131,13 +203,14 @@ def test_e2e_command_lines_vs_oracle():
         with open(pre + ".gpu.gfa", "wb") as f:
             r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
+        augment_stderr = r.stderr.decode()
         with open(pre + ".gpu.csv", "wb") as f:
             r = subprocess.run([sys.executable, "-m", "pantas_amd.call", *flags, pre + ".gpu.gfa", pre + ".gtf"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         with open(pre + ".or.gfa", "w") as f:
             a = augment_oracle.augment(pre + ".gaf", pre + ".gfa", f)
         assert open(pre + ".gpu.gfa", "rb").read() == open(pre + ".or.gfa", "rb").read()
-        assert f"Rejected alignments: {a.rejected}" in r.stderr.decode() or True
+        assert f"Rejected alignments: {a.rejected}" in augment_stderr
         rows = call_oracle.call(pre + ".or.gfa", pre + ".gtf", None, rca=3, novel=True)
         norm = call_oracle.normalise_row
         mine = open(pre + ".gpu.csv").read().splitlines()

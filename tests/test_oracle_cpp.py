@@ -1,6 +1,7 @@
-"""Pins the C++ form of the augment oracle (oracle/augment_oracle.cpp -- the `cpu_baseline` of bench.py: SURVEY.md 8-d rows
-2a / 2b) to the outputs of the real reference under tests/golden/: same bytes with one thread and with several, the
-reference's exception class where it dies."""
+"""Pins the C++ forms of the oracle (oracle/augment_oracle.cpp, oracle/call_oracle.cpp -- the `cpu_baseline` of bench.py:
+SURVEY.md 8-d rows 2a / 2b, and the checker of the whole-workload parity tests) to the outputs of the real reference under
+tests/golden/: same bytes (augment) / same row multisets (call) with one thread and with several, the reference's exception
+class where it dies, and the Python oracle on generated workloads."""
 import json
 import os
 import subprocess
@@ -74,3 +75,96 @@ def test_equals_python_oracle_on_a_generated_workload(exe, tmp_path):
         r = run(exe, pre + ".gaf", pre + ".gfa", threads)
         assert r.returncode == 0, r.stderr.decode()
         assert r.stdout == expected
+
+
+# ------------------------------------------------------------------------------------------------ call
+CALL_EXE = os.path.join(ROOT, "oracle", "bin", "call_oracle_cpp")
+
+
+def run_call(exe, flags, gfa, gtf, threads=1, extra=()):
+    assert exe      # (the fixture built both programs)
+    return subprocess.run([CALL_EXE, "--threads", str(threads), *extra, *flags, gfa, gtf], capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+@pytest.mark.parametrize("case", CASES)
+def test_call_golden_rows(exe, case, threads):
+    """the 18 flag sets of the goldens: every row each PYTHONHASHSEED prints, nothing outside the reference's own
+    alternatives -- and the same BYTES as oracle/call_oracle.py (rules R1-R4 are the same rules)"""
+    import call_oracle
+    from test_oracle_golden import _flags_to_opts, check_rows
+    d = os.path.join(GOLDEN, case)
+    meta = json.load(open(f"{d}/expected.json"))
+    assert meta["calls"]
+    for gc in meta["calls"]:
+        r = run_call(exe, gc["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf", threads)
+        assert r.returncode == 0, r.stderr
+        rows = r.stdout.splitlines()
+        assert rows[0] == call_oracle.HEADER
+        check_rows(rows[1:], gc)
+        if threads == 1:
+            assert rows[1:] == call_oracle.call(f"{d}/expected.aug.gfa", f"{d}/in.gtf", None, **_flags_to_opts(gc["flags"]))
+
+
+def test_call_crashes_where_the_reference_crashes(exe):
+    crashes = [c for c in json.load(open(os.path.join(GOLDEN, "crashes.json"))) if c["stage"] == "call"]
+    assert len(crashes) >= 5
+    cd = os.path.join(GOLDEN, "crashes")
+    for c in crashes:
+        for threads in (1, 4):
+            r = run_call(exe, c["flags"], f"{cd}/{c['call_input']}", f"{cd}/{c['name']}.gtf", threads)
+            assert r.returncode == 1, (c["name"], r.stderr)
+            assert r.stderr.strip().splitlines()[-1].startswith(c["exception"] + ":"), (c["name"], r.stderr, c["exception"])
+            assert len(r.stdout) == c["stdout_bytes"], c["name"]       # the header is out iff both inputs parsed
+
+
+@pytest.mark.parametrize("c", [c for c in json.load(open(os.path.join(EDGE, "cases.json"))) if c["stage"] == "call"], ids=lambda c: c["name"])
+def test_call_edge_inputs(exe, c):
+    """duplicate S / L lines, whitespace-led S lines, lone carriage returns: the reference's verdict, all of them
+    (the engine refuses two; the oracle restates the reference)"""
+    from test_edge_golden import check_call_rows
+    n = c["name"]
+    for threads in (1, 2):
+        r = run_call(exe, c["flags"], f"{EDGE}/{n}.aug.gfa", f"{EDGE}/{n}.gtf", threads)
+        if c["rc"]:
+            assert r.returncode == 1 and r.stderr.strip().splitlines()[-1].startswith(c["exception"] + ":"), r.stderr
+        else:
+            assert r.returncode == 0, r.stderr
+            check_call_rows(r.stdout.splitlines()[1:], json.load(open(f"{EDGE}/{n}.expected")))
+
+
+def test_call_equals_python_oracle_on_a_generated_workload(exe, tmp_path):
+    """6 000 genes, 1 M reads, 48 k junction links, 60 k links the reads added: the same bytes as oracle/call_oracle.py
+    (every row kind; > 10^5 rows), with 1 and 8 threads, and a digest that is the digest of the file"""
+    import io
+    import call_oracle
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "w")
+    Synth(seed=21, n_genes=6000, n_lines=1_000_000, base_id=10**7, intron_long_max=200, zipf_a=1.0).write(pre)
+    with open(pre + ".aug.gfa", "wb") as f:
+        subprocess.run([EXE, "--threads", "8", pre + ".gaf", pre + ".gfa"], stdout=f, check=True, stderr=subprocess.DEVNULL)
+    flags = ["--rca", "3", "--novel"]
+    out = io.StringIO()
+    call_oracle.call(pre + ".aug.gfa", pre + ".gtf", out, rca=3, novel=True)
+    expected = out.getvalue()
+    assert expected.count("\n") > 100_000
+    kinds = {tuple(l.split(",")[:2]) for l in expected.splitlines()[1:]}
+    assert kinds == {(t, a) for t in ("ES", "A3", "A5", "IR") for a in ("annotated", "novel")} | {("CE", "novel")}
+    digests = []
+    for threads in (1, 8):
+        r = run_call(exe, flags, pre + ".aug.gfa", pre + ".gtf", threads, extra=("--digest",))
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == expected
+        digests.append({k: v for k, v in json.loads(r.stderr.strip().splitlines()[-1]).items() if k in ("rows", "s1", "s2", "x")})
+    with open(pre + ".csv", "w") as f:
+        f.write(expected)
+    d = json.loads(subprocess.run([CALL_EXE, "--threads", "3", "--digest-csv", pre + ".csv"], capture_output=True, text=True, check=True).stdout)
+    assert digests[0] == digests[1] == d and d["rows"] == expected.count("\n") - 1
+    # the digest is of the row MULTISET (rows shuffled: same digest; one row changed: another)
+    lines = expected.splitlines()
+    with open(pre + ".csv", "w") as f:
+        f.write("\n".join([lines[0]] + lines[1:][::-1]) + "\n")
+    assert json.loads(subprocess.run([CALL_EXE, "--digest-csv", pre + ".csv"], capture_output=True, text=True, check=True).stdout) == d
+    with open(pre + ".csv", "w") as f:
+        f.write("\n".join(lines[:-1] + [lines[-1][:-1] + "7"]) + "\n")
+    assert json.loads(subprocess.run([CALL_EXE, "--digest-csv", pre + ".csv"], capture_output=True, text=True, check=True).stdout) != d
