@@ -50,9 +50,19 @@ def main(argv) -> int:
     return 0
 
 
-if __name__ == "__main__":
-    rc = main(sys.argv[1:])
-    sys.stdout.flush()
-    sys.stderr.flush()
-    # the output is complete: leave without tearing down 60 GB of graph arrays page by page (seconds at whole-genome scale)
+def _leave(rc: int) -> None:
+    """The output is complete: leave without tearing down 60 GB of graph arrays page by page (seconds at whole-genome scale).
+    PANTAS_CLEAN_EXIT=1 takes the ordinary way out (atexit handlers and library finalisers run: what a profiler or a coverage
+    tool around this process needs to write its own output)."""
+    for stream in (sys.stdout, sys.stderr):
+        try:
+            stream.flush()
+        except BrokenPipeError:       # the reader went away (`| head`): nothing left to deliver, no traceback either
+            pass
+    if os.environ.get("PANTAS_CLEAN_EXIT"):
+        sys.exit(rc)
     os._exit(rc)
+
+
+if __name__ == "__main__":
+    _leave(main(sys.argv[1:]))

@@ -82,7 +82,5 @@ def main(argv=None) -> int:
 
 
 if __name__ == "__main__":
-    rc = main()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(rc)      # (see augment.py: no page-by-page teardown of the graph arrays)
+    from .augment import _leave
+    _leave(main())      # (no page-by-page teardown of the graph arrays; PANTAS_CLEAN_EXIT=1 for the ordinary exit)

@@ -19,6 +19,7 @@
 // needs a single (block-sparse, exchange.hip) all-reduce.
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -29,8 +30,6 @@
 namespace pantas {
 
 constexpr uint64_t EMPTY_KEY = ~0ull;
-constexpr uint32_t REC_QUADS = 3;      // BatchView::rec: three 16-byte words per record
-constexpr uint32_t REC_OPS_MAX = SHORT_MAX_OPS - 1u;     // BatchView::rec holds the op count in 24 bits (saturated; only short-walk records are read through it)
 constexpr uint32_t COMMON_POS = 0x7FFFFFFFu;
 
 struct TableView {
@@ -804,6 +803,28 @@ void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   delete b;
 }
 
+// Two pinned staging buffers and their events PER DEVICE: an event belongs to the device that was current when it was made, and
+// the C ABI lets one process drive several devices (one handle each) -- buffers made under device 0 and recorded on a stream of
+// device 1 fail with hipErrorInvalidHandle.  One copy at a time per direction (the mutex); they live as long as the process.
+namespace {
+struct Staging {
+  void* pinned[2] = {nullptr, nullptr};
+  hipEvent_t done[2] = {nullptr, nullptr};
+};
+Staging& staging_of_current_device(std::map<int, Staging>& per_device, size_t bytes) {
+  int dev = 0;
+  HIP_OK(hipGetDevice(&dev));
+  Staging& s = per_device[dev];
+  if (!s.pinned[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIP_OK(hipHostMalloc(&s.pinned[k], bytes, hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming));
+    }
+  }
+  return s;
+}
+}  // namespace
+
 void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream) {
   constexpr size_t STAGE = size_t(32) << 20;
   if (bytes == 0) return;
@@ -812,17 +833,12 @@ void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     HIP_OK(hipStreamSynchronize(stream));
     return;
   }
-  // process-wide staging buffers (one copy at a time; they live as long as the process)
   static std::mutex mu;
-  static void* pinned[2] = {nullptr, nullptr};
-  static hipEvent_t done[2] = {nullptr, nullptr};
+  static std::map<int, Staging> per_device;
   std::lock_guard<std::mutex> lk(mu);
-  if (!pinned[0]) {
-    for (int k = 0; k < 2; ++k) {
-      HIP_OK(hipHostMalloc(&pinned[k], STAGE, hipHostMallocDefault));
-      HIP_OK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
-    }
-  }
+  Staging& sg = staging_of_current_device(per_device, STAGE);
+  void* const* pinned = sg.pinned;
+  hipEvent_t* done = sg.done;
   const unsigned threads = std::min<unsigned>(hw_threads(), 16);
   bool used[2] = {false, false};
   int k = 0;
@@ -850,15 +866,11 @@ void d2h_staged(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     return;
   }
   static std::mutex mu;
-  static void* pinned[2] = {nullptr, nullptr};
-  static hipEvent_t done[2] = {nullptr, nullptr};
+  static std::map<int, Staging> per_device;
   std::lock_guard<std::mutex> lk(mu);
-  if (!pinned[0]) {
-    for (int k = 0; k < 2; ++k) {
-      HIP_OK(hipHostMalloc(&pinned[k], STAGE, hipHostMallocDefault));
-      HIP_OK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
-    }
-  }
+  Staging& sg = staging_of_current_device(per_device, STAGE);
+  void* const* pinned = sg.pinned;
+  hipEvent_t* done = sg.done;
   const unsigned threads = std::min<unsigned>(hw_threads(), 16);
   const size_t n = (bytes + STAGE - 1) / STAGE;
   auto issue = [&](size_t i) {
@@ -1081,16 +1093,8 @@ static void table_grow(DeviceGraph& d, Table& t, uint32_t cap, uint32_t* n_keys,
 
 __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, const uint32_t* ops, uint4* rec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    const uint32_t n0 = node_off[i], k = node_off[i + 1] - n0, o0 = op_off[i], c = op_off[i + 1] - o0;
-    const uint32_t last = k ? k - 1u : 0u;
-    auto id = [&](uint32_t j) { return k ? nodes[n0 + (j < last ? j : last)] : 0u; };
-    rec[REC_QUADS * size_t(i)] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
-    rec[REC_QUADS * size_t(i) + 1] = make_uint4(id(1), id(2), id(3), id(4));
-    // the short walk's view of the cs (walk.h ShortOps), so that the dominant kernel neither reads ops[] nor scans it; only read for
-    // records of the short-walk class (fewer than SHORT_MAX_OPS ops, total below 2^16)
-    ShortOps so;
-    if (c < SHORT_MAX_OPS) short_ops_scan(ops + o0, c, so);
-    rec[REC_QUADS * size_t(i) + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
+    const uint32_t n0 = node_off[i], o0 = op_off[i];
+    make_rec_entry(rec, i, n0, node_off[i + 1] - n0, o0, op_off[i + 1] - o0, nodes, ops);
   }
 }
 

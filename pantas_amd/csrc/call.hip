@@ -228,6 +228,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.row_ptr = up_raw(*d, t.row_ptr, size_t(g.V) + 1); c.col = up_raw(*d, t.col, t.A);
   c.irow_ptr = up_raw(*d, t.irow_ptr, size_t(g.V) + 1); c.icol = up_raw(*d, t.icol, t.A); c.islot = up_raw(*d, t.islot, t.A);
   c.first_slot = up(*d, t.first_slot); c.src = up(*d, t.src); c.lflags = up(*d, t.lflags);
+  c.hid = t.hidden.empty() ? nullptr : up(*d, t.hidden);
   c.rc = up(*d, t.rc); c.nc = up(*d, t.nc); c.nflags = up(*d, t.nflags); c.ln = up(*d, g.seg_len); c.rank = up(*d, t.rank);
   c.ex_ptr = up(*d, t.ex_ptr); c.ex_tag = up(*d, t.ex_tag); c.ex_tx = up(*d, t.ex_tx); c.ex_gene = up(*d, t.ex_gene);
   c.jrow = up(*d, t.jrow);

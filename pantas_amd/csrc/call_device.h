@@ -69,6 +69,8 @@ struct CallView {
   const uint32_t* first_slot;   // [A] first slot of the same (u, v) pair
   const uint32_t* src;          // [A]
   const uint32_t* lflags;       // [A] valid on canonical slots
+  const uint8_t* hid;           // [A] or nullptr: bit 0 / 1 -- the slot is no member of its source's "O" / its target's "I" list
+                                // (a later S line of that name restarted the lists, call.py:153-154); gfaL still holds the link
   const int32_t* rc;            // [A]
   const int32_t* nc;            // [V]
   const uint32_t* nflags;       // [V]
@@ -158,6 +160,10 @@ PANTAS_HD bool is_junction(const CallView& c, uint32_t u, uint32_t v) {
   return s != CNONE && (c.lflags[s] & L_JUNC);
 }
 
+// slot s counts as an out-neighbour of its source / an in-neighbour of its target
+PANTAS_HD bool in_out_list(const CallView& c, uint32_t s) { return c.hid == nullptr || !(c.hid[s] & 1u); }
+PANTAS_HD bool in_in_list(const CallView& c, uint32_t s) { return c.hid == nullptr || !(c.hid[s] & 2u); }
+
 PANTAS_HD uint32_t ceil_mean(uint64_t total, uint32_t n) { return uint32_t((total + n - 1) / n); }
 
 // Error latch of one junction's evaluation
@@ -186,12 +192,14 @@ PANTAS_HD bool walk_exon(const CallView& c, uint32_t start, uint32_t goal, Ok ok
     ln_sum += c.ln[cur];
     if (cur == goal) return true;
     const uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
-    if (b == e) { f.raise(CE_ASSERT_PATH); return false; }
-    uint32_t nxt = c.col[e - 1];
+    uint32_t nxt = CNONE;
     for (uint32_t s = b; s < e; ++s) {
+      if (!in_out_list(c, s)) continue;
       const uint32_t nn = c.col[s];
-      if (c.rank[nn] <= c.rank[goal] && ok(nn)) { nxt = nn; break; }
+      nxt = nn;                                     // (the loop variable stays on the last out-neighbour)
+      if (c.rank[nn] <= c.rank[goal] && ok(nn)) break;
     }
+    if (nxt == CNONE) { f.raise(CE_ASSERT_PATH); return false; }
     cur = nxt;
     if (--guard == 0) { f.raise(CE_HANG); return false; }
   }
@@ -415,6 +423,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     PANTAS_DBG(T_DBG_ANN_SS, s);                    // :378
     if (n_tails) {
       for (uint32_t t = ob; t < oe; ++t) {          // every out-link line of u, duplicates included
+        if (!in_out_list(c, t)) continue;
         const uint32_t n = c.col[t];
         if (n == v) continue;
         const Ex en = ex_of(c, n);
@@ -445,6 +454,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     }
     if (n_heads) {
       for (uint32_t q0 = ib; q0 < ie; ++q0) {        // every in-link line of v
+        if (!in_in_list(c, c.islot[q0])) continue;
         const uint32_t n = c.icol[q0];
         if (n == u) continue;
         const Ex en = ex_of(c, n);
@@ -480,6 +490,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     for (uint32_t i = 0; i < exu.n && !both_any; ++i) both_any = exu.gene[i] == g && ex_has_gene(exv, exu.tag[i], g);
     bool done = !both_any;
     for (uint32_t t = ob; t < oe && !done; ++t) {
+      if (!in_out_list(c, t)) continue;
       const uint32_t n1 = c.col[t];
       if (n1 == v) continue;
       const Ex e1 = ex_of(c, n1);
@@ -487,6 +498,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
       for (uint32_t i = 0; i < e1.n && !n1_any; ++i) n1_any = ex_has_gene(exu, e1.tag[i], g) && ex_has_gene(exv, e1.tag[i], g);
       if (!n1_any) continue;
       for (uint32_t q = ib; q < ie && !done; ++q) {
+        if (!in_in_list(c, c.islot[q])) continue;
         const uint32_t n2 = c.icol[q];
         if (n2 == u) continue;
         if (c.rank[n2] < c.rank[n1]) continue;

@@ -369,7 +369,8 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     throw Error("ValueError", "GFA byte " + std::to_string(g.first_short_l_off) + ": L line with fewer than 6 fields");
   if (g.links_unknown_end || g.link_before_segment)
     throw Error("KeyError", "an L line names a segment with no S line before it");
-  if (g.dup_names) throw Error("Unsupported", "duplicate S lines for one segment name (call)");
+  if (g.dup_names && g.dup_ws)
+    throw Error("Unsupported", "several S lines for one segment name, one of them behind leading whitespace (call)");
   const uint32_t V = g.V;
   // ---- link layout -------------------------------------------------------------------------------
   RawVector<uint32_t> old_slot;     // fused: slot of the graph behind each slot of the layout (NONE32 = added link)
@@ -462,6 +463,15 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   }
   const size_t A = t.A;
   auto graph_slot = [&](size_t s) -> uint32_t { return old_slot.empty() ? uint32_t(s) : old_slot[s]; };
+  t.hidden.clear();
+  if (g.dup_names) {
+    // A later S line of a name replaces gfaS[name] and with it the segment's "O" / "I" lists (call.py:149-154): links read
+    // before it stay in gfaL (and in `junctions`) but are no neighbours any more.  Links the reads added stand behind the text.
+    t.hidden.resize(A);
+    for (size_t u = 0; u < V; ++u)
+      for (uint32_t s = t.row_ptr[u]; s < t.row_ptr[u + 1]; ++s)
+        t.hidden[s] = uint8_t((t.order[s] < g.seg_line_off[u] ? 1 : 0) | (t.order[s] < g.seg_line_off[t.col[s]] ? 2 : 0));
+  }
   size_t next_novel = 0;
   (void)next_novel;
 
@@ -984,6 +994,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.row_ptr = t.row_ptr; c.col = t.col;
   c.irow_ptr = t.irow_ptr; c.icol = t.icol; c.islot = t.islot;
   c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
+  c.hid = t.hidden.empty() ? nullptr : t.hidden.data();
   c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
   c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
   c.jrow = t.jrow.data();
@@ -1001,6 +1012,11 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
 void pass_lists(const Graph& g, const CallTables& t, const CallOptions& o, std::vector<uint32_t>& annotated,
                 std::vector<uint32_t>& novel, std::vector<uint32_t>& around, std::vector<uint32_t>& around_jidx) {
   annotated.clear(); novel.clear(); around.clear(); around_jidx.clear();
+  // Several S lines for one name: without --novel the reference is deterministic (the adjacency lists restart at the last
+  // S line, hidden slots above); with it, check_novel reaches the else branches of :623-631 / :677-685, the second of which
+  // reads a loop variable left over from an earlier junction of a SET iteration -- nothing to be bit-exact with
+  if (!t.hidden.empty() && o.novel)
+    throw Error("Unsupported", "several S lines for one segment name with --novel: what the reference prints depends on its hash seed (call.py:681-685)");
   auto matches = [&](uint32_t s) {
     if (!o.has_junction) return true;
     Span a = g.name_of(t.src[s]), b = g.name_of(t.col[s]);

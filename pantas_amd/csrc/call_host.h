@@ -42,6 +42,8 @@ struct CallTables {
   // ---- mirrored to the device -----------------------------------------------------------
   // (RawVector: [V] / [A] arrays, gigabytes at whole-genome scale -- huge pages, filled by many threads)
   RawVector<uint32_t> first_slot, src, lflags;
+  RawVector<uint8_t> hidden;     // [A], only for a graph with several S lines for one name: bit 0 -- the slot's L line stands in front
+                                 // of the LAST S line of its source (it is in gfaL, not in gfaS[u]["O"]: call.py:153-154); bit 1 -- of its target
   RawVector<int32_t> rc, nc;
   RawVector<uint32_t> nflags, rank;
   RawVector<uint32_t> ex_ptr;

@@ -21,6 +21,7 @@ struct pantas_graph {
   bool have_result = false;
   uint64_t lines = 0, rejected = 0, skipped = 0;
   uint64_t first_record_line = UINT64_MAX;   // of the run, over its batches (walk.h WALK_TILDE_FIRST)
+  uint64_t run_first_line = UINT64_MAX;      // smallest `first_line` a batch of the run was loaded with: 0 = the run holds the START of its file
   std::shared_ptr<Error> deferred;   // tokeniser error of a loaded batch, reported by finish (see gaf.h)
   int tokenizer = PANTAS_TOKENIZER_AUTO;
   double load_s = 0;
@@ -229,6 +230,7 @@ static int reset_run(pantas_graph* g, bool keep_tilde) {
     g->res = AugmentResult();
     g->lines = g->rejected = g->skipped = 0;
     g->first_record_line = UINT64_MAX;
+    g->run_first_line = UINT64_MAX;
     g->deferred.reset();
     g->stream.reset();
   });
@@ -325,6 +327,7 @@ static void load_gaf_common(pantas_graph* g, const char* data, size_t size, int 
     g->rejected += b.rejected;
     g->skipped += b.skipped;
     g->first_record_line = std::min(g->first_record_line, b.first_record_line);
+    g->run_first_line = std::min(g->run_first_line, first_line);
     if (b.deferred && !g->deferred) g->deferred = b.deferred;
   }
   if (stats) put_out(stats, s, "pantas_batch_stats");
@@ -478,7 +481,9 @@ __attribute__((visibility("default"))) int pantas_augment_finish(pantas_graph* g
   return guarded([&] {
     need_device(g);
     PhaseTimer pt("pantas_augment_finish");
-    check_device_status(*g->dev, g->first_record_line);      // a line that fails in the walk, before ...
+    // ('~' first with nothing left behind is the reference's UnboundLocalError only on the first record of the FILE: the first
+    // record of a rank's byte range has lines of another rank in front of it, and what they leave behind is not known here)
+    check_device_status(*g->dev, g->run_first_line == 0 ? g->first_record_line : UINT64_MAX);      // a line that fails in the walk, before ...
     if (g->deferred) {                          // ... the line the tokeniser stopped at
       Error e = *g->deferred;
       g->deferred.reset();

@@ -119,10 +119,12 @@ struct LineSummary {
   int32_t start, tail;
 };
 
-// Out concept:  void node(uint32_t i, uint32_t idx);  void op(uint32_t i, uint32_t word);
+// Out concept:  void op(uint32_t i, uint32_t word);  void ops_done(uint32_t n_ops);  void node(uint32_t i, uint32_t idx);
+// -- every op of the line (in order), then their number once, then every path node (in order)
 struct CountOnly {
   PANTAS_HD void node(uint32_t, uint32_t) {}
   PANTAS_HD void op(uint32_t, uint32_t) {}
+  PANTAS_HD void ops_done(uint32_t) {}
 };
 
 template <class Out>
@@ -256,6 +258,7 @@ PANTAS_HD void parse_gaf_line(const uint8_t* b, const uint8_t* e, int thr, const
     if (!found) em.push((1u << 3) | OP_STAR);
   }
   em.finish(start);
+  out.ops_done(em.written);
 
   // ---- dv: first "dv:f:<digit>" of any optional field
   {

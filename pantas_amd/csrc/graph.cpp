@@ -212,6 +212,10 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
   g->seg_line_off.reserve(ns);
   g->seg_name_off.reserve(ns);
   g->seg_name_len.reserve(ns);
+  std::vector<uint64_t> first_off;
+  std::vector<bool> first_defines;
+  first_off.reserve(ns);
+  first_defines.reserve(ns);
   for (auto& o : outs) {
     for (auto& s : o.s) {
       Span nm{base + s.name_off(), base + s.name_off() + s.name_len};
@@ -233,14 +237,23 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
         g->seg_line_off.push_back(s.line_off);
         g->seg_name_off.push_back(s.name_off());
         g->seg_name_len.push_back(uint16_t(s.name_len));
+        first_off.push_back(s.line_off);
+        first_defines.push_back(s.defines());
       } else {
         g->dup_names = true;
+        if (!s.defines() || !first_defines[*slot]) g->dup_ws = true;
         if (s.defines()) {
           g->seg_len[*slot] = s.seq_len();
           g->seg_line_off[*slot] = s.line_off;
         }
       }
     }
+  }
+  if (g->dup_names) {
+    // call.py keeps the LAST S line of a name and restarts the segment's adjacency lists there (:149-154); a link is only
+    // an error when it stands in front of the FIRST one (:174)
+    g->seg_first_off.resize(first_off.size());
+    std::copy(first_off.begin(), first_off.end(), g->seg_first_off.data());
   }
   }
   pt.lap(fast_names ? "name index (parallel)" : "name index (sequential)");
@@ -285,7 +298,8 @@ static std::unique_ptr<Graph> parse_graph(std::unique_ptr<Graph> g, unsigned thr
           ++c_unknown[i];
         } else {
           ++c_valid[i + 1];
-          if (g->seg_line_off[lu[k]] > r.line_off || g->seg_line_off[lv[k]] > r.line_off) c_before[i] = 1;
+          const RawVector<uint64_t>& first = g->dup_names ? g->seg_first_off : g->seg_line_off;
+          if (first[lu[k]] > r.line_off || first[lv[k]] > r.line_off) c_before[i] = 1;
           if (have_prev && lu[k] < prev) c_unsorted[i] = 1;
           prev = lu[k];
           have_prev = true;

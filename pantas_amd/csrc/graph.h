@@ -54,6 +54,8 @@ struct Graph {
   RawVector<uint32_t> irow_ptr, icol, islot;  // in CSR
   // facts the two consumers validate differently
   bool dup_names = false;              // some name has more than one S line
+  bool dup_ws = false;                 // ... and one of those lines stands behind leading whitespace (augment and call read such a line differently)
+  RawVector<uint64_t> seg_first_off;   // [V], only with dup_names: offset of the FIRST S line of the name (seg_line_off: the last)
   bool link_before_segment = false;    // an L line precedes the S line of one of its ends
   uint64_t links_unknown_end = 0;      // L lines naming a segment without S line
   uint64_t first_bad_p_off = UINT64_MAX;   // first P line without exactly 4 tokens

@@ -60,6 +60,7 @@ template <class V> Section sec(const V& v) { return Section{v.data(), v.size() *
 
 bool save_graph_cache(const Graph& g, const char* cache_path) {
   if (!g.names.dense || g.text.borrowed || g.path.empty()) return false;   // only file-backed graphs with decimal names
+  if (g.dup_names) return false;                                           // (several S lines for one name: parsed every time)
   Header h{};
   h.magic = MAGIC; h.version = CACHE_VERSION;
   h.gfa_size = g.text.size;

@@ -201,6 +201,7 @@ struct WriteOut {
   uint32_t* ops;
   __device__ __forceinline__ void node(uint32_t i, uint32_t idx) { nodes[i] = idx; }
   __device__ __forceinline__ void op(uint32_t i, uint32_t w) { ops[i] = w; }
+  __device__ __forceinline__ void ops_done(uint32_t) {}
 };
 
 __global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
@@ -217,6 +218,192 @@ __global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const u
     node_off[rec] = no;
     op_off[rec] = oo;
   });
+}
+
+
+// ================================================================================================================
+// ONE parse per line (round 3).  The two-pass form above reads and parses the text twice (count, scan, write) and then
+// gathers every record from three file-order arrays through a permutation: 25 + 25 + 15 ms for 7.4 GB / 50 M lines.
+// Here a line is parsed once and its record -- {LineHdr, k, c, ops, nodes}, PROV_HDR + c + k words -- is written straight
+// into a word array CONGRUENT WITH THE TEXT: the record of the line that starts at byte b lives at word ceil(b / 4), and a
+// line of L bytes has L / 4 words of room, which a GAF line never fills (a path node costs its name and a '>' in text, a cs op
+// two or three bytes, the twelve mandatory columns pay for the header).  No offsets have to be known before the parse, so there
+// is no count pass and no scan.  A line that does not fit (names of one or two characters) takes room from a small arena behind
+// the array by one atomic and is parsed a second time into it; when the arena runs out, or a line makes the reference raise, the
+// batch falls back to the two-pass form (which also words the error).
+// The sort that buckets the records by locus carries, per line, a 64-bit value {record address, k, c, class bits}: everything
+// the later passes need to size and order the batch sits in the sorted values, and the record itself is read exactly once, by
+// the gather that writes the batch (and its `rec` entries).
+constexpr uint32_t PROV_HDR = 6;                   // start, tail, line id, flags, k, c
+constexpr uint64_t VAL_K_SHIFT = 32, VAL_C_SHIFT = 44, VAL_DEL = 1ull << 56, VAL_STARS = 1ull << 57, VAL_INDEL = 1ull << 58, VAL_BIG = 1ull << 59;
+constexpr uint32_t VAL_SMALL_MAX = 4095;           // k and c ride in 12 bits each; beyond that VAL_BIG says "read them from the record"
+constexpr uint32_t N_TOTALS = 10;                  // kept, nodes, ops, rejected, skipped, del lines, del nodes, short records, short nodes, short ops
+constexpr uint32_t N_PARTIAL = N_TOTALS + 1;       // ... and, in a wave's row of partial sums, its first kept line (or NONE)
+
+struct ProvOut {
+  uint32_t* w;          // the record (global memory)
+  uint32_t cap;         // words behind the header
+  uint32_t c = 0, first = 0, last = 0;
+  bool ovf = false;
+  __device__ __forceinline__ void op(uint32_t i, uint32_t x) { if (i < cap) w[PROV_HDR + i] = x; else ovf = true; }
+  __device__ __forceinline__ void ops_done(uint32_t n) { c = n; }
+  __device__ __forceinline__ void node(uint32_t i, uint32_t idx) {
+    if (i == 0) first = idx;
+    last = idx;
+    const uint32_t j = c + i;
+    if (j < cap) w[PROV_HDR + j] = idx; else ovf = true;
+  }
+};
+
+__global__ void __launch_bounds__(LPB) parse_once_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
+                                                         DenseNames names, uint32_t first_line, uint32_t bits, uint32_t* prov, uint64_t prov_words,
+                                                         uint32_t* arena_next, uint32_t arena_words, uint32_t* key, unsigned long long* val, uint32_t* partial,
+                                                         unsigned long long* err, uint32_t* fallback) {
+  uint32_t t[N_TOTALS];
+#pragma unroll
+  for (uint32_t j = 0; j < N_TOTALS; ++j) t[j] = 0;
+  uint32_t my_kept_line = 0xFFFFFFFFu;
+  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
+    const uint64_t lb = ls[i], le = ls[i + 1];
+    const uint64_t slot = (lb + 3) >> 2, slot_end = le >> 2;
+    const uint32_t room = slot_end > slot ? uint32_t(slot_end - slot) : 0u;
+    ProvOut po{prov + slot, room > PROV_HDR ? room - PROV_HDR : 0u};
+    LineSummary r;
+    parse_gaf_line(b, e, thr, names, po, r, check_cr != 0u);
+    uint32_t k32 = 2u << bits;           // not a record: sorts behind both classes
+    unsigned long long v = 0;
+    if (r.status == TOK_ERROR) atomicMin(err, (static_cast<unsigned long long>(i) << 8) | r.err);
+    else if (r.status == TOK_REJECT) t[3] = 1;
+    else if (r.status == TOK_SKIP) t[4] = 1;
+    else {
+      uint64_t at = slot;
+      bool ok = true;
+      if (po.ovf || room < PROV_HDR) {
+        const uint32_t need = PROV_HDR + r.n_ops + r.n_nodes;
+        const uint32_t pos = atomicAdd(arena_next, need);
+        if (need > arena_words || pos > arena_words - need) { atomicOr(fallback, 1u); ok = false; }
+        else {
+          at = prov_words + pos;
+          ProvOut again{prov + at, need - PROV_HDR};
+          LineSummary r2;
+          parse_gaf_line(b, e, thr, names, again, r2, false);
+        }
+      }
+      if (ok) {
+        uint32_t* w = prov + at;
+        w[0] = uint32_t(r.start); w[1] = uint32_t(r.tail); w[2] = first_line + i; w[3] = r.flags; w[4] = r.n_nodes; w[5] = r.n_ops;
+        const bool is_short = short_walk_class(r.flags, r.n_nodes);
+        k32 = ((is_short ? 0u : 1u) << bits) | (r.n_nodes ? min(po.first, po.last) : 0u);
+        const bool big = r.n_nodes > VAL_SMALL_MAX || r.n_ops > VAL_SMALL_MAX;
+        v = static_cast<unsigned long long>(at) | (static_cast<unsigned long long>(big ? 0u : r.n_nodes) << VAL_K_SHIFT) |
+            (static_cast<unsigned long long>(big ? 0u : r.n_ops) << VAL_C_SHIFT) | ((r.flags & LINE_HAS_DEL) ? VAL_DEL : 0ull) |
+            ((r.flags & LINE_STARS) ? VAL_STARS : 0ull) | ((r.flags & LINE_ONE_INDEL) ? VAL_INDEL : 0ull) | (big ? VAL_BIG : 0ull);
+        t[0] = 1; t[1] = r.n_nodes; t[2] = r.n_ops;
+        my_kept_line = i;
+        if (r.flags & LINE_HAS_DEL) { t[5] = 1; t[6] = r.n_nodes; }
+        if (is_short) { t[7] = 1; t[8] = r.n_nodes; t[9] = r.n_ops; }
+      }
+    }
+    key[i] = k32;
+    val[i] = v;
+  });
+  // what this wave's 64 lines add to the batch totals: one row of partial sums per wave, summed by totals_kernel (ten
+  // same-address atomics per wave would queue 7.8 M deep at whole-genome scale)
+#pragma unroll
+  for (uint32_t j = 0; j < N_TOTALS; ++j) {
+    uint32_t x = t[j];
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    if (threadIdx.x == 0) partial[size_t(blockIdx.x) * N_PARTIAL + j] = x;
+  }
+  for (int d = 32; d > 0; d >>= 1) my_kept_line = min(my_kept_line, uint32_t(__shfl_down(my_kept_line, d, 64)));
+  if (threadIdx.x == 0) partial[size_t(blockIdx.x) * N_PARTIAL + N_TOTALS] = my_kept_line;
+}
+
+__global__ void __launch_bounds__(TPB) totals_kernel(const uint32_t* partial, uint32_t rows, unsigned long long* totals) {
+  unsigned long long t[N_TOTALS];
+#pragma unroll
+  for (uint32_t j = 0; j < N_TOTALS; ++j) t[j] = 0;
+  uint32_t first_kept = 0xFFFFFFFFu;
+  for (uint64_t r = uint64_t(blockIdx.x) * TPB + threadIdx.x; r < rows; r += uint64_t(gridDim.x) * TPB) {
+#pragma unroll
+    for (uint32_t j = 0; j < N_TOTALS; ++j) t[j] += partial[r * N_PARTIAL + j];
+    first_kept = min(first_kept, partial[r * N_PARTIAL + N_TOTALS]);
+  }
+  if (first_kept != 0xFFFFFFFFu) atomicMin(&totals[N_TOTALS], static_cast<unsigned long long>(first_kept));
+  __shared__ unsigned long long red[N_TOTALS];
+  if (threadIdx.x < N_TOTALS) red[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (uint32_t j = 0; j < N_TOTALS; ++j) {
+    unsigned long long x = t[j];
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    if ((threadIdx.x & 63u) == 0 && x) atomicAdd(&red[j], x);
+  }
+  __syncthreads();
+  if (threadIdx.x < N_TOTALS && red[threadIdx.x]) atomicAdd(&totals[threadIdx.x], red[threadIdx.x]);
+}
+
+__device__ __forceinline__ void val_sizes(unsigned long long v, const uint32_t* prov, uint32_t& k, uint32_t& c) {
+  if (v & VAL_BIG) { const uint32_t* w = prov + (v & 0xFFFFFFFFull); k = w[4]; c = w[5]; }
+  else { k = uint32_t(v >> VAL_K_SHIFT) & 0xFFFu; c = uint32_t(v >> VAL_C_SHIFT) & 0xFFFu; }
+}
+
+// inside every block of 2048 records of a class: by walk.h block_order_key, stable (the values carry what the key is made of)
+__global__ void __launch_bounds__(TPB) order_blocks2_kernel(uint32_t n, const unsigned long long* in, const uint32_t* prov, unsigned long long* out) {
+  __shared__ uint32_t sh[SORT_BLOCK];
+  const uint32_t a = blockIdx.x * SORT_BLOCK;
+  for (uint32_t j = threadIdx.x; j < SORT_BLOCK; j += TPB) {
+    uint32_t x = 0xFFFFFFFFu;
+    if (a + j < n) {
+      const unsigned long long v = in[a + j];
+      uint32_t k, c;
+      val_sizes(v, prov, k, c);
+      const uint32_t ok = ((v & VAL_INDEL) ? 0x20000u : 0u) | ((v & VAL_STARS) ? 0x10000u : 0u) | (k < 0xFFFFu ? k : 0xFFFFu);   // = block_order_key
+      x = (ok << 11) | j;
+    }
+    sh[j] = x;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= SORT_BLOCK; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < SORT_BLOCK; i += TPB) {
+        const uint32_t o = i ^ j;
+        if (o > i) {
+          const uint32_t x = sh[i], y = sh[o];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { sh[i] = y; sh[o] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t j = threadIdx.x; j < SORT_BLOCK; j += TPB)
+    if (a + j < n) out[a + j] = in[a + (sh[j] & (SORT_BLOCK - 1u))];
+}
+
+__global__ void __launch_bounds__(TPB) sizes2_kernel(uint32_t n, const unsigned long long* val, const uint32_t* prov, uint32_t* nn, uint32_t* no, uint32_t* del) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long v = val[i];
+  uint32_t k, c;
+  val_sizes(v, prov, k, c);
+  nn[i] = k; no[i] = c; del[i] = (v & VAL_DEL) ? 1u : 0u;
+}
+
+// the batch in its final order, every record read once from where its line left it; its `rec` entry with it
+__global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned long long* val, const uint32_t* prov, const uint32_t* node_off,
+                                                      const uint32_t* op_off, const uint32_t* del_scan, LineHdr* hdr, uint32_t* nodes, uint32_t* ops,
+                                                      uint32_t* del_idx, uint4* rec) {
+  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* w = prov + (val[i] & 0xFFFFFFFFull);
+  const uint32_t flags = w[3], k = w[4], c = w[5];
+  hdr[i] = LineHdr{int32_t(w[0]), int32_t(w[1]), w[2], flags};
+  const uint32_t n0 = node_off[i], o0 = op_off[i];
+  for (uint32_t j = 0; j < c; ++j) ops[o0 + j] = w[PROV_HDR + j];
+  for (uint32_t j = 0; j < k; ++j) nodes[n0 + j] = w[PROV_HDR + c + j];
+  if (flags & LINE_HAS_DEL) del_idx[del_scan[i]] = i;
+  make_rec_entry(rec, i, n0, k, o0, c, nodes, ops);
 }
 
 // ---- locus bucketing (device form of gaf.cpp bucket_by_locus) ---------------------------------
@@ -449,6 +636,117 @@ DeviceText prefetch_get(TextPrefetcher& p) {
 
 double prefetch_copy_seconds(const TextPrefetcher& p) { return p.copy_seconds; }
 
+
+// The one-parse form of the batch build (kernels above).  nullptr: this batch needs the two-pass form -- a line the reference
+// raises on, more lines without room than the arena takes, no records at all.
+static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& pool, Scanner& scan, const uint8_t* d_text, size_t size, const uint64_t* d_ls,
+                                        uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr, const DenseNames& names, uint64_t first_line_id,
+                                        GafBatch& st, DeviceTokenizeTimes& tm, PhaseTimer& pt) {
+  hipStream_t s = gi.stream;
+  int bits = 1;
+  while (bits < 32 && (uint64_t(1) << bits) < uint64_t(gi.V)) ++bits;
+  const uint64_t prov_words = text_padded_bytes(size) / 4;
+  const uint64_t arena_words = std::max<uint64_t>(uint64_t(1) << 20, prov_words / 16);
+  if (bits > 30 || prov_words + arena_words >= 0xFFFFFFF0ull || n_lines == 0) return nullptr;
+  double t0 = now();
+  DevBuf prov(pool), key(pool), val(pool), key2(pool), val2(pool), partial(pool), small(pool), sort_tmp(pool);
+  prov.alloc((prov_words + arena_words) * 4);
+  key.alloc(size_t(n_lines) * 4); val.alloc(size_t(n_lines) * 8);
+  const uint32_t waves = (n_lines + LPB - 1) / LPB;
+  partial.alloc(size_t(waves) * N_PARTIAL * 4);
+  // [0] err word, [1 .. N_TOTALS] totals, [N_TOTALS + 1] first kept line, then two words: arena cursor, fallback flag
+  constexpr size_t SMALL_WORDS64 = N_TOTALS + 3;
+  small.alloc(SMALL_WORDS64 * 8);
+  HIP_OK(hipMemsetAsync(small.p, 0, SMALL_WORDS64 * 8, s));
+  HIP_OK(hipMemsetAsync(small.p, 0xFF, 8, s));
+  HIP_OK(hipMemsetAsync(small.as<unsigned long long>() + 1 + N_TOTALS, 0xFF, 8, s));
+  uint32_t* d_arena_next = reinterpret_cast<uint32_t*>(small.as<unsigned long long>() + N_TOTALS + 2);
+  hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
+                     uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), key.as<uint32_t>(), val.as<unsigned long long>(),
+                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1);
+  HIP_OK(hipGetLastError());
+  hipLaunchKernelGGL(totals_kernel, dim3(std::min<uint32_t>(blocks_for(waves), 1024)), dim3(TPB), 0, s, partial.as<uint32_t>(), waves, small.as<unsigned long long>() + 1);
+  HIP_OK(hipGetLastError());
+  unsigned long long hs[SMALL_WORDS64];
+  HIP_OK(hipMemcpyAsync(hs, small.p, sizeof hs, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  tm.measure_s = now() - t0;
+  tm.write_s = 0;
+  pt.lap("parse (one pass)");
+  const uint32_t fallback = uint32_t(hs[N_TOTALS + 2] >> 32);
+  const uint64_t n_rec = hs[1], n_nodes = hs[2], n_ops = hs[3];
+  if (hs[0] != ~0ull || fallback || n_rec == 0) return nullptr;
+  if (n_nodes >= NONE32 || n_ops >= NONE32 || n_rec >= NONE32) throw Error("Unsupported", "more than 2^32-2 path nodes or cs ops in one batch");
+  st = GafBatch{};
+  st.bytes = size;
+  st.rejected = hs[4];
+  st.skipped = hs[5];
+  st.del_lines = hs[6];
+  st.del_nodes = hs[7];
+  st.lines_total = n_lines;
+  st.first_record_line = first_line_id + hs[N_TOTALS + 1];
+  partial.release();
+
+  // ---- bucket by locus: one stable sort on {class, lowest end node}; lines that are no records sort behind both classes
+  t0 = now();
+  const uint32_t n = uint32_t(n_rec), n_short = uint32_t(hs[8]);
+  key2.alloc(size_t(n_lines) * 4); val2.alloc(size_t(n_lines) * 8);
+  size_t need = 0;
+  HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key.as<uint32_t>(), key2.as<uint32_t>(), val.as<unsigned long long>(), val2.as<unsigned long long>(),
+                                            int(n_lines), 0, bits + 2, s));
+  sort_tmp.alloc(need);
+  HIP_OK(hipcub::DeviceRadixSort::SortPairs(sort_tmp.p, need, key.as<uint32_t>(), key2.as<uint32_t>(), val.as<unsigned long long>(), val2.as<unsigned long long>(),
+                                            int(n_lines), 0, bits + 2, s));
+  if (n_short) {
+    hipLaunchKernelGGL(order_blocks2_kernel, dim3((n_short + SORT_BLOCK - 1) / SORT_BLOCK), dim3(TPB), 0, s, n_short, val2.as<unsigned long long>(), prov.as<uint32_t>(),
+                       val.as<unsigned long long>());
+    HIP_OK(hipGetLastError());
+  }
+  if (n > n_short) {
+    hipLaunchKernelGGL(order_blocks2_kernel, dim3((n - n_short + SORT_BLOCK - 1) / SORT_BLOCK), dim3(TPB), 0, s, n - n_short, val2.as<unsigned long long>() + n_short,
+                       prov.as<uint32_t>(), val.as<unsigned long long>() + n_short);
+    HIP_OK(hipGetLastError());
+  }
+  DevBuf nn(pool), no(pool), dl(pool), dscan(pool), node_off1(pool), op_off1(pool);
+  nn.alloc((size_t(n) + 1) * 4); no.alloc((size_t(n) + 1) * 4); dl.alloc((size_t(n) + 1) * 4); dscan.alloc((size_t(n) + 1) * 4);
+  node_off1.alloc((size_t(n) + 1) * 4); op_off1.alloc((size_t(n) + 1) * 4);
+  HIP_OK(hipMemsetAsync(nn.as<uint32_t>() + n, 0, 4, s));
+  HIP_OK(hipMemsetAsync(no.as<uint32_t>() + n, 0, 4, s));
+  HIP_OK(hipMemsetAsync(dl.as<uint32_t>() + n, 0, 4, s));
+  hipLaunchKernelGGL(sizes2_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, val.as<unsigned long long>(), prov.as<uint32_t>(), nn.as<uint32_t>(), no.as<uint32_t>(),
+                     dl.as<uint32_t>());
+  HIP_OK(hipGetLastError());
+  scan.run(nn.as<uint32_t>(), node_off1.as<uint32_t>(), size_t(n) + 1, s);
+  scan.run(no.as<uint32_t>(), op_off1.as<uint32_t>(), size_t(n) + 1, s);
+  scan.run(dl.as<uint32_t>(), dscan.as<uint32_t>(), size_t(n) + 1, s);
+  DeviceBatchPtr out(new DeviceBatch());
+  out->n = n;
+  out->n_nodes = n_nodes;
+  out->n_ops = n_ops;
+  out->del_nodes = st.del_nodes;
+  out->n_del = uint32_t(st.del_lines);
+  out->n_short = n_short;
+  out->short_nodes = hs[9];
+  out->short_ops = hs[10];
+  DevBuf hdr1(pool), nodes1(pool), ops1(pool), del(pool);
+  hdr1.alloc((n_rec + 1) * sizeof(LineHdr)); nodes1.alloc((n_nodes + 1) * 4); ops1.alloc((n_ops + 1) * 4);
+  del.alloc((size_t(out->n_del) + 1) * 4);
+  HIP_OK(hipMalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
+  hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, val.as<unsigned long long>(), prov.as<uint32_t>(), node_off1.as<uint32_t>(),
+                     op_off1.as<uint32_t>(), dscan.as<uint32_t>(), hdr1.as<LineHdr>(), nodes1.as<uint32_t>(), ops1.as<uint32_t>(), del.as<uint32_t>(), out->rec);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(s));
+  out->hdr = hdr1.hand_over<LineHdr>();
+  out->node_off = node_off1.hand_over<uint32_t>();
+  out->op_off = op_off1.hand_over<uint32_t>();
+  out->nodes = nodes1.hand_over<uint32_t>();
+  out->ops = ops1.hand_over<uint32_t>();
+  out->del_idx = del.hand_over<uint32_t>();
+  tm.bucket_s = now() - t0;
+  pt.lap("bucket by locus (one pass)");
+  return out;
+}
+
 DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* data, size_t size, int thr, uint64_t first_line_id,
                                    GafBatch& st, DeviceTokenizeTimes* times, const DeviceText* resident) {
   if (!g.names.dense)
@@ -527,6 +825,18 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   // ---- measure
   // LDS per wave: the text of 64 average lines plus a quarter, between 4 and 64 KB
   const uint32_t stage_bytes = uint32_t(std::min<uint64_t>(64 * 1024, std::max<uint64_t>(4096, ((n_lines ? size / n_lines : 0) * 80 + 1279) / 1024 * 1024)));
+  // ---- one parse per line (PANTAS_TOKENIZER_PASSES=2: the two-pass form, which is also where a batch with a raising line ends up)
+  {
+    const char* passes = getenv("PANTAS_TOKENIZER_PASSES");
+    if (!(passes && passes[0] == '2') && !getenv("PANTAS_NO_BUCKET")) {
+      DeviceBatchPtr one = tokenize_one_pass(gi, pool, scan, d_text, size, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names, first_line_id, st, tm, pt);
+      if (one) {
+        tm.total_s = now() - t_begin;
+        if (times) *times = tm;
+        return one;
+      }
+    }
+  }
   DevBuf kept(pool), cnt_nodes(pool), cnt_ops(pool), meta(pool), small(pool);
   const size_t np1 = size_t(n_lines) + 1;
   kept.alloc(np1 * 4); cnt_nodes.alloc(np1 * 4); cnt_ops.alloc(np1 * 4); meta.alloc(np1);

@@ -42,7 +42,9 @@ class LibBackend:
     def load_shard(self, gaf_path, thr, begin, end, first_line):
         """Tokenises the shard batch by batch (a shard of any size: PANTAS_BATCH_BYTES of text per batch) and runs every
         batch's rare-key kernel -- the first pass of a streamed run (pantas_augment_stream_rare)."""
-        self.empty = begin == end and begin != 0     # (begin == end == 0 is an empty FILE: end 0 means "to EOF")
+        # begin == end is an empty shard -- of a file with fewer lines (or bytes) than ranks, every cut of the low ranks is 0 --
+        # except for an EMPTY FILE, whose one "shard" [0, 0) is passed on (end 0 means "to EOF" to the stream API: harmless there)
+        self.empty = begin == end and os.path.getsize(gaf_path) > 0
         if self.empty:                               # more ranks than lines: nothing to read, no batch, no kernel
             self.rare_ms = 0.0
             return dict(lines=0, rejected=0, del_path_nodes=0)
@@ -248,6 +250,10 @@ def replicates_main(argv=None) -> int:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    names = [os.path.basename(p) for p in a.GAF]
+    twice = sorted({n for n in names if names.count(n) > 1})
+    if twice:      # sample1/reads.gaf + sample2/reads.gaf would write the same two files, maybe from two ranks at once
+        ap.error(f"replicates with the same file name would overwrite each other's outputs in {a.out_dir}: {', '.join(twice)}")
     mine = a.GAF[rank::world]
     os.makedirs(a.out_dir, exist_ok=True)
     if not mine:

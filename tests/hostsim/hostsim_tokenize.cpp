@@ -20,6 +20,7 @@ struct WriteOut {
   uint32_t* ops;
   void node(uint32_t i, uint32_t idx) { nodes[i] = idx; }
   void op(uint32_t i, uint32_t w) { ops[i] = w; }
+  void ops_done(uint32_t) {}
 };
 
 static const char* kind_of(uint32_t te) {

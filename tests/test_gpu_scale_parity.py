@@ -117,7 +117,7 @@ def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads, check_augment=
         os.unlink(pre + ".gaf")
         res["call"] = _call_vs_cpp_oracle(pre, pre + ".gpu.gfa", oracle_threads)
         if os.environ.get("PANTAS_PARITY_JSON"):
-            json.dump(res, open(os.environ["PANTAS_PARITY_JSON"], "w"), indent=1)
+            json.dump(res, open(os.environ["PANTAS_PARITY_JSON"].format(scale=scale), "w"), indent=1)
     finally:
         stop.set()
         shutil.rmtree(tmp, ignore_errors=True)

@@ -55,7 +55,7 @@ def cases():
     out.append(dict(name="ws_s_call", stage="call_aug_ws", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0", "--novel"], engine="same"))
     # ---- duplicate S line in call ------------------------------------------------------------------------------
     out.append(dict(name="dup_s_call", stage="call_aug_dup_s", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0", "--novel"], engine="refuses"))
-    out.append(dict(name="dup_s_call_annotated", stage="call_aug_dup_s", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="refuses"))
+    out.append(dict(name="dup_s_call_annotated", stage="call_aug_dup_s", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="same"))
     # ---- duplicate L lines that disagree on JN ------------------------------------------------------------------
     out.append(dict(name="dup_l_jn_last", stage="call_aug_dup_l_last", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="refuses"))
     out.append(dict(name="dup_l_jn_first", stage="call_aug_dup_l_first", gfa=gfa, gaf=gaf, gtf=gtf, flags=["--rca", "0"], engine="same"))
