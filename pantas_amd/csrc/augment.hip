@@ -730,6 +730,7 @@ struct DeviceGraph {
   uint32_t* counters = nullptr;   // [{NC, IL0, OLL, RC first slot} x V | RC A]  (GraphView::cnt4, ::rc)
   std::unique_ptr<ScratchPool> scratch;   // tokenize.hip temporaries
   uint32_t* name_table = nullptr; // dense segment-name table for the GPU tokeniser (tokenize.hip), uploaded on first use
+  uint32_t* name_blocks = nullptr; // per 1024 entries of it: the node of the block's first name when the block counts up one by one (gaf_device.h NAME_BLOCK)
   uint32_t* small = nullptr;      // [0..1] status (u64), [2] hist n_keys, [3] hist overflow, [4] novel n_keys, [5] novel overflow, [6] cursor
   Table hist, novel;
   // multi-batch protocol: every batch's rare-key kernel must run before the first main kernel of the run
@@ -777,15 +778,32 @@ uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
     HIP_OK(hipSetDevice(dg.device));
     HIP_OK(hipMalloc(&dg.name_table, std::max<size_t>(1, g.names.table.size()) * 4));
     HIP_OK(hipMemcpyAsync(dg.name_table, g.names.table.data(), g.names.table.size() * 4, hipMemcpyHostToDevice, dg.stream));
+    // Names of a graph are numbers that count up with the S lines, nodes count up with the S lines: over long stretches
+    // table[x] = x + c.  One word per block of 1024 names says so (8 MB for a whole genome: it stays in the caches), and the
+    // tokeniser's lookups only go to the table itself -- a gigabyte, every lookup a trip to HBM -- where a block does not.
+    const size_t n = g.names.table.size(), nb = (n + NAME_BLOCK - 1) / NAME_BLOCK;
+    std::vector<uint32_t> blocks(std::max<size_t>(1, nb), NAME_BLOCK_MIXED);
+    parallel_chunks(nb, nb < 1024 ? 1u : hw_threads(), [&](unsigned, size_t b0, size_t b1) {
+      for (size_t b = b0; b < b1; ++b) {
+        const size_t lo = b * NAME_BLOCK, hi = std::min(n, lo + NAME_BLOCK);
+        const uint32_t first = g.names.table[lo];
+        bool runs = first != NONE32 && first < NAME_BLOCK_MIXED - NAME_BLOCK;
+        for (size_t x = lo + 1; x < hi && runs; ++x) runs = g.names.table[x] == first + uint32_t(x - lo);
+        if (runs) blocks[b] = first;
+      }
+    });
+    HIP_OK(hipMalloc(&dg.name_blocks, blocks.size() * 4));
+    HIP_OK(hipMemcpyAsync(dg.name_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, dg.stream));
     HIP_OK(hipStreamSynchronize(dg.stream));
   }
   return dg.name_table;
 }
+uint32_t* device_name_blocks(DeviceGraph& dg) { return dg.name_blocks; }
 
 void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->slow_dev, (void*)d->tilde_dev})
+  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->name_blocks, (void*)d->slow_dev, (void*)d->tilde_dev})
     if (p) (void)hipFree(p);
   d->scratch.reset();
   d->hist.free_all();
@@ -1094,7 +1112,7 @@ static void table_grow(DeviceGraph& d, Table& t, uint32_t cap, uint32_t* n_keys,
 __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, const uint32_t* ops, uint4* rec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t n0 = node_off[i], o0 = op_off[i];
-    make_rec_entry(rec, i, n0, node_off[i + 1] - n0, o0, op_off[i + 1] - o0, nodes, ops);
+    make_rec_entry(rec, i, n0, node_off[i + 1] - n0, o0, op_off[i + 1] - o0, nodes + n0, ops + o0);
   }
 }
 

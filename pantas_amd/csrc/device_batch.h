@@ -48,17 +48,18 @@ struct DeviceBatch {
 constexpr uint32_t REC_QUADS = 3;      // DeviceBatch::rec: three 16-byte words per record
 constexpr uint32_t REC_OPS_MAX = SHORT_MAX_OPS - 1u;     // rec holds the op count in 24 bits (saturated; only short-walk records are read through it)
 
-// rec[i] of a record whose k path nodes start at nodes[n0] and whose c cs ops start at ops[o0] (see DeviceBatch::rec)
+// rec[i] of a record whose k path nodes will stand at nodes[n0 ..] and whose c cs ops at ops[o0 ..] of the batch (see DeviceBatch::rec);
+// `nodes` / `ops` point at the record's first node / first op, wherever they are read from
 __device__ __forceinline__ void make_rec_entry(uint4* rec, size_t i, uint32_t n0, uint32_t k, uint32_t o0, uint32_t c, const uint32_t* nodes,
                                                const uint32_t* ops) {
   const uint32_t last = k ? k - 1u : 0u;
-  auto id = [&](uint32_t j) { return k ? nodes[n0 + (j < last ? j : last)] : 0u; };
+  auto id = [&](uint32_t j) { return k ? nodes[j < last ? j : last] : 0u; };
   rec[REC_QUADS * i] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
   rec[REC_QUADS * i + 1] = make_uint4(id(1), id(2), id(3), id(4));
   // the short walk's view of the cs (walk.h ShortOps), so that the dominant kernel neither reads ops[] nor scans it; only read for
   // records of the short-walk class (fewer than SHORT_MAX_OPS ops, total below 2^16)
   ShortOps so;
-  if (c < SHORT_MAX_OPS) short_ops_scan(ops + o0, c, so);
+  if (c < SHORT_MAX_OPS) short_ops_scan(ops, c, so);
   rec[REC_QUADS * i + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
 }
 
@@ -126,6 +127,8 @@ void build_batch_rec(DeviceGraph& dg, DeviceBatch& db);
 struct Graph;
 // dense name table (id - base -> node) in HBM, uploaded on first use and owned by the DeviceGraph
 uint32_t* device_name_table(DeviceGraph& dg, const Graph& g);
+// ... and its summary per block of NAME_BLOCK names (gaf_device.h DenseNames::blocks); valid after device_name_table
+uint32_t* device_name_blocks(DeviceGraph& dg);
 ScratchPool& scratch_pool(DeviceGraph& dg);
 
 }  // namespace pantas

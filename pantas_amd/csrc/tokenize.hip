@@ -133,10 +133,13 @@ __global__ void __launch_bounds__(TPB) line_starts_kernel(const uint4* text, con
 // parses straight from HBM.
 constexpr uint32_t LPB = 64;
 
+// Lines are taken in GROUPS of 64; a workgroup (one wave) walks the groups g, g + gridDim.x, ... -- one workgroup per group
+// was 781 000 single-wave workgroups with 12 KB of LDS each at whole-genome scale, and the kernels' run time was the time it
+// takes to LAUNCH that many (27.45 ms whatever the code in them did; profiles/r3_tokenizer_steps.txt).
 template <class Body>
-__device__ __forceinline__ void staged_lines(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, Body body) {
+__device__ __forceinline__ void staged_group(uint32_t group, const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, Body body) {
   extern __shared__ uint4 stage4[];
-  const uint32_t first = blockIdx.x * LPB;
+  const uint32_t first = group * LPB;
   const uint32_t last = min(first + LPB, n_lines);
   const uint64_t sb = ls[first], se = ls[last];   // se may be size + 1: the text is zero-padded
   const uint64_t a0 = sb & ~uint64_t(15);
@@ -145,22 +148,86 @@ __device__ __forceinline__ void staged_lines(const uint8_t* text, const uint64_t
   if (a1 - a0 <= uint64_t(stage_bytes)) {
     const uint4* src = reinterpret_cast<const uint4*>(text + a0);
     const uint32_t n16 = uint32_t((a1 - a0) >> 4);
-    for (uint32_t k = threadIdx.x; k < n16; k += LPB) stage4[k] = src[k];
+    // Eight 16-byte loads per lane in flight before the first one is stored: `stage4[k] = src[k]` in a plain loop is load, wait,
+    // store, next -- ten trips to HBM one after the other per wave, which is where these kernels spent their time (their run time
+    // did not move when the parse lost nine tenths of its instructions).  The loads are unconditional (index clamped): a load
+    // that may not have been issued makes the compiler wait for all of them.
+    constexpr uint32_t STAGE_UNROLL = 8;
+    for (uint32_t k0 = threadIdx.x; k0 < n16; k0 += LPB * STAGE_UNROLL) {
+      uint4 v[STAGE_UNROLL];
+#pragma unroll
+      for (uint32_t u = 0; u < STAGE_UNROLL; ++u) v[u] = src[min(k0 + u * LPB, n16 - 1u)];
+#pragma unroll
+      for (uint32_t u = 0; u < STAGE_UNROLL; ++u)
+        if (k0 + u * LPB < n16) stage4[k0 + u * LPB] = v[u];
+    }
     __syncthreads();
-    const uint8_t* stage = reinterpret_cast<const uint8_t*>(stage4);
-    if (i < last) body(i, stage + (ls[i] - a0), stage + (ls[i + 1] - 1 - a0));
+    // (the parser reads its line through aligned 32-bit words of the staged text: gaf_device.h TextWords)
+    if (i < last) body(i, reinterpret_cast<const uint32_t*>(stage4), uint32_t(ls[i] - a0), uint32_t(ls[i + 1] - 1 - a0));
   } else if (i < last) {
-    body(i, text + ls[i], text + ls[i + 1] - 1);
+    const uint64_t lb = ls[i], base = lb & ~uint64_t(3);
+    body(i, reinterpret_cast<const uint32_t*>(text + base), uint32_t(lb - base), uint32_t(ls[i + 1] - 1 - base));
   }
 }
+// The same for a kernel that carries ONE copy of its line parser: the text is always staged.  A group whose 64 lines do not fit the
+// staging buffer goes through it in rounds of as many leading lines as fit; a single line longer than the buffer is reported
+// through `too_long` (the batch then takes the two-pass kernels, whose parser also reads from HBM) and skipped.
+template <class Body>
+__device__ __forceinline__ void staged_rounds(uint32_t group, const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, uint32_t* too_long,
+                                              Body body) {
+  extern __shared__ uint4 stage4[];
+  const uint32_t first = group * LPB;
+  const uint32_t last = min(first + LPB, n_lines);
+  const uint32_t i = first + threadIdx.x;
+  const uint64_t my_b = i < last ? ls[i] : 0, my_e = i < last ? ls[i + 1] : 0;      // my line and its '\n' (or the text's end + 1)
+  uint32_t next = first;                   // first line not yet handled
+  while (next < last) {
+    const uint64_t a0 = __shfl(my_b, int(next - first), LPB) & ~uint64_t(15);
+    // lines next .. that end inside the buffer (line ends grow: the lanes that say yes are a prefix of the rest)
+    const bool fits = i >= next && i < last && ((my_e + 15) & ~uint64_t(15)) - a0 <= uint64_t(stage_bytes);
+    const uint32_t take = uint32_t(__popcll(__ballot(fits)));
+    if (take == 0) {                       // line `next` alone is longer than the buffer
+      if (threadIdx.x == 0) atomicOr(too_long, 1u);
+      ++next;
+      continue;
+    }
+    const uint64_t a1 = (__shfl(my_e, int(next + take - 1u - first), LPB) + 15) & ~uint64_t(15);
+    const uint4* src = reinterpret_cast<const uint4*>(text + a0);
+    const uint32_t n16 = uint32_t((a1 - a0) >> 4);
+    constexpr uint32_t STAGE_UNROLL = 8;
+    for (uint32_t k0 = threadIdx.x; k0 < n16; k0 += LPB * STAGE_UNROLL) {
+      uint4 v[STAGE_UNROLL];
+#pragma unroll
+      for (uint32_t u = 0; u < STAGE_UNROLL; ++u) v[u] = src[min(k0 + u * LPB, n16 - 1u)];
+#pragma unroll
+      for (uint32_t u = 0; u < STAGE_UNROLL; ++u)
+        if (k0 + u * LPB < n16) stage4[k0 + u * LPB] = v[u];
+    }
+    __syncthreads();
+    if (fits) body(i, reinterpret_cast<const uint32_t*>(stage4), uint32_t(my_b - a0), uint32_t(my_e - 1 - a0));
+    __syncthreads();                       // the staged text is overwritten by the next round / group
+    next += take;
+  }
+}
+
+template <class Body>
+__device__ __forceinline__ void staged_lines(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, Body body) {
+  const uint32_t groups = (n_lines + LPB - 1u) / LPB;
+  for (uint32_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    staged_group(g, text, ls, n_lines, stage_bytes, body);
+    __syncthreads();        // the staged text is overwritten by the next group
+  }
+}
+inline uint32_t line_group_grid(uint32_t n_lines) { return std::min<uint32_t>((n_lines + LPB - 1u) / LPB, 256u * 16u); }
 
 __global__ void __launch_bounds__(LPB) measure_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                       DenseNames names, uint32_t* kept, uint32_t* cnt_nodes, uint32_t* cnt_ops, uint8_t* meta,
                                                       unsigned long long* err) {
-  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
+  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint32_t* words, uint32_t b, uint32_t e) {
     CountOnly co;
     LineSummary r;
-    parse_gaf_line(b, e, thr, names, co, r, check_cr != 0u);
+    TextWords T(words);
+    parse_gaf_line_words(T, b, e, thr, names, co, r, check_cr != 0u);
     kept[i] = r.status == TOK_KEEP ? 1u : 0u;
     cnt_nodes[i] = r.n_nodes;
     cnt_ops[i] = r.n_ops;
@@ -202,18 +269,20 @@ struct WriteOut {
   __device__ __forceinline__ void node(uint32_t i, uint32_t idx) { nodes[i] = idx; }
   __device__ __forceinline__ void op(uint32_t i, uint32_t w) { ops[i] = w; }
   __device__ __forceinline__ void ops_done(uint32_t) {}
+  __device__ __forceinline__ void nodes_done(uint32_t) {}
 };
 
 __global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                     DenseNames names, const uint32_t* kept, const uint32_t* rec_of, const uint32_t* node_scan,
                                                     const uint32_t* op_scan, uint32_t first_line, LineHdr* hdr, uint32_t* node_off,
                                                     uint32_t* op_off, uint32_t* nodes, uint32_t* ops) {
-  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
+  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint32_t* words, uint32_t b, uint32_t e) {
     if (!kept[i]) return;
     const uint32_t rec = rec_of[i], no = node_scan[i], oo = op_scan[i];
     WriteOut wo{nodes + no, ops + oo};
     LineSummary r;
-    parse_gaf_line(b, e, thr, names, wo, r, check_cr != 0u);
+    TextWords T(words);
+    parse_gaf_line_words(T, b, e, thr, names, wo, r, check_cr != 0u);
     hdr[rec] = LineHdr{r.start, r.tail, first_line + i, r.flags};
     node_off[rec] = no;
     op_off[rec] = oo;
@@ -224,7 +293,7 @@ __global__ void __launch_bounds__(LPB) write_kernel(const uint8_t* text, const u
 // ================================================================================================================
 // ONE parse per line (round 3).  The two-pass form above reads and parses the text twice (count, scan, write) and then
 // gathers every record from three file-order arrays through a permutation: 25 + 25 + 15 ms for 7.4 GB / 50 M lines.
-// Here a line is parsed once and its record -- {LineHdr, k, c, ops, nodes}, PROV_HDR + c + k words -- is written straight
+// Here a line is parsed once and its record -- {LineHdr, k, c, nodes, ops}, PROV_HDR + k + c words -- is written straight
 // into a word array CONGRUENT WITH THE TEXT: the record of the line that starts at byte b lives at word ceil(b / 4), and a
 // line of L bytes has L / 4 words of room, which a GAF line never fills (a path node costs its name and a '>' in text, a cs op
 // two or three bytes, the twelve mandatory columns pay for the header).  No offsets have to be known before the parse, so there
@@ -241,74 +310,82 @@ constexpr uint32_t N_TOTALS = 10;                  // kept, nodes, ops, rejected
 constexpr uint32_t N_PARTIAL = N_TOTALS + 1;       // ... and, in a wave's row of partial sums, its first kept line (or NONE)
 
 struct ProvOut {
-  uint32_t* w;          // the record (global memory)
+  uint32_t* w;          // the record (global memory): header, nodes, ops
   uint32_t cap;         // words behind the header
-  uint32_t c = 0, first = 0, last = 0;
+  uint32_t k = 0, first = 0, last = 0;
   bool ovf = false;
-  __device__ __forceinline__ void op(uint32_t i, uint32_t x) { if (i < cap) w[PROV_HDR + i] = x; else ovf = true; }
-  __device__ __forceinline__ void ops_done(uint32_t n) { c = n; }
   __device__ __forceinline__ void node(uint32_t i, uint32_t idx) {
     if (i == 0) first = idx;
     last = idx;
-    const uint32_t j = c + i;
-    if (j < cap) w[PROV_HDR + j] = idx; else ovf = true;
+    if (i < cap) w[PROV_HDR + i] = idx; else ovf = true;
+  }
+  __device__ __forceinline__ void nodes_done(uint32_t n) { k = n; }
+  __device__ __forceinline__ void op(uint32_t i, uint32_t x) {
+    const uint32_t j = k + i;
+    if (j < cap) w[PROV_HDR + j] = x; else ovf = true;
   }
 };
 
-__global__ void __launch_bounds__(LPB) parse_once_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
+__global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))) parse_once_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                          DenseNames names, uint32_t first_line, uint32_t bits, uint32_t* prov, uint64_t prov_words,
                                                          uint32_t* arena_next, uint32_t arena_words, uint32_t* key, unsigned long long* val, uint32_t* partial,
-                                                         unsigned long long* err, uint32_t* fallback) {
+                                                         unsigned long long* err, uint32_t* fallback, uint32_t stop) {
   uint32_t t[N_TOTALS];
 #pragma unroll
   for (uint32_t j = 0; j < N_TOTALS; ++j) t[j] = 0;
   uint32_t my_kept_line = 0xFFFFFFFFu;
-  staged_lines(text, ls, n_lines, stage_bytes, [&](uint32_t i, const uint8_t* b, const uint8_t* e) {
+  const uint32_t groups = (n_lines + LPB - 1u) / LPB;
+  for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x)
+  staged_rounds(grp, text, ls, n_lines, stage_bytes, fallback, [&](uint32_t i, const uint32_t* words, uint32_t b, uint32_t e) {
     const uint64_t lb = ls[i], le = ls[i + 1];
     const uint64_t slot = (lb + 3) >> 2, slot_end = le >> 2;
     const uint32_t room = slot_end > slot ? uint32_t(slot_end - slot) : 0u;
-    ProvOut po{prov + slot, room > PROV_HDR ? room - PROV_HDR : 0u};
+    if (stop == 9u) { key[i] = words[b >> 2]; return; }        // (ablation: staging only)
+    // ONE call site of the parser (it is thousands of instructions long): a line whose record does not fit its own text is parsed
+    // a second time by the same code, into room taken from the arena
+    uint64_t at = slot;
+    uint32_t cap = room > PROV_HDR ? room - PROV_HDR : 0u;
     LineSummary r;
-    parse_gaf_line(b, e, thr, names, po, r, check_cr != 0u);
+    uint32_t first_node = 0, last_node = 0;
+    bool ok = true;
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+      ProvOut po{prov + at, cap};
+      TextWords T(words);
+      parse_gaf_line_words(T, b, e, thr, names, po, r, check_cr != 0u && pass == 0u, stop);
+      first_node = po.first; last_node = po.last;
+      if (pass == 1u || r.status != TOK_KEEP || !(po.ovf || room < PROV_HDR)) break;
+      const uint32_t need = PROV_HDR + r.n_ops + r.n_nodes;
+      const uint32_t pos = atomicAdd(arena_next, need);
+      if (need > arena_words || pos > arena_words - need) { atomicOr(fallback, 1u); ok = false; break; }
+      at = prov_words + pos;
+      cap = need - PROV_HDR;
+    }
+    if (stop) { key[i] = uint32_t(r.start) + r.status; return; }
     uint32_t k32 = 2u << bits;           // not a record: sorts behind both classes
     unsigned long long v = 0;
     if (r.status == TOK_ERROR) atomicMin(err, (static_cast<unsigned long long>(i) << 8) | r.err);
-    else if (r.status == TOK_REJECT) t[3] = 1;
-    else if (r.status == TOK_SKIP) t[4] = 1;
-    else {
-      uint64_t at = slot;
-      bool ok = true;
-      if (po.ovf || room < PROV_HDR) {
-        const uint32_t need = PROV_HDR + r.n_ops + r.n_nodes;
-        const uint32_t pos = atomicAdd(arena_next, need);
-        if (need > arena_words || pos > arena_words - need) { atomicOr(fallback, 1u); ok = false; }
-        else {
-          at = prov_words + pos;
-          ProvOut again{prov + at, need - PROV_HDR};
-          LineSummary r2;
-          parse_gaf_line(b, e, thr, names, again, r2, false);
-        }
-      }
-      if (ok) {
-        uint32_t* w = prov + at;
-        w[0] = uint32_t(r.start); w[1] = uint32_t(r.tail); w[2] = first_line + i; w[3] = r.flags; w[4] = r.n_nodes; w[5] = r.n_ops;
-        const bool is_short = short_walk_class(r.flags, r.n_nodes);
-        k32 = ((is_short ? 0u : 1u) << bits) | (r.n_nodes ? min(po.first, po.last) : 0u);
-        const bool big = r.n_nodes > VAL_SMALL_MAX || r.n_ops > VAL_SMALL_MAX;
-        v = static_cast<unsigned long long>(at) | (static_cast<unsigned long long>(big ? 0u : r.n_nodes) << VAL_K_SHIFT) |
-            (static_cast<unsigned long long>(big ? 0u : r.n_ops) << VAL_C_SHIFT) | ((r.flags & LINE_HAS_DEL) ? VAL_DEL : 0ull) |
-            ((r.flags & LINE_STARS) ? VAL_STARS : 0ull) | ((r.flags & LINE_ONE_INDEL) ? VAL_INDEL : 0ull) | (big ? VAL_BIG : 0ull);
-        t[0] = 1; t[1] = r.n_nodes; t[2] = r.n_ops;
-        my_kept_line = i;
-        if (r.flags & LINE_HAS_DEL) { t[5] = 1; t[6] = r.n_nodes; }
-        if (is_short) { t[7] = 1; t[8] = r.n_nodes; t[9] = r.n_ops; }
-      }
+    else if (r.status == TOK_REJECT) t[3] += 1;
+    else if (r.status == TOK_SKIP) t[4] += 1;
+    else if (ok) {
+      uint32_t* w = prov + at;
+      w[0] = uint32_t(r.start); w[1] = uint32_t(r.tail); w[2] = first_line + i; w[3] = r.flags; w[4] = r.n_nodes; w[5] = r.n_ops;
+      const bool is_short = short_walk_class(r.flags, r.n_nodes);
+      k32 = ((is_short ? 0u : 1u) << bits) | (r.n_nodes ? min(first_node, last_node) : 0u);
+      const bool big = r.n_nodes > VAL_SMALL_MAX || r.n_ops > VAL_SMALL_MAX;
+      v = static_cast<unsigned long long>(at) | (static_cast<unsigned long long>(big ? 0u : r.n_nodes) << VAL_K_SHIFT) |
+          (static_cast<unsigned long long>(big ? 0u : r.n_ops) << VAL_C_SHIFT) | ((r.flags & LINE_HAS_DEL) ? VAL_DEL : 0ull) |
+          ((r.flags & LINE_STARS) ? VAL_STARS : 0ull) | ((r.flags & LINE_ONE_INDEL) ? VAL_INDEL : 0ull) | (big ? VAL_BIG : 0ull);
+      t[0] += 1; t[1] += r.n_nodes; t[2] += r.n_ops;
+      my_kept_line = min(my_kept_line, i);
+      if (r.flags & LINE_HAS_DEL) { t[5] += 1; t[6] += r.n_nodes; }
+      if (is_short) { t[7] += 1; t[8] += r.n_nodes; t[9] += r.n_ops; }
     }
     key[i] = k32;
     val[i] = v;
   });
-  // what this wave's 64 lines add to the batch totals: one row of partial sums per wave, summed by totals_kernel (ten
-  // same-address atomics per wave would queue 7.8 M deep at whole-genome scale)
+  // what this wave's lines add to the batch totals: one row of partial sums per wave, summed by totals_kernel (a wave walks
+  // n_lines / 64 / gridDim.x groups: 32-bit sums hold as long as a batch has fewer than 2^32 path nodes, which it must)
 #pragma unroll
   for (uint32_t j = 0; j < N_TOTALS; ++j) {
     uint32_t x = t[j];
@@ -390,20 +467,54 @@ __global__ void __launch_bounds__(TPB) sizes2_kernel(uint32_t n, const unsigned 
   nn[i] = k; no[i] = c; del[i] = (v & VAL_DEL) ? 1u : 0u;
 }
 
-// the batch in its final order, every record read once from where its line left it; its `rec` entry with it
+// the batch in its final order, every record read from where its line left it; its `rec` entry with it.  A workgroup takes 256
+// consecutive records of the order: every lane fetches one record's header (six words of one sector, its LineHdr goes out as
+// one 16-byte store), then the nodes and the ops of the 256 records are moved OUTPUT-driven -- lane t writes words t, t + 256, ...
+// of the workgroup's contiguous stretch of nodes[] / ops[] and finds the record a word belongs to by a binary search in the 256
+// offsets (LDS): coalesced stores, and every load of a lane is independent of its other loads, so a lane keeps several trips
+// to memory in flight (one lane per record made fifteen dependent ones).
 __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned long long* val, const uint32_t* prov, const uint32_t* node_off,
                                                       const uint32_t* op_off, const uint32_t* del_scan, LineHdr* hdr, uint32_t* nodes, uint32_t* ops,
                                                       uint32_t* del_idx, uint4* rec) {
-  const uint32_t i = blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t* w = prov + (val[i] & 0xFFFFFFFFull);
-  const uint32_t flags = w[3], k = w[4], c = w[5];
-  hdr[i] = LineHdr{int32_t(w[0]), int32_t(w[1]), w[2], flags};
-  const uint32_t n0 = node_off[i], o0 = op_off[i];
-  for (uint32_t j = 0; j < c; ++j) ops[o0 + j] = w[PROV_HDR + j];
-  for (uint32_t j = 0; j < k; ++j) nodes[n0 + j] = w[PROV_HDR + c + j];
-  if (flags & LINE_HAS_DEL) del_idx[del_scan[i]] = i;
-  make_rec_entry(rec, i, n0, k, o0, c, nodes, ops);
+  __shared__ uint32_t s_slot[TPB], s_k[TPB], s_noff[TPB + 1], s_ooff[TPB + 1];
+  const uint32_t r0 = blockIdx.x * TPB, t = threadIdx.x, i = r0 + t;
+  const uint32_t cnt = min(TPB, n - r0);
+  uint32_t slot = 0, k = 0, c = 0, flags = 0;
+  if (t < cnt) {
+    slot = uint32_t(val[i] & 0xFFFFFFFFull);
+    const uint32_t* w = prov + slot;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    flags = w[3]; k = w[4]; c = w[5];
+    hdr[i] = LineHdr{int32_t(w0), int32_t(w1), w2, flags};
+    s_slot[t] = slot;
+    s_k[t] = k;
+    s_noff[t] = node_off[i];
+    s_ooff[t] = op_off[i];
+  }
+  if (t == 0) { s_noff[cnt] = node_off[r0 + cnt]; s_ooff[cnt] = op_off[r0 + cnt]; }
+  __syncthreads();
+  // record of output word p: the last one whose offset is <= p (records without nodes / ops share an offset with their successor)
+  auto owner = [&](const uint32_t* off, uint32_t p) {
+    uint32_t lo = 0, hi = cnt;      // off[lo] <= p < off[hi]
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  for (uint32_t p = s_noff[0] + t; p < s_noff[cnt]; p += TPB) {
+    const uint32_t r = owner(s_noff, p);
+    nodes[p] = prov[s_slot[r] + PROV_HDR + (p - s_noff[r])];
+  }
+  for (uint32_t p = s_ooff[0] + t; p < s_ooff[cnt]; p += TPB) {
+    const uint32_t r = owner(s_ooff, p);
+    ops[p] = prov[s_slot[r] + PROV_HDR + s_k[r] + (p - s_ooff[r])];
+  }
+  if (t < cnt) {
+    if (flags & LINE_HAS_DEL) del_idx[del_scan[i]] = i;
+    const uint32_t* w = prov + slot;
+    make_rec_entry(rec, i, s_noff[t], k, s_ooff[t], c, w + PROV_HDR, w + PROV_HDR + k);
+  }
 }
 
 // ---- locus bucketing (device form of gaf.cpp bucket_by_locus) ---------------------------------
@@ -646,13 +757,22 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   int bits = 1;
   while (bits < 32 && (uint64_t(1) << bits) < uint64_t(gi.V)) ++bits;
   const uint64_t prov_words = text_padded_bytes(size) / 4;
-  const uint64_t arena_words = std::max<uint64_t>(uint64_t(1) << 20, prov_words / 16);
+  uint64_t arena_words = std::max<uint64_t>(uint64_t(1) << 20, prov_words / 16);
+  if (const char* a = getenv("PANTAS_TOKENIZER_ARENA_WORDS")) arena_words = std::max<uint64_t>(1, strtoull(a, nullptr, 10));    // (tests: a batch that runs out of it)
   if (bits > 30 || prov_words + arena_words >= 0xFFFFFFF0ull || n_lines == 0) return nullptr;
   double t0 = now();
   DevBuf prov(pool), key(pool), val(pool), key2(pool), val2(pool), partial(pool), small(pool), sort_tmp(pool);
   prov.alloc((prov_words + arena_words) * 4);
   key.alloc(size_t(n_lines) * 4); val.alloc(size_t(n_lines) * 8);
-  const uint32_t waves = (n_lines + LPB - 1) / LPB;
+  // as many single-wave workgroups as the GPU holds at once (a grid that needs a second round of them waits for the first: 4096
+  // workgroups where 3328 fit took 39 ms instead of 27), each walking groups of 64 lines
+  uint32_t waves = line_group_grid(n_lines);
+  {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, parse_once_kernel, int(LPB), stage_bytes) == hipSuccess && per_cu > 0 &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, gi.device) == hipSuccess && cus > 0)
+      waves = std::min<uint32_t>((n_lines + LPB - 1u) / LPB, uint32_t(per_cu) * uint32_t(cus));
+  }
   partial.alloc(size_t(waves) * N_PARTIAL * 4);
   // [0] err word, [1 .. N_TOTALS] totals, [N_TOTALS + 1] first kept line, then two words: arena cursor, fallback flag
   constexpr size_t SMALL_WORDS64 = N_TOTALS + 3;
@@ -663,8 +783,29 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   uint32_t* d_arena_next = reinterpret_cast<uint32_t*>(small.as<unsigned long long>() + N_TOTALS + 2);
   hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
                      uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), key.as<uint32_t>(), val.as<unsigned long long>(),
-                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1);
+                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1, 0u);
   HIP_OK(hipGetLastError());
+  if (const char* ab = getenv("PANTAS_TOK_STOP")) {
+    // timing-only ablation of the parse (tools/tok_ablate.py): the kernel again, leaving every line after the named stage;
+    // its outputs are garbage, the real launch above has already written the batch's
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (const char* p = ab; *p; ++p) {
+      if (*p < '0' || *p > '9') continue;
+      DevBuf junk(pool);
+      junk.alloc(size_t(n_lines) * 4);
+      HIP_OK(hipEventRecord(e0, s));
+      hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
+                         uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), junk.as<uint32_t>(), val.as<unsigned long long>(),
+                         partial.as<uint32_t>(), small.as<unsigned long long>() + N_TOTALS + 2 /* (never written in this mode) */, d_arena_next + 1, uint32_t(*p - '0'));
+      HIP_OK(hipEventRecord(e1, s));
+      HIP_OK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+      fprintf(stderr, "[tok ablate] stop %c: %.3f ms for %u lines\n", *p, ms, n_lines);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
   hipLaunchKernelGGL(totals_kernel, dim3(std::min<uint32_t>(blocks_for(waves), 1024)), dim3(TPB), 0, s, partial.as<uint32_t>(), waves, small.as<unsigned long long>() + 1);
   HIP_OK(hipGetLastError());
   unsigned long long hs[SMALL_WORDS64];
@@ -691,6 +832,7 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   t0 = now();
   const uint32_t n = uint32_t(n_rec), n_short = uint32_t(hs[8]);
   key2.alloc(size_t(n_lines) * 4); val2.alloc(size_t(n_lines) * 8);
+  pt.lap("  sort buffers allocated");
   size_t need = 0;
   HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, key.as<uint32_t>(), key2.as<uint32_t>(), val.as<unsigned long long>(), val2.as<unsigned long long>(),
                                             int(n_lines), 0, bits + 2, s));
@@ -707,9 +849,12 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
                        prov.as<uint32_t>(), val.as<unsigned long long>() + n_short);
     HIP_OK(hipGetLastError());
   }
+  HIP_OK(hipStreamSynchronize(s));
+  pt.lap("  sort + block order");
   DevBuf nn(pool), no(pool), dl(pool), dscan(pool), node_off1(pool), op_off1(pool);
   nn.alloc((size_t(n) + 1) * 4); no.alloc((size_t(n) + 1) * 4); dl.alloc((size_t(n) + 1) * 4); dscan.alloc((size_t(n) + 1) * 4);
   node_off1.alloc((size_t(n) + 1) * 4); op_off1.alloc((size_t(n) + 1) * 4);
+  pt.lap("  size arrays allocated");
   HIP_OK(hipMemsetAsync(nn.as<uint32_t>() + n, 0, 4, s));
   HIP_OK(hipMemsetAsync(no.as<uint32_t>() + n, 0, 4, s));
   HIP_OK(hipMemsetAsync(dl.as<uint32_t>() + n, 0, 4, s));
@@ -732,6 +877,8 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   hdr1.alloc((n_rec + 1) * sizeof(LineHdr)); nodes1.alloc((n_nodes + 1) * 4); ops1.alloc((n_ops + 1) * 4);
   del.alloc((size_t(out->n_del) + 1) * 4);
   HIP_OK(hipMalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
+  HIP_OK(hipStreamSynchronize(s));
+  pt.lap("  sizes + scans; batch arrays allocated");
   hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, val.as<unsigned long long>(), prov.as<uint32_t>(), node_off1.as<uint32_t>(),
                      op_off1.as<uint32_t>(), dscan.as<uint32_t>(), hdr1.as<LineHdr>(), nodes1.as<uint32_t>(), ops1.as<uint32_t>(), del.as<uint32_t>(), out->rec);
   HIP_OK(hipGetLastError());
@@ -761,7 +908,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
 
   // ---- name table (kept with the graph between calls)
   uint32_t* d_table = device_name_table(dg, g);
-  const DenseNames names{d_table, g.names.base, uint64_t(g.names.table.size())};
+  const DenseNames names{d_table, g.names.base, uint64_t(g.names.table.size()), getenv("PANTAS_NAME_BLOCKS") ? device_name_blocks(dg) : nullptr};    // (measured flat at S4: 17.99 vs 17.50 ms -- the lookups are not what the kernel waits for; off)
 
   // ---- text
   const size_t padded = text_padded_bytes(size);
@@ -829,7 +976,11 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   {
     const char* passes = getenv("PANTAS_TOKENIZER_PASSES");
     if (!(passes && passes[0] == '2') && !getenv("PANTAS_NO_BUCKET")) {
-      DeviceBatchPtr one = tokenize_one_pass(gi, pool, scan, d_text, size, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names, first_line_id, st, tm, pt);
+      // (the one-parse kernel stages in rounds when a group does not fit: it takes a tighter buffer -- the text of 64 average lines
+      // plus a twelfth, 512-byte steps -- for more waves per CU)
+      const uint32_t stage_one = uint32_t(std::min<uint64_t>(64 * 1024, std::max<uint64_t>(4096, ((n_lines ? size / n_lines : 0) * 70 + 511) / 512 * 512)));
+      DeviceBatchPtr one = tokenize_one_pass(gi, pool, scan, d_text, size, ls.as<uint64_t>(), n_lines, getenv("PANTAS_TOK_STAGE") ? uint32_t(atoi(getenv("PANTAS_TOK_STAGE"))) : stage_one,
+                                             thr, check_cr, names, first_line_id, st, tm, pt);
       if (one) {
         tm.total_s = now() - t_begin;
         if (times) *times = tm;
@@ -848,7 +999,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   HIP_OK(hipMemsetAsync(small.as<uint8_t>() + 8, 0, 56, s));
   t0 = now();
   if (n_lines) {
-    hipLaunchKernelGGL(measure_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names,
+    hipLaunchKernelGGL(measure_kernel, dim3(line_group_grid(n_lines)), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names,
                        kept.as<uint32_t>(), cnt_nodes.as<uint32_t>(), cnt_ops.as<uint32_t>(), meta.as<uint8_t>(), small.as<unsigned long long>());
     HIP_OK(hipGetLastError());
     hipLaunchKernelGGL(limit_and_totals_kernel, dim3(std::min<uint32_t>(blocks_for(n_lines), 2048)), dim3(TPB), 0, s, n_lines,
@@ -898,7 +1049,7 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   nodes0.alloc((n_nodes + 1) * 4); ops0.alloc((n_ops + 1) * 4);
   t0 = now();
   if (n_lines) {
-    hipLaunchKernelGGL(write_kernel, dim3((n_lines + LPB - 1) / LPB), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names,
+    hipLaunchKernelGGL(write_kernel, dim3(line_group_grid(n_lines)), dim3(LPB), stage_bytes, s, d_text, ls.as<uint64_t>(), n_lines, stage_bytes, thr, check_cr, names,
                        kept.as<uint32_t>(), rec_of.as<uint32_t>(), node_scan.as<uint32_t>(), op_scan.as<uint32_t>(), uint32_t(first_line_id),
                        hdr0.as<LineHdr>(), node_off0.as<uint32_t>(), op_off0.as<uint32_t>(), nodes0.as<uint32_t>(), ops0.as<uint32_t>());
     HIP_OK(hipGetLastError());

@@ -79,6 +79,10 @@ PANTAS_HD uint32_t line_class_flags(uint32_t n_ops, uint32_t stars, uint32_t ind
   return (indels == 0 ? LINE_SIMPLE : indels == 1 ? LINE_ONE_INDEL : 0u) | (indels <= 1 && stars ? LINE_STARS : 0u);
 }
 
+// the GPU tokeniser's summary of the dense name table (gaf_device.h DenseNames::blocks, built in augment.hip device_name_table)
+constexpr uint32_t NAME_BLOCK = 1024;                 // names per entry
+constexpr uint32_t NAME_BLOCK_MIXED = 0xFFFFFFF0u;     // the block does not count up one by one: ask the table
+
 struct LineHdr {
   int32_t start;     // start position on the first node (after the 2-op clipping rule)
   int32_t tail;      // path_len - end position

@@ -21,6 +21,7 @@ struct WriteOut {
   void node(uint32_t i, uint32_t idx) { nodes[i] = idx; }
   void op(uint32_t i, uint32_t w) { ops[i] = w; }
   void ops_done(uint32_t) {}
+  void nodes_done(uint32_t) {}
 };
 
 static const char* kind_of(uint32_t te) {
@@ -51,8 +52,10 @@ static int dv_selfcheck() {
   }
   for (const std::string& s : cases) {
     const bool want = strtod(s.c_str(), nullptr) > 0.1;
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(s.data());
-    const bool got = tk_dv_above_tenth(b, b + s.size());
+    std::vector<uint32_t> words(s.size() / 4 + 2, 0u);       // (the parser reads its text through aligned words)
+    memcpy(words.data(), s.data(), s.size());
+    TextWords T(words.data());
+    const bool got = tk_dv_above_tenth(T, 0, uint32_t(s.size()));
     if (want != got) { printf("DV MISMATCH %s want %d got %d\n", s.c_str(), int(want), int(got)); return 1; }
   }
   printf("OK dv cases=%zu\n", cases.size());
@@ -72,7 +75,10 @@ int main(int argc, char** argv) {
     tokenize_gaf(*g, f.data, f.size, thr, 0, argc > 4 ? unsigned(atoi(argv[4])) : 1u, host);
 
     // ---- the device pipeline, serially
-    const uint8_t* text = reinterpret_cast<const uint8_t*>(f.data);
+    // (the device parser reads the text through aligned 32-bit words: up to three readable bytes behind the last line)
+    std::vector<uint32_t> padded((f.size + 3) / 4 + 2, 0u);
+    memcpy(padded.data(), f.data, f.size);
+    const uint8_t* text = reinterpret_cast<const uint8_t*>(padded.data());
     std::vector<uint64_t> ls;   // line i = [ls[i], ls[i+1] - 1)
     ls.push_back(0);
     for (size_t i = 0; i < f.size; ++i) if (text[i] == '\n') ls.push_back(i + 1);
@@ -81,10 +87,26 @@ int main(int argc, char** argv) {
     DenseNames names{g->names.table.data(), g->names.base, g->names.table.size()};
     std::vector<LineSummary> sum(n_lines);
     size_t err_line = n_lines;
+    // the byte-at-a-time form of the parser on the same line: what the word-at-a-time form must reproduce
+    auto plain = [&](size_t i, auto& sink, LineSummary& out_sum) {
+      const uint8_t* lb = text + ls[i];
+      const uintptr_t a = reinterpret_cast<uintptr_t>(lb) & ~uintptr_t(3);
+      TextWords T(reinterpret_cast<const uint32_t*>(a));
+      const uint32_t off = uint32_t(reinterpret_cast<uintptr_t>(lb) - a);
+      parse_gaf_line_bytewise(T, off, off + uint32_t(ls[i + 1] - 1 - ls[i]), thr, names, sink, out_sum);
+    };
     for (size_t i = 0; i < n_lines; ++i) {
       CountOnly co;
       parse_gaf_line(text + ls[i], text + ls[i + 1] - 1, thr, names, co, sum[i]);
       if (sum[i].status == TOK_ERROR && err_line == n_lines) err_line = i;
+      LineSummary ref;
+      CountOnly co2;
+      plain(i, co2, ref);
+      if (memcmp(&ref, &sum[i], sizeof ref) != 0) {
+        printf("MISMATCH line %zu: word-at-a-time parse (status %u err %u nodes %u ops %u flags %u start %d tail %d) differs from the plain one (%u %u %u %u %u %d %d)\n", i + 1,
+               sum[i].status, sum[i].err, sum[i].n_nodes, sum[i].n_ops, sum[i].flags, sum[i].start, sum[i].tail, ref.status, ref.err, ref.n_nodes, ref.n_ops, ref.flags, ref.start, ref.tail);
+        return 1;
+      }
     }
     GafBatch dev;
     dev.node_off.push_back(0);
@@ -103,6 +125,16 @@ int main(int argc, char** argv) {
       parse_gaf_line(text + ls[i], text + ls[i + 1] - 1, thr, names, wo, again);
       if (memcmp(&again, &s, sizeof s) != 0) { printf("MISMATCH line %zu: write pass summary differs from measure pass\n", i + 1); return 1; }
       if (dev.nodes.back() != 0xDEADBEEFu || dev.ops.back() != 0xDEADBEEFu) { printf("MISMATCH line %zu: write pass overran its slots\n", i + 1); return 1; }
+      {
+        std::vector<uint32_t> pn(s.n_nodes + 1, 0xDEADBEEFu), po(s.n_ops + 1, 0xDEADBEEFu);
+        WriteOut pw{pn.data(), po.data()};
+        LineSummary ref;
+        plain(i, pw, ref);
+        if (memcmp(pn.data(), &dev.nodes[nb], (s.n_nodes + 1) * 4) != 0 || memcmp(po.data(), &dev.ops[ob], (s.n_ops + 1) * 4) != 0) {
+          printf("MISMATCH line %zu: word-at-a-time parse emits other nodes / ops than the plain one\n", i + 1);
+          return 1;
+        }
+      }
       dev.nodes.pop_back();
       dev.ops.pop_back();
       dev.hdr.push_back(LineHdr{s.start, s.tail, uint32_t(i), s.flags});

@@ -53,18 +53,86 @@ def test_golden_batches_equal(case):
     assert bs.tokenizer == 2 and bs.rejected == json.load(open(f"{d}/expected.json"))["rejected"]
 
 
-def test_names_that_are_not_decimals_are_refused_or_routed():
+def test_names_that_are_not_decimals_are_refused_or_routed(tmp_path):
+    """segment names that are no canonical decimals (here: the micro golden with an 's' in front of every name): `auto` routes
+    the batch to the host tokeniser, `device` refuses it -- and the run behind `auto` is the reference's bytes for the renamed graph"""
+    import re
     from pantas_amd.engine import Graph, PantasError
-    d = os.path.join(GOLDEN, "mixedwidth")
-    g = Graph(f"{d}/in.gfa").to_device(0)
+    d = os.path.join(GOLDEN, "micro")
+    gfa, gaf = str(tmp_path / "n.gfa"), str(tmp_path / "n.gaf")
+    rename_gfa = lambda t: re.sub(r"(?m)^(S\t)(\d+)", r"\1s\2", re.sub(r"(?m)^(L\t)(\d+)(\t[+-]\t)(\d+)", r"\1s\2\3s\4", t))
+    text = open(f"{d}/in.gfa").read()
+    open(gfa, "w").write(rename_gfa(text))
+    open(gaf, "w").write(re.sub(r"([<>])(\d+)", r"\1s\2", open(f"{d}/in.gaf").read()))
+    g = Graph(gfa).to_device(0)
     g.set_tokenizer("auto")
-    b = g.load_gaf(f"{d}/in.gaf")
-    if b.stats.tokenizer == 2:
-        pytest.skip("this golden graph has decimal names")
+    b = g.load_gaf(gaf)
+    assert b.stats.tokenizer == 1 and b.stats.records > 0          # routed to the host tokeniser
     g.set_tokenizer("device")
     with pytest.raises(PantasError) as ei:
-        g.load_gaf(f"{d}/in.gaf")
+        g.load_gaf(gaf)
     assert ei.value.kind == "Unsupported"
+    g.set_tokenizer("auto")
+    with tempfile.TemporaryFile() as f:
+        g.augment(gaf, 20, f.fileno())
+        f.seek(0)
+        got = f.read().decode()
+    assert got == rename_gfa(open(f"{d}/expected.aug.gfa").read())
+
+
+def _with_env(**kw):
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in kw}
+        os.environ.update({k: str(v) for k, v in kw.items()})
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return cm()
+
+
+@pytest.mark.parametrize("names", ["short", "seven_digits"])
+def test_one_parse_per_line_equals_two_pass_and_host(tmp_path, names):
+    """the one-parse build (records written into a word array congruent with the text, round 3) against the two-pass build and the
+    host tokeniser: identical arrays.  "short": names of one to six characters -- lines whose records do not fit their own
+    text and take arena room; an arena of eight words: the batch falls back to the two-pass build."""
+    from pantas_amd.engine import Graph, Synth
+    pre = str(tmp_path / "s")
+    Synth(seed=41, n_genes=120, n_lines=60000, p_indel=0.15, p_novel_skip=0.05, base_id=10**6, read_len=150 if names == "short" else 100).write(pre)
+    if names == "short":       # segment 1000000 + i becomes i + 1: names of one to six characters, '>7>8>9' paths
+        import re
+        small = lambda m: m.group(1) + str(int(m.group(2)) - 10**6 + 1)
+        gfa = re.sub(r"(?m)^(L\t)(\d+)(\t[+-]\t)(\d+)", lambda m: m.group(1) + str(int(m.group(2)) - 10**6 + 1) + m.group(3) + str(int(m.group(4)) - 10**6 + 1),
+                     re.sub(r"(?m)^(S\t)(\d+)", small, open(pre + ".gfa").read()))
+        open(pre + ".gfa", "w").write(gfa)
+        open(pre + ".gaf", "w").write(re.sub(r"([<>])(\d+)", small, open(pre + ".gaf").read()))
+    g = Graph(pre + ".gfa").to_device(0)
+    h, one = both(g, pre + ".gaf")
+    assert_same(h, one)
+    with _with_env(PANTAS_TOKENIZER_PASSES=2):
+        _, two = both(g, pre + ".gaf")
+    assert_same(h, two)
+    with _with_env(PANTAS_TOKENIZER_ARENA_WORDS=8):
+        _, starved = both(g, pre + ".gaf")
+    assert_same(h, starved)
+    for x, y in zip(one[1], two[1]):
+        assert np.array_equal(x, y)
+    # and the walk that reads the `rec` entries the one-parse gather wrote prints the oracle's bytes
+    g.set_tokenizer("device")
+    with tempfile.TemporaryFile() as f:
+        bs, _ = g.augment(pre + ".gaf", 20, f.fileno())
+        f.seek(0)
+        got = f.read().decode()
+    want = io.StringIO()
+    a = augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    assert bs.rejected == a.rejected and got == want.getvalue()
 
 
 def test_synthetic_batches_equal_and_bucketed(tmp_path):

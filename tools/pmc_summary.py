@@ -11,7 +11,7 @@ for path in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row.get("Kernel_Name") or row.get("Kernel_name") or "?"
-            k = k.split("(")[0]
+            k = k.replace("(anonymous namespace)::", "").split("(")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in sorted(acc.items()):
     n = max(len(v) for v in cs.values())
