@@ -66,6 +66,56 @@ __global__ __launch_bounds__(256) void call_write_kernel(CallView c, const uint3
   }
 }
 
+// ---- evaluate once: count into a staging area per item, then move (call_host.h StageEmit) --------------------------------
+template <int PASS>
+__global__ __launch_bounds__(256) void call_stage_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx, uint32_t n, uint32_t* nrec, uint32_t* nword,
+                                                         uint32_t* ntask, uint8_t* fits, EventRec* stage_rec, uint32_t* stage_side, unsigned long long* status) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    StageEmit e{stage_rec + size_t(i) * STAGE_RECS, stage_side + size_t(i) * STAGE_WORDS};
+    Fault f;
+    run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
+    if (f.bad()) {
+      atomicMin(status, (static_cast<unsigned long long>(PASS) << 40) | (static_cast<unsigned long long>(i) << 8) | f.code);
+      e.recs = 0;
+      e.words = 0;
+      e.tasks = 0;
+    }
+    nrec[i] = e.recs;
+    nword[i] = e.words;
+    ntask[i] = e.tasks;
+    fits[i] = e.fits ? 1 : 0;
+  }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void call_place_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx, uint32_t n, const uint32_t* rec_off,
+                                                         const uint32_t* word_off, const uint32_t* task_off, const uint8_t* fits, const EventRec* stage_rec,
+                                                         const uint32_t* stage_side, EventRec* recs, uint32_t* side, uint32_t* task_list) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t r0 = rec_off[i], nr = rec_off[i + 1] - r0;
+    if (nr == 0) continue;
+    if (!fits[i]) {                               // more than the staging area holds: evaluated again, straight to its place
+      WriteEmit e{recs, side, r0, word_off[i], task_list, task_off[i]};
+      Fault f;
+      run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
+      continue;
+    }
+    const uint32_t w0 = word_off[i], nw = word_off[i + 1] - w0, t0 = task_off[i];
+    const EventRec* sr = stage_rec + size_t(i) * STAGE_RECS;
+    const uint32_t* ss = stage_side + size_t(i) * STAGE_WORDS;
+    for (uint32_t k = 0; k < nr; ++k) {
+      EventRec r = sr[k];
+      r.side_off += w0;
+      if (rec_is_task(r.type)) {
+        r.j1 += t0;
+        task_list[r.j1] = r0 + k;
+      }
+      recs[r0 + k] = r;
+    }
+    for (uint32_t k = 0; k < nw; ++k) side[w0 + k] = ss[k];
+  }
+}
+
 // Deferred intron walks: one thread per task, so the lanes of a wave walk 64 different introns (inside
 // the junction kernels a walking lane would leave the other 63 idle).  First launch decides and measures,
 // the paths are written by a second launch at the scanned offsets.
@@ -229,6 +279,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.irow_ptr = up_raw(*d, t.irow_ptr, size_t(g.V) + 1); c.icol = up_raw(*d, t.icol, t.A); c.islot = up_raw(*d, t.islot, t.A);
   c.first_slot = up(*d, t.first_slot); c.src = up(*d, t.src); c.lflags = up(*d, t.lflags);
   c.hid = t.hidden.empty() ? nullptr : up(*d, t.hidden);
+  c.nxt1 = up(*d, t.nxt1);
   c.rc = up(*d, t.rc); c.nc = up(*d, t.nc); c.nflags = up(*d, t.nflags); c.ln = up(*d, g.seg_len); c.rank = up(*d, t.rank);
   c.ex_ptr = up(*d, t.ex_ptr); c.ex_tag = up(*d, t.ex_tag); c.ex_tx = up(*d, t.ex_tx); c.ex_gene = up(*d, t.ex_gene);
   c.jrow = up(*d, t.jrow);
@@ -286,8 +337,20 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
     }
   };
   HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
+  // the junction passes are evaluated once (staged); the cassette items are a row scan that writes as many records as it
+  // visits links -- nothing to gain from staging them
+  const bool staged = PASS != 3 && !getenv("PANTAS_CALL_TWO_PASS");
+  uint8_t* d_fits = nullptr;
+  EventRec* stage_rec = nullptr;
+  uint32_t* stage_side = nullptr;
+  if (staged) {
+    d_fits = static_cast<uint8_t*>(dev(n));
+    stage_rec = static_cast<EventRec*>(dev(size_t(n) * STAGE_RECS * sizeof(EventRec)));
+    stage_side = u32(size_t(n) * STAGE_WORDS);
+  }
   HIP_OK(hipEventRecord(d.ev0, d.stream));
-  hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d.status);
+  if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status);
+  else hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d.status);
   HIP_OK(hipGetLastError());
   exclusive_scan(d, nrec, rec_off, n);
   exclusive_scan(d, nword, word_off, n);
@@ -317,7 +380,9 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
   EventRec* d_recs = static_cast<EventRec*>(dev(size_t(totals[0]) * sizeof(EventRec)));
   uint32_t* d_side = u32(totals[1]);
   uint32_t* d_tasks = u32(totals[2]);
-  hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, task_off,
+  if (staged) hipLaunchKernelGGL(call_place_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, task_off, d_fits, stage_rec,
+                                 stage_side, d_recs, d_side, d_tasks);
+  else hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, task_off,
                      d_recs, d_side, d_tasks);
   HIP_OK(hipGetLastError());
   // ---- deferred walks over the compacted task list

@@ -76,6 +76,7 @@ struct CallView {
   const uint32_t* nflags;       // [V]
   const uint32_t* ln;           // [V] len(sequence)
   const uint32_t* rank;         // [V] lexicographic rank of the segment name
+  const uint32_t* nxt1;         // [V] the one out-neighbour of a segment, CNONE when it has none or several
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
   // JN data hangs off the junction links only (5e5 of 2.6e8 slots at whole-genome scale): jrow[s] = ordinal of slot s
   // among the junction slots or CNONE, the four offset arrays are per junction ordinal (+ 1)
@@ -191,6 +192,14 @@ PANTAS_HD bool walk_exon(const CallView& c, uint32_t start, uint32_t goal, Ok ok
     if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;   // read only when a row is printed
     ln_sum += c.ln[cur];
     if (cur == goal) return true;
+    // one out-neighbour: it is taken whether it passes the test or not ("first that ..., else the last") -- one load per step
+    // where the general step makes five dependent ones (the walk is a chain of trips to memory: its length is its time)
+    const uint32_t one = c.nxt1[cur];
+    if (one != CNONE) {
+      cur = one;
+      if (--guard == 0) { f.raise(CE_HANG); return false; }
+      continue;
+    }
     const uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
     uint32_t nxt = CNONE;
     for (uint32_t s = b; s < e; ++s) {
@@ -706,13 +715,24 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
       for (uint32_t q = ib; q < ie; ++q) if (ex_has(ex_of(c, c.icol[q]), exv.tag[k])) return false;
       return true;
     };
+    // Each test walks a whole row of u / v (thousands of links the reads added on an expressed gene): it is made ONCE per exon
+    // and kept as a bit -- the pair loops below asked it up to (exons of u) x (exons of v) times, twice over
+    uint64_t end_ok = 0, start_ok = 0;
+    const bool masks = exu.n <= 64u && exv.n <= 64u;
+    if (masks) {
+      for (uint32_t i = 0; i < exu.n; ++i) if (ends_at_u(i)) end_ok |= 1ull << i;
+      if (end_ok)
+        for (uint32_t k = 0; k < exv.n; ++k) if (starts_at_v(k)) start_ok |= 1ull << k;
+    }
+    auto is_end = [&](uint32_t i) { return masks ? ((end_ok >> i) & 1ull) != 0ull : ends_at_u(i); };
+    auto is_start = [&](uint32_t k) { return masks ? ((start_ok >> k) & 1ull) != 0ull : starts_at_v(k); };
     uint32_t n_pairs = 0;
     uint32_t gene2 = CNONE;
     Fault gf;
     for (uint32_t i = 0; i < exu.n; ++i) {
-      if (!ends_at_u(i)) continue;
+      if (!is_end(i)) continue;
       for (uint32_t k = 0; k < exv.n; ++k) {
-        if (exu.tx[i] != exv.tx[k] || !starts_at_v(k)) continue;
+        if (exu.tx[i] != exv.tx[k] || !is_start(k)) continue;
         ++n_pairs;
         gene_accumulate(c, exu.tx[i], gene2, gf);
       }
@@ -722,9 +742,9 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
     emit.task();
     emit.push(n_pairs);
     for (uint32_t i = 0; i < exu.n; ++i) {
-      if (!ends_at_u(i)) continue;
+      if (!is_end(i)) continue;
       for (uint32_t k = 0; k < exv.n; ++k) {
-        if (exu.tx[i] != exv.tx[k] || !starts_at_v(k)) continue;
+        if (exu.tx[i] != exv.tx[k] || !is_start(k)) continue;
         emit.push(exu.tag[i]);
         emit.push(exv.tag[k]);
       }

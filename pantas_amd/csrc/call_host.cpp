@@ -921,6 +921,21 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   }
 
   pt.lap("name ranks");
+  // ---- the walks' fast step: inside an intron nearly every segment has exactly one out-neighbour, and the rule "first out-neighbour
+  // that ..., else the last" (:488-499, :843-852) then takes it whatever the test says
+  t.nxt1.resize(V);
+  parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+    for (size_t n = b; n < e; ++n) {
+      uint32_t only = CNONE, cnt = 0;
+      for (uint32_t s = t.row_ptr[n]; s < t.row_ptr[n + 1] && cnt < 2; ++s) {
+        if (!t.hidden.empty() && (t.hidden[s] & 1u)) continue;
+        only = t.col[s];
+        ++cnt;
+      }
+      t.nxt1[n] = cnt == 1 ? only : CNONE;
+    }
+  });
+  pt.lap("single out-neighbours");
   // ---- junction / novel lists in file order; IR-2 probes -----------------------------------------------
   {
     const unsigned C = A < 65536 ? 1u : threads;
@@ -995,6 +1010,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.irow_ptr = t.irow_ptr; c.icol = t.icol; c.islot = t.islot;
   c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
   c.hid = t.hidden.empty() ? nullptr : t.hidden.data();
+  c.nxt1 = t.nxt1.data();
   c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
   c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
   c.jrow = t.jrow.data();

@@ -46,6 +46,7 @@ struct CallTables {
                                  // of the LAST S line of its source (it is in gfaL, not in gfaS[u]["O"]: call.py:153-154); bit 1 -- of its target
   RawVector<int32_t> rc, nc;
   RawVector<uint32_t> nflags, rank;
+  RawVector<uint32_t> nxt1;      // [V] the segment's ONE out-neighbour, or CNONE when it has none or several (the intron walks' fast step)
   RawVector<uint32_t> ex_ptr;
   std::vector<uint32_t> ex_tag, ex_tx, ex_gene;
   RawVector<uint32_t> jrow;                                // [A] junction ordinal of a slot or CNONE
@@ -119,6 +120,40 @@ struct CountEmit {
   PANTAS_HD void push(uint32_t) { ++words; }
   PANTAS_HD void end(uint32_t) {}
 };
+// Evaluate ONCE (round 3): what an item emits is kept in a small staging area of its own (STAGE_RECS records, STAGE_WORDS payload
+// words) while it is counted; the write pass then only moves it to its scanned place.  An item that emits more than fits is
+// counted in full all the same (`fits` cleared) and evaluated a second time by the write pass, as every item was before.
+constexpr uint32_t STAGE_RECS = 4, STAGE_WORDS = 48;
+struct StageEmit {
+  EventRec* rec;          // STAGE_RECS slots
+  uint32_t* side;         // STAGE_WORDS slots
+  uint32_t recs = 0, words = 0, tasks = 0;
+  bool fits = true;
+  PANTAS_HD void begin(uint32_t type, uint32_t gene, uint32_t j0, uint32_t j1, uint32_t j2) {
+    if (recs < STAGE_RECS) {
+      EventRec& r = rec[recs];
+      r.type = type; r.gene = gene; r.j0 = j0; r.j1 = j1; r.j2 = j2; r.side_off = words; r.side_len = 0; r.mean = 0;
+    } else fits = false;
+  }
+  PANTAS_HD void task() {
+    if (recs < STAGE_RECS) rec[recs].j1 = tasks;       // the item's own task ordinal; the write pass adds the item's task offset
+    ++tasks;
+  }
+  PANTAS_HD void push(uint32_t w) {
+    if (words < STAGE_WORDS) side[words] = w; else fits = false;
+    ++words;
+  }
+  PANTAS_HD void end(uint32_t mean) {
+    if (recs < STAGE_RECS) {
+      EventRec& r = rec[recs];
+      r.side_len = words - r.side_off;
+      r.mean = mean;
+    }
+    ++recs;
+  }
+};
+PANTAS_HD bool rec_is_task(uint32_t type) { return type == T_IR_ANN || type == T_IR1_NOV || type == T_IR2_NOV; }
+
 struct WriteEmit {
   EventRec* rec;
   uint32_t* side;
