@@ -31,6 +31,20 @@ def test_golden_bytes(case):
     assert bs.rejected == json.load(open(f"{d}/expected.json"))["rejected"]
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_golden_bytes_through_the_sparse_counter_download(case, monkeypatch):
+    """the counters come back as non-zero 64-byte blocks + a bitmap (what a whole-genome run does); forced here on the goldens'
+    small graphs, where block borders fall inside nc / il0 / oll / rc and the last bitmap word is ragged"""
+    monkeypatch.setenv("PANTAS_SPARSE_DOWNLOAD", "1")
+    d = os.path.join(GOLDEN, case)
+    got, bs, _ = run_engine(f"{d}/in.gfa", f"{d}/in.gaf")
+    assert got == open(f"{d}/expected.aug.gfa").read()
+    monkeypatch.delenv("PANTAS_SPARSE_DOWNLOAD")
+    monkeypatch.setenv("PANTAS_DENSE_DOWNLOAD", "1")
+    again, _, _ = run_engine(f"{d}/in.gfa", f"{d}/in.gaf")
+    assert again == got
+
+
 def test_cli_matches_reference_streams():
     d = os.path.join(GOLDEN, "quirks")
     r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", f"{d}/in.gaf", f"{d}/in.gfa"],
