@@ -17,6 +17,7 @@
 #ifndef PANTAS_GPU_H
 #define PANTAS_GPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -52,7 +53,7 @@ void pantas_device_init(int device);
  * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
  * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
  * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
-#define PANTAS_ABI_VERSION 2
+#define PANTAS_ABI_VERSION 3
 int pantas_abi_version(void);
 
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
@@ -166,6 +167,36 @@ int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words);
 int pantas_counters_bitmap(pantas_graph* g, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words);
 int pantas_counters_pack(pantas_graph* g, const void* dev_bitmaps, uint32_t n_bitmaps, void** dev_staging, uint64_t* staging_words);
 int pantas_counters_unpack(pantas_graph* g);
+/* THE data-path collective of a read-sharded replicate behind the C ABI (round 3; north_star: "a single RCCL all-reduce over the
+ * node/edge coverage arrays when reads are split"; the reference has no counterpart -- one process per replicate,
+ * exps/3-homo-real/workflow/rules/pantas.smk:161): steps 1 - 3 above with the two collectives between them run on the caller's
+ * RCCL communicator -- bitmap, all-gather of the bitmaps, pack, all-reduce (uint32 sums) of the packed blocks, unpack; the dense
+ * all-reduce of all 4V + A counters instead when more than half of the blocks are touched or block_words is 0.  In place, on
+ * every rank; returns when the counters hold the sums.
+ *   comm:   an ncclComm_t of the ranks that hold the shards (this process's rank of it runs on the graph's device);
+ *   stream: a hipStream_t for the collectives, NULL = the graph's own stream;
+ *   api:    the RCCL entry points to call.  A process can hold two RCCLs (PyTorch ships its own beside /opt/rocm/lib): the
+ *           functions must be those of the library that MADE `comm`.  NULL: looked up in the process (dlsym RTLD_DEFAULT),
+ *           then in librccl.so.1 / librccl.so.  The signatures are rccl.h's with void* for ncclComm_t / hipStream_t. */
+typedef struct {
+  uint32_t struct_size, reserved0_;
+  int (*all_reduce)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, void* stream);   /* ncclAllReduce */
+  int (*all_gather)(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, void* stream);       /* ncclAllGather */
+  int (*comm_count)(const void* comm, int* count);                                                                         /* ncclCommCount */
+} pantas_rccl_api;
+typedef struct {
+  uint32_t struct_size, reserved0_;
+  uint32_t mode;              /* 0 dense, 1 block-sparse */
+  uint32_t world;             /* ranks of the communicator */
+  uint32_t block_words;
+  uint32_t reserved1_;
+  uint64_t counter_bytes;     /* 4 (4V + A) */
+  uint64_t exchanged_bytes;   /* what this rank handed to the collectives: gathered bitmaps + packed blocks, or counter_bytes */
+  float bitmap_ms, pack_ms, allreduce_ms, unpack_ms, total_ms;
+  float reserved2_;
+} pantas_allreduce_stats;
+int pantas_counters_allreduce(pantas_graph* g, const pantas_rccl_api* api, void* comm, void* stream, uint32_t block_words,
+                              pantas_allreduce_stats* out);
 /* sparse side results (links absent from the GFA, rare IL/OL keys): export from one rank /
  * merge into another.  Rows are 4 x uint64: {key, count, first_seen, kind (0 hist, 1 novel)} */
 int pantas_augment_sparse_count(pantas_graph* g, uint64_t* rows);

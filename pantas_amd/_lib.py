@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 2      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
+ABI_VERSION = 3      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
 
@@ -55,6 +55,23 @@ class BatchStats(_Sized):
 
 class LaunchStats(_Sized):
     _fields_ = _HEAD + [("rare_ms", C.c_float), ("main_ms", C.c_float), ("main_short_ms", C.c_float), ("reserved_", C.c_float)]
+
+
+_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+_COMM_COUNT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int))
+
+
+class RcclApi(_Sized):
+    """the RCCL entry points pantas_counters_allreduce calls: those of the library that made the communicator"""
+    _fields_ = _HEAD + [("all_reduce", _ALL_REDUCE), ("all_gather", _ALL_GATHER), ("comm_count", _COMM_COUNT)]
+
+
+class AllreduceStats(_Sized):
+    _fields_ = _HEAD + [("mode", C.c_uint32), ("world", C.c_uint32), ("block_words", C.c_uint32), ("reserved1_", C.c_uint32),
+                ("counter_bytes", C.c_uint64), ("exchanged_bytes", C.c_uint64),
+                ("bitmap_ms", C.c_float), ("pack_ms", C.c_float), ("allreduce_ms", C.c_float), ("unpack_ms", C.c_float),
+                ("total_ms", C.c_float), ("reserved2_", C.c_float)]
 
 
 class CallOpts(_Sized):
@@ -120,6 +137,7 @@ def _load():
         "pantas_counters_bitmap": (i32, [vp, C.c_uint32, P(vp), P(u64)]),
         "pantas_counters_pack": (i32, [vp, vp, C.c_uint32, P(vp), P(u64)]),
         "pantas_counters_unpack": (i32, [vp]),
+        "pantas_counters_allreduce": (i32, [vp, P(RcclApi), vp, vp, C.c_uint32, P(AllreduceStats)]),
         "pantas_augment_sparse_count": (i32, [vp, P(u64)]),
         "pantas_augment_sparse_export": (i32, [vp, P(u64), u64]),
         "pantas_augment_sparse_import": (i32, [vp, P(u64), u64]),

@@ -117,6 +117,12 @@ using CounterExchangePtr = std::unique_ptr<CounterExchange, CounterExchangeDelet
 void exchange_bitmap(DeviceGraph& dg, CounterExchangePtr& x, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words);
 void exchange_pack(DeviceGraph& dg, CounterExchange& x, const void* dev_bitmaps, uint32_t n_bitmaps, void** dev_staging, uint64_t* staging_words);
 void exchange_unpack(DeviceGraph& dg, CounterExchange& x);
+// for pantas_counters_allreduce (capi.cpp is host-only code: streams and device memory go through these)
+void exchange_drop(CounterExchange& x);                        // forget bitmap / staging of an exchange that is not finished
+void* exchange_stream(DeviceGraph& dg);                        // the graph's stream (a hipStream_t)
+void exchange_stream_wait(DeviceGraph& dg, void* stream);      // hipStreamSynchronize
+void* exchange_scratch_take(DeviceGraph& dg, size_t bytes);    // device memory from the graph's scratch pool ...
+void exchange_scratch_give(DeviceGraph& dg, void* p);          // ... and back
 uint64_t batch_lines(const DeviceBatch& db);
 uint64_t batch_short_records(const DeviceBatch& db);   // records of the short-walk class (walk.h), first in the batch
 float last_short_kernel_ms(const DeviceGraph& dg);      // short-walk kernel of the last launch_main alone

@@ -5,6 +5,7 @@
 #include "call.h"
 #include "synth.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 
 #include <unistd.h>
@@ -170,9 +171,13 @@ __attribute__((visibility("default"))) int pantas_graph_load_cached(const char* 
     auto h = std::make_unique<pantas_graph>();
     h->g = load_graph_cached(gfa_path, cache_path);
     if (used_cache) *used_cache = h->g ? 1 : 0;
-    if (!h->g) {
+    const bool timing = getenv("PANTAS_TIMING") != nullptr;
+    if (h->g) {
+      if (timing) fprintf(stderr, "[timing] graph cache: loaded %s in %.3f s\n", cache_path, now_s() - t0);
+    } else {
       h->g = load_graph(gfa_path);
-      if (write_if_missing) save_graph_cache(*h->g, cache_path);
+      const bool saved = write_if_missing && save_graph_cache(*h->g, cache_path);
+      if (timing) fprintf(stderr, "[timing] graph cache: parsed the GFA text (%.3f s)%s\n", now_s() - t0, saved ? ", cache written" : "");
     }
     h->load_s = now_s() - t0;
     *out = h.release();
@@ -474,6 +479,96 @@ __attribute__((visibility("default"))) int pantas_counters_unpack(pantas_graph* 
     need_device(g);
     if (!g->xchg) throw Error("ProtocolError", "pantas_counters_unpack before pantas_counters_pack");
     exchange_unpack(*g->dev, *g->xchg);
+  });
+}
+
+// ---- the collective itself (bitmap all-gather -> pack -> all-reduce -> unpack) on the caller's RCCL communicator ----------------
+namespace {
+struct RcclFns {
+  int (*all_reduce)(const void*, void*, size_t, int, int, void*, void*) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, void*, void*) = nullptr;
+  int (*comm_count)(const void*, int*) = nullptr;
+};
+RcclFns resolve_rccl(const pantas_rccl_api* api) {
+  RcclFns f;
+  if (api) {
+    const pantas_rccl_api a = get_in(api, "pantas_rccl_api");
+    f.all_reduce = a.all_reduce; f.all_gather = a.all_gather; f.comm_count = a.comm_count;
+  } else {
+    void* lib = RTLD_DEFAULT;
+    if (!dlsym(lib, "ncclAllReduce")) {
+      lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) throw Error("ArgumentError", "pantas_counters_allreduce: no RCCL in the process and librccl.so cannot be loaded; pass a pantas_rccl_api");
+    }
+    f.all_reduce = reinterpret_cast<decltype(f.all_reduce)>(dlsym(lib, "ncclAllReduce"));
+    f.all_gather = reinterpret_cast<decltype(f.all_gather)>(dlsym(lib, "ncclAllGather"));
+    f.comm_count = reinterpret_cast<decltype(f.comm_count)>(dlsym(lib, "ncclCommCount"));
+  }
+  if (!f.all_reduce || !f.all_gather || !f.comm_count) throw Error("ArgumentError", "pantas_counters_allreduce: ncclAllReduce / ncclAllGather / ncclCommCount missing");
+  return f;
+}
+constexpr int RCCL_UINT32 = 3, RCCL_SUM = 0;      // rccl.h: ncclUint32, ncclSum
+}  // namespace
+
+__attribute__((visibility("default"))) int pantas_counters_allreduce(pantas_graph* g, const pantas_rccl_api* api, void* comm, void* stream, uint32_t block_words,
+                                                                     pantas_allreduce_stats* out) {
+  return guarded([&] {
+    need_device(g);
+    need(comm != nullptr, "null communicator");
+    need(block_words == 0 || block_words == 8 || block_words == 16 || block_words == 32 || block_words == 64, "block_words must be 0, 8, 16, 32 or 64");
+    const RcclFns f = resolve_rccl(api);
+    auto ok = [](int rc, const char* what) { if (rc != 0) throw Error("RcclError", std::string(what) + " failed with ncclResult " + std::to_string(rc)); };
+    int world = 0;
+    ok(f.comm_count(comm, &world), "ncclCommCount");
+    need(world >= 1, "communicator without ranks");
+    const CounterPtrs cp = counter_ptrs(*g->dev);
+    void* counters = cp.base;
+    const uint64_t words = cp.words;
+    void* s = stream ? stream : exchange_stream(*g->dev);
+    auto stream_wait = [&](void* st2) { exchange_stream_wait(*g->dev, st2); };
+    pantas_allreduce_stats st{};
+    st.world = uint32_t(world);
+    st.block_words = block_words;
+    st.counter_bytes = words * 4;
+    st.exchanged_bytes = words * 4;
+    const double t0 = now_s();
+    bool done = false;
+    if (block_words && words) {
+      void* bm = nullptr;
+      uint64_t bw = 0;
+      exchange_bitmap(*g->dev, g->xchg, block_words, &bm, &bw);
+      void* all = exchange_scratch_take(*g->dev, size_t(world) * bw * 4);
+      ok(f.all_gather(bm, all, bw, RCCL_UINT32, comm, s), "ncclAllGather");
+      stream_wait(s);
+      st.bitmap_ms = float((now_s() - t0) * 1e3);
+      double t1 = now_s();
+      void* staging = nullptr;
+      uint64_t sw = 0;
+      exchange_pack(*g->dev, *g->xchg, all, uint32_t(world), &staging, &sw);
+      exchange_scratch_give(*g->dev, all);
+      st.pack_ms = float((now_s() - t1) * 1e3);
+      if (2 * sw <= words) {
+        t1 = now_s();
+        if (sw) { ok(f.all_reduce(staging, staging, sw, RCCL_UINT32, RCCL_SUM, comm, s), "ncclAllReduce"); stream_wait(s); }
+        st.allreduce_ms = float((now_s() - t1) * 1e3);
+        t1 = now_s();
+        exchange_unpack(*g->dev, *g->xchg);
+        st.unpack_ms = float((now_s() - t1) * 1e3);
+        st.mode = 1;
+        st.exchanged_bytes = sw * 4 + uint64_t(world) * bw * 4;
+        done = true;
+      } else {
+        exchange_drop(*g->xchg);          // too dense: the staging buffer is not used
+      }
+    }
+    if (!done) {
+      const double t1 = now_s();
+      if (words) { ok(f.all_reduce(counters, counters, words, RCCL_UINT32, RCCL_SUM, comm, s), "ncclAllReduce"); stream_wait(s); }
+      st.allreduce_ms = float((now_s() - t1) * 1e3);
+    }
+    st.total_ms = float((now_s() - t0) * 1e3);
+    if (out) put_out(out, st, "pantas_allreduce_stats");
   });
 }
 

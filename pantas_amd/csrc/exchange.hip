@@ -194,4 +194,16 @@ void exchange_unpack(DeviceGraph& dg, CounterExchange& x) {
   x.drop();
 }
 
+void exchange_drop(CounterExchange& x) { x.drop(); }
+void* exchange_stream(DeviceGraph& dg) { return graph_info(dg).stream; }
+void exchange_stream_wait(DeviceGraph& dg, void* stream) {
+  HIP_OK(hipSetDevice(graph_info(dg).device));
+  HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+}
+void* exchange_scratch_take(DeviceGraph& dg, size_t bytes) {
+  HIP_OK(hipSetDevice(graph_info(dg).device));
+  return scratch_pool(dg).take(bytes);
+}
+void exchange_scratch_give(DeviceGraph& dg, void* p) { scratch_pool(dg).give(p); }
+
 }  // namespace pantas

@@ -26,10 +26,34 @@ import numpy as np
 class LibBackend:
     """libpantas_gpu on one GPU."""
 
-    def __init__(self, gfa_path: str, device: int):
+    def __init__(self, gfa_path: str, device: int, dist=None):
+        """`dist` (an initialised torch.distributed with more than one rank): ONE rank parses the GFA text and leaves the binary
+        cache of the parsed arrays (graph_cache.cpp) where the others load it -- eight ranks on a 16-core quota parsing 19 GB each
+        would make the parse, not xGMI, the limit of the run (whole-genome graph: 11 s of parse, 2.4 s from the cache)."""
         from .engine import Graph, graph_cache_path
         self.device = device
-        self.g = Graph(gfa_path, cache=graph_cache_path(gfa_path)).to_device(device)
+        cache = graph_cache_path(gfa_path)
+        shared = None
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1 and not os.environ.get("PANTAS_EVERY_RANK_PARSES"):
+            if cache is None:       # no cache asked for: one for the length of this run, in memory-backed storage when there is any
+                import hashlib
+                tag = hashlib.sha1(f"{os.path.abspath(gfa_path)}:{os.path.getsize(gfa_path)}:{os.stat(gfa_path).st_mtime_ns}".encode()).hexdigest()[:16]
+                where = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else os.environ.get("TMPDIR", "/tmp")
+                cache = shared = os.path.join(where, f"pantas_{os.getuid()}_{tag}.pgc")
+            if dist.get_rank() == 0:
+                self.g = Graph(gfa_path, cache=cache)
+            dist.barrier()
+            if dist.get_rank() != 0:
+                self.g = Graph(gfa_path, cache=cache)       # (a graph the cache cannot hold -- names that are no decimals -- is parsed)
+            dist.barrier()
+            if shared and dist.get_rank() == 0:
+                try:
+                    os.unlink(shared)
+                except OSError:
+                    pass
+            self.g.to_device(device)
+        else:
+            self.g = Graph(gfa_path, cache=cache).to_device(device)
         self.g.augment_reset()
         self.batch = None
 
@@ -298,16 +322,23 @@ def main(argv=None) -> int:
     gaf, gfa = argv[0], argv[1]
     thr = int(argv[2]) if len(argv) > 2 else 20
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # a rehearsal of N ranks on a box with ONE GPU (tests): every rank on cuda:0, gloo carrying the device tensors
+    rehearsal = os.environ.get("PANTAS_DIST_REHEARSE_ON_ONE_GPU")
+    if rehearsal:
+        local = 0
     # stdout is the data channel (the augmented GFA): keep a private handle on it and point fd 1 at
     # stderr, because RCCL prints a version banner to stdout when the communicator comes up
     sys.stdout.flush()
     data_fd = os.dup(1)
     os.dup2(2, 1)
     torch.cuda.set_device(local)
-    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if rehearsal:
+        dist.init_process_group(backend="gloo")
+    else:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
     if dist.get_rank() == 0:
         print("Read GFA", file=sys.stderr)
-    be = LibBackend(gfa, local)
+    be = LibBackend(gfa, local, dist)
     if dist.get_rank() == 0:
         print("Augmentation by GAF alignments", file=sys.stderr)
     sys.stdout.flush()

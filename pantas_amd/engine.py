@@ -167,11 +167,33 @@ class Graph:
         ptr, words = self.counters()
         return self._device_i32(ptr, words, device)
 
+    def counters_numpy(self):
+        """a host copy of the dense device counters ({NC, IL0, OLL, RC first slot} per node, then RC per slot) without torch:
+        hipMemcpy through ctypes (tests of the C-ABI collective, whose process has no torch)"""
+        import numpy as np
+        ptr, words = self.counters()
+        out = np.empty(words, dtype=np.uint32)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rc = hip.hipMemcpy(out.ctypes.data, ptr, words * 4, 2)      # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy: {rc}")
+        return out
+
     # block-sparse counter exchange (exchange.hip; the collectives between the three steps are the caller's)
     def touched_bitmap(self, block_words: int = 16, device: int = 0):
         p, n = C.c_void_p(), C.c_uint64()
         check(lib.pantas_counters_bitmap(self._h, block_words, C.byref(p), C.byref(n)))
         return self._device_i32(p.value, n.value, device)
+
+    def counters_allreduce(self, comm, stream=None, block_words: int = 16, api=None):
+        """the read-sharded run's one collective through the C ABI (pantas_counters_allreduce): `comm` an ncclComm_t (integer
+        address), `api` an _lib.RcclApi with the entry points of the RCCL that made it (None: found in the process)"""
+        from ._lib import AllreduceStats
+        st = AllreduceStats()
+        check(lib.pantas_counters_allreduce(self._h, C.byref(api) if api is not None else None, C.c_void_p(comm),
+                                            C.c_void_p(stream) if stream else None, block_words, C.byref(st)))
+        return st
 
     def counters_pack(self, bitmaps, n_bitmaps: int, device: int = 0):
         p, n = C.c_void_p(), C.c_uint64()

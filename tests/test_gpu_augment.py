@@ -141,3 +141,25 @@ def test_sharded_driver_nccl_single_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     assert open(out).read() == open(f"{d}/expected.aug.gfa").read()
     assert f"Rejected alignments: {json.load(open(f'{d}/expected.json'))['rejected']}" in r.stderr
+
+
+def test_sharded_driver_two_ranks_one_parses_the_graph(tmp_path):
+    """two ranks of the read-sharded driver (both on the box's one GPU, gloo between them: PANTAS_DIST_REHEARSE_ON_ONE_GPU): rank 0
+    parses the GFA and leaves the binary cache, rank 1 loads it (round 3), each tokenises its byte range of the GAF, the flags and
+    the counters are exchanged, rank 0 writes -- the reference's bytes"""
+    d = os.path.join(GOLDEN, "synth_c")
+    out = tmp_path / "out.gfa"
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {**os.environ, "PANTAS_DIST_REHEARSE_ON_ONE_GPU": "1", "PANTAS_TIMING": "1"}
+    with open(out, "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "pantas_amd.distributed",
+                            f"{d}/in.gaf", f"{d}/in.gfa"], stdout=f, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(out).read() == open(f"{d}/expected.aug.gfa").read()
+    assert f"Rejected alignments: {json.load(open(f'{d}/expected.json'))['rejected']}" in r.stderr
+    # one rank read the text, the other the cache it left (graph_cache.cpp prints which under PANTAS_TIMING)
+    assert r.stderr.count("graph cache: loaded") >= 1, r.stderr[-3000:]

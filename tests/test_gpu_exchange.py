@@ -164,3 +164,73 @@ def test_bench_sharded_path_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3 and d["unit"] == "reads/s"
     assert d["allreduce"]["mode"] in ("block-sparse", "dense") and d["allreduce_ms"] > 0
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["call"]["events"] > 0
+
+
+ABI_COLLECTIVE = r"""
+import ctypes as C, io, os, sys, tempfile
+import numpy as np
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from pantas_amd import _lib
+from pantas_amd.engine import Graph, Synth
+import augment_oracle
+
+# a communicator of ONE rank made with the system's RCCL, no torch in the process
+rccl = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid = UniqueId()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+syn = Synth(**PARAMS)
+g = Graph(text=syn.gfa).to_device(0)
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+
+def counters():
+    t = g.counters_numpy()
+    return t.copy()
+
+g.augment_reset()
+b = g.load_gaf_mem(syn.gaf)
+g.launch(b)
+before = counters()
+assert before.any()
+# (1) entry points found in the process (the RCCL above was loaded RTLD_GLOBAL), block-sparse
+st = g.counters_allreduce(comm.value, block_words=16)
+assert (st.mode, st.world, st.block_words) == (1, 1, 16) and 0 < st.exchanged_bytes < st.counter_bytes, (st.mode, st.world, st.exchanged_bytes, st.counter_bytes)
+assert np.array_equal(counters(), before)          # a sum over one rank
+# (2) the same through an explicit table of entry points, every block size and dense
+api = _lib.RcclApi()
+api.all_reduce = _lib._ALL_REDUCE(("ncclAllReduce", rccl))
+api.all_gather = _lib._ALL_GATHER(("ncclAllGather", rccl))
+api.comm_count = _lib._COMM_COUNT(("ncclCommCount", rccl))
+for bw in (8, 32, 64, 0):
+    st = g.counters_allreduce(comm.value, block_words=bw, api=api)
+    assert st.world == 1 and st.mode == (1 if bw else 0), (bw, st.mode)
+    if bw == 0:
+        assert st.exchanged_bytes == st.counter_bytes
+    assert np.array_equal(counters(), before)
+# (3) and the run ends like any other: the oracle's bytes
+g.finish()
+with tempfile.TemporaryFile() as f:
+    g.write_gfa(f.fileno())
+    f.seek(0)
+    got = f.read().decode()
+pre = os.path.join(tempfile.mkdtemp(), "w")
+syn.write(pre)
+want = io.StringIO()
+augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+assert got == want.getvalue()
+assert rccl.ncclCommDestroy(comm) == 0
+print("OK", st.counter_bytes)
+"""
+
+
+def test_counters_allreduce_through_the_c_abi():
+    """pantas_counters_allreduce (round 3): bitmap all-gather -> pack -> all-reduce -> unpack on a caller's RCCL communicator,
+    without Python's torch.distributed in the process -- one rank here (the box has one GPU): the collectives run, the sums
+    of one rank are its own counters, the run's GFA is the oracle's"""
+    small = dict(PARAMS, n_genes=300, n_lines=60_000)
+    out = run_child(f"ROOT = {ROOT!r}\nPARAMS = {small!r}\n" + ABI_COLLECTIVE)
+    assert out.strip().splitlines()[-1].startswith("OK")
