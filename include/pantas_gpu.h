@@ -225,6 +225,12 @@ int pantas_augment_stream_info(const pantas_graph* g, uint64_t* batches, uint64_
 int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_out, pantas_batch_stats* stats,
                        pantas_launch_stats* launch);
 
+/* ---- quant: scripts/quantify.py main() :233-406 (host code, no device needed) ----
+ * PSI / dPSI of the events of n replicates of condition 1 against n replicates of condition 2 (`pantas call` CSVs), written as CSV
+ * to fd_out: the bytes the reference prints (row order, float formatting).  w: -w, both: --both.  Errors carry the class the
+ * reference raises (TypeError, ValueError, AttributeError) in pantas_last_error_kind(). */
+int pantas_quant_run(const char* const* c1_paths, const char* const* c2_paths, uint32_t n_replicates, int32_t w, int32_t both, int fd_out);
+
 /* ---- call: scripts/call.py main() :132-1105 ------------------------------------------------ */
 typedef struct {
   uint32_t struct_size, reserved0_;

@@ -137,6 +137,7 @@ def _load():
         "pantas_counters_bitmap": (i32, [vp, C.c_uint32, P(vp), P(u64)]),
         "pantas_counters_pack": (i32, [vp, vp, C.c_uint32, P(vp), P(u64)]),
         "pantas_counters_unpack": (i32, [vp]),
+        "pantas_quant_run": (i32, [P(C.c_char_p), P(C.c_char_p), C.c_uint32, i32, i32, i32]),
         "pantas_counters_allreduce": (i32, [vp, P(RcclApi), vp, vp, C.c_uint32, P(AllreduceStats)]),
         "pantas_augment_sparse_count": (i32, [vp, P(u64)]),
         "pantas_augment_sparse_export": (i32, [vp, P(u64), u64]),

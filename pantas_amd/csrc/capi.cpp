@@ -4,6 +4,7 @@
 #include "augment.h"
 #include "call.h"
 #include "synth.h"
+#include "quant.h"
 
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -149,6 +150,20 @@ __attribute__((visibility("default"))) const char* pantas_last_error_kind(void) 
 __attribute__((visibility("default"))) const char* pantas_version(void) { return "pantas-mi355x 0.1 (gfx950)"; }
 __attribute__((visibility("default"))) int pantas_device_count(void) { return device_count(); }
 __attribute__((visibility("default"))) int pantas_abi_version(void) { return PANTAS_ABI_VERSION; }
+
+__attribute__((visibility("default"))) int pantas_quant_run(const char* const* c1_paths, const char* const* c2_paths, uint32_t n_replicates, int32_t w, int32_t both,
+                                                            int fd_out) {
+  return guarded([&] {
+    need(c1_paths && c2_paths && n_replicates >= 1, "bad argument");
+    std::vector<std::string> a, b;
+    for (uint32_t i = 0; i < n_replicates; ++i) {
+      need(c1_paths[i] && c2_paths[i], "null path");
+      a.emplace_back(c1_paths[i]);
+      b.emplace_back(c2_paths[i]);
+    }
+    quant_run(a, b, w, both != 0, fd_out);
+  });
+}
 __attribute__((visibility("default"))) void pantas_device_warmup(int device) { try { warm_up_device(device); } catch (...) {} }
 __attribute__((visibility("default"))) void pantas_device_init(int device) { try { init_device(device); } catch (...) {} }
 

@@ -1,0 +1,539 @@
+// `pantas quant` in native code: PSI / dPSI of the events of two conditions over their replicates.
+//
+// Restates scripts/quantify.py (Event :65-160, eq_event :218-231, the replicate merge :243-344, psi :196-216; bracketed numbers
+// below are its lines) the way pantas_amd/quantify.py does -- the merge is a hash join on what eq_event compares instead of the
+// reference's linear scan per event -- for event files of whole-genome size: six replicates of 68 M rows are 80 GB of CSV, hours in
+// an interpreter.  Rows are parsed by all threads straight from the mapped files into 48-byte records {128-bit key, coverages,
+// where the row stands}; the join is sharded by key (every shard has a table of its own, first-seen order kept per shard and merged
+// back by sequence number); output rows are rendered in blocks by all threads and written in order.
+//
+// Numbers print as Python prints them: statistics.mean is exact rational arithmetic rounded once (here: the doubles summed as
+// 128-bit integers, one correctly rounded division), floats print as repr() (shortest digits that round-trip; fixed notation for
+// 1e-4 <= |x| < 1e16), and `max(0, psi)` of a psi that is not positive is the INT 0 -- "0 - 0" prints as "0", not "0.0".
+// Not restated: Python's float() / int() beyond plain decimal text ("1_000", "inf", other Unicode digits), lone '\r' line ends.
+#include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unistd.h>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "quant.h"
+
+namespace pantas {
+
+namespace {
+
+enum : uint32_t { T_ES = 0, T_CE = 1, T_IR = 2, T_A3 = 3, T_A5 = 4, N_TYPES = 5 };    // ETYPES order of the output (:361)
+const char* const HEADER = "etype,annotation_type,chrom,gene,strand,junction1_name,junction2_name,junction3_name,"
+                           "junction1_nodes,junction2_nodes,junction3_nodes,W1,W2,psi_c1,psi_c2,dpsi\n";
+
+struct Key {
+  uint64_t a, b;
+  bool operator==(const Key& o) const { return a == o.a && b == o.b; }
+};
+struct KeyHash {
+  size_t operator()(const Key& k) const { return size_t(k.a); }
+};
+
+struct Rec {               // one row that passed the -w threshold
+  Key key;
+  double ev, ca;           // event / canonical coverage
+  uint64_t off;            // where the row starts in its file
+  uint32_t file;           // replicate index
+  uint32_t pad_;
+};
+
+struct RowError {
+  uint32_t file = 0xFFFFFFFFu;
+  uint64_t off = 0;
+  std::string kind, msg;
+  bool set() const { return file != 0xFFFFFFFFu; }
+};
+
+inline uint64_t mix(uint64_t h, uint64_t x) {
+  h ^= x + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  return h ^ (h >> 32);
+}
+inline void key_bytes(Key& k, Span s) {
+  k.a = mix(k.a, s.size());
+  k.b = mix(k.b, s.size() * 31 + 7);
+  for (const char* c = s.b; c < s.e; ++c) { k.a = mix(k.a, uint8_t(*c)); k.b = mix(k.b, uint8_t(*c) * 0x100000001B3ull); }
+}
+inline void key_int(Key& k, int64_t v) {
+  k.a = mix(k.a, uint64_t(v));
+  k.b = mix(k.b, uint64_t(v) * 0xc4ceb9fe1a85ec53ull + 1);
+}
+
+// float(text) if text != "." else -1 [:14-16]
+bool coverage(Span s, double& v) {
+  if (s.size() == 1 && *s.b == '.') { v = -1; return true; }
+  Span t = strip(s);
+  if (t.size() == 0 || t.size() > 64) return false;
+  char buf[72];
+  memcpy(buf, t.b, t.size());
+  buf[t.size()] = 0;
+  char* end = nullptr;
+  v = strtod(buf, &end);
+  return end == buf + t.size();
+}
+
+// ids of a '>'-joined path into the key; ".." (elided IR interior) and "?" are skipped [:9-12]
+bool node_ids(Span s, Key& k) {
+  const char* p = s.b;
+  uint64_t n = 0;
+  for (;;) {
+    const char* q = static_cast<const char*>(memchr(p, '>', size_t(s.e - p)));
+    Span piece{p, q ? q : s.e};
+    const bool skip = (piece.size() == 2 && piece.b[0] == '.' && piece.b[1] == '.') || (piece.size() == 1 && piece.b[0] == '?');
+    if (!skip) {
+      int64_t v;
+      if (!parse_py_int(strip(piece), v)) return false;
+      key_int(k, v);
+      ++n;
+    }
+    if (!q) break;
+    p = q + 1;
+  }
+  key_int(k, int64_t(n) ^ 0x5555);          // (tuples of different lengths differ)
+  return true;
+}
+
+struct Fields {
+  Span f[14];
+};
+// line.strip().split(","): false when it is not 14 fields
+bool split_row(Span line, Fields& out, uint32_t& n) {
+  Span s = strip(line);
+  n = 0;
+  const char* p = s.b;
+  for (;;) {
+    const char* q = static_cast<const char*>(memchr(p, ',', size_t(s.e - p)));
+    if (n < 14) out.f[n] = Span{p, q ? q : s.e};
+    ++n;
+    if (!q) break;
+    p = q + 1;
+  }
+  return n == 14;
+}
+inline bool is(Span s, const char* lit) { return s.size() == strlen(lit) && memcmp(s.b, lit, s.size()) == 0; }
+
+// one row -> its record; false: the header line.  Throws Error where the reference raises.
+bool parse_row(Span line, uint32_t file, uint64_t off, Rec& r, uint32_t& type) {
+  Fields F;
+  uint32_t n;
+  const bool full = split_row(line, F, n);
+  if (n >= 1 && is(F.f[0], "event_type")) return false;
+  if (!full) throw Error("TypeError", "an event row has 14 columns, this one has " + std::to_string(n));
+  double c1, c2, c3;
+  if (!coverage(F.f[9], c1) || !coverage(F.f[11], c2) || !coverage(F.f[13], c3)) throw Error("ValueError", "could not convert string to float");
+  const Span et = F.f[0];
+  Key k{0x243F6A8885A308D3ull, 0x13198A2E03707344ull};
+  key_bytes(k, F.f[2]);      // chrom
+  key_bytes(k, F.f[3]);      // gene
+  const Span p1 = F.f[8], p2 = F.f[10], p3 = F.f[12];
+  if (is(et, "ES") || is(et, "CE")) {
+    type = is(et, "ES") ? T_ES : T_CE;
+    const double pair_cov = std::floor((c2 + c3) / 2);           // (c2 + c3) // 2
+    // the key holds the event junctions' ids, then the canonical ones' (eq_event :218-231); the pair keeps the order of the row
+    bool ok;
+    if (type == T_ES) {              // skipping junction = event, the two inclusion junctions = canonical
+      ok = node_ids(p1, k) && node_ids(p2, k) && node_ids(p3, k);
+      r.ev = c1; r.ca = pair_cov;
+    } else {                         // cassette exon: the other way round
+      ok = node_ids(p2, k) && node_ids(p3, k) && node_ids(p1, k);
+      r.ev = pair_cov; r.ca = c1;
+    }
+    if (!ok) throw Error("ValueError", "invalid literal for int() in a node path");
+  } else if (is(et, "A5") || is(et, "A3") || is(et, "IR")) {
+    bool first_is_event;
+    if (is(et, "A5")) { type = T_A5; first_is_event = is(F.f[4], "+"); }
+    else if (is(et, "A3")) { type = T_A3; first_is_event = !is(F.f[4], "+"); }
+    else { type = T_IR; first_is_event = !(is(F.f[1], "novel") && is(F.f[6], "?")); }
+    const Span evp = first_is_event ? p1 : p2, cap = first_is_event ? p2 : p1;
+    r.ev = first_is_event ? c1 : c2;
+    r.ca = first_is_event ? c2 : c1;
+    if (!node_ids(evp, k)) throw Error("ValueError", "invalid literal for int() in a node path");
+    Key kc = k;
+    if (!node_ids(cap, kc)) throw Error("ValueError", "invalid literal for int() in a node path");
+    if (type != T_IR) k = kc;                                    // IR: only the event junction identifies the event (:224-226)
+  } else {
+    throw Error("AttributeError", "unknown event type '" + std::string(et.b, et.size()) + "'");
+  }
+  key_int(k, int64_t(type));
+  r.key = k;
+  r.off = off;
+  r.file = file;
+  r.pad_ = 0;
+  return true;
+}
+
+// ---- Python's numbers ---------------------------------------------------------------------------------------------------
+struct Num {               // an int or a float, as Python would hold it
+  bool is_int;
+  double v;
+};
+void py_repr(std::string& s, double x) {
+  if (std::isnan(x)) { s += "nan"; return; }
+  if (std::isinf(x)) { s += x < 0 ? "-inf" : "inf"; return; }
+  char buf[64];
+  auto res = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::scientific);     // shortest digits that round-trip
+  std::string_view t(buf, size_t(res.ptr - buf));
+  size_t i = 0;
+  bool neg = false;
+  if (t[i] == '-') { neg = true; ++i; }
+  const size_t epos = t.find('e');
+  std::string digits;
+  for (size_t k = i; k < epos; ++k) if (t[k] != '.') digits += t[k];
+  const int exp10 = atoi(std::string(t.substr(epos + 1)).c_str());
+  if (neg) s += '-';
+  if (exp10 >= -4 && exp10 < 16) {             // repr: fixed notation
+    if (exp10 < 0) {
+      s += "0.";
+      s.append(size_t(-exp10 - 1), '0');
+      s += digits;
+    } else {
+      const size_t int_digits = size_t(exp10) + 1;
+      if (digits.size() <= int_digits) {
+        s += digits;
+        s.append(int_digits - digits.size(), '0');
+        s += ".0";
+      } else {
+        s.append(digits, 0, int_digits);
+        s += '.';
+        s.append(digits, int_digits, std::string::npos);
+      }
+    }
+  } else {
+    s += digits[0];
+    if (digits.size() > 1) { s += '.'; s.append(digits, 1, std::string::npos); }
+    s += 'e';
+    s += exp10 < 0 ? '-' : '+';
+    const int a = exp10 < 0 ? -exp10 : exp10;
+    if (a < 10) s += '0';
+    s += std::to_string(a);
+  }
+}
+void py_print(std::string& s, Num n) {
+  if (n.is_int) s += std::to_string(int64_t(n.v));
+  else py_repr(s, n.v);
+}
+
+// statistics.mean of doubles: the exact sum, one correctly rounded division.  The values are finite and within a factor 2^60 of
+// each other in every case the join produces (ratios of read counts); otherwise long double is the fallback.
+double exact_mean(const double* v, size_t n) {
+  if (n == 1) return v[0];
+  int emin = 0x7fffffff, emax = -0x7fffffff;
+  for (size_t i = 0; i < n; ++i) {
+    if (v[i] == 0) continue;
+    if (!std::isfinite(v[i])) { long double s = 0; for (size_t k = 0; k < n; ++k) s += v[k]; return double(s / (long double)n); }
+    int e;
+    (void)std::frexp(v[i], &e);
+    emin = std::min(emin, e - 53);
+    emax = std::max(emax, e);
+  }
+  if (emin == 0x7fffffff) return 0.0;
+  if (emax - emin > 110 || n > 4096) { long double s = 0; for (size_t k = 0; k < n; ++k) s += v[k]; return double(s / (long double)n); }
+  __int128 sum = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (v[i] == 0) continue;
+    const double m = std::ldexp(v[i], -emin);          // an integer below 2^(emax - emin) <= 2^110
+    const bool neg = m < 0;
+    const double am = neg ? -m : m;
+    // split into two exact halves (a double holds 53 bits)
+    const double hi = std::floor(std::ldexp(am, -60));
+    const double lo = am - std::ldexp(hi, 60);
+    const __int128 x = (static_cast<__int128>(static_cast<unsigned long long>(hi)) << 60) + static_cast<__int128>(static_cast<unsigned long long>(lo));
+    sum += neg ? -x : x;
+  }
+  if (sum == 0) return 0.0;
+  const bool neg = sum < 0;
+  unsigned __int128 a = neg ? static_cast<unsigned __int128>(-sum) : static_cast<unsigned __int128>(sum);
+  // a / n * 2^emin, rounded to nearest even: scale a so that the quotient has at least 64 significant bits
+  int shift = 0;
+  while ((a >> 120) == 0) { a <<= 4; shift += 4; }       // (a < 2^124 after the loop; n < 2^12)
+  const unsigned __int128 q = a / n, rem = a % n;
+  // q has ~108+ bits: take the top 53 with a sticky bit
+  int qbits = 0;
+  for (unsigned __int128 t = q; t; t >>= 1) ++qbits;
+  const int drop = qbits - 53;
+  unsigned __int128 top = q >> drop;
+  const unsigned __int128 rest = q & ((static_cast<unsigned __int128>(1) << drop) - 1);
+  const unsigned __int128 half = static_cast<unsigned __int128>(1) << (drop - 1);
+  const bool sticky = rem != 0;
+  if (rest > half || (rest == half && (sticky || (top & 1)))) ++top;
+  const double r = std::ldexp(double(static_cast<unsigned long long>(top)), drop + emin - shift);
+  return neg ? -r : r;
+}
+
+struct Event {
+  Key key;
+  uint64_t seq;            // position of its first row among the rows of its type, files in order: the dict's insertion order
+  uint64_t off;            // its first row
+  uint32_t file;
+  uint32_t slots;          // len(self.replicates): 1 + the last replicate that held it
+};
+
+struct Condition {
+  uint32_t R = 0;                                   // replicates
+  std::vector<const MappedFile*> files;
+  // per type and shard: the events in first-seen order, their coverages (slot-major: [event][replicate]{ev, ca}), the key -> index table
+  struct Shard {
+    std::vector<Event> ev;
+    std::vector<double> cov;
+    std::unordered_map<Key, uint32_t, KeyHash> ix;
+  };
+  std::vector<Shard> shard[N_TYPES];
+};
+
+constexpr uint32_t SHARDS = 64;
+inline uint32_t shard_of(const Key& k) { return uint32_t(k.b >> 40) % SHARDS; }
+
+// psi over the replicates [:196-216]: mean of canonical / (canonical + event) over those with reads; the int -1 if none has
+Num psi_of(const double* cov, uint32_t slots) {
+  double vals[64];
+  std::vector<double> big;
+  double* v = vals;
+  if (slots > 64) { big.resize(slots); v = big.data(); }
+  size_t n = 0;
+  for (uint32_t i = 0; i < slots; ++i) {
+    const double ev = cov[2 * i], ca = cov[2 * i + 1], den = ca + ev;
+    if (den != 0) {
+      const double x = ca / den;
+      if (x != -1) v[n++] = x;
+    }
+  }
+  if (n == 0) return Num{true, -1};
+  return Num{false, exact_mean(v, n)};
+}
+// int(statistics.mean(column)) as "canonical/event"
+void weights(std::string& s, const double* cov, uint32_t slots) {
+  for (int col = 1; col >= 0; --col) {
+    double vals[64];
+    std::vector<double> big;
+    double* v = vals;
+    if (slots > 64) { big.resize(slots); v = big.data(); }
+    bool whole = true;
+    double sum = 0;
+    for (uint32_t i = 0; i < slots; ++i) {
+      v[i] = cov[2 * i + uint32_t(col)];
+      whole = whole && v[i] == std::floor(v[i]) && std::fabs(v[i]) < 9e15;
+      sum += v[i];
+    }
+    // whole numbers: their sum is exact, sum / n is one correctly rounded division like float(Fraction(sum, n))
+    const double m = (whole && std::fabs(sum) < 9e15) ? sum / double(slots) : exact_mean(v, slots);
+    s += std::to_string(int64_t(m));          // int(): towards zero
+    if (col == 1) s += '/';
+  }
+}
+Num zero_or(Num p) { return (p.v > 0) ? p : Num{true, 0}; }      // max(0, psi): the first argument unless psi is greater
+Num minus(Num a, Num b) { return Num{a.is_int && b.is_int, a.v - b.v}; }
+
+// e.prefix() [:162-176] from the event's first row
+void prefix(std::string& s, const Condition& c, const Event& e) {
+  const MappedFile& f = *c.files[e.file];
+  const char* b = f.data + e.off;
+  const char* nl = static_cast<const char*>(memchr(b, '\n', f.size - e.off));
+  Fields F;
+  uint32_t n;
+  split_row(Span{b, nl ? nl : f.data + f.size}, F, n);
+  auto put = [&](Span x) { s.append(x.b, x.size()); s += ','; };
+  for (int k = 0; k < 5; ++k) put(F.f[k]);
+  const Span n1 = F.f[5], n2 = F.f[6], n3 = F.f[7], p1 = F.f[8], p2 = F.f[10], p3 = F.f[12];
+  const Span et = F.f[0];
+  if (is(et, "ES") || is(et, "CE")) {
+    const bool swap = p3.sv() < p2.sv();                   // sorted([p2, p3])
+    const Span lo = swap ? p3 : p2, hi = swap ? p2 : p3;
+    if (is(et, "ES")) { put(n2); put(n3); put(n1); put(lo); put(hi); put(p1); }
+    else { put(n1); put(n2); put(n3); put(p1); put(lo); put(hi); }
+  } else {
+    bool first_is_event;
+    if (is(et, "A5")) first_is_event = is(F.f[4], "+");
+    else if (is(et, "A3")) first_is_event = !is(F.f[4], "+");
+    else first_is_event = !(is(F.f[1], "novel") && is(n2, "?"));
+    const Span evn = first_is_event ? n1 : n2, can = first_is_event ? n2 : n1, evp = first_is_event ? p1 : p2, cap = first_is_event ? p2 : p1;
+    put(can); put(evn); s += ".,"; put(cap); put(evp); s += ".,";
+  }
+}
+
+void write_all(int fd, const char* p, size_t n) {
+  while (n) {
+    const ssize_t w = ::write(fd, p, n);
+    if (w < 0) throw Error("OSError", "write failed");
+    p += w;
+    n -= size_t(w);
+  }
+}
+
+void read_condition(const std::vector<std::string>& paths, std::vector<std::unique_ptr<MappedFile>>& keep, int w, unsigned threads, Condition& c) {
+  c.R = uint32_t(paths.size());
+  const unsigned T = std::max(1u, threads);
+  // ---- parse: every file cut into T stretches at line starts, every stretch into one vector of records per type
+  std::vector<std::vector<Rec>> recs[N_TYPES];
+  for (auto& v : recs) v.resize(size_t(c.R) * T);
+  RowError first_err;
+  std::mutex mu;
+  for (uint32_t fi = 0; fi < c.R; ++fi) {
+    keep.emplace_back(new MappedFile());
+    keep.back()->open(paths[fi].c_str());
+    const MappedFile& f = *keep.back();
+    c.files.push_back(&f);
+    std::vector<size_t> cut(T + 1, f.size);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; ++t) {
+      size_t x = std::max(cut[t - 1], f.size * t / T);
+      if (x > 0 && x < f.size) {
+        const void* q = memchr(f.data + x - 1, '\n', f.size - x + 1);
+        x = q ? size_t(static_cast<const char*>(q) - f.data) + 1 : f.size;
+      }
+      cut[t] = x;
+    }
+    parallel_chunks(T, T, [&](unsigned, size_t lo, size_t hi) {
+      for (size_t t = lo; t < hi; ++t) {
+        size_t pos = cut[t];
+        try {
+          while (pos < cut[t + 1]) {
+            const void* q = memchr(f.data + pos, '\n', f.size - pos);
+            const size_t stop = q ? size_t(static_cast<const char*>(q) - f.data) : f.size;
+            Rec r;
+            uint32_t type = 0;
+            const uint64_t off = pos;
+            pos = stop + 1;
+            if (!parse_row(Span{f.data + off, f.data + stop}, fi, off, r, type)) continue;
+            if (r.ca < double(w) || r.ev < double(w)) continue;                     // [:262, :280, :311, :343]
+            recs[type][size_t(fi) * T + t].push_back(r);
+          }
+        } catch (const Error& e) {
+          std::lock_guard<std::mutex> lk(mu);
+          const uint64_t at = pos;
+          if (!first_err.set() || fi < first_err.file || (fi == first_err.file && at < first_err.off)) { first_err.file = fi; first_err.off = at; first_err.kind = e.kind; first_err.msg = e.what(); }
+        }
+      }
+    });
+    if (first_err.set()) throw Error(first_err.kind, first_err.msg.substr(first_err.kind.size() + 2));      // the reference reads the files in order
+  }
+  // ---- merge: per type, the rows of all replicates in (file, row) order; sharded by key, every shard by a thread of its own
+  for (uint32_t type = 0; type < N_TYPES; ++type) {
+    auto& chunks = recs[type];
+    std::vector<uint64_t> base(chunks.size() + 1, 0);
+    for (size_t i = 0; i < chunks.size(); ++i) base[i + 1] = base[i] + chunks[i].size();
+    c.shard[type].resize(SHARDS);
+    if (base.back() == 0) continue;
+    const uint32_t R = c.R;
+    parallel_chunks(SHARDS, std::min<unsigned>(T, SHARDS), [&](unsigned, size_t lo, size_t hi) {
+      for (size_t s = lo; s < hi; ++s) {
+        Condition::Shard& sh = c.shard[type][s];
+        for (size_t i = 0; i < chunks.size(); ++i) {
+          const std::vector<Rec>& v = chunks[i];
+          for (size_t k = 0; k < v.size(); ++k) {
+            const Rec& r = v[k];
+            if (shard_of(r.key) != s) continue;
+            auto it = sh.ix.find(r.key);
+            uint32_t e;
+            if (it == sh.ix.end()) {
+              e = uint32_t(sh.ev.size());
+              sh.ix.emplace(r.key, e);
+              sh.ev.push_back(Event{r.key, base[i] + k, r.off, r.file, 0});
+              sh.cov.resize(sh.cov.size() + size_t(2) * R, 0.0);
+            } else e = it->second;
+            Event& ev = sh.ev[e];
+            ev.slots = std::max(ev.slots, r.file + 1);                // add_replicate pads up to this replicate [:155-160]
+            sh.cov[size_t(e) * 2 * R + 2 * r.file] = r.ev;
+            sh.cov[size_t(e) * 2 * R + 2 * r.file + 1] = r.ca;
+          }
+        }
+      }
+    });
+    std::vector<std::vector<Rec>>().swap(chunks);
+  }
+}
+
+struct Ref {                // an event of a condition by shard and index, in first-seen order
+  uint64_t seq;
+  uint32_t shard, idx;
+};
+std::vector<Ref> in_order(const Condition& c, uint32_t type) {
+  std::vector<Ref> v;
+  size_t n = 0;
+  for (const auto& sh : c.shard[type]) n += sh.ev.size();
+  v.reserve(n);
+  for (uint32_t s = 0; s < c.shard[type].size(); ++s)
+    for (uint32_t i = 0; i < c.shard[type][s].ev.size(); ++i) v.push_back(Ref{c.shard[type][s].ev[i].seq, s, i});
+  par_sort(v.begin(), v.end(), [](const Ref& a, const Ref& b) { return a.seq < b.seq; });
+  return v;
+}
+
+}  // namespace
+
+void quant_run(const std::vector<std::string>& c1, const std::vector<std::string>& c2, int w, bool both, int fd_out, unsigned threads) {
+  if (threads == 0) threads = hw_threads();
+  std::vector<std::unique_ptr<MappedFile>> keep;
+  Condition A, B;
+  read_condition(c1, keep, w, threads, A);
+  read_condition(c2, keep, w, threads, B);
+  write_all(fd_out, HEADER, strlen(HEADER));
+  constexpr size_t BLOCK = 1 << 15;
+  for (uint32_t type = 0; type < N_TYPES; ++type) {
+    // phase 0: the events of condition 1 in their order (with their partner of condition 2, or alone); phase 1: those only condition 2 has
+    for (int phase = 0; phase < (both ? 1 : 2); ++phase) {
+      const Condition& X = phase == 0 ? A : B;
+      const Condition& Y = phase == 0 ? B : A;
+      if (X.shard[type].empty()) continue;
+      const std::vector<Ref> order = in_order(X, type);
+      const size_t nb = (order.size() + BLOCK - 1) / BLOCK;
+      for (size_t b0 = 0; b0 < nb; b0 += threads) {
+        const size_t b1 = std::min(nb, b0 + threads);
+        std::vector<std::string> out(b1 - b0);
+        parallel_chunks(b1 - b0, unsigned(b1 - b0), [&](unsigned, size_t lo, size_t hi) {
+          for (size_t bi = lo; bi < hi; ++bi) {
+            std::string& s = out[bi];
+            const size_t i0 = (b0 + bi) * BLOCK, i1 = std::min(order.size(), i0 + BLOCK);
+            for (size_t i = i0; i < i1; ++i) {
+              const Condition::Shard& sx = X.shard[type][order[i].shard];
+              const Event& e = sx.ev[order[i].idx];
+              const double* cx = sx.cov.data() + size_t(order[i].idx) * 2 * X.R;
+              const Condition::Shard* sy = Y.shard[type].empty() ? nullptr : &Y.shard[type][order[i].shard];
+              const uint32_t* partner = nullptr;
+              if (sy) { auto it = sy->ix.find(e.key); if (it != sy->ix.end()) partner = &it->second; }
+              if (phase == 0) {
+                if (partner) {
+                  const Event& f = sy->ev[*partner];
+                  const double* cy = sy->cov.data() + size_t(*partner) * 2 * Y.R;
+                  const Num p1 = psi_of(cx, e.slots), p2 = psi_of(cy, f.slots);
+                  Num d = minus(zero_or(p1), zero_or(p2));
+                  if (p1.v == -1 && p2.v == -1) d = Num{true, -1};
+                  prefix(s, X, e);
+                  weights(s, cx, e.slots); s += ',';
+                  weights(s, cy, f.slots); s += ',';
+                  py_print(s, p1); s += ','; py_print(s, p2); s += ','; py_print(s, d); s += '\n';
+                } else if (!both) {
+                  const Num p1 = psi_of(cx, e.slots);
+                  if (p1.v == -1) continue;
+                  prefix(s, X, e);
+                  weights(s, cx, e.slots); s += ",.,";
+                  py_print(s, p1); s += ",1,"; py_print(s, minus(zero_or(p1), Num{true, 1})); s += '\n';
+                }
+              } else if (!partner) {
+                const Num p2 = psi_of(cx, e.slots);
+                if (p2.v == -1) continue;
+                prefix(s, X, e);
+                s += ".,";
+                weights(s, cx, e.slots); s += ",1,";
+                py_print(s, p2); s += ','; py_print(s, minus(Num{true, 1}, zero_or(p2))); s += '\n';
+              }
+            }
+          }
+        });
+        for (const std::string& s : out) write_all(fd_out, s.data(), s.size());
+      }
+    }
+  }
+}
+
+}  // namespace pantas

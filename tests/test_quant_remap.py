@@ -21,15 +21,51 @@ def expected(name):
     return gzip.open(os.path.join(Q, name + ".gz"), "rt").read()
 
 
+@pytest.mark.parametrize("how", ["native", "python"])
 @pytest.mark.parametrize("case", META["quant"], ids=lambda c: c["expected"])
-def test_quantify_bytes(case):
+def test_quantify_bytes(case, how):
+    """the native join (csrc/quant.cpp, what the command line runs) and the interpreted mirror: the reference's bytes"""
     from pantas_amd import quantify
     n = case["replicates"]
     out = io.StringIO()
     a = quantify.build_parser().parse_args([*case["flags"], "--c1", *C1[:n], "--c2", *C2[:n]])
-    quantify.quantify(a.c1, a.c2, a.w, a.both, out)
+    (quantify.quantify if how == "native" else quantify.quantify_python)(a.c1, a.c2, a.w, a.both, out)
     assert out.getvalue() == expected(case["expected"])
     assert case["rows"] > 50
+
+
+def test_native_quant_equals_the_mirror_on_generated_replicates(tmp_path):
+    """three + three replicates of `call --rca 3 --novel` events on one graph (the C++ oracles make them: ~10^5 rows each, every
+    event kind, events shared by some replicates and missing from others): the native join prints what the interpreted mirror
+    prints, with and without --both and -w"""
+    import bench  # noqa: F401  (path set-up)
+    from pantas_amd import quantify
+    from pantas_amd.engine import Synth
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    kw = dict(n_genes=1500, n_lines=250_000, base_id=10**7, intron_long_max=200, zipf_a=1.0)
+    pre = str(tmp_path / "g")
+    Synth(seed=9, **kw).write(pre)
+    csvs = []
+    for r in range(6):
+        gaf = pre + f".r{r}"
+        Synth(seed=9, line_offset=(r + 1) * kw["n_lines"], gaf_only=1, **kw).write(gaf)
+        with open(gaf + ".aug.gfa", "wb") as f:
+            subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", "8", gaf + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.DEVNULL, check=True)
+        with open(gaf + ".csv", "wb") as f:
+            subprocess.run([os.path.join(ROOT, "oracle", "bin", "call_oracle_cpp"), "--threads", "8", "--rca", "3", "--novel", gaf + ".aug.gfa", pre + ".gtf"],
+                           stdout=f, stderr=subprocess.DEVNULL, check=True)
+        os.unlink(gaf + ".aug.gfa")
+        csvs.append(gaf + ".csv")
+    rows = sum(1 for _ in open(csvs[0]))
+    assert rows > 20_000
+    for w, both in ((0, False), (0, True), (5, False), (-1, False)):
+        a, b = io.StringIO(), io.StringIO()
+        quantify.quantify(csvs[:3], csvs[3:], w, both, a)
+        quantify.quantify_python(csvs[:3], csvs[3:], w, both, b)
+        assert a.getvalue() == b.getvalue(), (w, both)
+        assert a.getvalue().count("\n") > 1000
+    kinds = {l.split(",", 1)[0] for l in a.getvalue().splitlines()[1:]}
+    assert kinds == {"ES", "CE", "IR", "A3", "A5"}
 
 
 def test_quantify_cli_and_unequal_replicates():
@@ -61,6 +97,9 @@ def test_inputs_the_reference_raises_on():
                 quantify.quantify([path], [C2[0]], 0, False, io.StringIO())
             else:
                 remap.remap(path, os.path.join(Q, "anno.gtf"), 100, io.StringIO())
+        if c["script"] == "quantify":       # ... and the interpreted mirror likewise
+            with pytest.raises(classes[c["exception"]]):
+                quantify.quantify_python([path], [C2[0]], 0, False, io.StringIO())
 
 
 def test_dispatcher_quant_and_remap(tmp_path):
