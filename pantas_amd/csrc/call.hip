@@ -119,34 +119,39 @@ __global__ __launch_bounds__(256) void call_place_kernel(CallView c, const uint3
 // Deferred intron walks: one thread per task, so the lanes of a wave walk 64 different introns (inside
 // the junction kernels a walking lane would leave the other 63 idle).  First launch decides and measures,
 // the paths are written by a second launch at the scanned offsets.
-__global__ __launch_bounds__(256) void walk_count_kernel(CallView c, const EventRec* recs, const uint32_t* side,
-                                                         const uint32_t* task_list, uint32_t n, TaskOut* out, uint32_t* np,
-                                                         unsigned long long* status) {
+__global__ __launch_bounds__(256) void walk_bound_kernel(CallView c, const EventRec* recs, const uint32_t* side, const uint32_t* task_list, uint32_t n, uint32_t* bound) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) bound[i] = walk_bound(c, recs[task_list[i]], side);
+}
+
+// ONE walk per task (round 3): it decides, measures AND writes its path into the room its bound reserved.  over[i] = length of a
+// path that outgrew the room (or had none): those few are written by walk_redo_kernel at the end of the buffer.
+__global__ __launch_bounds__(256) void walk_once_kernel(CallView c, const EventRec* recs, const uint32_t* side, const uint32_t* task_list, uint32_t n,
+                                                        const uint32_t* bound_off, TaskOut* out, uint32_t* paths, uint32_t* over, unsigned long long* status) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     Fault f;
     TaskOut o;
-    run_walk_task(c, recs[task_list[i]], side, nullptr, o, f);
+    BoundEmit be{paths + bound_off[i], bound_off[i + 1] - bound_off[i]};
+    run_walk_task(c, recs[task_list[i]], side, &be, o, f);
     if (f.bad()) {
       atomicMin(status, (3ull << 40) | (static_cast<unsigned long long>(i) << 8) | f.code);
       o.status = 0;
       o.np = 0;
     }
-    o.path_off = 0;
+    o.path_off = bound_off[i];
     out[i] = o;
-    np[i] = o.status == 1 ? o.np : 0u;
+    over[i] = (o.status == 1 && o.np > be.cap) ? o.np : 0u;
   }
 }
 
-__global__ __launch_bounds__(256) void walk_write_kernel(CallView c, const EventRec* recs, const uint32_t* side,
-                                                         const uint32_t* task_list, uint32_t n, TaskOut* out,
-                                                         const uint32_t* path_off, uint32_t* paths) {
+__global__ __launch_bounds__(256) void walk_redo_kernel(CallView c, const EventRec* recs, const uint32_t* side, const uint32_t* task_list, uint32_t n,
+                                                        const uint32_t* over, const uint32_t* over_off, uint32_t base, TaskOut* out, uint32_t* paths) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    out[i].path_off = path_off[i];
-    if (out[i].status != 1) continue;
+    if (!over[i]) continue;
     Fault f;
     TaskOut o;
-    PathEmit pe{paths, path_off[i]};
+    PathEmit pe{paths, base + over_off[i]};
     run_walk_task(c, recs[task_list[i]], side, &pe, o, f);
+    out[i].path_off = base + over_off[i];
   }
 }
 
@@ -391,17 +396,34 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
   uint32_t path_total = 0;
   uint32_t* d_paths = nullptr;
   if (nt) {
-    uint32_t* np = u32(nt);
-    uint32_t* path_off = u32(size_t(nt) + 1);
     const uint32_t tb = uint32_t(std::min<uint64_t>((uint64_t(nt) + 255) / 256, 1u << 16));
-    hipLaunchKernelGGL(walk_count_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, d_tout, np, d.status);
-    exclusive_scan(d, np, path_off, nt);
+    uint32_t* bound = u32(nt);
+    uint32_t* bound_off = u32(size_t(nt) + 1);
+    uint32_t* over = u32(nt);
+    uint32_t* over_off = u32(size_t(nt) + 1);
+    hipLaunchKernelGGL(walk_bound_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, bound);
+    exclusive_scan(d, bound, bound_off, nt);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(&path_total, path_off + nt, 4, hipMemcpyDeviceToHost, d.stream));
+    uint32_t bounded = 0;
+    HIP_OK(hipMemcpyAsync(&bounded, bound_off + nt, 4, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    d_paths = u32(bounded);
+    hipLaunchKernelGGL(walk_once_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, bound_off, d_tout, d_paths, over, d.status);
+    exclusive_scan(d, over, over_off, nt);
+    HIP_OK(hipGetLastError());
+    uint32_t extra = 0;
+    HIP_OK(hipMemcpyAsync(&extra, over_off + nt, 4, hipMemcpyDeviceToHost, d.stream));
     check_status();
-    d_paths = u32(path_total);
-    hipLaunchKernelGGL(walk_write_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, d_tout, path_off, d_paths);
-    HIP_OK(hipGetLastError());
+    path_total = bounded;
+    if (extra) {                       // paths without a bound, or longer than theirs: a buffer with room behind, walked again
+      if (uint64_t(bounded) + extra >= 0xFFFFFFFFull) throw Error("Unsupported", "more than 2^32-2 path segments in one pass");
+      uint32_t* all = u32(size_t(bounded) + extra);
+      HIP_OK(hipMemcpyAsync(all, d_paths, size_t(bounded) * 4, hipMemcpyDeviceToDevice, d.stream));
+      hipLaunchKernelGGL(walk_redo_kernel, dim3(tb), dim3(256), 0, d.stream, c, d_recs, d_side, d_tasks, nt, over, over_off, bounded, d_tout, all);
+      HIP_OK(hipGetLastError());
+      d_paths = all;
+      path_total = bounded + extra;
+    }
   }
   HIP_OK(hipEventRecord(d.ev1, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));

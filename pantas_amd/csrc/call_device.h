@@ -796,9 +796,30 @@ struct PathEmit {
   uint32_t i;
   PANTAS_HD void push(uint32_t w) { out[i++] = w; }
 };
+// A walk that writes its path while it decides: room for `cap` segments (an upper bound known before the walk, walk_bound); a path
+// that outgrows it is counted to its end and written by a second walk.
+struct BoundEmit {
+  uint32_t* out;
+  uint32_t cap;
+  uint32_t n = 0;
+  PANTAS_HD void push(uint32_t w) { if (n < cap) out[n] = w; ++n; }
+};
+// Upper bound of a walk's path: it runs from `start` to `goal` through segments whose names sort at or below the goal's, and in a
+// graph whose names follow its topological order (every graph vg writes) each step moves up: at most rank(goal) - rank(start) + 1
+// segments.  0: no bound offered (the names run the other way, or the span is huge) -- such a walk is measured first, then written.
+constexpr uint32_t WALK_BOUND_MAX = 1u << 20;
+PANTAS_HD uint32_t walk_bound(const CallView& c, const EventRec& r, const uint32_t* side) {
+  uint32_t start, goal;
+  if (r.type == T_IR_ANN) { start = side[r.side_off]; goal = side[r.side_off + 1]; }
+  else { start = c.src[r.j0]; goal = c.col[r.j0]; }
+  const uint32_t a = c.rank[start], b = c.rank[goal];
+  if (b < a || b - a >= WALK_BOUND_MAX) return 0;
+  return b - a + 1u;
+}
 
-// Walks the intron of an IR record.  path == nullptr: decide (status, np, mean); else: write the path.
-PANTAS_HD void run_walk_task(const CallView& c, const EventRec& r, const uint32_t* side, PathEmit* path, TaskOut& out, Fault& f) {
+// Walks the intron of an IR record.  path == nullptr: decide (status, np, mean); else: also hand every segment of the path to it.
+template <class Emit>
+PANTAS_HD void run_walk_task(const CallView& c, const EventRec& r, const uint32_t* side, Emit* path, TaskOut& out, Fault& f) {
   out.np = 0;
   out.mean = 0;
   out.status = 0;
@@ -809,7 +830,7 @@ PANTAS_HD void run_walk_task(const CallView& c, const EventRec& r, const uint32_
   if (r.type == T_IR_ANN) {
     const uint32_t n1 = side[r.side_off], n2 = side[r.side_off + 1], pick = side[r.side_off + 2];
     auto ok = [&](uint32_t nn) { return ex_has(ex_of(c, nn), pick); };
-    if (!walk_exon<PathEmit>(c, n1, n2, ok, path, np, ncs, ln, nc_ok, f)) return;
+    if (!walk_exon<Emit>(c, n1, n2, ok, path, np, ncs, ln, nc_ok, f)) return;
   } else if (r.type == T_IR1_NOV) {
     const Ex ex0 = ex_of(c, u), ex1 = ex_of(c, v);
     auto ok = [&](uint32_t nn) {
@@ -818,10 +839,10 @@ PANTAS_HD void run_walk_task(const CallView& c, const EventRec& r, const uint32_
         if (ex_has(ex0, en.tag[i]) && ex_has(ex1, en.tag[i])) return true;
       return false;
     };
-    if (!walk_exon<PathEmit>(c, u, v, ok, path, np, ncs, ln, nc_ok, f)) return;
+    if (!walk_exon<Emit>(c, u, v, ok, path, np, ncs, ln, nc_ok, f)) return;
     if (int64_t(ln) < int64_t(c.minintron)) return;          // sum of LN over the whole path (:853)
   } else {
-    if (!walk_greedy<PathEmit>(c, u, v, path, np, ncs, ln, nc_ok, f)) return;
+    if (!walk_greedy<Emit>(c, u, v, path, np, ncs, ln, nc_ok, f)) return;
     if (int64_t(ln) < int64_t(c.minintron)) return;          // inner nodes only (:1052)
   }
   if (r.type != T_IR_ANN) {

@@ -123,7 +123,7 @@ struct CountEmit {
 // Evaluate ONCE (round 3): what an item emits is kept in a small staging area of its own (STAGE_RECS records, STAGE_WORDS payload
 // words) while it is counted; the write pass then only moves it to its scanned place.  An item that emits more than fits is
 // counted in full all the same (`fits` cleared) and evaluated a second time by the write pass, as every item was before.
-constexpr uint32_t STAGE_RECS = 4, STAGE_WORDS = 48;
+constexpr uint32_t STAGE_RECS = 4, STAGE_WORDS = 96;
 struct StageEmit {
   EventRec* rec;          // STAGE_RECS slots
   uint32_t* side;         // STAGE_WORDS slots

@@ -45,9 +45,13 @@ struct Rec {               // one row that passed the -w threshold
   Key key;
   double ev, ca;           // event / canonical coverage
   uint64_t off;            // where the row starts in its file
+  uint64_t seq;            // its place among the rows of its type, files in order (stretch of the file << 40 | row of the stretch)
   uint32_t file;           // replicate index
   uint32_t pad_;
 };
+
+constexpr uint32_t SHARDS = 64;
+inline uint32_t shard_of(const Key& k) { return uint32_t(k.b >> 40) % SHARDS; }
 
 struct RowError {
   uint32_t file = 0xFFFFFFFFu;
@@ -292,9 +296,6 @@ struct Condition {
   std::vector<Shard> shard[N_TYPES];
 };
 
-constexpr uint32_t SHARDS = 64;
-inline uint32_t shard_of(const Key& k) { return uint32_t(k.b >> 40) % SHARDS; }
-
 // psi over the replicates [:196-216]: mean of canonical / (canonical + event) over those with reads; the int -1 if none has
 Num psi_of(const double* cov, uint32_t slots) {
   double vals[64];
@@ -374,9 +375,10 @@ void write_all(int fd, const char* p, size_t n) {
 void read_condition(const std::vector<std::string>& paths, std::vector<std::unique_ptr<MappedFile>>& keep, int w, unsigned threads, Condition& c) {
   c.R = uint32_t(paths.size());
   const unsigned T = std::max(1u, threads);
-  // ---- parse: every file cut into T stretches at line starts, every stretch into one vector of records per type
+  // ---- parse: every file cut into T stretches at line starts, every stretch into one vector of records per type AND shard of the
+  // join (a shard's thread then reads its own records only: 64 shards each looking at all 4e8 records was most of the run)
   std::vector<std::vector<Rec>> recs[N_TYPES];
-  for (auto& v : recs) v.resize(size_t(c.R) * T);
+  for (auto& v : recs) v.resize(size_t(c.R) * T * SHARDS);
   RowError first_err;
   std::mutex mu;
   for (uint32_t fi = 0; fi < c.R; ++fi) {
@@ -397,6 +399,7 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
     parallel_chunks(T, T, [&](unsigned, size_t lo, size_t hi) {
       for (size_t t = lo; t < hi; ++t) {
         size_t pos = cut[t];
+        uint64_t count[N_TYPES] = {0, 0, 0, 0, 0};
         try {
           while (pos < cut[t + 1]) {
             const void* q = memchr(f.data + pos, '\n', f.size - pos);
@@ -407,7 +410,8 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
             pos = stop + 1;
             if (!parse_row(Span{f.data + off, f.data + stop}, fi, off, r, type)) continue;
             if (r.ca < double(w) || r.ev < double(w)) continue;                     // [:262, :280, :311, :343]
-            recs[type][size_t(fi) * T + t].push_back(r);
+            r.seq = (uint64_t(size_t(fi) * T + t) << 40) | count[type]++;
+            recs[type][(size_t(fi) * T + t) * SHARDS + shard_of(r.key)].push_back(r);
           }
         } catch (const Error& e) {
           std::lock_guard<std::mutex> lk(mu);
@@ -419,27 +423,26 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
     if (first_err.set()) throw Error(first_err.kind, first_err.msg.substr(first_err.kind.size() + 2));      // the reference reads the files in order
   }
   // ---- merge: per type, the rows of all replicates in (file, row) order; sharded by key, every shard by a thread of its own
+  const size_t stretches = size_t(c.R) * T;
   for (uint32_t type = 0; type < N_TYPES; ++type) {
     auto& chunks = recs[type];
-    std::vector<uint64_t> base(chunks.size() + 1, 0);
-    for (size_t i = 0; i < chunks.size(); ++i) base[i + 1] = base[i] + chunks[i].size();
     c.shard[type].resize(SHARDS);
-    if (base.back() == 0) continue;
     const uint32_t R = c.R;
     parallel_chunks(SHARDS, std::min<unsigned>(T, SHARDS), [&](unsigned, size_t lo, size_t hi) {
       for (size_t s = lo; s < hi; ++s) {
         Condition::Shard& sh = c.shard[type][s];
-        for (size_t i = 0; i < chunks.size(); ++i) {
-          const std::vector<Rec>& v = chunks[i];
-          for (size_t k = 0; k < v.size(); ++k) {
-            const Rec& r = v[k];
-            if (shard_of(r.key) != s) continue;
+        size_t n = 0;
+        for (size_t i = 0; i < stretches; ++i) n += chunks[i * SHARDS + s].size();
+        sh.ix.reserve(n);
+        for (size_t i = 0; i < stretches; ++i) {
+          std::vector<Rec>& v = chunks[i * SHARDS + s];
+          for (const Rec& r : v) {
             auto it = sh.ix.find(r.key);
             uint32_t e;
             if (it == sh.ix.end()) {
               e = uint32_t(sh.ev.size());
               sh.ix.emplace(r.key, e);
-              sh.ev.push_back(Event{r.key, base[i] + k, r.off, r.file, 0});
+              sh.ev.push_back(Event{r.key, r.seq, r.off, r.file, 0});
               sh.cov.resize(sh.cov.size() + size_t(2) * R, 0.0);
             } else e = it->second;
             Event& ev = sh.ev[e];
@@ -447,6 +450,7 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
             sh.cov[size_t(e) * 2 * R + 2 * r.file] = r.ev;
             sh.cov[size_t(e) * 2 * R + 2 * r.file + 1] = r.ca;
           }
+          std::vector<Rec>().swap(v);
         }
       }
     });
@@ -475,8 +479,11 @@ void quant_run(const std::vector<std::string>& c1, const std::vector<std::string
   if (threads == 0) threads = hw_threads();
   std::vector<std::unique_ptr<MappedFile>> keep;
   Condition A, B;
+  PhaseTimer pt("quant");
   read_condition(c1, keep, w, threads, A);
+  pt.lap("condition 1: rows parsed, replicates merged");
   read_condition(c2, keep, w, threads, B);
+  pt.lap("condition 2: rows parsed, replicates merged");
   write_all(fd_out, HEADER, strlen(HEADER));
   constexpr size_t BLOCK = 1 << 15;
   for (uint32_t type = 0; type < N_TYPES; ++type) {
@@ -534,6 +541,7 @@ void quant_run(const std::vector<std::string>& c1, const std::vector<std::string
       }
     }
   }
+  pt.lap("joined, rendered, written");
 }
 
 }  // namespace pantas

@@ -43,7 +43,7 @@ static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, Out&
   for (size_t k = 0; k < task_list.size(); ++k) {
     Fault f;
     TaskOut to;
-    run_walk_task(c, o.recs[r0 + task_list[k]], o.side.data() + w0, nullptr, to, f);
+    run_walk_task<PathEmit>(c, o.recs[r0 + task_list[k]], o.side.data() + w0, nullptr, to, f);
     if (f.bad()) throw Error(call_error_kind(f.code), call_error_text(f.code));
     poff[k + 1] = poff[k] + (to.status == 1 ? to.np : 0);
     o.tasks[t0 + k] = to;

@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--replicates", type=int, default=0,
                     help="also time N replicates of the GAF through ONE `pantas_amd.distributed replicates` process (graph parsed once, "
                          "call on the augment result without the GFA text round trip) and compare its files with the command lines'")
+    ap.add_argument("--quant", type=int, default=0,
+                    help="also time `pantas quant` over N + N replicates: the events CSV of this run under 2 N names (every event matches: the "
+                         "join's worst case -- all rows kept, all rows printed)")
     ap.add_argument("--heartbeat", default=None, help="append a line to this file every 30 s (gpurun takes 7 silent minutes for a hang)")
     a = ap.parse_args()
     if a.heartbeat:
@@ -177,6 +180,17 @@ def main():
         res["total_s"] = res["augment"]["wall_s"] + res["call"]["wall_s"]
         if a.replicates:
             res["replicates"] = replicates_leg(a, pre, env, py)
+        if a.quant:
+            t0 = time.perf_counter()
+            r = subprocess.run([py, "-m", "pantas_amd.quantify", "--c1", *[pre + ".csv"] * a.quant, "--c2", *[pre + ".csv"] * a.quant],
+                               stdout=open(pre + ".quant.csv", "wb"), stderr=subprocess.PIPE, env=env, cwd=ROOT)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError(f"quant: rc {r.returncode}: {r.stderr.decode(errors='replace')[-2000:]}")
+            res["quant"] = {"replicates_per_condition": a.quant, "input_rows": 2 * a.quant * res["call"]["events"], "wall_s": dt,
+                            "rows_per_s": 2 * a.quant * res["call"]["events"] / dt, "out_bytes": os.path.getsize(pre + ".quant.csv"),
+                            "what": "native join (csrc/quant.cpp) through `python -m pantas_amd.quantify`"}
+            os.unlink(pre + ".quant.csv")
         if a.null_out:
             dt, err, _ = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], "/dev/null", env)
             res["augment_to_dev_null"] = {"wall_s": dt, "phases": [p for p in phases(err) if "tokenize_gaf_device" not in p]}
