@@ -6,6 +6,7 @@
 #include "synth.h"
 #include "quant.h"
 
+#include <atomic>
 #include <dlfcn.h>
 #include <fcntl.h>
 
@@ -165,14 +166,40 @@ __attribute__((visibility("default"))) int pantas_quant_run(const char* const* c
   });
 }
 __attribute__((visibility("default"))) void pantas_device_warmup(int device) { try { warm_up_device(device); } catch (...) {} }
-__attribute__((visibility("default"))) void pantas_device_init(int device) { try { init_device(device); } catch (...) {} }
+static std::atomic<int> g_init_device{-1};      // the device of the last pantas_device_init: where a GFA is parsed when a GPU is there
+__attribute__((visibility("default"))) void pantas_device_init(int device) { try { init_device(device); g_init_device.store(device); } catch (...) {} }
+
+// The GFA parsed on the GPU when the process has one (PANTAS_GFA_LOADER=host keeps it on the host cores, =device insists): the device
+// form takes the graphs a graph builder writes and hands everything else back (load_graph_device returns nullptr).  The two loaders
+// build the same arrays (tests/test_gpu_graph_loader.py compares them through the binary cache both can write).
+static std::unique_ptr<Graph> load_graph_anywhere(const char* gfa_path) {
+  const char* how = getenv("PANTAS_GFA_LOADER");
+  const bool host_only = how && !strcmp(how, "host");
+  const bool insist = how && !strcmp(how, "device");
+  if (!host_only) {
+    int dev = g_init_device.load();
+    if (dev < 0 && insist) dev = getenv("PANTAS_DEVICE") ? atoi(getenv("PANTAS_DEVICE")) : 0;
+    if (dev >= 0) {
+      std::unique_ptr<Graph> g;
+      try {
+        g = load_graph_device(gfa_path, dev);
+      } catch (const Error& e) {
+        if (insist || e.kind == "FileNotFoundError") throw;
+        g = nullptr;                        // (a HIP error while parsing: the host loader does not need the device)
+      }
+      if (g) return g;
+      if (insist) throw Error("Unsupported", "PANTAS_GFA_LOADER=device: this GFA is not one the device form takes (or there is no device)");
+    }
+  }
+  return load_graph(gfa_path);
+}
 
 __attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_path, pantas_graph** out) {
   return guarded([&] {
     need(gfa_path && out, "null argument");
     double t0 = now_s();
     auto h = std::make_unique<pantas_graph>();
-    h->g = load_graph(gfa_path);
+    h->g = load_graph_anywhere(gfa_path);
     h->load_s = now_s() - t0;
     *out = h.release();
   });
@@ -190,7 +217,7 @@ __attribute__((visibility("default"))) int pantas_graph_load_cached(const char* 
     if (h->g) {
       if (timing) fprintf(stderr, "[timing] graph cache: loaded %s in %.3f s\n", cache_path, now_s() - t0);
     } else {
-      h->g = load_graph(gfa_path);
+      h->g = load_graph_anywhere(gfa_path);
       const bool saved = write_if_missing && save_graph_cache(*h->g, cache_path);
       if (timing) fprintf(stderr, "[timing] graph cache: parsed the GFA text (%.3f s)%s\n", now_s() - t0, saved ? ", cache written" : "");
     }

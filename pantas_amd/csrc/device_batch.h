@@ -113,6 +113,8 @@ struct ScratchPool {
 // through two pinned 32 MB buffers that several host threads fill (the text upload of tokenize.hip reaches 50 GB/s that
 // way).  Synchronous: returns when the bytes are on the device.  Small copies go straight through hipMemcpyAsync.
 void h2d_staged(void* dst, const void* src, size_t bytes, hipStream_t stream);
+// the other way, into pageable host memory (several host threads copy one pinned buffer out while the next piece is on its way)
+void d2h_staged(void* dst, const void* src, size_t bytes, hipStream_t stream);
 
 // what tokenize.hip needs from a DeviceGraph without seeing its tables
 struct DeviceGraphInfo {

@@ -77,6 +77,10 @@ inline void require_augmentable(const Graph& g) {
 
 // Parses the GFA at `path`.  Throws Error on inputs the reference's first GFA pass dies on.
 std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
+// The same arrays built on the GPU (tokenize.hip): for the graphs a graph builder writes; nullptr for anything else -- no device, a
+// small file, names that are no decimals in a dense range, duplicate or whitespace-led S lines, lone carriage returns -- which the
+// host loader then takes.
+std::unique_ptr<Graph> load_graph_device(const char* path, int device);
 // Same over text already in memory (the buffer must outlive the graph).
 std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads = 0);
 

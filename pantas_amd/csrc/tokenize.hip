@@ -24,6 +24,7 @@
 #include "augment.h"
 #include "device_batch.h"
 #include "gaf_device.h"
+#include "graph.h"
 
 namespace pantas {
 
@@ -1158,6 +1159,421 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   tm.total_s = now() - t_begin;
   if (times) *times = tm;
   return out;
+}
+
+
+// ================================================================================================================
+// GFA text -> the graph's arrays ON THE GPU (round 3; the host loader is graph.cpp, the reference's parsers
+// scripts/alignments_augmentation_from_gaf.py:121-126, scripts/call.py:145-181, scripts/gfautils.py:92-128).
+// Both command lines spent 4.4 - 4.9 s of a whole-genome run in the host parse of 19 - 23 GB of GFA text on the box's sixteen
+// granted cores; the same text goes over PCIe in 0.4 s and is classified at memory speed.  The device form takes the graphs
+// a graph builder writes -- every S / L line starts at the first byte of its line, names are canonical decimals in a dense
+// range, one S line per name, both ends of every link known -- and gives ANYTHING else back to the host loader (nullptr), which
+// knows every rule of the three reference parsers.  Same arrays, byte for byte: tests compare the two loaders through the
+// binary graph cache they both can write.
+//   line index (as for the GAF)  ->  one lane per line: kind, name / link ends as numbers, sequence length  ->  S lines numbered
+//   by a scan (= node index: order of first appearance), name table by scatter  ->  links: ends through the table, stable radix
+//   sorts by source (rows in L-line file order) and by target (in-lists in file order)  ->  arrays to the host.
+// P lines are counted where they stand (a P line of a chromosome is hundreds of megabytes: no lane walks that): the host looks at
+// the few of them afterwards.
+namespace {
+
+enum : uint8_t { GK_OTHER = 0, GK_S = 1, GK_L = 2, GK_P = 3 };
+struct KindIs {
+  uint8_t want;
+  __host__ __device__ uint32_t operator()(uint8_t k) const { return k == want ? 1u : 0u; }
+};
+struct GfaLine { unsigned long long a, b; };     // S: {name as a number, seq len | name delta << 32 | name len << 48}; L: {source, target}
+
+struct GfaFlags {        // [0] odd (a line the device form does not take), [1] L lines with fewer than 6 tokens: first offset
+  unsigned long long odd, first_short_l;
+};
+
+// a token of at most 18 plain digits without a leading zero (Span parse_canonical_u64)
+__device__ __forceinline__ bool gfa_number(TextWords& T, uint32_t b, uint32_t e, unsigned long long& v) {
+  const uint32_t n = e - b;
+  if (n == 0 || n > 18) return false;
+  if (n > 1 && T.at(b) == '0') return false;
+  unsigned long long x = 0;
+  for (uint32_t c = b; c < e; ++c) {
+    const uint32_t d = T.at(c) - '0';
+    if (d > 9u) return false;
+    x = x * 10ull + d;
+  }
+  v = x;
+  return true;
+}
+
+__global__ void __launch_bounds__(LPB) gfa_lines_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, uint8_t* kind, GfaLine* rec,
+                                                        unsigned long long* flags, uint32_t* too_long_scratch) {
+  const uint32_t groups = (n_lines + LPB - 1u) / LPB;
+  for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    // lines that do not fit the staging buffer: a P line is named by its first byte, anything else is odd
+    {
+      const uint32_t i = grp * LPB + threadIdx.x;
+      if (i < n_lines) {
+        const uint64_t lb = ls[i], le = ls[i + 1];
+        if (le - lb > uint64_t(stage_bytes) - 32u) {
+          const uint8_t c = lb < le - 1 ? text[lb] : 0;
+          kind[i] = c == 'P' ? GK_P : GK_OTHER;
+          if (c == 'S' || c == 'L' || c == ' ' || (c >= 9 && c <= 13)) atomicMin(&flags[0], static_cast<unsigned long long>(lb));
+        }
+      }
+    }
+    staged_rounds(grp, text, ls, n_lines, stage_bytes, too_long_scratch, [&](uint32_t i, const uint32_t* words, uint32_t b, uint32_t e) {
+      TextWords T(words);
+      uint8_t k = GK_OTHER;
+      GfaLine r{0, 0};
+      const uint64_t off = ls[i];
+      auto odd = [&] { atomicMin(&flags[0], static_cast<unsigned long long>(off)); };
+      // (a '\r' in front of the '\n' is whitespace at the line's end; one anywhere else was looked for when the text was copied)
+      uint32_t end = e;
+      while (end > b && tk_ws(T.at(end - 1u))) --end;
+      const uint32_t c0 = b < end ? T.at(b) : 0u;
+      if (b < end && tk_ws(c0)) odd();                                   // whitespace in front of a line: the host knows what each parser makes of it
+      else if (c0 == 'S' || c0 == 'L') {
+        uint32_t tb[6], te[6], n = 0, p = b;
+        while (n < 6u) {
+          while (p < end && tk_ws(T.at(p))) ++p;
+          if (p >= end) break;
+          tb[n] = p;
+          while (p < end && !tk_ws(T.at(p))) ++p;
+          te[n] = p;
+          ++n;
+        }
+        if (c0 == 'S') {
+          unsigned long long id;
+          if (n < 3u || !gfa_number(T, tb[1], te[1], id) || te[2] - tb[2] >= (1u << 30) || tb[1] - b > 65535u) odd();
+          else { k = GK_S; r.a = id; r.b = static_cast<unsigned long long>(te[2] - tb[2]) | (static_cast<unsigned long long>(tb[1] - b) << 32) | (static_cast<unsigned long long>(te[1] - tb[1]) << 48); }
+        } else if (end - b > 1u) {                                        // (a bare "L" is no link: the loader skips it)
+          unsigned long long u, v;
+          if (n < 4u || !gfa_number(T, tb[1], te[1], u) || !gfa_number(T, tb[3], te[3], v)) odd();
+          else {
+            k = GK_L; r.a = u; r.b = v;
+            if (n < 6u) atomicMin(&flags[1], static_cast<unsigned long long>(off));
+          }
+        }
+      } else if (c0 == 'P') k = GK_P;
+      kind[i] = k;
+      rec[i] = r;
+    });
+  }
+}
+
+// S lines -> node arrays; id range; the name table is filled by a second kernel once base and size are known
+__global__ void __launch_bounds__(TPB) gfa_nodes_kernel(uint32_t n_lines, const uint8_t* kind, const GfaLine* rec, const uint64_t* ls, const uint32_t* s_ord,
+                                                        uint32_t* seg_len, uint64_t* seg_line_off, uint64_t* seg_name_off, uint16_t* seg_name_len,
+                                                        unsigned long long* id_min, unsigned long long* id_max, uint32_t* len_max) {
+  unsigned long long lo = ~0ull, hi = 0;
+  uint32_t lm = 0;
+  for (uint64_t i = uint64_t(blockIdx.x) * TPB + threadIdx.x; i < n_lines; i += uint64_t(gridDim.x) * TPB) {
+    if (kind[i] != GK_S) continue;
+    const GfaLine r = rec[i];
+    const uint32_t node = s_ord[i];
+    const uint32_t len = uint32_t(r.b & 0xFFFFFFFFull);
+    seg_len[node] = len;
+    seg_line_off[node] = ls[i];
+    seg_name_off[node] = ls[i] + ((r.b >> 32) & 0xFFFFull);
+    seg_name_len[node] = uint16_t(r.b >> 48);
+    lo = min(lo, r.a); hi = max(hi, r.a); lm = max(lm, len);
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    lo = min(lo, static_cast<unsigned long long>(__shfl_down(lo, d, 64)));
+    hi = max(hi, static_cast<unsigned long long>(__shfl_down(hi, d, 64)));
+    lm = max(lm, uint32_t(__shfl_down(lm, d, 64)));
+  }
+  if ((threadIdx.x & 63u) == 0) { atomicMin(id_min, lo); atomicMax(id_max, hi); atomicMax(len_max, lm); }
+}
+// where the P lines start (a handful): the host counts their tokens
+__global__ void __launch_bounds__(TPB) gfa_plines_kernel(uint32_t n_lines, const uint8_t* kind, const uint64_t* ls, uint32_t cap, uint64_t* list, uint32_t* n) {
+  for (uint64_t i = uint64_t(blockIdx.x) * TPB + threadIdx.x; i < n_lines; i += uint64_t(gridDim.x) * TPB) {
+    if (kind[i] != GK_P) continue;
+    const uint32_t k = atomicAdd(n, 1u);
+    if (k < cap) { list[2 * k] = ls[i]; list[2 * k + 1] = ls[i + 1] - 1; }
+  }
+}
+__global__ void __launch_bounds__(TPB) gfa_table_kernel(uint32_t n_lines, const uint8_t* kind, const GfaLine* rec, const uint32_t* s_ord, unsigned long long base,
+                                                        uint32_t* table, unsigned long long* flags, const uint64_t* ls) {
+  for (uint64_t i = uint64_t(blockIdx.x) * TPB + threadIdx.x; i < n_lines; i += uint64_t(gridDim.x) * TPB) {
+    if (kind[i] != GK_S) continue;
+    if (atomicCAS(&table[rec[i].a - base], NONE32, s_ord[i]) != NONE32) atomicMin(&flags[0], static_cast<unsigned long long>(ls[i]));     // a second S line of the name
+  }
+}
+// L lines in file order: ends through the table
+__global__ void __launch_bounds__(TPB) gfa_links_kernel(uint32_t n_lines, const uint8_t* kind, const GfaLine* rec, const uint64_t* ls, const uint32_t* l_ord,
+                                                        unsigned long long base, unsigned long long size, const uint32_t* table, const uint64_t* seg_line_off,
+                                                        uint32_t* fsrc, uint32_t* fdst, uint64_t* foff, uint32_t* fidx, uint32_t* out_cnt, uint32_t* in_cnt,
+                                                        unsigned long long* flags, uint32_t* before) {
+  for (uint64_t i = uint64_t(blockIdx.x) * TPB + threadIdx.x; i < n_lines; i += uint64_t(gridDim.x) * TPB) {
+    if (kind[i] != GK_L) continue;
+    const GfaLine r = rec[i];
+    const uint32_t f = l_ord[i];
+    uint32_t u = NONE32, v = NONE32;
+    if (r.a >= base && r.a - base < size) u = table[r.a - base];
+    if (r.b >= base && r.b - base < size) v = table[r.b - base];
+    if (u == NONE32 || v == NONE32) { atomicMin(&flags[0], static_cast<unsigned long long>(ls[i])); u = v = 0; }      // an end without S line: the host words it
+    else if (seg_line_off[u] > ls[i] || seg_line_off[v] > ls[i]) *before = 1u;
+    fsrc[f] = u; fdst[f] = v; foff[f] = ls[i]; fidx[f] = f;
+    atomicAdd(&out_cnt[u], 1u);
+    atomicAdd(&in_cnt[v], 1u);
+  }
+}
+__global__ void __launch_bounds__(TPB) gfa_out_kernel(uint32_t A, const uint32_t* oidx, const uint32_t* fdst, const uint64_t* foff, uint32_t* col, uint64_t* slot_off,
+                                                      uint32_t* slot_of) {
+  const uint32_t q = blockIdx.x * TPB + threadIdx.x;
+  if (q >= A) return;
+  const uint32_t f = oidx[q];
+  col[q] = fdst[f];
+  slot_off[q] = foff[f];
+  slot_of[f] = q;
+}
+__global__ void __launch_bounds__(TPB) gfa_in_kernel(uint32_t A, const uint32_t* iidx, const uint32_t* fsrc, const uint32_t* slot_of, uint32_t* icol, uint32_t* islot) {
+  const uint32_t q = blockIdx.x * TPB + threadIdx.x;
+  if (q >= A) return;
+  const uint32_t f = iidx[q];
+  icol[q] = fsrc[f];
+  islot[q] = slot_of[f];
+}
+
+struct DevMem {                      // plain device allocations of one load (there is no DeviceGraph and no pool yet)
+  std::vector<void*> all;
+  ~DevMem() { for (void* p : all) (void)hipFree(p); }
+  template <class X> X* get(size_t n) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(X)));
+    all.push_back(p);
+    return static_cast<X*>(p);
+  }
+  void drop(void* p) {
+    for (size_t i = 0; i < all.size(); ++i) if (all[i] == p) { (void)hipFree(p); all.erase(all.begin() + long(i)); return; }
+  }
+};
+
+template <class X>
+void scan_u32(DevMem& m, const uint32_t* in, uint32_t* out, size_t n_plus_1, hipStream_t s, X& tmp, size_t& tmp_bytes) {
+  size_t need = 0;
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, int(n_plus_1), s));
+  if (need > tmp_bytes) { tmp = m.get<uint8_t>(need); tmp_bytes = need; }
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp, need, in, out, int(n_plus_1), s));
+}
+
+}  // namespace
+
+// nullptr: not a graph for the device form (or no device) -- the caller takes the host loader
+std::unique_ptr<Graph> load_graph_device(const char* path, int device) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= device) return nullptr;
+  PhaseTimer pt("load_graph_device");
+  auto g = std::make_unique<Graph>();
+  g->path = path;
+  g->text.open(path);
+  const char* data = g->text.data;
+  const size_t size = g->text.size;
+  if (size < (size_t(1) << 20) || size >= (size_t(1) << 44)) return nullptr;          // small graphs: the host is done before the copy is
+  HIP_OK(hipSetDevice(device));
+  hipStream_t s = take_stream(device);
+  DevMem m;
+  // ---- text
+  const size_t padded = text_padded_bytes(size);
+  uint8_t* d_text = m.get<uint8_t>(padded);
+  HIP_OK(hipMemsetAsync(d_text + size, 0, padded - size, s));
+  void* pinned[2] = {nullptr, nullptr};
+  hipEvent_t pinned_done[2] = {nullptr, nullptr};
+  size_t pinned_bytes = 0;
+  const bool lone_cr = upload_text(pinned, pinned_done, pinned_bytes, data, size, d_text, s);
+  for (int k = 0; k < 2; ++k) { if (pinned[k]) (void)hipHostFree(pinned[k]); if (pinned_done[k]) (void)hipEventDestroy(pinned_done[k]); }
+  if (lone_cr) return nullptr;                 // universal newlines: the host loader reads a copy with them applied
+  pt.lap("text -> HBM");
+  // ---- line index
+  const uint32_t tiles = uint32_t((size + TILE - 1) / TILE);
+  uint8_t* scan_tmp = nullptr;
+  size_t scan_tmp_bytes = 0;
+  uint32_t* tile_cnt = m.get<uint32_t>(size_t(tiles) + 1);
+  uint32_t* tile_off = m.get<uint32_t>(size_t(tiles) + 1);
+  HIP_OK(hipMemsetAsync(tile_cnt, 0, (size_t(tiles) + 1) * 4, s));
+  hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, reinterpret_cast<const uint4*>(d_text), tile_cnt);
+  HIP_OK(hipGetLastError());
+  scan_u32(m, tile_cnt, tile_off, size_t(tiles) + 1, s, scan_tmp, scan_tmp_bytes);
+  uint32_t newlines = 0;
+  HIP_OK(hipMemcpyAsync(&newlines, tile_off + tiles, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  const bool open_tail = data[size - 1] != '\n';
+  const uint64_t n_lines64 = uint64_t(newlines) + (open_tail ? 1 : 0);
+  if (n_lines64 >= 0x7FFFFFFFull) return nullptr;
+  const uint32_t n_lines = uint32_t(n_lines64);
+  uint64_t* ls = m.get<uint64_t>(size_t(n_lines) + 2);
+  HIP_OK(hipMemsetAsync(ls, 0, 8, s));
+  hipLaunchKernelGGL(line_starts_kernel, dim3(tiles), dim3(TPB), 0, s, reinterpret_cast<const uint4*>(d_text), tile_off, ls);
+  HIP_OK(hipGetLastError());
+  if (open_tail) {
+    const uint64_t end1 = uint64_t(size) + 1;
+    HIP_OK(hipMemcpyAsync(ls + n_lines, &end1, 8, hipMemcpyHostToDevice, s));
+    HIP_OK(hipStreamSynchronize(s));
+  }
+  pt.lap("line index");
+  // ---- every line: kind, numbers
+  uint8_t* kind = m.get<uint8_t>(size_t(n_lines) + 1);
+  GfaLine* rec = m.get<GfaLine>(n_lines);
+  unsigned long long* flags = m.get<unsigned long long>(8);      // [0] odd line, [1] first short L, [2] id min, [3] id max, [4].lo len max, [5].lo link before segment
+  HIP_OK(hipMemsetAsync(flags, 0xFF, 24, s));
+  HIP_OK(hipMemsetAsync(flags + 3, 0, 40, s));
+  uint32_t* too_long = reinterpret_cast<uint32_t*>(flags + 6);
+  const uint32_t stage_bytes = uint32_t(std::min<uint64_t>(48 * 1024, std::max<uint64_t>(4096, ((size / std::max<uint32_t>(n_lines, 1)) * 96 + 2047) / 1024 * 1024)));
+  {
+    int per_cu = 0, cus = 0;
+    uint32_t grid = 4096;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gfa_lines_kernel, int(LPB), stage_bytes) == hipSuccess && per_cu > 0 &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      grid = uint32_t(per_cu) * uint32_t(cus);
+    grid = std::min<uint32_t>(grid, (n_lines + LPB - 1) / LPB);
+    hipLaunchKernelGGL(gfa_lines_kernel, dim3(std::max(grid, 1u)), dim3(LPB), stage_bytes, s, d_text, ls, n_lines, stage_bytes, kind, rec, flags, too_long);
+    HIP_OK(hipGetLastError());
+  }
+  // S / L ordinals (file order) by scans of the kinds
+  uint32_t* s_ord = m.get<uint32_t>(size_t(n_lines) + 1);
+  uint32_t* l_ord = m.get<uint32_t>(size_t(n_lines) + 1);
+  {
+    // (two small transform kernels would do; hipcub's transform iterator keeps it in the scan)
+    auto to_flag = [=](uint8_t want) { return hipcub::TransformInputIterator<uint32_t, KindIs, const uint8_t*>(kind, KindIs{want}); };
+    size_t need = 0;
+    auto it_s = to_flag(GK_S);
+    auto it_l = to_flag(GK_L);
+    HIP_OK(hipMemsetAsync(kind + n_lines, 0, 1, s));
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, it_s, s_ord, int(n_lines) + 1, s));
+    if (need > scan_tmp_bytes) { scan_tmp = m.get<uint8_t>(need); scan_tmp_bytes = need; }
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, need, it_s, s_ord, int(n_lines) + 1, s));
+    HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, need, it_l, l_ord, int(n_lines) + 1, s));
+  }
+  // the P lines' places
+  constexpr uint32_t P_CAP = 1u << 16;
+  uint64_t* d_plist = m.get<uint64_t>(size_t(2) * P_CAP);
+  uint32_t* d_pn = m.get<uint32_t>(1);
+  HIP_OK(hipMemsetAsync(d_pn, 0, 4, s));
+  hipLaunchKernelGGL(gfa_plines_kernel, dim3(uint32_t(std::min<uint64_t>((uint64_t(n_lines) + TPB - 1) / TPB, 1u << 16))), dim3(TPB), 0, s, n_lines, kind, ls, P_CAP, d_plist, d_pn);
+  HIP_OK(hipGetLastError());
+  uint32_t n_p = 0;
+  HIP_OK(hipMemcpyAsync(&n_p, d_pn, 4, hipMemcpyDeviceToHost, s));
+  uint32_t counts[2] = {0, 0};
+  unsigned long long hflags[8];
+  HIP_OK(hipMemcpyAsync(&counts[0], s_ord + n_lines, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(&counts[1], l_ord + n_lines, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(hflags, flags, 64, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  pt.lap("lines classified");
+  if (hflags[0] != ~0ull) return nullptr;        // an odd line (among them: an S / L line longer than the staging buffer)
+  const uint32_t V = counts[0], A = counts[1];
+  if (V == 0 || V >= NONE32 - 1 || A >= NONE32 - 1) return nullptr;
+  if (n_p > P_CAP) return nullptr;                // (a graph of more than 65 536 paths: the host loader)
+  std::vector<uint64_t> plist(size_t(2) * n_p);
+  if (n_p) HIP_OK(hipMemcpy(plist.data(), d_plist, size_t(16) * n_p, hipMemcpyDeviceToHost));
+  // ---- nodes
+  uint32_t* seg_len = m.get<uint32_t>(V);
+  uint64_t* seg_line_off = m.get<uint64_t>(V);
+  uint64_t* seg_name_off = m.get<uint64_t>(V);
+  uint16_t* seg_name_len = m.get<uint16_t>(V);
+  const uint32_t lgrid = uint32_t(std::min<uint64_t>((uint64_t(n_lines) + TPB - 1) / TPB, 1u << 16));
+  hipLaunchKernelGGL(gfa_nodes_kernel, dim3(lgrid), dim3(TPB), 0, s, n_lines, kind, rec, ls, s_ord, seg_len, seg_line_off, seg_name_off, seg_name_len, flags + 2, flags + 3,
+                     reinterpret_cast<uint32_t*>(flags + 4));
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(hflags, flags, 64, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  const uint64_t lo = hflags[2], hi = hflags[3];
+  if (hi - lo >= std::max<uint64_t>(uint64_t(V) * 16, 1u << 20)) return nullptr;      // (the host keeps such names in a hash map)
+  const uint64_t tsize = hi - lo + 1;
+  uint32_t* table = m.get<uint32_t>(tsize);
+  HIP_OK(hipMemsetAsync(table, 0xFF, tsize * 4, s));
+  hipLaunchKernelGGL(gfa_table_kernel, dim3(lgrid), dim3(TPB), 0, s, n_lines, kind, rec, s_ord, lo, table, flags, ls);
+  HIP_OK(hipGetLastError());
+  // ---- links
+  uint32_t* fsrc = m.get<uint32_t>(A);
+  uint32_t* fdst = m.get<uint32_t>(A);
+  uint64_t* foff = m.get<uint64_t>(A);
+  uint32_t* fidx = m.get<uint32_t>(A);
+  uint32_t* out_cnt = m.get<uint32_t>(size_t(V) + 1);
+  uint32_t* in_cnt = m.get<uint32_t>(size_t(V) + 1);
+  uint32_t* row_ptr = m.get<uint32_t>(size_t(V) + 1);
+  uint32_t* irow_ptr = m.get<uint32_t>(size_t(V) + 1);
+  HIP_OK(hipMemsetAsync(out_cnt, 0, (size_t(V) + 1) * 4, s));
+  HIP_OK(hipMemsetAsync(in_cnt, 0, (size_t(V) + 1) * 4, s));
+  hipLaunchKernelGGL(gfa_links_kernel, dim3(lgrid), dim3(TPB), 0, s, n_lines, kind, rec, ls, l_ord, lo, tsize, table, seg_line_off, fsrc, fdst, foff, fidx, out_cnt, in_cnt,
+                     flags, reinterpret_cast<uint32_t*>(flags + 5));
+  HIP_OK(hipGetLastError());
+  scan_u32(m, out_cnt, row_ptr, size_t(V) + 1, s, scan_tmp, scan_tmp_bytes);
+  scan_u32(m, in_cnt, irow_ptr, size_t(V) + 1, s, scan_tmp, scan_tmp_bytes);
+  HIP_OK(hipMemcpyAsync(hflags, flags, 64, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipStreamSynchronize(s));
+  if (hflags[0] != ~0ull) return nullptr;             // a second S line of a name, a link end without S line
+  m.drop(kind); m.drop(rec); m.drop(s_ord); m.drop(l_ord); m.drop(d_text); m.drop(ls);
+  pt.lap("nodes, name table, link ends");
+  int bits = 1;
+  while (bits < 32 && (uint64_t(1) << bits) < uint64_t(V)) ++bits;
+  uint32_t* col = m.get<uint32_t>(A);
+  uint64_t* slot_off = m.get<uint64_t>(A);
+  uint32_t* icol = m.get<uint32_t>(A);
+  uint32_t* islot = m.get<uint32_t>(A);
+  if (A) {
+    uint32_t* key2 = m.get<uint32_t>(A);
+    uint32_t* oidx = m.get<uint32_t>(A);
+    uint32_t* iidx = m.get<uint32_t>(A);
+    uint32_t* slot_of = m.get<uint32_t>(A);
+    size_t need = 0;
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, fsrc, key2, fidx, oidx, int(A), 0, bits, s));
+    uint8_t* sort_tmp = m.get<uint8_t>(need);
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, need, fsrc, key2, fidx, oidx, int(A), 0, bits, s));          // rows: the links of a source in file order
+    HIP_OK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, need, fdst, key2, fidx, iidx, int(A), 0, bits, s));          // in-lists: file order too (call.py:175)
+    hipLaunchKernelGGL(gfa_out_kernel, dim3(blocks_for(A)), dim3(TPB), 0, s, A, oidx, fdst, foff, col, slot_off, slot_of);
+    hipLaunchKernelGGL(gfa_in_kernel, dim3(blocks_for(A)), dim3(TPB), 0, s, A, iidx, fsrc, slot_of, icol, islot);
+    HIP_OK(hipGetLastError());
+  }
+  HIP_OK(hipStreamSynchronize(s));
+  pt.lap("CSR (two stable sorts)");
+  // ---- to the host
+  g->V = V;
+  g->A = A;
+  g->n_lines = n_lines;
+  g->n_s_lines = V;
+  g->n_l_lines = A;
+  g->names.dense = true;
+  g->names.base = lo;
+  g->max_seg_len = uint32_t(hflags[4]);
+  g->link_before_segment = uint32_t(hflags[5]) != 0;
+  g->first_short_l_off = hflags[1] == ~0ull ? UINT64_MAX : hflags[1];
+  auto down = [&](auto& vec, const void* src, size_t n) {
+    vec.resize(n);
+    if (n) d2h_staged(vec.data(), src, n * sizeof(vec[0]), s);
+  };
+  down(g->names.table, table, tsize);
+  down(g->seg_len, seg_len, V);
+  down(g->seg_line_off, seg_line_off, V);
+  down(g->seg_name_off, seg_name_off, V);
+  down(g->seg_name_len, seg_name_len, V);
+  down(g->row_ptr, row_ptr, size_t(V) + 1);
+  down(g->col, col, A);
+  down(g->slot_off, slot_off, A);
+  down(g->irow_ptr, irow_ptr, size_t(V) + 1);
+  down(g->icol, icol, A);
+  down(g->islot, islot, A);
+  HIP_OK(hipStreamSynchronize(s));
+  pt.lap("arrays -> host");
+  // ---- the P lines (a handful, each as long as a chromosome): exactly four tokens, or call.py:156 raises
+  {
+    g->n_p_lines = n_p;
+    std::vector<uint64_t> bad(n_p, UINT64_MAX);
+    parallel_chunks(n_p, unsigned(std::max<size_t>(1, std::min<size_t>(n_p, hw_threads()))), [&](unsigned, size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i) {
+        Tokens tk(strip(Span{data + plist[2 * i], data + std::min<uint64_t>(plist[2 * i + 1], size)}));
+        Span t;
+        int n = 0;
+        while (n < 5 && tk.next(t)) ++n;
+        if (n != 4) bad[i] = plist[2 * i];
+      }
+    });
+    uint64_t first = UINT64_MAX;
+    for (uint64_t b : bad) first = std::min(first, b);
+    g->first_bad_p_off = first;
+  }
+  pt.lap("P lines (host)");
+  return g;
 }
 
 // loads this file's code object ahead of its first real kernel (warm_up_device, on a thread beside the graph parse)
