@@ -482,7 +482,7 @@ def main():
             dom_name, dom_ms, dom_bytes, dom_recs = "augment main kernels of all resident batches", avg_main, alg_bytes, records
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
-        for tf in ("r2_traffic.json", "r1_traffic.json"):
+        for tf in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if scale in tj and not args.lines and not args.del_hot:
