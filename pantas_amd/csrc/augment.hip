@@ -54,6 +54,7 @@ struct GraphView {
   uint2* info;                // [V] {word, target of the node's first out-slot or NONE32}: all the short walk needs to know about a
                               // node in ONE 8-byte gather (instead of word, two row bounds and the dependent col[] load from three
                               // arrays); the flag bits of .x mirror word[]
+  uint4* info3;               // [V] {word, targets of the node's first THREE out-slots, NONE32 beyond its degree} (walk.h NodeInfo3, round 3)
   const uint32_t* row_ptr;    // [V+1]
   const uint32_t* col;        // [A]
   uint32_t* cnt4;             // [4 V] per node {NC, IL[0], OL[len], RC of the node's first out-slot}: the counters one kept node
@@ -93,6 +94,7 @@ __device__ __forceinline__ void add_node4(const GraphView& g, uint32_t n, uint32
 struct DevInfo {
   const GraphView& g;
   __device__ __forceinline__ NodeInfo info(uint32_t n) const { return reinterpret_cast<const NodeInfo*>(g.info)[n]; }
+  __device__ __forceinline__ NodeInfo3 info3(uint32_t n) const { return reinterpret_cast<const NodeInfo3*>(g.info3)[n]; }
 };
 
 __device__ __forceinline__ uint32_t mix64(uint64_t k) {
@@ -170,6 +172,7 @@ struct RareSink {
     if (!(__builtin_nontemporal_load(&g.word[n]) & flag)) {
       atomicOr(&g.word[n], flag);
       atomicOr(&g.info[n].x, flag);
+      atomicOr(&g.info3[n].x, flag);
     }
   }
   __device__ void edge(uint32_t, uint32_t, uint64_t) const {}
@@ -258,6 +261,7 @@ struct RareAggSink {
     if (!(__builtin_nontemporal_load(&g.word[n]) & flag)) {
       atomicOr(&g.word[n], flag);
       atomicOr(&g.info[n].x, flag);
+      atomicOr(&g.info3[n].x, flag);
     }
   }
 };
@@ -332,6 +336,12 @@ struct AggSink {
   uint4* nvq = nullptr;       // NVQ kernels: links absent from the graph met by the short walk, queued for the end of the chunk
   uint32_t* nvq_n = nullptr;
   static constexpr uint32_t NVQ_CAP = 192;
+  // the kernel over 16-byte node records (walk_short_w): hits on a node's second / third out-slot by node-table slot (low / high half),
+  // and the workgroup's queue of links whose slot the walk could not tell (absent from the graph, a fourth or later slot)
+  uint32_t* ncnt2 = nullptr;
+  uint4* lq = nullptr;
+  uint32_t* lq_n = nullptr;
+  static constexpr uint32_t LQ_CAP = 512;
 
   // link (a, b) that is not in the graph: aggregate in LDS, else straight to the global table
   __device__ __forceinline__ void novel(uint32_t a, uint32_t b, uint64_t order) const {
@@ -492,6 +502,46 @@ struct AggSink {
       if (order < __atomic_load_n(&fmin[h], __ATOMIC_RELAXED)) atomicMin(&fmin[h], static_cast<unsigned long long>(order));
     } else {
       table_update(g.slow->hist, hist_key(n, side, COMMON_POS), 0u, order);
+    }
+  }
+  // ---- walk_short_w ----
+  // link (a -> b), slot unknown: the first slot of a's row that holds b, else a link the graph does not have.  Through the small slot
+  // table: the reads of an expressed gene take the same fourth exit hundreds of times per chunk, and single global atomics on one
+  // address serialise (measured: 6.6 ms instead of 2.0 with them going straight to memory)
+  __device__ __forceinline__ void link_direct(uint32_t a, uint32_t b, uint64_t order) const {
+    const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
+    for (uint32_t s = lo; s < hi; ++s) {
+      if (g.col[s] == b) { bump_slot(s); return; }
+    }
+    novel(a, b, order);
+  }
+  __device__ __forceinline__ void link_later(uint32_t a, uint32_t b, uint64_t order) const {
+    const uint32_t i = __hip_atomic_fetch_add(lq_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (i < LQ_CAP) lq[i] = make_uint4(a, b, uint32_t(order), uint32_t(order >> 32));
+    else link_direct(a, b, order);
+  }
+  // one kept node: NC + 1, IL[0] / OL[len] + steps, one hit on out-slot code - 1 (code 1 .. 3), first-seen order of a flagged side
+  __device__ __forceinline__ void bump_w(uint32_t n, uint32_t flags, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
+    const bool f_il = a_il && (flags & FLAG_IL), f_ol = a_ol && (flags & FLAG_OL);
+    const uint32_t h = probe<LOG_N>(nkey, n);
+    if (h != LDS_EMPTY) {
+      const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) | (static_cast<unsigned long long>(a_ol) << 32) |
+                                     (static_cast<unsigned long long>(code == 1u ? 1u : 0u) << 48);
+      atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
+      if (code >= 2u) __hip_atomic_fetch_add(&ncnt2[h], code == 2u ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (exact_order == 0 && (f_il | f_ol)) {
+        const unsigned long long cur = __atomic_load_n(reinterpret_cast<const unsigned long long*>(omin + 2u * h), __ATOMIC_RELAXED);
+        if (f_il && line_id < uint32_t(cur)) atomicMin(&omin[2u * h], line_id);
+        if (f_ol && line_id < uint32_t(cur >> 32)) atomicMin(&omin[2u * h + 1u], line_id);
+      }
+    } else {
+      add_node4(g, n, 1u, a_il, a_ol, code == 1u ? 1u : 0u);
+      if (code >= 2u) __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)g.rc + (g.row_ptr[n] + code - 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (exact_order != 0 || h == LDS_EMPTY) {
+      const uint64_t ord = exact_order != 0 ? exact_order : event_order(line_id, 0, 1);
+      if (f_il) order_min(n, SIDE_IL, ord);
+      if (f_ol) order_min(n, SIDE_OL, ord);
     }
   }
   // link (a -> b) given a's CSR row bounds
@@ -678,14 +728,123 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
   }
 }
 
-__global__ void clear_flags_kernel(uint32_t* word, uint2* info, uint32_t n) {
-  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { word[i] &= LEN_MASK; info[i].x &= LEN_MASK; }
+// ---- the short-walk class over 16-byte node records (round 3; walk.h walk_short_w) --------------------------------------
+// Same chunking, tables and flush as augment_main_agg_kernel<..., short-walk class>; what differs is what a node visit does
+// about its link: matched against the three targets that came with the node's record, a hit is one more field of the
+// node's own increments -- no per-line list of deferred links, no lookup loop behind the node loop, no slot table.
+template <class Agg>
+struct ShortSinkW {
+  const Agg& s;
+  uint32_t line_id;
+  __device__ __forceinline__ void kept(uint32_t node, uint32_t flags, uint32_t line_id_, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
+    s.bump_w(node, flags, line_id_, a_il, a_ol, code, exact_order);
+  }
+  // a link whose slot the walk could not tell (one link in fifty, one line in nine): into the workgroup's queue, looked up at the end
+  // of the chunk.  Measured against this (S4, 2.07 ms): entries of path indices in four LDS slots of the thread's own, compacted at
+  // the end of the chunk (no atomic inside the node loop, but two more dependent loads per lookup there: 2.15); the thread's first
+  // in a slot of its own and only further ones through the counter (2.10); three per line in a register, queued behind the loop (2.56)
+  __device__ __forceinline__ void later(uint32_t a, uint32_t b, uint32_t idx) const { s.link_later(a, b, event_order(line_id, idx, 0)); }
+};
+
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint32_t MINW, int PF>
+__global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
+  GraphView g = g_in;
+  g.ablate = 0u;
+  constexpr uint32_t LOG_S = 8;       // slot table of the queued links only
+  using Sink = AggSink<LOG_N, LOG_S, LOG_F, true>;
+  constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS;
+  __shared__ uint32_t skey[CS];
+  __shared__ uint32_t scnt[CS];
+  static_assert(CHUNK * PACKED_MAX_PATH < 65536u && CHUNK * (SHORT_MAX_PATH_INDEL + 2u) < 65536u, "a 16-bit field could overflow");
+  static_assert(PF <= 4, "rec holds the ids of the first five path nodes");
+  __shared__ unsigned long long fmin[CF];
+  __shared__ unsigned long long vkey[CF];
+  __shared__ unsigned long long vmin[CF];
+  __shared__ uint32_t vcnt[CF];
+  __shared__ uint32_t fkey[CF];
+  __shared__ uint32_t nkey[CN];
+  __shared__ __attribute__((aligned(8))) uint32_t ncnt[2 * CN];
+  __shared__ uint32_t ncnt2[CN];
+  __shared__ __attribute__((aligned(8))) uint32_t omin[2 * CN];
+  __shared__ uint4 lq[Sink::LQ_CAP];
+  __shared__ uint32_t lq_n;
+  const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
+  const uint32_t per_xcd = (n_chunks + 7u) / 8u;       // workgroup w takes chunk (w % 8) * n/8 + w / 8: an XCD walks one contiguous eighth
+  for (uint32_t c0 = blockIdx.x; c0 < 8u * per_xcd; c0 += gridDim.x) {
+    const uint32_t c = (c0 & 7u) * per_xcd + (c0 >> 3);
+    if (c >= n_chunks) continue;
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
+      omin[i] = ~0u; omin[CN + i] = ~0u;
+      nkey[i] = LDS_EMPTY;
+      ncnt[i] = 0u; ncnt[CN + i] = 0u; ncnt2[i] = 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < CF; i += THREADS) { fkey[i] = LDS_EMPTY; fmin[i] = ~0ull; vkey[i] = EMPTY_KEY; vmin[i] = ~0ull; vcnt[i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) { skey[i] = LDS_EMPTY; scnt[i] = 0u; }
+    if (threadIdx.x == 0) lq_n = 0u;
+    __syncthreads();
+    Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin, nullptr, nullptr};
+    sink.ncnt2 = ncnt2; sink.lq = lq; sink.lq_n = &lq_n;
+    const DevInfo ga{g};
+    const uint32_t lo = begin + c * CHUNK;
+    const uint32_t hi = min(end, lo + CHUNK);
+    for (uint32_t r0 = lo, round = 0; r0 < hi; r0 += THREADS, ++round) {
+      const uint32_t i = r0 + ((round & 1u) ? THREADS - 1u - threadIdx.x : threadIdx.x);     // odd rounds the other way round (see above)
+      if (i >= hi) continue;
+      const LineHdr h = b.hdr[i];
+      const uint4 r = b.rec[REC_QUADS * size_t(i)], r2 = b.rec[REC_QUADS * size_t(i) + 1], r3 = b.rec[REC_QUADS * size_t(i) + 2];
+      const uint32_t first_ids[5] = {r.w, r2.x, r2.y, r2.z, r2.w};
+      ShortOps so;
+      so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
+      const ShortSinkW<Sink> ss{sink, h.line_id};
+      const int st = walk_short_w<PF>(ga, h, b.nodes + r.x, r.z & 0xFFu, ss, first_ids, so);
+      if (st != WALK_OK) report_status(g, h.line_id, st);
+    }
+    __syncthreads();
+    {
+      const uint32_t m = min(lq_n, Sink::LQ_CAP);
+      for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
+        const uint4 e = lq[i];
+        sink.link_direct(e.x, e.y, (static_cast<uint64_t>(e.w) << 32) | e.z);
+      }
+      __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
+      const uint32_t n = nkey[i];
+      if (n == LDS_EMPTY) continue;
+      const unsigned long long v = reinterpret_cast<const unsigned long long*>(ncnt)[i];
+      add_node4(g, n, uint32_t(v) & 0xFFFFu, uint32_t(v >> 16) & 0xFFFFu, uint32_t(v >> 32) & 0xFFFFu, uint32_t(v >> 48));
+      const uint32_t v2 = ncnt2[i];
+      if (v2) {
+        const uint32_t row = g.row_ptr[n];
+        if (v2 & 0xFFFFu) atomicAdd(&g.rc[row + 1u], v2 & 0xFFFFu);
+        if (v2 >> 16) atomicAdd(&g.rc[row + 2u], v2 >> 16);
+      }
+      if (omin[2 * i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(omin[2 * i], 0, 1));
+      if (omin[2 * i + 1] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(omin[2 * i + 1], 0, 1));
+    }
+    for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
+      const uint32_t sl = skey[i];
+      if (sl != LDS_EMPTY && scnt[i]) atomicAdd(&g.rc[sl], scnt[i]);
+    }
+    for (uint32_t i = threadIdx.x; i < CF; i += THREADS) {
+      const uint32_t k = fkey[i];
+      if (k != LDS_EMPTY && fmin[i] != ~0ull) table_update(g.slow->hist, hist_key(k >> 1, k & 1u, COMMON_POS), 0u, fmin[i]);
+      if (vkey[i] != EMPTY_KEY) table_update(g.slow->novel, vkey[i], vcnt[i], vmin[i]);
+    }
+    __syncthreads();
+  }
 }
 
-__global__ void build_info_kernel(const uint32_t* word, const uint32_t* row_ptr, const uint32_t* col, uint2* info, uint32_t n) {
+__global__ void clear_flags_kernel(uint32_t* word, uint2* info, uint4* info3, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { word[i] &= LEN_MASK; info[i].x &= LEN_MASK; info3[i].x &= LEN_MASK; }
+}
+
+__global__ void build_info_kernel(const uint32_t* word, const uint32_t* row_ptr, const uint32_t* col, uint2* info, uint4* info3, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t lo = row_ptr[i], hi = row_ptr[i + 1];
-    info[i] = make_uint2(word[i], lo < hi ? col[lo] : 0xFFFFFFFFu);
+    const uint32_t t0 = lo < hi ? col[lo] : NO_TARGET;
+    info[i] = make_uint2(word[i], t0);
+    info3[i] = make_uint4(word[i], t0, lo + 1u < hi ? col[lo + 1u] : NO_TARGET, lo + 2u < hi ? col[lo + 2u] : NO_TARGET);
   }
 }
 
@@ -726,6 +885,7 @@ struct DeviceGraph {
   uint64_t A = 0;
   uint32_t* word = nullptr;
   uint2* info = nullptr;          // {word, first out-target} per node (GraphView::info)
+  uint4* info3 = nullptr;         // {word, first three out-targets} per node (GraphView::info3)
   uint32_t* row_ptr = nullptr;
   uint32_t* col = nullptr;
   uint32_t* counters = nullptr;   // [{NC, IL0, OLL, RC first slot} x V | RC A]  (GraphView::cnt4, ::rc)
@@ -759,7 +919,7 @@ struct DeviceGraph {
   }
   GraphView view() const {
     GraphView g{};
-    g.word = word; g.info = info; g.row_ptr = row_ptr; g.col = col;
+    g.word = word; g.info = info; g.info3 = info3; g.row_ptr = row_ptr; g.col = col;
     g.cnt4 = counters; g.rc = counters + 4 * size_t(V);
     g.slow = slow_dev;
     g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;
@@ -804,7 +964,7 @@ uint32_t* device_name_blocks(DeviceGraph& dg) { return dg.name_blocks; }
 void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
-  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->name_blocks, (void*)d->slow_dev, (void*)d->tilde_dev})
+  for (void* p : {(void*)d->word, (void*)d->info, (void*)d->info3, (void*)d->row_ptr, (void*)d->col, (void*)d->counters, (void*)d->small, (void*)d->name_table, (void*)d->name_blocks, (void*)d->slow_dev, (void*)d->tilde_dev})
     if (p) (void)hipFree(p);
   d->scratch.reset();
   d->hist.free_all();
@@ -1025,9 +1185,10 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   h2d_staged(d->col, g.col.data(), size_t(g.A) * 4, d->stream);
   pt.lap("CSR to HBM");
   HIP_OK(hipMalloc(&d->info, std::max<size_t>(1, g.V) * 8));
+  HIP_OK(hipMalloc(&d->info3, std::max<size_t>(1, g.V) * 16));
   if (g.V) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(g.V) + 255) / 256, 1u << 16));
-    hipLaunchKernelGGL(build_info_kernel, dim3(blocks), dim3(256), 0, d->stream, d->word, d->row_ptr, d->col, d->info, g.V);
+    hipLaunchKernelGGL(build_info_kernel, dim3(blocks), dim3(256), 0, d->stream, d->word, d->row_ptr, d->col, d->info, d->info3, g.V);
     HIP_OK(hipGetLastError());
   }
   table_alloc(d->hist, 1024, d->small + 2, d->small + 3);
@@ -1060,7 +1221,7 @@ void reset_counters(DeviceGraph& d) {
   table_clear(d.novel, d.stream);
   if (d.V) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(d.V) + 255) / 256, 4096));
-    hipLaunchKernelGGL(clear_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, d.V);
+    hipLaunchKernelGGL(clear_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, d.info3, d.V);
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
@@ -1305,9 +1466,9 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   if (b.n) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
     // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
-    // the rest with the general aggregating kernel beside it on a second stream: 73 = the round-1 short walk (gathers two
-    // nodes ahead), 80 / 85 / 97 / 100 / 101 = this round's (see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 101;   // read per launch: tools/ab_variants.py switches it
+    // the rest with the general aggregating kernel beside it on a second stream: 101 = round 2's short walk, 110 = round 3's (default;
+    // see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
+    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 110;   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1339,41 +1500,29 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         split = true;
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
       } else switch (variant) {
-        // measured and dropped this round (profiles/r2_ab_s4_defer_lean_occupancy.txt): 7 or 6 waves per SIMD to give the
-        // variants registers (2.80 - 3.43 ms against 2.58: occupancy is worth more than anything it buys), a second, lean
-        // instance of the walk for waves without indel lines inside the same kernel (2.59: its registers add up)
-        PANTAS_SPLIT(73, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // round 1
-        PANTAS_SPLIT(80, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // mid round 2: deferred lookups of links off the first out-slot
-        PANTAS_SPLIT(85, (d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true), (d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2))   // 80 + links absent from the graph queued per workgroup and inserted at the end of the chunk
-        case 97:   // 85 with the chunks dealt to the XCDs in contiguous eighths of the locus order
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
-          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
-          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
-          if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1>),
-                                            dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
-          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
-          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
-          break;
-        case 100:   // 97 with the line's ShortOps read from the record instead of scanned from ops[]
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
-          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
-          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
-          if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true>),
-                                            dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
-          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
-          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
-          break;
-        default:
-          // 101: workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own: workgroup b takes chunk (b % 8) * n/8 + b/8,
-          // so that neighbouring chunks, which share the nodes of an expressed gene, meet in ONE L2 (97; runs of 16 or 64 chunks per XCD
-          // instead of eighths measured in between, profiles/r2_ab_s4_xcd.txt); the line's ShortOps comes with the record (third 16-byte
-          // word, made when the batch comes to be) instead of being scanned from ops[] by every launch (100); odd rounds of a chunk run
-          // the other way round, so that no wave gets the dearest lines of every round (101).
+        // (variants 73 / 80 / 85 / 97 / 100 -- round 1's short walk and round 2's steps towards 101 -- were retired in round 3; their
+        // measurements are in DESIGN.md section 3 and profiles/r2_ab_s4_*.txt)
+        case 101:
+          // round 2's short walk over 8-byte node records {length, first out-target}: links off the first out-slot deferred per line and
+          // looked up behind the node loop, links absent from the graph queued per workgroup; chunks dealt to the XCDs in eighths; the
+          // line's ShortOps with the record; odd rounds of a chunk the other way round.  The A/B partner of the default.
           HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.ev[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true, true>),
                                             dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
+          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          break;
+        default:
+          // 110 (round 3): the short-walk class over 16-byte node records (walk.h walk_short_w, augment_short_w_kernel): a link is matched
+          // against its node's first three out-targets where the node is visited and counted in the node's own table entry; same chunk
+          // order, record layout and round order as 101.  S4: 2.07 against 2.17 ms (profiles/r3_ab_s4_wide.txt); two nodes ahead instead
+          // of one measured the same (2.11).
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
+          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          if (b.n_short) hipLaunchKernelGGL((augment_short_w_kernel<512, 2048, 10, 7, 8, 1>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
@@ -1433,12 +1582,13 @@ __global__ void collect_flags_kernel(const uint32_t* word, uint32_t n, uint32_t*
   }
 }
 
-__global__ void apply_flags_kernel(uint32_t* word, uint2* info, const uint32_t* codes, uint32_t n, uint32_t V) {
+__global__ void apply_flags_kernel(uint32_t* word, uint2* info, uint4* info3, const uint32_t* codes, uint32_t n, uint32_t V) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t c = codes[i];
     if ((c >> 1) < V) {
       atomicOr(&word[c >> 1], (c & 1u) ? FLAG_OL : FLAG_IL);
       atomicOr(&info[c >> 1].x, (c & 1u) ? FLAG_OL : FLAG_IL);
+      atomicOr(&info3[c >> 1].x, (c & 1u) ? FLAG_OL : FLAG_IL);
     }
   }
 }
@@ -1471,7 +1621,7 @@ void import_flags(DeviceGraph& d, const uint32_t* codes, size_t n) {
   uint32_t* in = static_cast<uint32_t*>(scratch_pool(d).take(n * 4));
   HIP_OK(hipMemcpyAsync(in, codes, n * 4, hipMemcpyHostToDevice, d.stream));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((n + 255) / 256, 4096));
-  hipLaunchKernelGGL(apply_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, in, uint32_t(n), d.V);
+  hipLaunchKernelGGL(apply_flags_kernel, dim3(blocks), dim3(256), 0, d.stream, d.word, d.info, d.info3, in, uint32_t(n), d.V);
   HIP_OK(hipStreamSynchronize(d.stream));
   scratch_pool(d).give(in);
   d.imported_flags += n;

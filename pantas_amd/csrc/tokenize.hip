@@ -331,7 +331,7 @@ struct ProvOut {
 __global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))) parse_once_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                          DenseNames names, uint32_t first_line, uint32_t bits, uint32_t* prov, uint64_t prov_words,
                                                          uint32_t* arena_next, uint32_t arena_words, uint32_t* key, unsigned long long* val, uint32_t* partial,
-                                                         unsigned long long* err, uint32_t* fallback, uint32_t stop) {
+                                                         unsigned long long* err, uint32_t* fallback, uint32_t stop, uint32_t align_min) {
   uint32_t t[N_TOTALS];
 #pragma unroll
   for (uint32_t j = 0; j < N_TOTALS; ++j) t[j] = 0;
@@ -345,8 +345,16 @@ __global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (stop == 9u) { key[i] = words[b >> 2]; return; }        // (ablation: staging only)
     // ONE call site of the parser (it is thousands of instructions long): a line whose record does not fit its own text is parsed
     // a second time by the same code, into room taken from the arena
-    uint64_t at = slot;
-    uint32_t cap = room > PROV_HDR ? room - PROV_HDR : 0u;
+    // The record starts at the next 64-byte boundary inside the line's own words when that leaves it align_min words: the gather
+    // that builds the batch reads the records in locus order, i.e. at random, and a 14-word record that starts anywhere straddles
+    // two 64-byte sectors more often than not (11 GB fetched for 7 GB of records at S4).  A record that does not fit there is parsed
+    // again into the whole of the line's words, one that does not fit those into the arena.
+    const uint64_t slot_al = (slot + 15u) & ~uint64_t(15);
+    const uint32_t room_al = slot_end > slot_al ? uint32_t(slot_end - slot_al) : 0u;
+    const bool aligned = room_al >= align_min;
+    uint64_t at = aligned ? slot_al : slot;
+    uint32_t cur = aligned ? room_al : room;
+    uint32_t cap = cur > PROV_HDR ? cur - PROV_HDR : 0u;
     LineSummary r;
     uint32_t first_node = 0, last_node = 0;
     bool ok = true;
@@ -356,11 +364,13 @@ __global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))
       TextWords T(words);
       parse_gaf_line_words(T, b, e, thr, names, po, r, check_cr != 0u && pass == 0u, stop);
       first_node = po.first; last_node = po.last;
-      if (pass == 1u || r.status != TOK_KEEP || !(po.ovf || room < PROV_HDR)) break;
+      if (pass == 1u || r.status != TOK_KEEP || !(po.ovf || cur < PROV_HDR)) break;
       const uint32_t need = PROV_HDR + r.n_ops + r.n_nodes;
+      if (need <= room) { at = slot; cur = room; cap = room - PROV_HDR; continue; }      // (only an aligned first try gets here)
       const uint32_t pos = atomicAdd(arena_next, need);
       if (need > arena_words || pos > arena_words - need) { atomicOr(fallback, 1u); ok = false; break; }
       at = prov_words + pos;
+      cur = need;
       cap = need - PROV_HDR;
     }
     if (stop) { key[i] = uint32_t(r.start) + r.status; return; }
@@ -793,9 +803,13 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   HIP_OK(hipMemsetAsync(small.p, 0xFF, 8, s));
   HIP_OK(hipMemsetAsync(small.as<unsigned long long>() + 1 + N_TOTALS, 0xFF, 8, s));
   uint32_t* d_arena_next = reinterpret_cast<uint32_t*>(small.as<unsigned long long>() + N_TOTALS + 2);
+  // words a 64-byte-aligned start has to leave a line's record for the record to start there (PANTAS_TOK_ALIGN_MIN; 0 = never aligned)
+  uint32_t align_min = 24;
+  if (const char* a = getenv("PANTAS_TOK_ALIGN_MIN")) align_min = uint32_t(atoi(a));
+  if (align_min == 0) align_min = 0xFFFFFFFFu;
   hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
                      uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), key.as<uint32_t>(), val.as<unsigned long long>(),
-                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1, 0u);
+                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1, 0u, align_min);
   HIP_OK(hipGetLastError());
   if (const char* ab = getenv("PANTAS_TOK_STOP")) {
     // timing-only ablation of the parse (tools/tok_ablate.py): the kernel again, leaving every line after the named stage;
@@ -809,7 +823,7 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
       HIP_OK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
                          uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), junk.as<uint32_t>(), val.as<unsigned long long>(),
-                         partial.as<uint32_t>(), small.as<unsigned long long>() + N_TOTALS + 2 /* (never written in this mode) */, d_arena_next + 1, uint32_t(*p - '0'));
+                         partial.as<uint32_t>(), small.as<unsigned long long>() + N_TOTALS + 2 /* (never written in this mode) */, d_arena_next + 1, uint32_t(*p - '0'), align_min);
       HIP_OK(hipEventRecord(e1, s));
       HIP_OK(hipEventSynchronize(e1));
       float ms = 0;

@@ -455,6 +455,105 @@ PANTAS_UNROLL
   return WALK_OK;
 }
 
+// ---- the short walk over 16-byte node records (round 3) ----------------------------------------------------------------
+// One link in five of a spliced read is NOT its node's first out-slot (a bubble's second allele, a junction's second
+// exit), so three lines in four have one: with the 8-byte record every such link is a lookup of its own (row bounds, a scan
+// of col[], a probe of the slot table) that a whole wave pays for.  Here a node's record holds the targets of its first
+// THREE out-slots (NONE beyond the degree), and the link to the neighbour kept node is matched against them where the node
+// is visited: a hit on slot 0 / 1 / 2 goes into the node's own table entry with its other increments (slot_code 1 / 2 / 3).
+// What is left -- links absent from the graph, later slots of a node with more than three -- is handed to the sink
+// (link_later: the kernel queues it per workgroup and looks it up at the end of the chunk).
+//   forward lines: the link leaves THIS node for the NEXT kept node, which is nearly always the next path node: matched
+//     against that id now (it is in the pipeline registers), taken when the next kept node turns out to be that one;
+//   reverse lines: the link leaves this node for the PREVIOUS kept node (pending): matched exactly.
+// No state but the pending node's id and one meta word crosses a pass of the loop.
+//   GraphAcc:  NodeInfo3 info3(node)
+//   Sink:      void kept(node, flags, line_id, il_steps, ol_steps, slot_code, exact_order)   slot_code: 0 none, 1 .. 3 = out-slot 0 .. 2 hit once
+//              void later(a, b, idx)             the link a -> b, slot unknown (any slot, or absent from the graph); idx = path index of
+//                                                the pending node: the link's first-seen order is event_order(line_id, idx, 0) -- idx
+//                                                grows from one such link of a line to the next, which is all the order of a link
+//                                                absent from the graph is compared on inside a line
+struct alignas(16) NodeInfo3 {
+  uint32_t word, t0, t1, t2;
+};
+constexpr uint32_t NO_TARGET = 0xFFFFFFFFu;
+
+template <int PF, class GraphAcc, class Sink>
+PANTAS_HD int walk_short_w(const GraphAcc& ga, const LineHdr& h, const uint32_t* nodes, uint32_t k, const Sink& sink, const uint32_t* first_ids,
+                           const ShortOps& so) {
+  if (k == 0) return WALK_OK;
+  const uint32_t T = so.T;
+  const bool rev = (h.flags & LINE_REV) != 0;
+  const bool exact = (h.flags & LINE_HAS_DEL) != 0;
+  const bool all_colon = (so.ns | so.x) == 0u;
+  uint32_t P = 0, kept = 0;
+  bool pending = false;
+  // the pending kept node: id, and {plain entries (bits 0, 1), slot code of its link (bits 2, 3), path index (bits 8 .. 12), IL / OL flags (30, 31)}
+  uint32_t p_node = 0, p_meta = 0;
+  auto flush = [&](bool is_last, uint32_t code) {
+    const uint32_t p_plain = p_meta & 3u;
+    const bool enter = p_plain != 0u && kept != 1u, leave = p_plain != 0u && !is_last;
+    sink.kept(p_node, p_meta & (FLAG_IL | FLAG_OL), h.line_id, (rev ? leave : enter) ? p_plain : 0u, (rev ? enter : leave) ? p_plain : 0u, code,
+              exact ? event_order(h.line_id, kept - 1u, 1) : 0ull);
+  };
+  const uint32_t last = k - 1u;
+  uint32_t nid[PF + 1];
+  NodeInfo3 inf[PF];
+PANTAS_UNROLL
+  for (int j = 0; j <= PF; ++j) nid[j] = first_ids[j];
+PANTAS_UNROLL
+  for (int j = 0; j < PF; ++j) inf[j] = ga.info3(nid[j]);
+  // unrolled PF + 1 times so that the pipeline registers rotate by renaming: a move of a value still in flight is a full wait
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll PF + 1
+#endif
+  for (uint32_t i = 0; i < k; ++i) {
+    const uint32_t node = nid[0];
+    const NodeInfo3 cur = inf[0];
+    const uint32_t ahead = i + uint32_t(PF) + 1u;
+    const uint32_t new_id = nodes[ahead < last ? ahead : last];
+    const NodeInfo3 new_inf = ga.info3(nid[PF]);
+    const int32_t r = int32_t(cur.word & LEN_MASK) - (i == 0 ? h.start : 0) - (i == last ? h.tail - 1 : 0);
+    if (r > 0) {
+      if (P >= T) return WALK_OPS_EXHAUSTED;
+      const uint32_t room = uint32_t(r), left = T - P;
+      const uint32_t le = room < left ? room : left;
+      bool keep;
+      uint32_t plain;
+      if (all_colon) { keep = true; plain = 1u; }
+      else short_node_summary(so, P, le, keep, plain);
+      P += le;
+      if (keep) {
+        const uint32_t target = rev ? p_node : nid[1];      // nid[1] = this node again on the last path node: a forward line's last code is never read
+        uint32_t code = cur.t0 == target ? 1u : cur.t1 == target ? 2u : cur.t2 == target ? 3u : 0u;
+        if (rev && !pending) code = 0u;
+        if (pending) {
+          uint32_t pc = (p_meta >> 2) & 3u;
+          bool later;
+          if (!rev) {
+            if (((p_meta >> 8) & 31u) + 1u != i) pc = 0u;      // a dropped node or one without room in between: the code was for another target
+            later = pc == 0u;
+          } else later = code == 0u;
+          if (later) sink.later(rev ? node : p_node, rev ? p_node : node, (p_meta >> 8) & 31u);
+          flush(false, pc);
+        }
+        p_node = node;
+        p_meta = plain | (code << 2) | ((i & 31u) << 8) | (cur.word & (FLAG_IL | FLAG_OL));
+        pending = true;
+        ++kept;
+      }
+    }
+PANTAS_UNROLL
+    for (int j = 0; j < PF; ++j) nid[j] = nid[j + 1];
+    nid[PF] = new_id;
+PANTAS_UNROLL
+    for (int j = 0; j + 1 < PF; ++j) inf[j] = inf[j + 1];
+    inf[PF - 1] = new_inf;
+  }
+  if (pending) flush(true, rev ? ((p_meta >> 2) & 3u) : 0u);
+  return WALK_OK;
+}
+
 // The rare-key pass over a one-indel line: only the nodes that hold a piece of the '-' can own a deletion-derived key, so
 // every other kept node is just counted (its index orders the events) and the piece-by-piece compaction (PieceAcc, fed
 // exactly as walk_line feeds it) runs for those one or two nodes alone.  Sink: the walk_line sink concept (rare() matters).

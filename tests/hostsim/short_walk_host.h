@@ -16,6 +16,27 @@ struct HostInfo {
     const uint32_t lo = g.row_ptr[n], hi = g.row_ptr[n + 1];
     return NodeInfo{word[n], lo < hi ? g.col[lo] : 0xFFFFFFFFu};
   }
+  // the 16-byte record of walk_short_w: targets of the first three out-slots
+  NodeInfo3 info3(uint32_t n) const {
+    const uint32_t lo = g.row_ptr[n], hi = g.row_ptr[n + 1];
+    return NodeInfo3{word[n], lo < hi ? g.col[lo] : NO_TARGET, lo + 1 < hi ? g.col[lo + 1] : NO_TARGET, lo + 2 < hi ? g.col[lo + 2] : NO_TARGET};
+  }
+};
+
+// walk_short_w's sink in terms of a walk_line sink: a slot code is a hit on that out-slot of the node, link_later is looked up at once
+template <class GenSink>
+struct ShortWFromGeneral {
+  GenSink& s;
+  const Graph& g;
+  void kept(uint32_t node, uint32_t word, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
+    s.nc(node);
+    const uint64_t order = exact_order ? exact_order : event_order(line_id, 0, 1);
+    if (a_il) s.common(node, word, SIDE_IL, a_il, order);
+    if (a_ol) s.common(node, word, SIDE_OL, a_ol, order);
+    if (code) s.edge(node, g.col[g.row_ptr[node] + code - 1u], 0);
+  }
+  uint32_t line_id;
+  void later(uint32_t a, uint32_t b, uint32_t idx) const { s.edge(a, b, event_order(line_id, idx, 0)); }
 };
 
 // walk_short's sink in terms of a walk_line sink (nc / common / edge)
@@ -54,7 +75,15 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
   for (uint32_t j = 0; j < 4 && k; ++j) first_ids[j] = nodes[j < k - 1 ? j : k - 1];
   // every instance the kernels use takes its turn: gathers one / two nodes ahead, deferred link lookups, the lean
   // instance for lines without an indel
-  switch (h.line_id & 3u) {
+  static const bool wide_only = getenv("HOSTSIM_WIDE_WALK") != nullptr;      // every short-walk line through walk_short_w
+  const uint32_t sel = wide_only ? 4u + (h.line_id & 1u) : h.line_id % 6u;
+  switch (sel) {
+    case 4: case 5: {     // round 3: 16-byte node records, links matched against the first three out-slots where the node is visited
+      const ShortWFromGeneral<GenSink> sw{s, g, h.line_id};
+      ShortOps so;
+      short_ops_scan(ops, c, so);
+      return sel == 4 ? walk_short_w<1>(ga, h, nodes, k, sw, first_ids, so) : walk_short_w<2>(ga, h, nodes, k, sw, first_ids, so);
+    }
     case 0: return walk_short<1>(ga, h, nodes, k, ops, c, ss, first_ids);
     case 1: {      // with the line's ShortOps handed in (the GPU batch keeps it beside the record) and ops[] out of reach
       ShortOps so;

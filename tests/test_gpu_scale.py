@@ -102,11 +102,7 @@ def test_kernel_variants_and_record_order_give_identical_gfa():
     base = _augmented_sha({})
     assert int(base[1]) > 5e8
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0"}) == base
-    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "73"}) == base      # the round-1 short-walk kernel
-    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "80"}) == base      # deferred link lookups without the novel-link queue
-    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "85"}) == base      # ... with it, chunks in launch order (the default deals them to the XCDs in eighths)
-    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "97"}) == base      # ... XCD-aware, the op summary scanned from ops[] (the default reads it from the record)
-    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "100"}) == base     # ... the summary from the record, every round taken the same way round
+    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "101"}) == base     # round 2's short walk (8-byte node records, deferred link lookups); the default is round 3's
     assert _augmented_sha({"PANTAS_NO_BUCKET": "1"}) == base
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0", "PANTAS_NO_BUCKET": "1", "PANTAS_THREADS": "3"}) == base
 

@@ -124,6 +124,27 @@ def test_sources_vs_oracle_exact(hostsim, tmp_path, seed, genes, lines, kw, flag
     assert mine == ref
 
 
+def test_wide_short_walk_source(hostsim, tmp_path):
+    """walk.h walk_short_w (16-byte node records: links matched against a node's first three out-slots where it is visited; round 3's
+    dominant kernel) for EVERY short-walk line: the goldens' bytes, and the oracle on workloads with many bubbles (second / third
+    out-slots), links the graph does not have, indels, dropped nodes in between."""
+    env = {**os.environ, "HOSTSIM_WIDE_WALK": "1"}
+    for case in CASES:
+        d = os.path.join(GOLDEN, case)
+        r = subprocess.run([hostsim["augment"], f"{d}/in.gaf", f"{d}/in.gfa"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == open(f"{d}/expected.aug.gfa").read(), case
+    from pantas_amd import synth
+    for seed, kw in ((31, dict(bubble_rate=0.3, p_novel_skip=0.15, p_novel_ce=0.1)), (32, dict(p_indel=0.4, p_sub=0.5, bubble_rate=0.2)),
+                     (33, dict(bubble_rate=0.5, p_novel_ss=0.2, p_intron=0.2))):
+        pre = str(tmp_path / f"w{seed}")
+        synth.write_all(pre, seed=seed, n_genes=30, n_lines=8000, **kw)
+        want = io.StringIO()
+        augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+        r = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and r.stdout == want.getvalue(), seed
+
+
 @pytest.mark.parametrize("fan,isw", [(10, 5), (40, 5), (300, 5), (40, 2)])
 def test_intronic_search_beyond_local_frontier(hostsim, tmp_path, fan, isw):
     from hub_case import write_hub_case

@@ -50,6 +50,11 @@ def main():
     for v in args.variants.split(","):
         # "main" or "main:rare" (PANTAS_MAIN_KERNEL : PANTAS_RARE_KERNEL)
         v, _, rv = v.partition(":")
+        rv, _, abl = rv.partition(":")      # "main:rare:ablate" -- PANTAS_ABLATE for this variant (timing only: results wrong by construction)
+        if abl:
+            os.environ["PANTAS_ABLATE"] = abl
+        else:
+            os.environ.pop("PANTAS_ABLATE", None)
         os.environ["PANTAS_MAIN_KERNEL"] = v
         if rv:
             os.environ["PANTAS_RARE_KERNEL"] = rv
@@ -72,6 +77,9 @@ def main():
         sp[:, 2] >>= 32       # first-seen: the line id decides between lines; kernels may differ in the low (within-line) bits
         h.update(np.ascontiguousarray(sp[np.lexsort(sp.T[::-1])]).tobytes())
         dig = h.hexdigest()[:16]
+        if abl:
+            print(json.dumps({"variant": int(v), "ablate": int(abl), "main_ms": round(sum(ms) / len(ms), 4), "short_ms": round(sum(short) / len(short), 4)}), flush=True)
+            continue
         ref = ref or dig
         avg_s = sum(short) / len(short)
         print(json.dumps({"variant": int(v), "rare_variant": rv or "default", "del_hot": args.del_hot, "scale": args.scale, "main_ms": round(sum(ms) / len(ms), 4), "main_min": round(min(ms), 4),
