@@ -345,10 +345,10 @@ __global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (stop == 9u) { key[i] = words[b >> 2]; return; }        // (ablation: staging only)
     // ONE call site of the parser (it is thousands of instructions long): a line whose record does not fit its own text is parsed
     // a second time by the same code, into room taken from the arena
-    // The record starts at the next 64-byte boundary inside the line's own words when that leaves it align_min words: the gather
-    // that builds the batch reads the records in locus order, i.e. at random, and a 14-word record that starts anywhere straddles
-    // two 64-byte sectors more often than not (11 GB fetched for 7 GB of records at S4).  A record that does not fit there is parsed
-    // again into the whole of the line's words, one that does not fit those into the arena.
+    // (A/B switch, off by default: the record starts at the next 64-byte boundary inside the line's own words when that leaves it
+    // align_min words, so that the gather, which reads the records in locus order, i.e. at random, touches one sector per record
+    // instead of two; a record that does not fit there is parsed again into the whole of the line's words, one that does not fit
+    // those into the arena.)
     const uint64_t slot_al = (slot + 15u) & ~uint64_t(15);
     const uint32_t room_al = slot_end > slot_al ? uint32_t(slot_end - slot_al) : 0u;
     const bool aligned = room_al >= align_min;
@@ -803,8 +803,10 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   HIP_OK(hipMemsetAsync(small.p, 0xFF, 8, s));
   HIP_OK(hipMemsetAsync(small.as<unsigned long long>() + 1 + N_TOTALS, 0xFF, 8, s));
   uint32_t* d_arena_next = reinterpret_cast<uint32_t*>(small.as<unsigned long long>() + N_TOTALS + 2);
-  // words a 64-byte-aligned start has to leave a line's record for the record to start there (PANTAS_TOK_ALIGN_MIN; 0 = never aligned)
-  uint32_t align_min = 24;
+  // words a 64-byte-aligned start has to leave a line's record for the record to start there (PANTAS_TOK_ALIGN_MIN; 0 = never aligned,
+  // the default: measured at S4 with 20 / 24 / 28 the gather gains 0.2 ms and the parse loses 0.1 - 0.9 to second passes --
+  // the gather is not bound by the sectors a record straddles; profiles/r3_tok_align_ab.txt)
+  uint32_t align_min = 0;
   if (const char* a = getenv("PANTAS_TOK_ALIGN_MIN")) align_min = uint32_t(atoi(a));
   if (align_min == 0) align_min = 0xFFFFFFFFu;
   hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
