@@ -257,21 +257,44 @@ PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit
 // the GFA (rule R3).  dir 0: follow out-links from `start`, targets = {n : (anchor, n) junction};
 // dir 1: follow in-links, targets = {p : (p, anchor) junction}.
 constexpr uint32_t FRONTIER_LOCAL = 24;
+constexpr uint32_t FRONTIER_TARGETS = 8;
 PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t anchor, uint32_t dir, Fault& f) {
+  // The targets -- the other ends of the anchor's junction links -- are a handful: taken from the anchor's own row (dir 0) or
+  // in-list (dir 1) once, so that a node is tested when it ENTERS the set and against that handful, instead of every member of
+  // the set being looked up in a row at every pop (a frontier that runs into a node with thousands of novel links made one lane
+  // of the novel-link pass run for 1.3 s at S5).  L_JUNC sits on the first slot of a pair, which is the slot is_junction finds.
+  uint32_t tg[FRONTIER_TARGETS];
+  uint32_t n_tg = 0;
+  bool tg_all = true;           // false: more targets than tg holds -- every test asks is_junction
+  {
+    const uint32_t b = dir == 0 ? c.row_ptr[anchor] : c.irow_ptr[anchor];
+    const uint32_t e = dir == 0 ? c.row_ptr[anchor + 1] : c.irow_ptr[anchor + 1];
+    for (uint32_t s = b; s < e && tg_all; ++s) {
+      const uint32_t slot = dir == 0 ? s : c.islot[s];
+      const uint32_t fs = c.first_slot[slot];
+      if (fs != slot || !(c.lflags[fs] & L_JUNC)) continue;      // (a later duplicate of a pair: its first slot is listed too)
+      if (n_tg == FRONTIER_TARGETS) { tg_all = false; break; }
+      tg[n_tg++] = dir == 0 ? c.col[s] : c.icol[s];
+    }
+  }
+  auto is_target = [&](uint32_t x) {
+    if (!tg_all) return dir == 0 ? is_junction(c, anchor, x) : is_junction(c, x, anchor);
+    bool hit = false;
+    for (uint32_t i = 0; i < FRONTIER_TARGETS; ++i) hit |= i < n_tg && tg[i] == x;
+    return hit;
+  };
   uint32_t local[FRONTIER_LOCAL];
   uint32_t* vis = local;      // sorted set of node indices; moves to an arena slice when it outgrows `local`
   uint32_t cap = FRONTIER_LOCAL;
   uint32_t n = 1;
   vis[0] = start;
+  // the first member of the (sorted) set that is a target = the smallest target in it; members only leave by the pop below,
+  // which is not reached while there is one
+  uint32_t tmin = is_target(start) ? start : CNONE;
   int32_t left = 1;
   int32_t level = 0;
   for (;;) {
-    uint32_t hit = CNONE;
-    for (uint32_t i = 0; i < n; ++i) {
-      const bool t = dir == 0 ? is_junction(c, anchor, vis[i]) : is_junction(c, vis[i], anchor);
-      if (t) { hit = vis[i]; break; }
-    }
-    if (hit != CNONE) return level < c.isw ? hit : CNONE;
+    if (tmin != CNONE) return level < c.isw ? tmin : CNONE;
     if (level >= c.isw) return CNONE;
     if (n == 0) return CNONE;
     const uint32_t x = vis[0];
@@ -301,6 +324,7 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
       for (uint32_t i = n; i > lo; --i) vis[i] = vis[i - 1];
       vis[lo] = y;
       ++n;
+      if (y < tmin && is_target(y)) tmin = y;
     }
     if (left == 0) { ++level; left = int32_t(n); }
   }

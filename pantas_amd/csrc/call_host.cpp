@@ -664,11 +664,19 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       k.nb = nb; k.ne = ne;
       std::unordered_map<std::string_view, uint32_t> ids;   // tag -> local id (order of first appearance in the chunk)
       std::vector<uint32_t> tmp;
+      const char* prev = nullptr;     // the EX value of the chunk's previous tagged node: the segments of one exon (a bubble cuts it
+      uint32_t prev_len = 0;          // into dozens) carry the same value, whose ids are then in tmp already
       for (size_t n = nb; n < ne; ++n) {
         if (!sa[n].has_ex) continue;
-        tmp.clear();
         const char* p = base + sa[n].ex_off;
         const char* e = p + sa[n].ex_len;
+        if (prev && prev_len == sa[n].ex_len && memcmp(prev, p, prev_len) == 0) {
+          t.ex_ptr[n] = uint32_t(tmp.size());
+          k.occ.insert(k.occ.end(), tmp.begin(), tmp.end());
+          continue;
+        }
+        prev = p; prev_len = sa[n].ex_len;
+        tmp.clear();
         for (;;) {
           const char* cm = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
           Span tag{p, cm ? cm : e};
@@ -734,14 +742,20 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       std::vector<uint32_t> tmp;
       for (size_t c = cb; c < ce; ++c) {
         const ExChunk& k = ck[c];
-        size_t in = 0;
+        size_t in = 0, prev_in = SIZE_MAX;
+        uint32_t prev_cnt = 0;
         for (size_t n = k.nb; n < k.ne; ++n) {
           const uint32_t lo = t.ex_ptr[n], cnt = t.ex_ptr[n + 1] - lo;      // (ex_ptr[n + 1] of the chunk's last node belongs to the next chunk: already final)
           if (!cnt) continue;
-          tmp.assign(k.occ.begin() + long(in), k.occ.begin() + long(in + cnt));
+          // (the same local ids as the previous tagged node's -- the next segment of the same exon: tmp holds their global form)
+          const bool same = prev_in != SIZE_MAX && prev_cnt == cnt && std::equal(k.occ.begin() + long(in), k.occ.begin() + long(in + cnt), k.occ.begin() + long(prev_in));
+          if (!same) {
+            tmp.assign(k.occ.begin() + long(in), k.occ.begin() + long(in + cnt));
+            for (uint32_t& x : tmp) x = ick[c].to_global[x];
+            std::sort(tmp.begin(), tmp.end());
+          }
+          prev_in = in; prev_cnt = cnt;
           in += cnt;
-          for (uint32_t& x : tmp) x = ick[c].to_global[x];
-          std::sort(tmp.begin(), tmp.end());
           for (uint32_t j = 0; j < cnt; ++j) {
             const uint32_t id = tmp[j];
             t.ex_tag[lo + j] = id;

@@ -218,9 +218,13 @@ OrderedOutput::OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, u
     im->slots.resize(n_pieces);
     Impl* q = im;
     im->writer = std::thread([q] {
+      const bool timing = getenv("PANTAS_TIMING") != nullptr;
+      double waited = 0, wrote = 0;
+      uint64_t bytes = 0;
       for (size_t k = 0; k < q->slots.size(); ++k) {
         const char* p;
         size_t left;
+        const double t0 = timing ? now_s() : 0;
         {
           std::unique_lock<std::mutex> lk(q->mu);
           q->cv_ready.wait(lk, [&] { return q->slots[k].ready || q->failed; });
@@ -228,6 +232,9 @@ OrderedOutput::OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, u
           p = q->slots[k].p;
           left = q->slots[k].n;
         }
+        const double t1 = timing ? now_s() : 0;
+        waited += t1 - t0;
+        bytes += left;
         while (left) {
           const ssize_t w = ::write(q->fd, p, left);
           if (w < 0) {
@@ -239,12 +246,15 @@ OrderedOutput::OrderedOutput(int fd, size_t n_pieces, uint64_t expected_bytes, u
           }
           p += w; left -= size_t(w);
         }
+        if (timing) wrote += now_s() - t1;
         std::lock_guard<std::mutex> lk(q->mu);
         if (q->failed) break;
         q->total += q->slots[k].n;
         q->slots[k].done = true;
         q->cv_done[k % Impl::DONE_CVS].notify_all();
       }
+      if (timing) fprintf(stderr, "[timing] writer thread: %.3f s in write() for %.2f GB (%.2f GB/s), %.3f s waiting for the next piece, %zu pieces\n",
+                          wrote, bytes / 1e9, wrote > 0 ? bytes / 1e9 / wrote : 0.0, waited, q->slots.size());
       std::lock_guard<std::mutex> lk(q->mu);
       for (auto& cv : q->cv_done) cv.notify_all();
     });
