@@ -53,7 +53,7 @@ void pantas_device_init(int device);
  * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
  * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
  * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
-#define PANTAS_ABI_VERSION 3
+#define PANTAS_ABI_VERSION 4
 int pantas_abi_version(void);
 
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
@@ -70,6 +70,10 @@ typedef struct {
 
 /* alignments_augmentation_from_gaf.py:121-126 (first GFA pass) / call.py:145-181 */
 int pantas_graph_load(const char* gfa_path, pantas_graph** out);
+/* The same graph for a caller that goes on to pantas_call_prepare (ABI 4): when the text is parsed on the GPU (after
+ * pantas_device_init), the tags call.py reads off the S / L lines (:25-32, :145-181: NC, RC, EX, JN, ID) are taken in the same
+ * visit of the text, and pantas_call_prepare does not walk the lines again.  Results are those of pantas_graph_load. */
+int pantas_graph_load_for_call(const char* gfa_path, pantas_graph** out);
 /* Binary cache of the parsed graph (the graph is shared by all replicates).  Loads `cache_path` when
  * it was made from exactly this GFA file (size, mtime, hash of both ends); otherwise parses the GFA and, if
  * write_if_missing, writes the cache.  *used_cache (may be NULL) = 1 when the text was not parsed.  Graphs whose

@@ -60,7 +60,7 @@ def run(args) -> int:
         _lap("imports done")
         from ._lib import lib
         lib.pantas_device_init(device)         # HIP runtime start-up and the streams of the run, while the process is small
-        g = Graph(args.GFA)
+        g = Graph(args.GFA, for_call=True)
         _lap("graph loaded")
         _stamp("Parsing GTF..")
         g.call_prepare(args.GTF, device)

@@ -486,10 +486,21 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
 
   pt.lap("gtf + link layout");
   // ---- phase A (parallel): locate the tags of every S line and every link slot -----------------
-  RawVector<SegAttr> sa(reuse ? 0 : V);
-  t.nc.resize(V);
-  t.nflags.resize(V);
-  if (reuse) {
+  // (the GPU loader may have read the tags while the text was in HBM: graph.h CallTagScan)
+  std::unique_ptr<CallTagScan> ct;
+  if (!reuse && g.call_tags && g.call_tags->nc.size() == V && g.call_tags->la.size() == g.A && !getenv("PANTAS_CALL_TAGS_HOST")) ct = std::move(g.call_tags);
+  RawVector<SegAttr> sa((reuse || ct) ? 0 : V);
+  if (ct) { t.nc = std::move(ct->nc); t.nflags = std::move(ct->nflags); }
+  else { t.nc.resize(V); t.nflags.resize(V); }
+  if (ct) {
+    if (aug) parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t n = b; n < e; ++n) {
+        if (aug->nc[n] > uint32_t(INT32_MAX)) throw Error("Unsupported", "node coverage beyond 2^31");
+        t.nc[n] = int32_t(aug->nc[n]);
+        t.nflags[n] |= N_HAS_NC;
+      }
+    });
+  } else if (reuse) {
     // the S lines were read (and their tags checked) by the build whose tables are taken over: only the counters are new
     parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
       for (size_t n = b; n < e; ++n) {
@@ -528,6 +539,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   // tag records of the GRAPH's L lines, by graph slot: read from the text, or taken over from the previous build
   RawVector<LinkAttr> la_graph;
   if (reuse) la_graph = std::move(previous->reuse.la_graph);
+  else if (ct) la_graph = std::move(ct->la);
   else {
     la_graph.resize(g.A);
     parallel_chunks(g.A, g.A < 4096 ? 1 : threads, [&](unsigned, size_t b, size_t e) {
@@ -666,16 +678,15 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
       std::vector<uint32_t> tmp;
       const char* prev = nullptr;     // the EX value of the chunk's previous tagged node: the segments of one exon (a bubble cuts it
       uint32_t prev_len = 0;          // into dozens) carry the same value, whose ids are then in tmp already
-      for (size_t n = nb; n < ne; ++n) {
-        if (!sa[n].has_ex) continue;
-        const char* p = base + sa[n].ex_off;
-        const char* e = p + sa[n].ex_len;
-        if (prev && prev_len == sa[n].ex_len && memcmp(prev, p, prev_len) == 0) {
+      auto one = [&](size_t n, uint64_t ex_off, uint32_t ex_len) {
+        const char* p = base + ex_off;
+        const char* e = p + ex_len;
+        if (prev && prev_len == ex_len && memcmp(prev, p, prev_len) == 0) {
           t.ex_ptr[n] = uint32_t(tmp.size());
           k.occ.insert(k.occ.end(), tmp.begin(), tmp.end());
-          continue;
+          return;
         }
-        prev = p; prev_len = sa[n].ex_len;
+        prev = p; prev_len = ex_len;
         tmp.clear();
         for (;;) {
           const char* cm = static_cast<const char*>(memchr(p, ',', size_t(e - p)));
@@ -689,6 +700,14 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
         sort_unique(tmp);
         t.ex_ptr[n] = uint32_t(tmp.size());        // count for now, offset after the scan below
         k.occ.insert(k.occ.end(), tmp.begin(), tmp.end());
+      };
+      if (ct) {      // the tagged nodes as a list (ascending)
+        const uint32_t* first = ct->ex_node.data();
+        const uint32_t* last = first + ct->ex_node.size();
+        for (size_t q = size_t(std::lower_bound(first, last, uint32_t(nb)) - first); q < ct->ex_node.size() && ct->ex_node[q] < ne; ++q)
+          one(ct->ex_node[q], ct->ex_off[q], ct->ex_len[q]);
+      } else {
+        for (size_t n = nb; n < ne; ++n) if (sa[n].has_ex) one(n, sa[n].ex_off, sa[n].ex_len);
       }
     });
     pt.lap("intern EX: per-chunk maps (parallel)");

@@ -24,7 +24,7 @@ struct CallOptions {
 struct StrRef { uint64_t off; uint32_t len; };
 
 // tag record of one L line (call_host.cpp fills it; kept per graph slot between builds on the same graph, see CallTables::Reusable)
-struct LinkAttr { uint64_t jn_off; uint32_t jn_len; bool has_jn, has_id, has_rc; int32_t rc; };
+using LinkAttr = LinkTagRec;      // (graph.h: the GPU loader can fill them)
 
 struct CallTables {
   // ---- link layout the call path works on: the graph's CSR, or (fused augment -> call) a copy

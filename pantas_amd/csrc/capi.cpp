@@ -172,7 +172,7 @@ __attribute__((visibility("default"))) void pantas_device_init(int device) { try
 // The GFA parsed on the GPU when the process has one (PANTAS_GFA_LOADER=host keeps it on the host cores, =device insists): the device
 // form takes the graphs a graph builder writes and hands everything else back (load_graph_device returns nullptr).  The two loaders
 // build the same arrays (tests/test_gpu_graph_loader.py compares them through the binary cache both can write).
-static std::unique_ptr<Graph> load_graph_anywhere(const char* gfa_path) {
+static std::unique_ptr<Graph> load_graph_anywhere(const char* gfa_path, bool call_tags = false) {
   const char* how = getenv("PANTAS_GFA_LOADER");
   const bool host_only = how && !strcmp(how, "host");
   const bool insist = how && !strcmp(how, "device");
@@ -182,7 +182,7 @@ static std::unique_ptr<Graph> load_graph_anywhere(const char* gfa_path) {
     if (dev >= 0) {
       std::unique_ptr<Graph> g;
       try {
-        g = load_graph_device(gfa_path, dev);
+        g = load_graph_device(gfa_path, dev, call_tags);
       } catch (const Error& e) {
         if (insist || e.kind == "FileNotFoundError") throw;
         g = nullptr;                        // (a HIP error while parsing: the host loader does not need the device)
@@ -200,6 +200,17 @@ __attribute__((visibility("default"))) int pantas_graph_load(const char* gfa_pat
     double t0 = now_s();
     auto h = std::make_unique<pantas_graph>();
     h->g = load_graph_anywhere(gfa_path);
+    h->load_s = now_s() - t0;
+    *out = h.release();
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_graph_load_for_call(const char* gfa_path, pantas_graph** out) {
+  return guarded([&] {
+    need(gfa_path && out, "null argument");
+    double t0 = now_s();
+    auto h = std::make_unique<pantas_graph>();
+    h->g = load_graph_anywhere(gfa_path, true);
     h->load_s = now_s() - t0;
     *out = h.release();
   });

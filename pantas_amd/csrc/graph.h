@@ -35,6 +35,19 @@ struct NameIndex {
   }
 };
 
+// Tags of the S / L lines as `pantas call` reads them (scripts/call.py:145-181), taken on the GPU while the text of the graph is
+// in HBM for the loader (tokenize.hip gfa_tags_kernel; round 3).  Only made for a text every tag of which is of the plain form the
+// writers produce -- anything else leaves it absent and call_host.cpp scans the lines itself (and words the error).
+struct LinkTagRec { uint64_t jn_off; uint32_t jn_len; bool has_jn, has_id, has_rc; int32_t rc; };      // = call_host.h LinkAttr
+struct CallTagScan {
+  RawVector<int32_t> nc;             // [V] NC value (0 without the tag)
+  RawVector<uint32_t> nflags;        // [V] call_device.h N_HAS_NC
+  RawVector<uint32_t> ex_node;       // nodes whose S line carries an EX tag, ascending ...
+  RawVector<uint64_t> ex_off;        // ... offset and length of its value in the text
+  RawVector<uint32_t> ex_len;
+  RawVector<LinkTagRec> la;          // [A] by graph slot
+};
+
 struct Graph {
   MappedFile text;
   RawVector<char> text_owned;      // the text with universal newlines applied (common.h lone_cr): `text` then points here, not at the file
@@ -62,6 +75,7 @@ struct Graph {
   uint64_t first_short_l_off = UINT64_MAX; // first non-bare L line with fewer than 6 tokens
   uint64_t ws_only_seg_off = UINT64_MAX;   // first S line behind leading whitespace whose name no plain S line defines
   uint32_t max_seg_len = 0;
+  mutable std::unique_ptr<CallTagScan> call_tags;   // load_graph_device(.., call_tags = true); build_call_tables takes it
 
   Span name_of(uint32_t node) const {
     const char* b = text.data + seg_name_off[node];
@@ -80,7 +94,7 @@ std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
 // The same arrays built on the GPU (tokenize.hip): for the graphs a graph builder writes; nullptr for anything else -- no device, a
 // small file, names that are no decimals in a dense range, duplicate or whitespace-led S lines, lone carriage returns -- which the
 // host loader then takes.
-std::unique_ptr<Graph> load_graph_device(const char* path, int device);
+std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call_tags = false);
 // Same over text already in memory (the buffer must outlive the graph).
 std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads = 0);
 

@@ -1287,6 +1287,117 @@ __global__ void __launch_bounds__(LPB) gfa_lines_kernel(const uint8_t* text, con
   }
 }
 
+// ---- the tags of the S / L lines as `pantas call` reads them (call_host.cpp build_call_tables phase A; scripts/call.py:25-32,
+// :145-181), for the command line that goes on to call: a second staged pass over the text, once the S / L ordinals are known.
+// A tag is name:type:value with exactly two ':'; NC / LN / RC values are ints, IL / OL values lists of int.int; the value of EX
+// (S lines) and JN (L lines) is kept as a span of the text, the presence of ID (L lines) as a flag; a later tag of a name
+// overrides an earlier one.  Only the plain form is taken -- digits without sign or '_' for the ints (an optional '-' inside
+// IL / OL), a value below 2^31 -- anything else sets `odd` and the host scans the lines itself (and words the error).
+constexpr uint32_t TAG_HAS_NC = 1u, TAG_HAS_EX = 2u;      // nflags: bit 0 = call_device.h N_HAS_NC
+__device__ __forceinline__ bool tag_plain_int(TextWords& T, uint32_t b, uint32_t e, uint32_t& v) {
+  const uint32_t n = e - b;
+  if (n == 0 || n > 10) return false;
+  unsigned long long x = 0;
+  for (uint32_t c = b; c < e; ++c) {
+    const uint32_t d = T.at(c) - '0';
+    if (d > 9u) return false;
+    x = x * 10ull + d;
+  }
+  if (x > 0x7FFFFFFFull) return false;
+  v = uint32_t(x);
+  return true;
+}
+__device__ __forceinline__ bool tag_plain_hist(TextWords& T, uint32_t b, uint32_t e) {
+  // pieces between ',' and '.': an optional '-' and 1 .. 18 digits each
+  uint32_t digits = 0;
+  bool minus = false;
+  for (uint32_t c = b; c <= e; ++c) {
+    const uint32_t ch = c < e ? T.at(c) : uint32_t(',');
+    if (ch == ',' || ch == '.') { if (digits == 0) return false; digits = 0; minus = false; }
+    else if (ch == '-') { if (digits != 0 || minus) return false; minus = true; }
+    else if (ch - '0' <= 9u) { if (++digits > 18u) return false; }
+    else return false;
+  }
+  return true;
+}
+__global__ void __launch_bounds__(LPB) gfa_tags_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, const uint8_t* kind,
+                                                       const uint32_t* s_ord, const uint32_t* l_ord, int32_t* nc, uint32_t* nflags, uint64_t* ex_off, uint32_t* ex_len,
+                                                       LinkTagRec* la_file, unsigned long long* odd, uint32_t* too_long_scratch) {
+  const uint32_t groups = (n_lines + LPB - 1u) / LPB;
+  for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x)
+    staged_rounds(grp, text, ls, n_lines, stage_bytes, too_long_scratch, [&](uint32_t i, const uint32_t* words, uint32_t b, uint32_t e) {
+      const uint8_t k = kind[i];
+      if (k != GK_S && k != GK_L) return;
+      TextWords T(words);
+      const uint64_t off = ls[i];
+      uint32_t end = e;
+      while (end > b && tk_ws(T.at(end - 1u))) --end;
+      uint32_t p = b;
+      const uint32_t skip = k == GK_S ? 3u : 6u;
+      for (uint32_t n = 0; n < skip; ++n) {
+        while (p < end && tk_ws(T.at(p))) ++p;
+        while (p < end && !tk_ws(T.at(p))) ++p;
+      }
+      uint32_t val = 0, fl = 0, sp_b = 0, sp_n = 0;       // NC / RC value; flags; span of EX / JN
+      bool has_val = false, has_span = false, has_id = false, bad = false;
+      for (;;) {
+        while (p < end && tk_ws(T.at(p))) ++p;
+        if (p >= end) break;
+        const uint32_t tb = p;
+        uint32_t c1 = 0, c2 = 0, colons = 0;
+        while (p < end && !tk_ws(T.at(p))) {
+          if (T.at(p) == ':') { if (colons == 0) c1 = p; else if (colons == 1) c2 = p; ++colons; }
+          ++p;
+        }
+        if (colons != 2u) { bad = true; break; }            // (the reference: ValueError, call.py:28)
+        if (c1 - tb != 2u) continue;
+        const uint32_t n0 = T.at(tb), n1 = T.at(tb + 1u), vb = c2 + 1u, ve = p;
+        const uint32_t name = n0 | (n1 << 8);
+        const uint32_t own = k == GK_S ? ('N' | ('C' << 8)) : ('R' | ('C' << 8));
+        if (name == ('N' | ('C' << 8)) || name == ('R' | ('C' << 8)) || name == ('L' | ('N' << 8))) {
+          uint32_t v;
+          if (!tag_plain_int(T, vb, ve, v)) { bad = true; break; }
+          if (name == own) { val = v; has_val = true; }
+        } else if (name == ('I' | ('L' << 8)) || name == ('O' | ('L' << 8))) {
+          if (!tag_plain_hist(T, vb, ve)) { bad = true; break; }
+        } else if (name == (k == GK_S ? ('E' | ('X' << 8)) : ('J' | ('N' << 8)))) { sp_b = vb; sp_n = ve - vb; has_span = true; }
+        else if (k == GK_L && name == ('I' | ('D' << 8))) has_id = true;
+      }
+      if (bad) { atomicMin(odd, static_cast<unsigned long long>(off)); return; }
+      (void)fl;
+      if (k == GK_S) {
+        const uint32_t node = s_ord[i];
+        nc[node] = int32_t(val);
+        nflags[node] = (has_val ? TAG_HAS_NC : 0u) | (has_span ? TAG_HAS_EX : 0u);
+        ex_off[node] = off + (sp_b - b);
+        ex_len[node] = sp_n;
+      } else {
+        LinkTagRec r;
+        r.jn_off = has_span ? off + (sp_b - b) : 0ull;
+        r.jn_len = has_span ? sp_n : 0u;
+        r.has_jn = has_span; r.has_id = has_id; r.has_rc = has_val;
+        r.rc = int32_t(val);
+        la_file[l_ord[i]] = r;
+      }
+    });
+}
+// nodes with an EX tag, ascending: node, offset, length (positions from a scan of the flags)
+__global__ void __launch_bounds__(TPB) gfa_ex_list_kernel(uint32_t V, const uint32_t* nflags_in, const uint32_t* pos, const uint64_t* ex_off, const uint32_t* ex_len,
+                                                          uint32_t* o_node, uint64_t* o_off, uint32_t* o_len, uint32_t* nflags_out) {
+  const uint32_t n = blockIdx.x * TPB + threadIdx.x;
+  if (n >= V) return;
+  const uint32_t f = nflags_in[n];
+  nflags_out[n] = f & TAG_HAS_NC;
+  if (f & TAG_HAS_EX) { const uint32_t q = pos[n]; o_node[q] = n; o_off[q] = ex_off[n]; o_len[q] = ex_len[n]; }
+}
+struct HasEx {
+  __host__ __device__ uint32_t operator()(uint32_t f) const { return (f & TAG_HAS_EX) ? 1u : 0u; }
+};
+__global__ void __launch_bounds__(TPB) gfa_la_slots_kernel(uint32_t A, const uint32_t* oidx, const LinkTagRec* la_file, LinkTagRec* la_slot) {
+  const uint32_t q = blockIdx.x * TPB + threadIdx.x;
+  if (q < A) la_slot[q] = la_file[oidx[q]];
+}
+
 // S lines -> node arrays; id range; the name table is filled by a second kernel once base and size are known
 __global__ void __launch_bounds__(TPB) gfa_nodes_kernel(uint32_t n_lines, const uint8_t* kind, const GfaLine* rec, const uint64_t* ls, const uint32_t* s_ord,
                                                         uint32_t* seg_len, uint64_t* seg_line_off, uint64_t* seg_name_off, uint16_t* seg_name_len,
@@ -1387,7 +1498,7 @@ void scan_u32(DevMem& m, const uint32_t* in, uint32_t* out, size_t n_plus_1, hip
 }  // namespace
 
 // nullptr: not a graph for the device form (or no device) -- the caller takes the host loader
-std::unique_ptr<Graph> load_graph_device(const char* path, int device) {
+std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call_tags) {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= device) return nullptr;
   PhaseTimer pt("load_graph_device");
@@ -1531,14 +1642,64 @@ std::unique_ptr<Graph> load_graph_device(const char* path, int device) {
   HIP_OK(hipMemcpyAsync(hflags, flags, 64, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
   if (hflags[0] != ~0ull) return nullptr;             // a second S line of a name, a link end without S line
-  m.drop(kind); m.drop(rec); m.drop(s_ord); m.drop(l_ord); m.drop(d_text); m.drop(ls);
   pt.lap("nodes, name table, link ends");
+  // ---- the tags `pantas call` reads, while the text is here (asked for by the command line that goes on to call)
+  int32_t* tg_nc = nullptr;
+  uint32_t* tg_nflags = nullptr;
+  uint32_t* tg_ex_node = nullptr; uint64_t* tg_ex_off = nullptr; uint32_t* tg_ex_len = nullptr;
+  LinkTagRec* la_file = nullptr;
+  uint32_t n_ex = 0;
+  bool have_tags = false;
+  if (call_tags) {
+    tg_nc = m.get<int32_t>(V);
+    uint32_t* raw = m.get<uint32_t>(size_t(V) + 1);
+    uint64_t* ex_off = m.get<uint64_t>(V);
+    uint32_t* ex_len = m.get<uint32_t>(V);
+    la_file = m.get<LinkTagRec>(A);
+    HIP_OK(hipMemsetAsync(flags + 7, 0xFF, 8, s));
+    {
+      int per_cu = 0, cus = 0;
+      uint32_t grid = 4096;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gfa_tags_kernel, int(LPB), stage_bytes) == hipSuccess && per_cu > 0 &&
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        grid = uint32_t(per_cu) * uint32_t(cus);
+      grid = std::min<uint32_t>(grid, (n_lines + LPB - 1) / LPB);
+      hipLaunchKernelGGL(gfa_tags_kernel, dim3(std::max(grid, 1u)), dim3(LPB), stage_bytes, s, d_text, ls, n_lines, stage_bytes, kind, s_ord, l_ord, tg_nc, raw, ex_off, ex_len,
+                         la_file, flags + 7, too_long);
+      HIP_OK(hipGetLastError());
+    }
+    uint32_t* pos = m.get<uint32_t>(size_t(V) + 1);
+    HIP_OK(hipMemsetAsync(raw + V, 0, 4, s));
+    {
+      hipcub::TransformInputIterator<uint32_t, HasEx, const uint32_t*> it(raw, HasEx{});
+      size_t need = 0;
+      HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, it, pos, int(V) + 1, s));
+      if (need > scan_tmp_bytes) { scan_tmp = m.get<uint8_t>(need); scan_tmp_bytes = need; }
+      HIP_OK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, need, it, pos, int(V) + 1, s));
+    }
+    unsigned long long tag_odd = 0;
+    HIP_OK(hipMemcpyAsync(&n_ex, pos + V, 4, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipMemcpyAsync(&tag_odd, flags + 7, 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    have_tags = tag_odd == ~0ull;          // else: a tag of another form somewhere -- the host scans the lines (and words what it finds)
+    if (have_tags) {
+      tg_nflags = m.get<uint32_t>(V);
+      tg_ex_node = m.get<uint32_t>(n_ex); tg_ex_off = m.get<uint64_t>(n_ex); tg_ex_len = m.get<uint32_t>(n_ex);
+      hipLaunchKernelGGL(gfa_ex_list_kernel, dim3(blocks_for(V)), dim3(TPB), 0, s, V, raw, pos, ex_off, ex_len, tg_ex_node, tg_ex_off, tg_ex_len, tg_nflags);
+      HIP_OK(hipGetLastError());
+      HIP_OK(hipStreamSynchronize(s));
+    } else { m.drop(tg_nc); m.drop(la_file); tg_nc = nullptr; la_file = nullptr; }
+    m.drop(raw); m.drop(ex_off); m.drop(ex_len); m.drop(pos);
+    pt.lap("tags of the S / L lines (for call)");
+  }
+  m.drop(kind); m.drop(rec); m.drop(s_ord); m.drop(l_ord); m.drop(d_text); m.drop(ls);
   int bits = 1;
   while (bits < 32 && (uint64_t(1) << bits) < uint64_t(V)) ++bits;
   uint32_t* col = m.get<uint32_t>(A);
   uint64_t* slot_off = m.get<uint64_t>(A);
   uint32_t* icol = m.get<uint32_t>(A);
   uint32_t* islot = m.get<uint32_t>(A);
+  LinkTagRec* la_slot = nullptr;
   if (A) {
     uint32_t* key2 = m.get<uint32_t>(A);
     uint32_t* oidx = m.get<uint32_t>(A);
@@ -1552,6 +1713,11 @@ std::unique_ptr<Graph> load_graph_device(const char* path, int device) {
     hipLaunchKernelGGL(gfa_out_kernel, dim3(blocks_for(A)), dim3(TPB), 0, s, A, oidx, fdst, foff, col, slot_off, slot_of);
     hipLaunchKernelGGL(gfa_in_kernel, dim3(blocks_for(A)), dim3(TPB), 0, s, A, iidx, fsrc, slot_of, icol, islot);
     HIP_OK(hipGetLastError());
+    if (have_tags) {
+      la_slot = m.get<LinkTagRec>(A);
+      hipLaunchKernelGGL(gfa_la_slots_kernel, dim3(blocks_for(A)), dim3(TPB), 0, s, uint32_t(A), oidx, la_file, la_slot);
+      HIP_OK(hipGetLastError());
+    }
   }
   HIP_OK(hipStreamSynchronize(s));
   pt.lap("CSR (two stable sorts)");
@@ -1581,6 +1747,16 @@ std::unique_ptr<Graph> load_graph_device(const char* path, int device) {
   down(g->irow_ptr, irow_ptr, size_t(V) + 1);
   down(g->icol, icol, A);
   down(g->islot, islot, A);
+  if (have_tags) {
+    auto ct = std::make_unique<CallTagScan>();
+    down(ct->nc, tg_nc, V);
+    down(ct->nflags, tg_nflags, V);
+    down(ct->ex_node, tg_ex_node, n_ex);
+    down(ct->ex_off, tg_ex_off, n_ex);
+    down(ct->ex_len, tg_ex_len, n_ex);
+    if (A) down(ct->la, la_slot, A);
+    g->call_tags = std::move(ct);
+  }
   HIP_OK(hipStreamSynchronize(s));
   pt.lap("arrays -> host");
   // ---- the P lines (a handful, each as long as a chromosome): exactly four tokens, or call.py:156 raises

@@ -38,9 +38,10 @@ def graph_cache_path(gfa_path: str):
 class Graph:
     """A GFA loaded into the CSR node/link layout (host) and, after ``to_device``, HBM."""
 
-    def __init__(self, gfa_path: str = None, *, text=None, cache: str = None):
+    def __init__(self, gfa_path: str = None, *, text=None, cache: str = None, for_call: bool = False):
         """From a GFA file, or from (address, size) of GFA text kept alive by the caller.  ``cache``: path of the
-        binary cache of the parsed arrays (used when it matches the file, written otherwise)."""
+        binary cache of the parsed arrays (used when it matches the file, written otherwise).  ``for_call``: the caller goes
+        on to ``call_prepare`` (the tags of the lines are taken while the text is parsed, pantas_graph_load_for_call)."""
         h = C.c_void_p()
         self.used_cache = False
         if cache is not None and text is None:
@@ -50,6 +51,8 @@ class Graph:
         elif text is not None:
             self._keep = text
             check(lib.pantas_graph_load_mem(C.c_char_p(text[0]), text[1], C.byref(h)))
+        elif for_call:
+            check(lib.pantas_graph_load_for_call(os.fsencode(gfa_path), C.byref(h)))
         else:
             check(lib.pantas_graph_load(os.fsencode(gfa_path), C.byref(h)))
         self._h = h

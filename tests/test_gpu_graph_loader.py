@@ -85,3 +85,57 @@ def test_graphs_the_device_form_hands_back(tmp_path):
         auto, ra = cache_of(p, "auto", tmp_path)
         assert rh.stats_line == ra.stats_line, name
         assert host == auto, name           # (None == None where the graph is not one the cache holds: duplicate names, names that are no decimals)
+
+
+def _call(aug_gfa, gtf, env_extra, flags=("--rca", "2", "--novel")):
+    env = {**os.environ, "PANTAS_TIMING": "1", **env_extra}
+    return subprocess.run([sys.executable, "-m", "pantas_amd.call", *flags, aug_gfa, gtf], capture_output=True, cwd=ROOT, env=env)
+
+
+def test_tags_for_call_taken_by_the_device_loader(tmp_path):
+    """`pantas call` on a graph the device loader takes: the tags of the S / L lines (NC, RC, EX, JN, ID) come from the loader's visit of
+    the text in HBM (gfa_tags_kernel, pantas_graph_load_for_call) -- the CSV must be the one the host scan of the lines gives, with both
+    flag sets; a tag of another form anywhere sends the scan back to the host, which raises what the reference raises"""
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "g")
+    Synth(seed=6, n_genes=2500, n_lines=400_000, base_id=10**7, p_novel_skip=0.05, p_novel_ce=0.03, bubble_rate=0.05).write(pre)
+    with open(pre + ".aug.gfa", "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for flags in (("--rca", "2", "--novel"), ("--rca", "1")):
+        dev = _call(pre + ".aug.gfa", pre + ".gtf", {}, flags)
+        assert dev.returncode == 0, dev.stderr.decode()[-3000:]
+        assert b"tags of the S / L lines (for call)" in dev.stderr, dev.stderr.decode()[-3000:]
+        assert b"tag scan" in dev.stderr
+        host = _call(pre + ".aug.gfa", pre + ".gtf", {"PANTAS_CALL_TAGS_HOST": "1"}, flags)
+        assert host.returncode == 0, host.stderr.decode()[-3000:]
+        assert dev.stdout == host.stdout and dev.stdout.count(b"\n") > 1000
+        plain = _call(pre + ".aug.gfa", pre + ".gtf", {"PANTAS_GFA_LOADER": "host"}, flags)
+        assert plain.returncode == 0 and plain.stdout == dev.stdout
+    # tags of other forms: ints python takes and the plain scan does not ('+', '_', leading zeros are fine for both), a tag without its
+    # second ':', an int that is none, a hist value with an empty piece -- equal output or equal failure, with and without the device scan
+    text = open(pre + ".aug.gfa").read().split("\n")
+    s_at = [i for i, l in enumerate(text) if l.startswith("S") and "EX:Z:" in l][50]
+    l_at = [i for i, l in enumerate(text) if l.startswith("L") and "JN:Z:" in l][20]
+    import re
+    variants = {
+        "plus_int": (s_at, lambda l: re.sub(r"NC:i:(\d+)", r"NC:i:+\1", l)),
+        "underscore_int": (l_at, lambda l: re.sub(r"RC:i:(\d+)", r"RC:i:0_\1", l) if re.search(r"RC:i:\d", l) else l + "\tRC:i:1_0"),
+        "two_fields": (s_at, lambda l: l + "\tXX:Z"),
+        "bad_int": (l_at, lambda l: l + "\tRC:i:12x"),
+        "hist_empty_piece": (s_at, lambda l: l + "\tIL:Z:3..4"),
+        "later_nc_wins": (s_at, lambda l: l + "\tNC:i:77"),
+        "four_fields": (l_at, lambda l: l + "\tJN:Z:a:b"),
+    }
+    for name, (at, fn) in variants.items():
+        t = list(text)
+        t[at] = fn(t[at])
+        p = str(tmp_path / f"{name}.gfa")
+        open(p, "w").write("\n".join(t))
+        dev = _call(p, pre + ".gtf", {})
+        host = _call(p, pre + ".gtf", {"PANTAS_GFA_LOADER": "host"})
+        assert dev.returncode == host.returncode, (name, dev.stderr.decode()[-1500:], host.stderr.decode()[-1500:])
+        assert dev.stdout == host.stdout, name
+        if dev.returncode != 0:
+            last = lambda r: [l for l in r.stderr.decode().splitlines() if l and not l.startswith("[timing]")][-1]
+            assert last(dev) == last(host), name
