@@ -240,6 +240,7 @@ struct InternChunk {
   std::vector<uint32_t> to_global;   // filled by merge_interned
 };
 std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& ck, unsigned threads) {
+  PhaseTimer mt("merge_interned");
   const size_t C = ck.size();
   size_t total_local = 0;
   for (const InternChunk& k : ck) total_local += k.span.size();
@@ -252,6 +253,7 @@ std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& c
       for (size_t i = 0; i < ck[c].span.size(); ++i) hash[c][i] = std::hash<std::string_view>{}(sv_of(ck[c].span[i]));
     }
   });
+  mt.lap("hashes");
   struct Entry { StrRef span; uint64_t place; uint32_t id; };
   std::vector<std::unordered_map<std::string_view, uint32_t>> maps(S);
   std::vector<std::vector<Entry>> entries(S);
@@ -267,6 +269,7 @@ std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& c
         }
     }
   });
+  mt.lap("shard maps");
   // distinct strings by the place they were first seen
   std::vector<size_t> ebase(S + 1, 0);
   for (unsigned sh = 0; sh < S; ++sh) ebase[sh + 1] = ebase[sh] + entries[sh].size();
@@ -292,6 +295,7 @@ std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& c
       cut.swap(next);
     }
   }
+  mt.lap("order by first place");
   std::vector<StrRef> global(D);
   parallel_chunks(D, D < par_min(65536) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
     for (size_t r = b; r < e; ++r) {
@@ -311,6 +315,7 @@ std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& c
       }
     }
   });
+  mt.lap("ids back to the chunks");
   return global;
 }
 
