@@ -235,85 +235,79 @@ void parse_gtf(const MappedFile& f, Gtf& gtf, CallTables& t, unsigned threads = 
 // in the order it met them; chunks are in file order.  One pass per distinct string on one thread was 1.3 s for the 4e6 EX
 // tags of a whole-genome graph; here the strings are dealt to shards by hash, every shard (one thread each) walks the
 // chunks in order and keeps the first place it saw each of its strings, the places are sorted, and the rank is the id.
+// 64-bit mix over bytes: "the same GTF" for CallTables::Reusable, the keys of merge_interned
+static uint64_t bytes_hash(const char* p, size_t n) {
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+  }
+  for (; i < n; ++i) h = (h ^ uint8_t(p[i])) * 0x100000001B3ull;
+  return h;
+}
+
 struct InternChunk {
   std::vector<StrRef> span;          // local id -> text (offsets into `base`), in local first-appearance order
   std::vector<uint32_t> to_global;   // filled by merge_interned
 };
 std::vector<StrRef> merge_interned(const char* base, std::vector<InternChunk>& ck, unsigned threads) {
+  // Sort-based (round 3; the first form dealt the strings to per-thread hash maps: 0.9 s for the 2e6 distinct EX tags of a
+  // whole-genome graph, most of it cache misses of the maps): every local string as {hash, place}, sorted by hash -- equal
+  // hashes by the strings themselves, then by place --, so that the copies of a string stand together, the first of them being its
+  // first appearance; the first appearances sorted by place give the ids.
   PhaseTimer mt("merge_interned");
   const size_t C = ck.size();
-  size_t total_local = 0;
-  for (const InternChunk& k : ck) total_local += k.span.size();
-  const unsigned S = total_local < par_min(size_t(1) << 16) ? 1u : std::max(1u, threads);
+  std::vector<size_t> cbase(C + 1, 0);
+  for (size_t c = 0; c < C; ++c) cbase[c + 1] = cbase[c] + ck[c].span.size();
+  const size_t N = cbase[C];
   auto sv_of = [&](const StrRef& r) { return std::string_view(base + r.off, r.len); };
-  std::vector<std::vector<uint64_t>> hash(C);
+  struct Item { uint64_t hash, place; };      // place = chunk << 32 | local id: the order of first appearance
+  RawVector<Item> it(N);
   parallel_chunks(C, unsigned(std::min<size_t>(C, threads ? threads : 1)), [&](unsigned, size_t cb, size_t ce) {
-    for (size_t c = cb; c < ce; ++c) {
-      hash[c].resize(ck[c].span.size());
-      for (size_t i = 0; i < ck[c].span.size(); ++i) hash[c][i] = std::hash<std::string_view>{}(sv_of(ck[c].span[i]));
-    }
+    for (size_t c = cb; c < ce; ++c)
+      for (size_t i = 0; i < ck[c].span.size(); ++i) it[cbase[c] + i] = Item{bytes_hash(base + ck[c].span[i].off, ck[c].span[i].len), (uint64_t(c) << 32) | uint64_t(i)};
   });
   mt.lap("hashes");
-  struct Entry { StrRef span; uint64_t place; uint32_t id; };
-  std::vector<std::unordered_map<std::string_view, uint32_t>> maps(S);
-  std::vector<std::vector<Entry>> entries(S);
-  parallel_chunks(S, S, [&](unsigned, size_t sb, size_t se) {
-    for (size_t sh = sb; sh < se; ++sh) {
-      auto& m = maps[sh];
-      auto& ev = entries[sh];
-      for (size_t c = 0; c < C; ++c)
-        for (size_t i = 0; i < ck[c].span.size(); ++i) {
-          if (hash[c][i] % S != sh) continue;
-          auto ins = m.emplace(sv_of(ck[c].span[i]), uint32_t(ev.size()));
-          if (ins.second) ev.push_back(Entry{ck[c].span[i], (uint64_t(c) << 32) | uint64_t(i), 0u});
-        }
-    }
-  });
-  mt.lap("shard maps");
-  // distinct strings by the place they were first seen
-  std::vector<size_t> ebase(S + 1, 0);
-  for (unsigned sh = 0; sh < S; ++sh) ebase[sh + 1] = ebase[sh] + entries[sh].size();
-  const size_t D = ebase[S];
-  if (D >= size_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 distinct tags");
-  std::vector<std::pair<uint64_t, uint32_t>> order(D);      // (place, shard-major index)
-  parallel_chunks(S, S, [&](unsigned, size_t sb, size_t se) {
-    for (size_t sh = sb; sh < se; ++sh)
-      for (size_t k = 0; k < entries[sh].size(); ++k) order[ebase[sh] + k] = {entries[sh][k].place, uint32_t(ebase[sh] + k)};
-  });
+  auto span_at = [&](uint64_t place) -> const StrRef& { return ck[size_t(place >> 32)].span[size_t(place & 0xFFFFFFFFull)]; };
+  par_sort(it.begin(), it.end(), [&](const Item& a, const Item& b) {
+    if (a.hash != b.hash) return a.hash < b.hash;
+    const std::string_view x = sv_of(span_at(a.place)), y = sv_of(span_at(b.place));
+    if (x != y) return x < y;                  // (two strings of one hash: apart)
+    return a.place < b.place;
+  }, N < par_min(size_t(1) << 16) ? 1u : threads);
+  mt.lap("sorted by hash");
+  // group heads: the first copy of every distinct string (smallest place of its group)
+  RawVector<uint32_t> group(N);              // item -> index of its group among the heads, in sorted order
+  std::vector<std::pair<uint64_t, uint32_t>> heads;      // (place of the first appearance, group)
   {
-    // every shard's run is sorted already (chunks in order, local ids in order): sort runs in parallel, then merge pairwise
-    std::vector<size_t> cut(ebase);
-    while (cut.size() > 2) {
-      std::vector<size_t> next;
-      const size_t pairs = (cut.size() - 1) / 2;
-      parallel_chunks(pairs, unsigned(std::min<size_t>(pairs, threads ? threads : 1)), [&](unsigned, size_t pb, size_t pe) {
-        for (size_t q = pb; q < pe; ++q)
-          std::inplace_merge(order.begin() + long(cut[2 * q]), order.begin() + long(cut[2 * q + 1]), order.begin() + long(cut[2 * q + 2]));
-      });
-      for (size_t q = 0; q < cut.size(); q += 2) next.push_back(cut[q]);
-      if (next.back() != D) next.push_back(D);
-      cut.swap(next);
-    }
+    RawVector<uint8_t> is_head(N);
+    parallel_chunks(N, N < par_min(65536) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t k = b; k < e; ++k)
+        is_head[k] = k == 0 || it[k].hash != it[k - 1].hash || sv_of(span_at(it[k].place)) != sv_of(span_at(it[k - 1].place));
+    });
+    size_t d = 0;
+    for (size_t k = 0; k < N; ++k) { d += is_head[k]; group[k] = uint32_t(d - 1); }
+    heads.resize(d);
+    parallel_chunks(N, N < par_min(65536) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+      for (size_t k = b; k < e; ++k) if (is_head[k]) heads[group[k]] = {it[k].place, group[k]};
+    });
   }
+  const size_t D = heads.size();
+  if (D >= size_t(CNONE)) throw Error("Unsupported", "more than 2^32-2 distinct tags");
+  par_sort(heads.begin(), heads.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; },
+           D < par_min(size_t(1) << 16) ? 1u : threads);
   mt.lap("order by first place");
   std::vector<StrRef> global(D);
+  std::vector<uint32_t> id_of_group(D);
   parallel_chunks(D, D < par_min(65536) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
-    for (size_t r = b; r < e; ++r) {
-      const uint32_t flat = order[r].second;
-      const size_t sh = size_t(std::upper_bound(ebase.begin(), ebase.end(), size_t(flat)) - ebase.begin()) - 1;
-      Entry& en = entries[sh][flat - ebase[sh]];
-      en.id = uint32_t(r);
-      global[r] = en.span;
-    }
+    for (size_t r = b; r < e; ++r) { id_of_group[heads[r].second] = uint32_t(r); global[r] = span_at(heads[r].first); }
   });
-  parallel_chunks(C, unsigned(std::min<size_t>(C, threads ? threads : 1)), [&](unsigned, size_t cb, size_t ce) {
-    for (size_t c = cb; c < ce; ++c) {
-      ck[c].to_global.resize(ck[c].span.size());
-      for (size_t i = 0; i < ck[c].span.size(); ++i) {
-        const size_t sh = hash[c][i] % S;
-        ck[c].to_global[i] = entries[sh][maps[sh].find(sv_of(ck[c].span[i]))->second].id;
-      }
-    }
+  for (size_t c = 0; c < C; ++c) ck[c].to_global.resize(ck[c].span.size());
+  parallel_chunks(N, N < par_min(65536) ? 1u : threads, [&](unsigned, size_t b, size_t e) {
+    for (size_t k = b; k < e; ++k) ck[size_t(it[k].place >> 32)].to_global[size_t(it[k].place & 0xFFFFFFFFull)] = id_of_group[group[k]];
   });
   mt.lap("ids back to the chunks");
   return global;
@@ -331,20 +325,6 @@ void build_call_tables(const Graph& g, const char* gtf_path, CallTables& t, unsi
   MappedFile f;
   f.open(gtf_path);
   build_call_tables_mem(g, f.data, f.size, t, threads);
-}
-
-// 64-bit mix over the bytes of the GTF: "the same GTF" for CallTables::Reusable
-static uint64_t bytes_hash(const char* p, size_t n) {
-  uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
-  size_t i = 0;
-  for (; i + 8 <= n; i += 8) {
-    uint64_t w;
-    memcpy(&w, p + i, 8);
-    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
-    h ^= h >> 32;
-  }
-  for (; i < n; ++i) h = (h ^ uint8_t(p[i])) * 0x100000001B3ull;
-  return h;
 }
 
 void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size, CallTables& t, unsigned threads,
