@@ -342,6 +342,7 @@ struct AggSink {
   uint4* lq = nullptr;
   uint32_t* lq_n = nullptr;
   static constexpr uint32_t LQ_CAP = 512;
+  uint32_t wab = 0;             // ablation bits of the ABL instance of augment_short_w_kernel (0 elsewhere: the tests fold away)
 
   // link (a, b) that is not in the graph: aggregate in LDS, else straight to the global table
   __device__ __forceinline__ void novel(uint32_t a, uint32_t b, uint64_t order) const {
@@ -516,12 +517,15 @@ struct AggSink {
     novel(a, b, order);
   }
   __device__ __forceinline__ void link_later(uint32_t a, uint32_t b, uint64_t order) const {
+    if (wab & 32u) return;
     const uint32_t i = __hip_atomic_fetch_add(lq_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (i < LQ_CAP) lq[i] = make_uint4(a, b, uint32_t(order), uint32_t(order >> 32));
     else link_direct(a, b, order);
   }
   // one kept node: NC + 1, IL[0] / OL[len] + steps, one hit on out-slot code - 1 (code 1 .. 3), first-seen order of a flagged side
   __device__ __forceinline__ void bump_w(uint32_t n, uint32_t flags, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
+    if (wab & 256u) { if ((n ^ flags ^ line_id ^ a_il ^ a_ol ^ code) == 0x12345677u) ncnt[0] = 1; return; }
+    if (wab & 512u) { const uint32_t hh = probe<LOG_N>(nkey, n); if (hh != LDS_EMPTY) atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + hh, 1ull | (uint64_t(a_il) << 16) | (uint64_t(a_ol) << 32) | (uint64_t(code == 1u) << 48)); return; }
     const bool f_il = a_il && (flags & FLAG_IL), f_ol = a_ol && (flags & FLAG_OL);
     const uint32_t h = probe<LOG_N>(nkey, n);
     if (h != LDS_EMPTY) {
@@ -746,9 +750,12 @@ struct ShortSinkW {
   __device__ __forceinline__ void later(uint32_t a, uint32_t b, uint32_t idx) const { s.link_later(a, b, event_order(line_id, idx, 0)); }
 };
 
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint32_t MINW, int PF>
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint32_t MINW, int PF, bool ABL = false>
 __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   GraphView g = g_in;
+  // timing-only ablations (PANTAS_ABLATE, tools/w_ablate_pmc.sh; results wrong by construction) exist in the ABL instance only:
+  // 32 nothing queued, 512 a kept node is one probe and one 64-bit atomic, 256 a kept node is nothing (32 + 256: the bare walk)
+  const uint32_t wab = ABL ? g.ablate : 0u;
   g.ablate = 0u;
   constexpr uint32_t LOG_S = 8;       // slot table of the queued links only
   using Sink = AggSink<LOG_N, LOG_S, LOG_F, true>;
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphVie
     if (threadIdx.x == 0) lq_n = 0u;
     __syncthreads();
     Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin, nullptr, nullptr};
-    sink.ncnt2 = ncnt2; sink.lq = lq; sink.lq_n = &lq_n;
+    sink.ncnt2 = ncnt2; sink.lq = lq; sink.lq_n = &lq_n; sink.wab = wab;
     const DevInfo ga{g};
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
@@ -1493,7 +1500,12 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else {
-      if (g.ablate) {
+      if (g.ablate && variant >= 110) {
+        // timing experiments on the round-3 kernel: its ABL instance (the general class is not launched: no such records in the workloads)
+        if (b.n_short) hipLaunchKernelGGL((augment_short_w_kernel<512, 2048, 10, 7, 8, 1, true>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
+        HIP_OK(hipEventRecord(d.ev[3], d.stream));
+        split = true;
+      } else if (g.ablate) {
         // timing experiments: the default pair of kernels with the ablation switches compiled in, one after the other
         PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2, true, true);
         HIP_OK(hipEventRecord(d.ev[3], d.stream));
