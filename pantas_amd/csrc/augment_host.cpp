@@ -1,4 +1,5 @@
 #include "augment.h"
+#include <sys/mman.h>
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -214,6 +215,7 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
   const uint64_t bound = uint64_t(size) + 61ull * g.n_s_lines + 16ull * g.n_l_lines + 24ull * r.hist.size() + tail.size() + 4096;
   OrderedOutput sink(fd, n_pieces + 1, uint64_t(size) + uint64_t(size) / 4 + tail.size(), bound);
   const unsigned T = unsigned(std::min<size_t>(std::max<size_t>(n_pieces, 1), threads));
+  const bool drop_text = g.text.fd >= 0 && !g.text.borrowed && g.text_owned.empty() && size >= (size_t(1) << 30) && !getenv("PANTAS_KEEP_TEXT_MAPPED");
   std::atomic<size_t> next{0};
   std::atomic<bool> failed{false};
   std::shared_ptr<Error> first_err;
@@ -226,6 +228,12 @@ void write_augmented_gfa(const Graph& g, const AugmentResult& r, int fd, unsigne
       try {
         buf.clear();
         if (!failed.load(std::memory_order_relaxed)) format_range(g, r, has_hist, cut[p], cut[p + 1], buf);
+        // this stretch of the mapped text has been read for the last time: its page-table entries go now, by the thread that is about
+        // to wait for the writer anyway, instead of all 23 GB of them at exit, where nothing runs beside it (profiles/r2_exit_probe.txt)
+        if (drop_text) {
+          const uintptr_t page = 4096, b0 = (uintptr_t(g.text.data) + cut[p] + page - 1) / page * page, b1 = (uintptr_t(g.text.data) + cut[p + 1]) / page * page;
+          if (b1 > b0) (void)madvise(reinterpret_cast<void*>(b0), b1 - b0, MADV_DONTNEED);
+        }
       } catch (const Error& e) {
         std::lock_guard<std::mutex> lk(err_mu);
         if (!first_err) first_err = std::make_shared<Error>(e);
