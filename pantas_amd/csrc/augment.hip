@@ -526,7 +526,9 @@ struct AggSink {
   __device__ __forceinline__ void bump_w(uint32_t n, uint32_t flags, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
     if (wab & 256u) { if ((n ^ flags ^ line_id ^ a_il ^ a_ol ^ code) == 0x12345677u) ncnt[0] = 1; return; }
     if (wab & 512u) { const uint32_t hh = probe<LOG_N>(nkey, n); if (hh != LDS_EMPTY) atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + hh, 1ull | (uint64_t(a_il) << 16) | (uint64_t(a_ol) << 32) | (uint64_t(code == 1u) << 48)); return; }
-    const bool f_il = a_il && (flags & FLAG_IL), f_ol = a_ol && (flags & FLAG_OL);
+    // (most nodes carry no flag: one test in front of the two per side)
+    bool f_il = false, f_ol = false;
+    if (flags) { f_il = a_il && (flags & FLAG_IL); f_ol = a_ol && (flags & FLAG_OL); }
     const uint32_t h = probe<LOG_N>(nkey, n);
     if (h != LDS_EMPTY) {
       const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) | (static_cast<unsigned long long>(a_ol) << 32) |
