@@ -53,7 +53,7 @@ void pantas_device_init(int device);
  * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
  * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
  * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
-#define PANTAS_ABI_VERSION 4
+#define PANTAS_ABI_VERSION 5
 int pantas_abi_version(void);
 
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
@@ -84,6 +84,12 @@ void pantas_graph_free(pantas_graph* g);
 int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out);
 /* copies node_len / row_ptr / col to the HBM of `device` and allocates the counters */
 int pantas_graph_to_device(pantas_graph* g, int device);
+/* Gives the handle's device memory back (graph arrays, resident batches, call tables, what the GPU loader left parked) while the
+ * host side stays: a finished augment run can still be written (pantas_augment_write_gfa), pantas_graph_to_device brings the
+ * graph back.  For a process that has an output file of tens of GB to write after its last kernel: memory freed at exit is
+ * scrubbed by the driver while the NEXT process waits for its first large hipMalloc (2 - 3 s after a whole-genome run); freed
+ * here, that happens beside the writing.  (ABI 5; the reference has no counterpart.) */
+int pantas_graph_release_device(pantas_graph* g);
 
 /* ---- augment: alignments_augmentation_from_gaf.py main() :110-427 ------------------------- */
 typedef struct {

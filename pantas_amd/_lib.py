@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 4      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
+ABI_VERSION = 5      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
 
@@ -121,6 +121,7 @@ def _load():
         "pantas_device_init": (None, [i32]),
         "pantas_graph_load": (i32, [C.c_char_p, P(vp)]),
         "pantas_graph_load_for_call": (i32, [C.c_char_p, P(vp)]),
+        "pantas_graph_release_device": (i32, [vp]),
         "pantas_graph_free": (None, [vp]),
         "pantas_graph_get_stats": (i32, [vp, P(GraphStats)]),
         "pantas_graph_to_device": (i32, [vp, i32]),

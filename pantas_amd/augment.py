@@ -41,6 +41,7 @@ def main(argv) -> int:
         print(f"Rejected alignments: {bs.rejected}", file=sys.stderr)
         print("Annotating GFA", file=sys.stderr)
         sys.stdout.flush()
+        g.release_device()      # the device's part is over: its memory is scrubbed beside the writing, not in front of the next process
         g.write_gfa(sys.stdout.fileno())
         _lap("GFA written")
     except PantasError as e:

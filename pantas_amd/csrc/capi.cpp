@@ -237,9 +237,21 @@ __attribute__((visibility("default"))) int pantas_graph_load_cached(const char* 
   });
 }
 
+__attribute__((visibility("default"))) int pantas_graph_release_device(pantas_graph* g) {
+  return guarded([&] {
+    need(g, "null argument");
+    g->stream.reset();
+    g->xchg.reset();
+    g->call_dev.reset();
+    g->dev.reset();
+    release_parked_device_memory();
+  });
+}
+
 __attribute__((visibility("default"))) void pantas_graph_free(pantas_graph* g) {
   release_deferred();      // nothing parked outlives the handle it came from
   delete g;
+  release_parked_device_memory();
 }
 
 __attribute__((visibility("default"))) int pantas_graph_get_stats(const pantas_graph* g, pantas_graph_stats* out) {

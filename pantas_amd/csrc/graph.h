@@ -95,6 +95,8 @@ std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
 // small file, names that are no decimals in a dense range, duplicate or whitespace-led S lines, lone carriage returns -- which the
 // host loader then takes.
 std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call_tags = false);
+// the device memory of finished loads is parked, not freed (tokenize.hip): given back here
+void release_parked_device_memory();
 // Same over text already in memory (the buffer must outlive the graph).
 std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads = 0);
 

@@ -1473,18 +1473,38 @@ __global__ void __launch_bounds__(TPB) gfa_in_kernel(uint32_t A, const uint32_t*
   islot[q] = slot_of[f];
 }
 
+// Device memory a load is done with is PARKED, not freed: on this driver a hipMalloc that is handed recently freed (and written)
+// memory waits for it to be scrubbed -- 16 GB: 1.9 s, 36 GB in eight blocks: 2.7 - 3.0 s, where fresh memory takes a millisecond
+// (tools/hipmalloc_probe.hip, profiles/r3_hipmalloc_probe.txt) -- and the loader's 60 - 85 GB were freed right in front of the
+// hipMalloc of the graph arrays (1.6 s on some runs) and, half way through, of its own CSR buffers (1.1 - 1.3 s).  With 288 GB of
+// HBM the blocks simply stay allocated until the handle they were made for is freed (release_parked_device_memory, capi.cpp)
+// or the process ends; beyond 40 % of the device's memory they are freed at once.
+std::mutex g_park_mu;
+std::vector<void*> g_parked;
+size_t g_parked_bytes = 0;
+void park_or_free(void* p, size_t bytes) {
+  if (!p) return;
+  size_t free_b = 0, total_b = 0;
+  const bool keep = !getenv("PANTAS_FREE_DEVICE_AT_ONCE") && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+  std::lock_guard<std::mutex> lk(g_park_mu);
+  if (keep && g_parked_bytes + bytes <= total_b / 5 * 2) { g_parked.push_back(p); g_parked_bytes += bytes; }
+  else (void)hipFree(p);
+}
+
 struct DevMem {                      // plain device allocations of one load (there is no DeviceGraph and no pool yet)
-  std::vector<void*> all;
-  ~DevMem() { for (void* p : all) (void)hipFree(p); }
+  std::vector<std::pair<void*, size_t>> all;
+  ~DevMem() { for (auto& b : all) park_or_free(b.first, b.second); }
   template <class X> X* get(size_t n) {
     void* p = nullptr;
-    HIP_OK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(X)));
-    all.push_back(p);
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(X);
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      release_parked_device_memory();          // (out of memory with blocks parked: give them back and try once more)
+      HIP_OK(hipMalloc(&p, bytes));
+    }
+    all.emplace_back(p, bytes);
     return static_cast<X*>(p);
   }
-  void drop(void* p) {
-    for (size_t i = 0; i < all.size(); ++i) if (all[i] == p) { (void)hipFree(p); all.erase(all.begin() + long(i)); return; }
-  }
+  void drop(void*) {}                // (parked with the rest when the load ends: see above)
 };
 
 template <class X>
@@ -1496,6 +1516,16 @@ void scan_u32(DevMem& m, const uint32_t* in, uint32_t* out, size_t n_plus_1, hip
 }
 
 }  // namespace
+
+void release_parked_device_memory() {
+  std::vector<void*> todo;
+  {
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    todo.swap(g_parked);
+    g_parked_bytes = 0;
+  }
+  for (void* p : todo) (void)hipFree(p);
+}
 
 // nullptr: not a graph for the device form (or no device) -- the caller takes the host loader
 std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call_tags) {

@@ -58,6 +58,10 @@ class Graph:
         self._h = h
         self.path = gfa_path
 
+    def release_device(self):
+        """Give the device memory of this handle back; host results (a finished augment run) stay."""
+        check(lib.pantas_graph_release_device(self._h))
+
     def close(self):
         if self._h:
             lib.pantas_graph_free(self._h)

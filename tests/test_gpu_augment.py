@@ -163,3 +163,23 @@ def test_sharded_driver_two_ranks_one_parses_the_graph(tmp_path):
     assert f"Rejected alignments: {json.load(open(f'{d}/expected.json'))['rejected']}" in r.stderr
     # one rank read the text, the other the cache it left (graph_cache.cpp prints which under PANTAS_TIMING)
     assert r.stderr.count("graph cache: loaded") >= 1, r.stderr[-3000:]
+
+
+def test_release_device_keeps_the_finished_run(tmp_path):
+    """pantas_graph_release_device (ABI 5): the device memory goes back after the last kernel, the finished run can still be written,
+    and the graph can go back to the device for another run"""
+    import tempfile
+    from pantas_amd.engine import Graph
+    d = os.path.join(GOLDEN, "synth_b")
+    g = Graph(f"{d}/in.gfa").to_device(0)
+    g.augment(f"{d}/in.gaf", 20, -1)
+    g.release_device()
+    with tempfile.TemporaryFile() as f:
+        g.write_gfa(f.fileno())
+        f.seek(0)
+        assert f.read().decode() == open(f"{d}/expected.aug.gfa").read()
+    g.to_device(0)
+    with tempfile.TemporaryFile() as f:
+        g.augment(f"{d}/in.gaf", 20, f.fileno())
+        f.seek(0)
+        assert f.read().decode() == open(f"{d}/expected.aug.gfa").read()

@@ -23,5 +23,28 @@ int main() {
     printf("%3d x %6.2f GB: hipMalloc %8.3f ms (%.3f ms/GB), first touch %7.3f ms, hipFree %8.3f ms\n", c.n, c.bytes / double(GB), (t1 - t0) * 1e3,
            (t1 - t0) * 1e3 / (c.n * c.bytes / double(GB)), (t2 - t1) * 1e3, (t3 - t2) * 1e3);
   }
+  // the pattern of the GFA loader: tens of GB allocated, WRITTEN, freed -- and then the next allocations
+  for (int rep = 0; rep < 3; ++rep) {
+    std::vector<void*> p(6);
+    const size_t sz[6] = {23 * GB, 4 * GB, 8 * GB, 2 * GB, 2 * GB, 6 * GB};
+    double t0 = now();
+    for (int i = 0; i < 6; ++i) hipMalloc(&p[i], sz[i]);
+    double t1 = now();
+    for (int i = 0; i < 6; ++i) hipMemsetAsync(p[i], 1, sz[i], nullptr);
+    hipDeviceSynchronize();
+    double t2 = now();
+    for (int i = 0; i < 6; ++i) hipFree(p[i]);
+    double t3 = now();
+    void* q[8];
+    for (int i = 0; i < 8; ++i) hipMalloc(&q[i], (i + 1) * GB);
+    double t4 = now();
+    for (int i = 0; i < 8; ++i) hipMemsetAsync(q[i], 2, (i + 1) * GB, nullptr);
+    hipDeviceSynchronize();
+    double t5 = now();
+    for (int i = 0; i < 8; ++i) hipFree(q[i]);
+    double t6 = now();
+    printf("45 GB: hipMalloc %.1f ms, written in %.1f ms, hipFree %.1f ms; then 36 GB in 8 blocks: hipMalloc %.1f ms, written in %.1f ms, hipFree %.1f ms\n",
+           (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, (t6 - t5) * 1e3);
+  }
   return 0;
 }
