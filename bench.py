@@ -560,6 +560,13 @@ def main():
                                                 if stats[0].tokenizer == 2 else None)},
         })
         if keep_for_e2e:
+            # The command lines are timed as processes of their own.  This process gives its device memory back first and waits for the
+            # driver to scrub it (freed memory is wiped before it is handed out again, and the hipMalloc that gets it waits: 16 GB 1.9 s,
+            # tools/hipmalloc_probe.hip) -- otherwise the children's first allocations would pay for what THIS process held.
+            for b in batches:
+                b.free()
+            g.release_device()
+            time.sleep(6.0)
             out["e2e"] = e2e_leg(syns, scale, kw, with_cache=not args.no_e2e_cache)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(kw, args.cpu_sample, lines, syn.stats.junction_links)

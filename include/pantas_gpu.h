@@ -254,7 +254,9 @@ typedef struct {
   uint32_t shard_rank;    /* multi-GPU: evaluate every shard_world-th junction / novel link, starting at */
   uint32_t shard_world;   /* shard_rank (0 or 1 = everything); rows of all shards together = the full CSV */
   int32_t debug;          /* --debug: the reference's "Checking ..." lines (call.py:254,317,...,1002) to fd_err */
-  int32_t reserved1_;
+  int32_t release_device; /* nonzero (ABI 5): the handle's device memory is given back as soon as the kernels' results are on the host, before the
+                           * rows are rendered and written -- what pantas_graph_release_device does, in the one place a caller cannot reach; the
+                           * handle then needs pantas_call_prepare before another pantas_call_run */
 } pantas_call_opts;
 
 typedef struct {

@@ -77,7 +77,7 @@ class AllreduceStats(_Sized):
 class CallOpts(_Sized):
     _fields_ = _HEAD + [("rca", C.c_int32), ("isw", C.c_int32), ("minintronsize", C.c_int32), ("events", C.c_uint32),
                 ("novel", C.c_int32), ("no_annotated", C.c_int32), ("junction", C.c_char_p),
-                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("debug", C.c_int32), ("reserved1_", C.c_int32)]
+                ("shard_rank", C.c_uint32), ("shard_world", C.c_uint32), ("debug", C.c_int32), ("release_device", C.c_int32)]
 
 
 class CallStats(_Sized):

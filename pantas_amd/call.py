@@ -69,7 +69,8 @@ def run(args) -> int:
         sys.stderr.flush()
         g.call(sys.stdout.fileno(), sys.stderr.fileno(), rca=args.rca, novel=args.novel,
                no_annotated=args.annotated, events=args.events, isw=args.isw,
-               minintronsize=args.minintronsize, junction=args.junction, debug=args.debug)
+               minintronsize=args.minintronsize, junction=args.junction, debug=args.debug,
+               release_device=True)     # one run, then exit: the device memory is scrubbed beside the rendering, not in front of the next process
         _lap("events written")
     except PantasError as e:
         print(f"{e.kind}: {e}", file=sys.stderr)

@@ -1026,6 +1026,10 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
     CallOutput co;
     CallTimes times;
     run_call(*g->call_dev, *g->g, *g->call_tables, o, co, times);
+    if (opts->release_device) {       // (see pantas_graph_release_device: scrubbed beside the rendering, not in front of the next process)
+      g->stream.reset(); g->xchg.reset(); g->call_dev.reset(); g->dev.reset();
+      release_parked_device_memory();
+    }
     const RawVector<EventRec>& recs = co.recs;
     double t0 = now_s();
     // the reference prints rows as it finds them and dies on an input it cannot handle; here nothing may reach stdout

@@ -278,13 +278,13 @@ class Graph:
 
     def call(self, fd_csv: int = -1, fd_err: int = -1, rca: int = -1, novel: bool = False,
              no_annotated: bool = False, events=("ES", "SS", "IR"), isw: int = 5, minintronsize: int = 100,
-             junction=None, shard=(0, 1), debug: bool = False) -> CallStats:
+             junction=None, shard=(0, 1), debug: bool = False, release_device: bool = False) -> CallStats:
         mask = 0
         for e in events:
             mask |= {"ES": 1, "SS": 2, "IR": 4}.get(e, 0)
         o = CallOpts(rca=rca, isw=isw, minintronsize=minintronsize, events=mask, novel=int(bool(novel)),
                      no_annotated=int(bool(no_annotated)), junction=None if junction is None else os.fsencode(junction),
-                     shard_rank=shard[0], shard_world=shard[1], debug=int(bool(debug)))
+                     shard_rank=shard[0], shard_world=shard[1], debug=int(bool(debug)), release_device=int(bool(release_device)))
         st = CallStats()
         check(lib.pantas_call_run(self._h, C.byref(o), fd_csv, fd_err, C.byref(st)))
         return st

@@ -153,3 +153,26 @@ def test_sharded_call_driver_nccl_single_rank(tmp_path):
     assert rows[0] == call_oracle.HEADER
     gc = [c for c in json.load(open(f"{d}/expected.json"))["calls"] if c["flags"] == flags][0]
     check_rows(rows[1:], gc)
+
+
+def test_release_device_after_the_kernels():
+    """pantas_call_opts.release_device (ABI 5): the same rows, and the handle has to be prepared again before another run"""
+    from pantas_amd.engine import Graph, PantasError
+    d = os.path.join(GOLDEN, "synth_c")
+    g = Graph(f"{d}/expected.aug.gfa")
+    g.call_prepare(f"{d}/in.gtf", 0)
+    with tempfile.TemporaryFile() as f:
+        g.call(f.fileno(), -1, rca=2, novel=True)
+        f.seek(0)
+        want = f.read()
+    with tempfile.TemporaryFile() as f:
+        g.call(f.fileno(), -1, rca=2, novel=True, release_device=True)
+        f.seek(0)
+        assert f.read() == want and want.count(b"\n") > 10
+    with pytest.raises(PantasError):
+        g.call(-1, -1, rca=2, novel=True)
+    g.call_prepare(f"{d}/in.gtf", 0)
+    with tempfile.TemporaryFile() as f:
+        g.call(f.fileno(), -1, rca=2, novel=True)
+        f.seek(0)
+        assert f.read() == want
