@@ -922,12 +922,13 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
     for (uint32_t n = 0; n < V && fixed_width; ++n) fixed_width = g.seg_name_len[n] == w;
   }
   if (fixed_width) {
-    // equal-length canonical decimals: string order == numeric order
-    parallel_chunks(V, V < 4096 ? 1 : threads, [&](unsigned, size_t nb, size_t ne) {
-      for (size_t n = nb; n < ne; ++n) {
-        uint64_t id = 0;
-        parse_canonical_u64(g.name_of(uint32_t(n)), id);
-        t.rank[n] = uint32_t(id - g.names.base);
+    // equal-length canonical decimals: string order == numeric order, and a name's number is its place in the dense name table
+    // (read from there: parsing 2.5e8 names back out of the text cost 0.18 s of cache misses)
+    const size_t TS = g.names.table.size();
+    parallel_chunks(TS, TS < 4096 ? 1 : threads, [&](unsigned, size_t ib, size_t ie) {
+      for (size_t i = ib; i < ie; ++i) {
+        const uint32_t n = g.names.table[i];
+        if (n != NONE32) t.rank[n] = uint32_t(i);
       }
     });
   } else {
