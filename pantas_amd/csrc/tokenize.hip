@@ -1498,7 +1498,8 @@ struct DevMem {                      // plain device allocations of one load (th
     void* p = nullptr;
     const size_t bytes = std::max<size_t>(n, 1) * sizeof(X);
     if (hipMalloc(&p, bytes) != hipSuccess) {
-      release_parked_device_memory();          // (out of memory with blocks parked: give them back and try once more)
+      (void)hipGetLastError();                 // (the failure is handled here: later checks of the last error must not see it)
+      release_parked_device_memory();          // out of memory with blocks parked: give them back and try once more
       HIP_OK(hipMalloc(&p, bytes));
     }
     all.emplace_back(p, bytes);
