@@ -1166,6 +1166,7 @@ static void table_clear(Table& t, hipStream_t s) {
 DeviceGraphPtr upload_graph(const Graph& g, int device) {
   if (device_count() <= device) throw Error("NoDevice", "no HIP device " + std::to_string(device) + " (the augment kernels have no CPU path)");
   HIP_OK(hipSetDevice(device));
+  release_parked_device_memory_if_low();      // (what the GPU GFA loader left parked must not be why these allocations fail)
   PhaseTimer pt("upload_graph");
   DeviceGraphPtr d(new DeviceGraph());
   d->device = device;

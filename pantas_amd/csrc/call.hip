@@ -269,6 +269,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device)
     throw Error("NoDevice", "no HIP device " + std::to_string(device) + " (the call kernels have no CPU path)");
   HIP_OK(hipSetDevice(device));
+  release_parked_device_memory_if_low();
   PhaseTimer pt("upload_call");
   g_up_malloc_s = g_up_copy_s = 0;
   g_up_bytes = 0;

@@ -1528,6 +1528,13 @@ void release_parked_device_memory() {
   for (void* p : todo) (void)hipFree(p);
 }
 
+// called where the large allocations of a handle are made (graph arrays, call tables): parked blocks must never be the reason
+// one of them fails
+void release_parked_device_memory_if_low() {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total_b / 4) release_parked_device_memory();
+}
+
 // nullptr: not a graph for the device form (or no device) -- the caller takes the host loader
 std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call_tags) {
   int n_dev = 0;
