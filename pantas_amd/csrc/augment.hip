@@ -756,7 +756,9 @@ template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint
 __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphView g_in, BatchView b, uint32_t begin, uint32_t end) {
   GraphView g = g_in;
   // timing-only ablations (PANTAS_ABLATE, tools/w_ablate_pmc.sh; results wrong by construction) exist in the ABL instance only:
-  // 32 nothing queued, 512 a kept node is one probe and one 64-bit atomic, 256 a kept node is nothing (32 + 256: the bare walk)
+  // 32 nothing queued, 512 a kept node is one probe and one 64-bit atomic, 256 a kept node is nothing (32 + 256: the bare walk);
+  // two A/B bits that leave the results right: 1024 every round of a chunk taken the same way round (2.13 against 2.09 ms at S4),
+  // 2048 chunks in launch order instead of dealt to the XCDs in eighths (2.19)
   const uint32_t wab = ABL ? g.ablate : 0u;
   g.ablate = 0u;
   constexpr uint32_t LOG_S = 8;       // slot table of the queued links only
@@ -780,7 +782,8 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphVie
   const uint32_t n_chunks = (end - begin + CHUNK - 1) / CHUNK;
   const uint32_t per_xcd = (n_chunks + 7u) / 8u;       // workgroup w takes chunk (w % 8) * n/8 + w / 8: an XCD walks one contiguous eighth
   for (uint32_t c0 = blockIdx.x; c0 < 8u * per_xcd; c0 += gridDim.x) {
-    const uint32_t c = (c0 & 7u) * per_xcd + (c0 >> 3);
+    uint32_t c = (c0 & 7u) * per_xcd + (c0 >> 3);
+    if (ABL && (wab & 2048u)) c = c0;                      // (A/B: chunks in launch order)
     if (c >= n_chunks) continue;
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       omin[i] = ~0u; omin[CN + i] = ~0u;
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphVie
     const uint32_t lo = begin + c * CHUNK;
     const uint32_t hi = min(end, lo + CHUNK);
     for (uint32_t r0 = lo, round = 0; r0 < hi; r0 += THREADS, ++round) {
-      const uint32_t i = r0 + ((round & 1u) ? THREADS - 1u - threadIdx.x : threadIdx.x);     // odd rounds the other way round (see above)
+      const uint32_t i = r0 + (((round & 1u) && !(ABL && (wab & 1024u))) ? THREADS - 1u - threadIdx.x : threadIdx.x);     // odd rounds the other way round (see above; A/B bit 1024: not)
       if (i >= hi) continue;
       const LineHdr h = b.hdr[i];
       const uint4 r = b.rec[REC_QUADS * size_t(i)], r2 = b.rec[REC_QUADS * size_t(i) + 1], r3 = b.rec[REC_QUADS * size_t(i) + 2];
