@@ -53,7 +53,7 @@ void pantas_device_init(int device);
  * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
  * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
  * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
-#define PANTAS_ABI_VERSION 5
+#define PANTAS_ABI_VERSION 6
 int pantas_abi_version(void);
 
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
@@ -240,6 +240,12 @@ int pantas_augment_run(pantas_graph* g, const char* gaf_path, int thr, int fd_ou
  * to fd_out: the bytes the reference prints (row order, float formatting).  w: -w, both: --both.  Errors carry the class the
  * reference raises (TypeError, ValueError, AttributeError) in pantas_last_error_kind(). */
 int pantas_quant_run(const char* const* c1_paths, const char* const* c2_paths, uint32_t n_replicates, int32_t w, int32_t both, int fd_out);
+
+/* ---- remap: scripts/remap.py main() :29-222 (host code, no device needed; ABI 6) ----
+ * Reference-genome coordinates for the junctions of a `pantas quant` CSV, written as CSV to fd_out: the bytes the reference prints.
+ * min_intron_size: -i (default 100).  Errors carry the class the reference raises (ValueError, IndexError, AttributeError,
+ * AssertionError) in pantas_last_error_kind(); nothing is written then. */
+int pantas_remap_run(const char* csv_path, const char* gtf_path, int64_t min_intron_size, int fd_out);
 
 /* ---- call: scripts/call.py main() :132-1105 ------------------------------------------------ */
 typedef struct {

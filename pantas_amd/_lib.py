@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 5      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
+ABI_VERSION = 6      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
 
@@ -140,6 +140,7 @@ def _load():
         "pantas_counters_pack": (i32, [vp, vp, C.c_uint32, P(vp), P(u64)]),
         "pantas_counters_unpack": (i32, [vp]),
         "pantas_quant_run": (i32, [P(C.c_char_p), P(C.c_char_p), C.c_uint32, i32, i32, i32]),
+        "pantas_remap_run": (i32, [C.c_char_p, C.c_char_p, C.c_int64, i32]),
         "pantas_counters_allreduce": (i32, [vp, P(RcclApi), vp, vp, C.c_uint32, P(AllreduceStats)]),
         "pantas_augment_sparse_count": (i32, [vp, P(u64)]),
         "pantas_augment_sparse_export": (i32, [vp, P(u64), u64]),

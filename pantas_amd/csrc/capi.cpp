@@ -5,6 +5,7 @@
 #include "call.h"
 #include "synth.h"
 #include "quant.h"
+#include "remap.h"
 
 #include <atomic>
 #include <dlfcn.h>
@@ -163,6 +164,12 @@ __attribute__((visibility("default"))) int pantas_quant_run(const char* const* c
       b.emplace_back(c2_paths[i]);
     }
     quant_run(a, b, w, both != 0, fd_out);
+  });
+}
+__attribute__((visibility("default"))) int pantas_remap_run(const char* csv_path, const char* gtf_path, int64_t min_intron_size, int fd_out) {
+  return guarded([&] {
+    need(csv_path && gtf_path, "null argument");
+    remap_run(csv_path, gtf_path, min_intron_size, fd_out);
   });
 }
 __attribute__((visibility("default"))) void pantas_device_warmup(int device) { try { warm_up_device(device); } catch (...) {} }

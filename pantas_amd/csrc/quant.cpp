@@ -544,4 +544,6 @@ void quant_run(const std::vector<std::string>& c1, const std::vector<std::string
   pt.lap("joined, rendered, written");
 }
 
+void py_float_repr(std::string& s, double x) { py_repr(s, x); }
+
 }  // namespace pantas

@@ -1,6 +1,7 @@
 """`pantas remap`: reference-genome coordinates for the junctions of a quantification CSV.
 
-Mirror of the reference's ``scripts/remap.py`` (same command line, columns, row order and number printing).
+Same command line, columns, row order and number printing as the reference's ``scripts/remap.py``: `remap` runs the native form
+(csrc/remap.cpp, `pantas_remap_run`), `remap_python` is the line-by-line mirror the native form is tested against.
 For each of the three junction names of a row the reference transcript copy (``<tid>_R<k>.<exon>[.<exon>]``) is
 looked up in the GTF's exon table (``remap.py:45-63``); one exon index = retained intron reported as the whole
 exon, two = the intron between them (``:118-142``).  Annotated alternative-splice-site rows are put shorter
@@ -96,7 +97,40 @@ def position(name: str, chrom: str, exons_of: dict) -> str:
     return f"{chrom}:{s}-{e}" + ("?" if imprecise else "")
 
 
+_RAISES = {"ValueError": ValueError, "IndexError": IndexError, "AttributeError": AttributeError, "AssertionError": AssertionError,
+           "KeyError": KeyError, "FileNotFoundError": FileNotFoundError, "OSError": OSError}
+
+
 def remap(csv_path: str, gtf_path: str, min_intron_size: int = 100, out=sys.stdout):
+    """the native form in libpantas_gpu (csrc/remap.cpp: rows on all host threads) -- what the command line runs; `remap_python`
+    below is the same computation in the interpreter and what the native code is held to (tests/test_quant_remap.py).
+    PANTAS_REMAP=python runs the interpreted form."""
+    import os
+    if os.environ.get("PANTAS_REMAP") == "python":
+        return remap_python(csv_path, gtf_path, min_intron_size, out)
+    import tempfile
+    from ._lib import PantasError, lib
+    try:
+        fd = out.fileno()
+        direct = True
+    except (AttributeError, OSError, ValueError):
+        direct = False
+    if direct:
+        out.flush()
+        rc = lib.pantas_remap_run(os.fsencode(csv_path), os.fsencode(gtf_path), int(min_intron_size), fd)
+    else:                       # a text stream without a descriptor (tests): through a temporary file
+        with tempfile.TemporaryFile() as f:
+            rc = lib.pantas_remap_run(os.fsencode(csv_path), os.fsencode(gtf_path), int(min_intron_size), f.fileno())
+            f.seek(0)
+            if rc == 0:
+                out.write(f.read().decode())
+    if rc != 0:
+        kind = (lib.pantas_last_error_kind() or b"").decode()
+        msg = (lib.pantas_last_error() or b"").decode()
+        raise _RAISES[kind](msg) if kind in _RAISES else PantasError(rc, kind, msg)
+
+
+def remap_python(csv_path: str, gtf_path: str, min_intron_size: int = 100, out=sys.stdout):
     exons_of = exon_table(csv_path, gtf_path)
     print(HEADER, file=out)
     for fields in data_rows(csv_path):

@@ -75,15 +75,96 @@ def test_quantify_cli_and_unequal_replicates():
     assert r.returncode == META["unequal"]["returncode"] and r.stdout == META["unequal"]["stdout"]
 
 
+@pytest.mark.parametrize("how", ["native", "python"])
 @pytest.mark.parametrize("case", META["remap"], ids=lambda c: c["expected"])
-def test_remap_bytes(case, tmp_path):
+def test_remap_bytes(case, how, tmp_path):
+    """the native form (csrc/remap.cpp, what the command line runs) and the interpreted mirror: the reference's bytes"""
     from pantas_amd import remap
     src = str(tmp_path / case["input"])
     open(src, "w").write(expected(case["input"]))
     out = io.StringIO()
     a = remap.build_parser().parse_args([*case["flags"], src, os.path.join(Q, "anno.gtf")])
-    remap.remap(a.CSV, a.GTF, a.min_intron_size, out)
+    (remap.remap if how == "native" else remap.remap_python)(a.CSV, a.GTF, a.min_intron_size, out)
     assert out.getvalue() == expected(case["expected"])
+
+
+def test_native_remap_equals_the_mirror_on_perturbed_rows(tmp_path):
+    """rows of a golden quantification with their fields disturbed one at a time (names without a reference copy, exon indices out of
+    range or negative, a third index, imprecise haplotype copies on novel rows, swapped junction lengths, dpsi spellings python's
+    float() takes, CRLF line ends, a row too short / too long, GTF lines without transcript_id): the native form prints what the mirror
+    prints or raises what it raises, on one thread's worth of rows and on a file large enough to be cut into chunks"""
+    import random
+    from pantas_amd import remap
+    rows = expected("quant_0_3.csv").splitlines()
+    header, data = rows[0], rows[1:]
+    gtf = os.path.join(Q, "anno.gtf")
+    rng = random.Random(5)
+
+    def run(fn, path, gtf_path=gtf, i=100):
+        out = io.StringIO()
+        try:
+            fn(path, gtf_path, i, out)
+            return ("ok", out.getvalue())
+        except Exception as e:      # noqa: BLE001  (the class is what is compared)
+            return (type(e).__name__, None)
+
+    def mutate(fields):
+        k = rng.randrange(14)
+        f = list(fields)
+        j = rng.choice([5, 6, 7])
+        if k == 0: f[j] = "?"
+        elif k == 1: f[j] = f[j].replace("_R", "_H")
+        elif k == 2: f[j] = f[j] + ".3"
+        elif k == 3: f[j] = f[j].split(".")[0] + ".0"
+        elif k == 4: f[j] = f[j].split(".")[0] + ".-1"
+        elif k == 5: f[j] = f[j].split(".")[0] + ".999"
+        elif k == 6: f[j] = f[j].split(".")[0] + ".x"
+        elif k == 7: f[15] = rng.choice(["1e-3", " 0.5 ", "-0.0", "nan", "-inf", "1_0.5", "+.5", "5.", "abc", "1__0", ""])
+        elif k == 8: f[1] = rng.choice(["annotated", "novel"]); f[0] = rng.choice(["ES", "A3", "A5", "IR", "CE", ""])
+        elif k == 9: f[5], f[6] = f[6], f[5]
+        elif k == 10: f[j] = "x_R1_"
+        elif k == 11: f[j] = ""
+        elif k == 12: f[2] = "chr:1"
+        else: f[j] = "noUnderscoreR.1.2"
+        return f
+
+    # single rows: every disturbance alone, result or exception class equal
+    for n in range(400):
+        f = mutate(rng.choice(data).split(","))
+        p = str(tmp_path / "one.csv")
+        open(p, "w").write(header + "\n" + ",".join(f) + "\n")
+        assert run(remap.remap, p) == run(remap.remap_python, p), f
+    for bad in (["a"] * 15, ["a"] * 17, ["a"] * 7, [""]):
+        p = str(tmp_path / "one.csv")
+        open(p, "w").write(header + "\n" + data[0] + "\n" + ",".join(bad) + "\n" + data[1] + "\n")
+        assert run(remap.remap, p) == run(remap.remap_python, p), bad
+    # a large file (chunks on many threads): the disturbances that do not raise, then one that does in the middle
+    big = [header]
+    while sum(len(x) for x in big) < 3_000_000:
+        f = mutate(rng.choice(data).split(","))
+        p = str(tmp_path / "probe.csv")
+        open(p, "w").write(header + "\n" + ",".join(f) + "\n")
+        if run(remap.remap_python, p)[0] == "ok":
+            big.append(",".join(f))
+    p = str(tmp_path / "big.csv")
+    open(p, "w").write("\n".join(big) + "\n")
+    a, b = run(remap.remap, p), run(remap.remap_python, p)
+    assert a == b and a[0] == "ok" and a[1].count("\n") > 1000
+    open(p, "w", newline="").write("\r\n".join(big) + "\r\n")
+    assert run(remap.remap, p) == b
+    big[len(big) // 2] = big[len(big) // 2].replace(",", ",,", 1)
+    open(p, "w").write("\n".join(big) + "\n")
+    assert run(remap.remap, p) == run(remap.remap_python, p) == ("ValueError", None)
+    # GTF lines the script dies on
+    lines = open(gtf).read().splitlines()
+    ex = next(i for i, l in enumerate(lines) if "\texon\t" in l)
+    for name, fn in (("no_tid", lambda l: l.replace("transcript_id", "transcript_name")), ("short", lambda l: "\t".join(l.split("\t")[:2])),
+                     ("empty", lambda l: ""), ("bad_int", lambda l: l.replace("\t" + l.split("\t")[3] + "\t", "\tx\t", 1))):
+        g2 = str(tmp_path / f"{name}.gtf")
+        open(g2, "w").write("\n".join(lines[:ex] + [fn(lines[ex])] + lines[ex + 1:]) + "\n")
+        src = str(tmp_path / "q.csv")
+        open(src, "w").write(expected("quant_0_3.csv"))
+        assert run(remap.remap, src, g2)[0] == run(remap.remap_python, src, g2)[0], name
 
 
 def test_inputs_the_reference_raises_on():
@@ -97,6 +178,9 @@ def test_inputs_the_reference_raises_on():
                 quantify.quantify([path], [C2[0]], 0, False, io.StringIO())
             else:
                 remap.remap(path, os.path.join(Q, "anno.gtf"), 100, io.StringIO())
+        if c["script"] != "quantify":       # ... and the interpreted mirror likewise
+            with pytest.raises(classes[c["exception"]]):
+                remap.remap_python(path, os.path.join(Q, "anno.gtf"), 100, io.StringIO())
         if c["script"] == "quantify":       # ... and the interpreted mirror likewise
             with pytest.raises(classes[c["exception"]]):
                 quantify.quantify_python([path], [C2[0]], 0, False, io.StringIO())

@@ -190,6 +190,16 @@ def main():
             res["quant"] = {"replicates_per_condition": a.quant, "input_rows": 2 * a.quant * res["call"]["events"], "wall_s": dt,
                             "rows_per_s": 2 * a.quant * res["call"]["events"] / dt, "out_bytes": os.path.getsize(pre + ".quant.csv"),
                             "what": "native join (csrc/quant.cpp) through `python -m pantas_amd.quantify`"}
+            t0 = time.perf_counter()
+            r = subprocess.run([py, "-m", "pantas_amd.remap", pre + ".quant.csv", pre + ".gtf"], stdout=open(pre + ".remap.csv", "wb"), stderr=subprocess.PIPE,
+                               env=env, cwd=ROOT)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError(f"remap: rc {r.returncode}: {r.stderr.decode(errors='replace')[-2000:]}")
+            n_rows = sum(buf.count(b"\n") for buf in iter(lambda f=open(pre + ".quant.csv", "rb"): f.read(1 << 26), b"")) - 1
+            res["remap"] = {"input_rows": n_rows, "wall_s": dt, "rows_per_s": n_rows / dt, "out_bytes": os.path.getsize(pre + ".remap.csv"),
+                            "phases": phases(r.stderr.decode(errors="replace")), "what": "native form (csrc/remap.cpp) through `python -m pantas_amd.remap`"}
+            os.unlink(pre + ".remap.csv")
             os.unlink(pre + ".quant.csv")
         if a.null_out:
             dt, err, _ = timed([py, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], "/dev/null", env)
