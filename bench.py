@@ -354,7 +354,7 @@ def emit(out: dict, args) -> None:
                                "call_events": e2e["call"]["events"]} if "call" in e2e else
                               {"error": (e2e.get("error") or e2e.get("skipped") or "")[:120]})
     line["details"] = details_path
-    print(json.dumps(line), flush=True)
+    print(json.dumps(out if getattr(args, "full_line", False) else line), flush=True)
 
 
 def main():
@@ -369,6 +369,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=800_000)
     ap.add_argument("--del-hot", type=float, default=0.0,
                     help="share of the deletion reads aimed at 1 000 fixed (node, position) sites: the skew of real indel variants")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the whole details object as the line (tools/*.sh read phase times from it); the default line is the "
+                         "short one of the contract, with the details in gpurun_out/bench_details_n<N>.json")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-call", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")

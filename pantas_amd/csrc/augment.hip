@@ -934,7 +934,14 @@ struct DeviceGraph {
     g.word = word; g.info = info; g.info3 = info3; g.row_ptr = row_ptr; g.col = col;
     g.cnt4 = counters; g.rc = counters + 4 * size_t(V);
     g.slow = slow_dev;
-    g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;
+#ifdef PANTAS_EXPERIMENTS
+    g.ablate = getenv("PANTAS_ABLATE") ? uint32_t(atoi(getenv("PANTAS_ABLATE"))) : 0u;      // timing experiments: results wrong by construction
+#else
+    // the shipped library has no timing-only instances: a run that asks for one is refused, not silently wrong
+    if (getenv("PANTAS_ABLATE") && atoi(getenv("PANTAS_ABLATE")) != 0)
+      throw Error("Unsupported", "PANTAS_ABLATE is a timing experiment of builds made with `make EXPERIMENTS=1`; this library does not have it");
+    g.ablate = 0u;
+#endif
     return g;
   }
 };
@@ -949,7 +956,7 @@ ScratchPool& scratch_pool(DeviceGraph& dg) {
 uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
   if (!dg.name_table) {
     HIP_OK(hipSetDevice(dg.device));
-    HIP_OK(hipMalloc(&dg.name_table, std::max<size_t>(1, g.names.table.size()) * 4));
+    HIP_OK(dmalloc(&dg.name_table, std::max<size_t>(1, g.names.table.size()) * 4));
     HIP_OK(hipMemcpyAsync(dg.name_table, g.names.table.data(), g.names.table.size() * 4, hipMemcpyHostToDevice, dg.stream));
     // Names of a graph are numbers that count up with the S lines, nodes count up with the S lines: over long stretches
     // table[x] = x + c.  One word per block of 1024 names says so (8 MB for a whole genome: it stays in the caches), and the
@@ -965,7 +972,7 @@ uint32_t* device_name_table(DeviceGraph& dg, const Graph& g) {
         if (runs) blocks[b] = first;
       }
     });
-    HIP_OK(hipMalloc(&dg.name_blocks, blocks.size() * 4));
+    HIP_OK(dmalloc(&dg.name_blocks, blocks.size() * 4));
     HIP_OK(hipMemcpyAsync(dg.name_blocks, blocks.data(), blocks.size() * 4, hipMemcpyHostToDevice, dg.stream));
     HIP_OK(hipStreamSynchronize(dg.stream));
   }
@@ -1150,9 +1157,9 @@ static uint32_t pow2_at_least(uint64_t x) {
 static void table_alloc(Table& t, uint32_t cap, uint32_t* n_keys, uint32_t* overflow) {
   if (t.cap >= cap) { t.v.n_keys = n_keys; t.v.overflow = overflow; return; }
   t.free_all();
-  HIP_OK(hipMalloc(&t.v.keys, size_t(cap) * 8));
-  HIP_OK(hipMalloc(&t.v.cnt, size_t(cap) * 4));
-  HIP_OK(hipMalloc(&t.v.first, size_t(cap) * 8));
+  HIP_OK(dmalloc(&t.v.keys, size_t(cap) * 8));
+  HIP_OK(dmalloc(&t.v.cnt, size_t(cap) * 4));
+  HIP_OK(dmalloc(&t.v.first, size_t(cap) * 8));
   t.cap = cap;
   t.v.mask = cap - 1;
   t.v.n_keys = n_keys;
@@ -1180,25 +1187,25 @@ DeviceGraphPtr upload_graph(const Graph& g, int device) {
   pt.lap("streams");
   for (auto& e : d->ev) HIP_OK(hipEventCreate(&e));
   pt.lap("events");
-  HIP_OK(hipMalloc(&d->word, std::max<size_t>(1, g.V) * 4));
-  HIP_OK(hipMalloc(&d->row_ptr, (size_t(g.V) + 1) * 4));
-  HIP_OK(hipMalloc(&d->col, std::max<size_t>(1, g.A) * 4));
+  HIP_OK(dmalloc(&d->word, std::max<size_t>(1, g.V) * 4));
+  HIP_OK(dmalloc(&d->row_ptr, (size_t(g.V) + 1) * 4));
+  HIP_OK(dmalloc(&d->col, std::max<size_t>(1, g.A) * 4));
   {
     // zero padding behind the counters: the exchange kernels (exchange.hip) read whole blocks
     const size_t w = 4 * size_t(g.V) + g.A;
     const size_t padded = std::max<size_t>(1, (w + COUNTER_PAD_WORDS - 1) / COUNTER_PAD_WORDS) * COUNTER_PAD_WORDS;
-    HIP_OK(hipMalloc(&d->counters, padded * 4));
+    HIP_OK(dmalloc(&d->counters, padded * 4));
     HIP_OK(hipMemsetAsync(d->counters + w, 0, (padded - w) * 4, d->stream));
   }
-  HIP_OK(hipMalloc(&d->small, 64));
-  HIP_OK(hipMalloc(&d->slow_dev, sizeof(SlowTables)));
+  HIP_OK(dmalloc(&d->small, 64));
+  HIP_OK(dmalloc(&d->slow_dev, sizeof(SlowTables)));
   pt.lap("hipMalloc of the graph arrays and counters");
   h2d_staged(d->word, g.seg_len.data(), size_t(g.V) * 4, d->stream);
   h2d_staged(d->row_ptr, g.row_ptr.data(), (size_t(g.V) + 1) * 4, d->stream);
   h2d_staged(d->col, g.col.data(), size_t(g.A) * 4, d->stream);
   pt.lap("CSR to HBM");
-  HIP_OK(hipMalloc(&d->info, std::max<size_t>(1, g.V) * 8));
-  HIP_OK(hipMalloc(&d->info3, std::max<size_t>(1, g.V) * 16));
+  HIP_OK(dmalloc(&d->info, std::max<size_t>(1, g.V) * 8));
+  HIP_OK(dmalloc(&d->info3, std::max<size_t>(1, g.V) * 16));
   if (g.V) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(g.V) + 255) / 256, 1u << 16));
     hipLaunchKernelGGL(build_info_kernel, dim3(blocks), dim3(256), 0, d->stream, d->word, d->row_ptr, d->col, d->info, d->info3, g.V);
@@ -1220,7 +1227,7 @@ void set_tilde_table(DeviceGraph& d, const std::vector<TildeEntry>& tab) {
   if (d.tilde_dev) { (void)hipFree(d.tilde_dev); d.tilde_dev = nullptr; }
   d.tilde_n = uint32_t(tab.size());
   if (!tab.empty()) {
-    HIP_OK(hipMalloc(&d.tilde_dev, tab.size() * sizeof(TildeEntry)));
+    HIP_OK(dmalloc(&d.tilde_dev, tab.size() * sizeof(TildeEntry)));
     HIP_OK(hipMemcpy(d.tilde_dev, tab.data(), tab.size() * sizeof(TildeEntry), hipMemcpyHostToDevice));
   }
 }
@@ -1250,7 +1257,7 @@ void reset_counters(DeviceGraph& d) {
 template <class T>
 static T* to_device(const std::vector<T>& v, hipStream_t s) {
   T* p = nullptr;
-  HIP_OK(hipMalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
+  HIP_OK(dmalloc(&p, std::max<size_t>(1, v.size()) * sizeof(T)));
   if (!v.empty()) HIP_OK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
   return p;
 }
@@ -1294,7 +1301,7 @@ __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uin
 void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
   if (b.rec) { (void)hipFree(b.rec); b.rec = nullptr; }
-  HIP_OK(hipMalloc(&b.rec, std::max<size_t>(1, b.n) * REC_QUADS * sizeof(uint4)));
+  HIP_OK(dmalloc(&b.rec, std::max<size_t>(1, b.n) * REC_QUADS * sizeof(uint4)));
   if (b.n) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 16));
     hipLaunchKernelGGL(build_rec_kernel, dim3(blocks), dim3(256), 0, d.stream, b.n, b.node_off, b.op_off, b.nodes, b.ops, b.rec);
@@ -1506,6 +1513,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else {
+#ifdef PANTAS_EXPERIMENTS
+      if (g.ablate) fprintf(stderr, "pantas: PANTAS_ABLATE=%u -- timing experiment, THE RESULTS OF THIS RUN ARE INVALID\n", g.ablate);
       if (g.ablate && variant >= 110) {
         // timing experiments on the round-3 kernel: its ABL instance (the general class is not launched: no such records in the workloads)
         if (b.n_short) hipLaunchKernelGGL((augment_short_w_kernel<512, 2048, 10, 7, 8, 1, true>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
@@ -1517,7 +1526,9 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         HIP_OK(hipEventRecord(d.ev[3], d.stream));
         split = true;
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
-      } else switch (variant) {
+      } else
+#endif
+      switch (variant) {
         // (variants 73 / 80 / 85 / 97 / 100 -- round 1's short walk and round 2's steps towards 101 -- were retired in round 3; their
         // measurements are in DESIGN.md section 3 and profiles/r2_ab_s4_*.txt)
         case 101:
@@ -1809,7 +1820,7 @@ void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   pt.lap("host arrays");
   uint32_t* planar = nullptr;       // [nc V | il0 V | oll V | rc A], padded with zeros to whole bitmap words of the sparse download
   const uint64_t padded = (words + 32 * NZ_BLOCK_WORDS - 1) / (32 * NZ_BLOCK_WORDS) * (32 * NZ_BLOCK_WORDS);
-  HIP_OK(hipMalloc(&planar, std::max<uint64_t>(1, padded) * 4));
+  HIP_OK(dmalloc(&planar, std::max<uint64_t>(1, padded) * 4));
   if (padded > words) HIP_OK(hipMemsetAsync(planar + words, 0, (padded - words) * 4, d.stream));
   if (d.A) HIP_OK(hipMemcpyAsync(planar + 3 * V, d.counters + 4 * V, size_t(d.A) * 4, hipMemcpyDeviceToDevice, d.stream));
   if (V) {

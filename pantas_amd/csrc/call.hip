@@ -229,7 +229,7 @@ static void exclusive_scan(DeviceCall& d, const uint32_t* a, uint32_t* out, uint
     HIP_OK(hipStreamSynchronize(d.stream));
     if (d.scan_tmp) (void)hipFree(d.scan_tmp);
     d.scan_tmp = nullptr;
-    HIP_OK(hipMalloc(&d.scan_tmp, need));
+    HIP_OK(dmalloc(&d.scan_tmp, need));
     d.scan_tmp_bytes = need;
   }
   HIP_OK(hipcub::DeviceScan::ExclusiveSum(d.scan_tmp, need, a, out, int(n), d.stream));
@@ -243,7 +243,7 @@ template <class T>
 static const T* up_raw(DeviceCall& d, const T* src, size_t n) {
   void* p = nullptr;
   const double t0 = now_s();
-  HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
+  HIP_OK(dmalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
   d.allocs.push_back(p);
   const double t1 = now_s();
   if (n) h2d_staged(p, src, n * sizeof(T), d.stream);
@@ -259,7 +259,7 @@ static const T* up(DeviceCall& d, const std::vector<T, A>& v) { return up_raw(d,
 template <class T>
 static T* dalloc(DeviceCall& d, size_t n) {
   void* p = nullptr;
-  HIP_OK(hipMalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
+  HIP_OK(dmalloc(&p, std::max<size_t>(1, n) * sizeof(T)));
   d.allocs.push_back(p);
   return static_cast<T*>(p);
 }
@@ -324,7 +324,7 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
                      PassOut& po, float& ms) {
   const uint32_t n = uint32_t(slots.size());
   if (!n) return;
-  auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(hipMalloc(&p, std::max<size_t>(bytes, 4))); po.tmp.push_back(p); return p; };
+  auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(dmalloc(&p, std::max<size_t>(bytes, 4))); po.tmp.push_back(p); return p; };
   auto u32 = [&](size_t count) { return static_cast<uint32_t*>(dev(count * 4)); };
   uint32_t* d_slots = u32(n);
   uint32_t* d_jidx = jidx ? u32(n) : nullptr;

@@ -819,7 +819,7 @@ static void stream_rare_pass(pantas_graph* g, const char* gaf_path, int thr, uin
     st->max_batch_bytes = std::max(st->max_batch_bytes, e - b);
     b = e;
   }
-  st->resident_budget = env_u64("PANTAS_RESIDENT_BYTES", device_free_bytes(*g->dev) / 10 * 6);
+  st->resident_budget = env_u64("PANTAS_RESIDENT_BYTES", (device_free_bytes(*g->dev) + parked_device_bytes()) / 10 * 6);   // (parked loader blocks are given back on demand)
   const bool on_device = effective_tokenizer(g) == PANTAS_TOKENIZER_DEVICE;
   TextPrefetcherPtr pf;
   // one batch: nothing to overlap, the tokeniser copies the text itself (and needs no second text buffer)

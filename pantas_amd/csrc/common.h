@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdio>
+#include <cmath>
 #include <string>
 #include <string_view>
 #include <stdexcept>
@@ -110,6 +111,56 @@ inline bool parse_canonical_u64(Span t, uint64_t& v) {
 
 // Python int(str) for the ASCII subset: optional sign, digits with single '_' separators.  Values beyond 2^60 are
 // refused, or with `saturate` become +-2^61 (for fields that are only compared or range-checked afterwards).
+// ---- Python's str.strip() / float(str) for the native forms of quantify.py and remap.py (shared: ADVICE r3) -------------------
+inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
+inline Span py_strip(Span s) {
+  while (s.b < s.e && py_space(static_cast<unsigned char>(*s.b))) ++s.b;
+  while (s.e > s.b && py_space(static_cast<unsigned char>(s.e[-1]))) --s.e;
+  return s;
+}
+// float(s): decimal literals with '_' between digits, inf / infinity / nan in any case, surrounding whitespace; nothing else
+// (strtod alone would take hex floats and "nan(...)" and refuse "1_0").  false = Python raises ValueError.
+inline bool parse_py_float(Span s0, double& out) {
+  const Span s = py_strip(s0);
+  if (s.b == s.e) return false;
+  const char* p = s.b;
+  bool neg = false;
+  if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
+  auto word = [&](const char* w) {
+    const size_t n = strlen(w);
+    if (size_t(s.e - p) != n) return false;
+    for (size_t i = 0; i < n; ++i) if (tolower(static_cast<unsigned char>(p[i])) != w[i]) return false;
+    return true;
+  };
+  if (word("inf") || word("infinity")) { out = neg ? -INFINITY : INFINITY; return true; }
+  if (word("nan")) { out = neg ? -NAN : NAN; return true; }
+  // [digits][.digits][(e|E)[sign]digits], at least one digit in the mantissa; '_' only between two digits
+  std::string t;
+  if (neg) t += '-';
+  bool any = false, prev_digit = false;
+  auto digits = [&]() {
+    bool got = false;
+    while (p < s.e) {
+      if (*p >= '0' && *p <= '9') { t += *p; got = true; prev_digit = true; ++p; }
+      else if (*p == '_' && prev_digit && p + 1 < s.e && p[1] >= '0' && p[1] <= '9') { prev_digit = false; ++p; }
+      else break;
+    }
+    prev_digit = false;
+    return got;
+  };
+  any |= digits();
+  if (p < s.e && *p == '.') { t += '.'; ++p; any |= digits(); }
+  if (!any) return false;
+  if (p < s.e && (*p == 'e' || *p == 'E')) {
+    t += 'e'; ++p;
+    if (p < s.e && (*p == '+' || *p == '-')) { t += *p; ++p; }
+    if (!digits()) return false;
+  }
+  if (p != s.e) return false;
+  out = strtod(t.c_str(), nullptr);
+  return true;
+}
+
 inline bool parse_py_int(Span t, int64_t& v, bool saturate = false) {
   const char* c = t.b;
   if (c >= t.e) return false;

@@ -63,6 +63,13 @@ __device__ __forceinline__ void make_rec_entry(uint4* rec, size_t i, uint32_t n0
   rec[REC_QUADS * i + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
 }
 
+// the GPU GFA loader parks its device memory instead of freeing it (tokenize.hip); no allocation may fail while blocks are parked
+void release_parked_device_memory();
+size_t parked_device_bytes();
+// hipMalloc that gives parked blocks back and tries once more before it reports out-of-memory
+hipError_t device_malloc_retry(void** p, size_t bytes);
+template <class T> inline hipError_t dmalloc(T** p, size_t bytes) { return device_malloc_retry(reinterpret_cast<void**>(p), bytes); }
+
 // Scratch memory of the GPU tokeniser, kept with the DeviceGraph between batches: hipMalloc / hipFree / hipHostMalloc
 // cost milliseconds each, a batch needs about twenty temporaries.  take() hands out the smallest free block that
 // fits (or allocates), give() returns it; everything is released with the graph.
@@ -81,7 +88,9 @@ struct ScratchPool {
     void* p = nullptr;
     const size_t rounded = (bytes + 4095) / 4096 * 4096;
     if (hipMalloc(&p, rounded) != hipSuccess) {
-      trim();   // give cached blocks back and try once more
+      (void)hipGetLastError();
+      trim();   // give cached blocks back -- and what the GPU GFA loader left parked (tokenize.hip) -- and try once more
+      release_parked_device_memory();
       hipError_t e = hipMalloc(&p, rounded);
       if (e != hipSuccess) throw Error("HipError", std::string("hipMalloc: ") + hipGetErrorString(e));
     }

@@ -97,6 +97,7 @@ std::unique_ptr<Graph> load_graph(const char* path, unsigned threads = 0);
 std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call_tags = false);
 // the device memory of finished loads is parked, not freed (tokenize.hip): given back here
 void release_parked_device_memory();
+size_t parked_device_bytes();
 void release_parked_device_memory_if_low();      // ... when less than a quarter of the device's memory is free
 // Same over text already in memory (the buffer must outlive the graph).
 std::unique_ptr<Graph> load_graph_mem(const char* data, size_t size, unsigned threads = 0);

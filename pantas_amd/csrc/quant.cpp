@@ -78,14 +78,7 @@ inline void key_int(Key& k, int64_t v) {
 // float(text) if text != "." else -1 [:14-16]
 bool coverage(Span s, double& v) {
   if (s.size() == 1 && *s.b == '.') { v = -1; return true; }
-  Span t = strip(s);
-  if (t.size() == 0 || t.size() > 64) return false;
-  char buf[72];
-  memcpy(buf, t.b, t.size());
-  buf[t.size()] = 0;
-  char* end = nullptr;
-  v = strtod(buf, &end);
-  return end == buf + t.size();
+  return parse_py_float(s, v);          // Python's float(), not strtod's grammar (common.h)
 }
 
 // ids of a '>'-joined path into the key; ".." (elided IR interior) and "?" are skipped [:9-12]
@@ -176,6 +169,50 @@ bool parse_row(Span line, uint32_t file, uint64_t off, Rec& r, uint32_t& type) {
   r.file = file;
   r.pad_ = 0;
   return true;
+}
+
+// What a key stands for, spelled out: chrom, gene, type and the node ids in the key's order -- the fields eq_event compares [:218-231].
+// PANTAS_QUANT_VERIFY=1 compares these strings whenever two rows meet on one 128-bit key (a collision would otherwise merge two events
+// silently).  Off by default: it parses the event's first row again on every hit.
+std::string row_identity(Span line) {
+  Fields F;
+  uint32_t n;
+  std::string s;
+  if (!split_row(line, F, n)) return s;
+  auto ids = [&](Span path) {
+    const char* p = path.b;
+    for (;;) {
+      const char* q = static_cast<const char*>(memchr(p, '>', size_t(path.e - p)));
+      Span piece{p, q ? q : path.e};
+      const bool skip = (piece.size() == 2 && piece.b[0] == '.' && piece.b[1] == '.') || (piece.size() == 1 && piece.b[0] == '?');
+      int64_t v;
+      if (!skip && parse_py_int(strip(piece), v)) { s += std::to_string(v); s += '>'; }
+      if (!q) break;
+      p = q + 1;
+    }
+    s += ';';
+  };
+  const Span et = F.f[0];
+  s.append(F.f[2].b, F.f[2].size()); s += ',';
+  s.append(F.f[3].b, F.f[3].size()); s += ',';
+  s.append(et.b, et.size()); s += ',';
+  const Span p1 = F.f[8], p2 = F.f[10], p3 = F.f[12];
+  if (is(et, "ES")) { ids(p1); ids(p2); ids(p3); }
+  else if (is(et, "CE")) { ids(p2); ids(p3); ids(p1); }
+  else {
+    bool first_is_event;
+    if (is(et, "A5")) first_is_event = is(F.f[4], "+");
+    else if (is(et, "A3")) first_is_event = !is(F.f[4], "+");
+    else first_is_event = !(is(F.f[1], "novel") && is(F.f[6], "?"));
+    ids(first_is_event ? p1 : p2);
+    if (!is(et, "IR")) ids(first_is_event ? p2 : p1);
+  }
+  return s;
+}
+inline Span row_at(const MappedFile& f, uint64_t off) {
+  const char* b = f.data + off;
+  const char* nl = static_cast<const char*>(memchr(b, '\n', f.size - off));
+  return Span{b, nl ? nl : f.data + f.size};
 }
 
 // ---- Python's numbers ---------------------------------------------------------------------------------------------------
@@ -428,6 +465,8 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
     auto& chunks = recs[type];
     c.shard[type].resize(SHARDS);
     const uint32_t R = c.R;
+    static const bool verify = getenv("PANTAS_QUANT_VERIFY") != nullptr;
+    std::atomic<bool> collided{false};
     parallel_chunks(SHARDS, std::min<unsigned>(T, SHARDS), [&](unsigned, size_t lo, size_t hi) {
       for (size_t s = lo; s < hi; ++s) {
         Condition::Shard& sh = c.shard[type][s];
@@ -444,7 +483,11 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
               sh.ix.emplace(r.key, e);
               sh.ev.push_back(Event{r.key, r.seq, r.off, r.file, 0});
               sh.cov.resize(sh.cov.size() + size_t(2) * R, 0.0);
-            } else e = it->second;
+            } else {
+              e = it->second;
+              if (verify && row_identity(row_at(*c.files[r.file], r.off)) != row_identity(row_at(*c.files[sh.ev[e].file], sh.ev[e].off)))
+                collided.store(true);
+            }
             Event& ev = sh.ev[e];
             ev.slots = std::max(ev.slots, r.file + 1);                // add_replicate pads up to this replicate [:155-160]
             sh.cov[size_t(e) * 2 * R + 2 * r.file] = r.ev;
@@ -455,6 +498,7 @@ void read_condition(const std::vector<std::string>& paths, std::vector<std::uniq
       }
     });
     std::vector<std::vector<Rec>>().swap(chunks);
+    if (collided.load()) throw Error("RuntimeError", "pantas quant: two different events share one 128-bit key (PANTAS_QUANT_VERIFY)");
   }
 }
 

@@ -40,58 +40,17 @@ struct Fail {                      // thrown inside the per-row code, caught per
   std::string what;
 };
 
-inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f); }
-Span py_strip(Span s) {
-  while (s.b < s.e && py_space(static_cast<unsigned char>(*s.b))) ++s.b;
-  while (s.e > s.b && py_space(static_cast<unsigned char>(s.e[-1]))) --s.e;
-  return s;
-}
 // int(s)
 int64_t py_int(Span s) {
   int64_t v;
   if (!parse_py_int(py_strip(s), v)) throw Fail{"ValueError", "invalid literal for int() with base 10: '" + std::string(s.b, s.size()) + "'"};
   return v;
 }
-// float(s): decimal literals with '_' between digits, inf / infinity / nan in any case, surrounding whitespace
+// float(s)
 double py_float(Span s0) {
-  const Span s = py_strip(s0);
-  auto bad = [&]() -> double { throw Fail{"ValueError", "could not convert string to float: '" + std::string(s0.b, s0.size()) + "'"}; };
-  if (s.b == s.e) return bad();
-  const char* p = s.b;
-  bool neg = false;
-  if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
-  auto word = [&](const char* w) {
-    const size_t n = strlen(w);
-    if (size_t(s.e - p) != n) return false;
-    for (size_t i = 0; i < n; ++i) if (tolower(static_cast<unsigned char>(p[i])) != w[i]) return false;
-    return true;
-  };
-  if (word("inf") || word("infinity")) return neg ? -INFINITY : INFINITY;
-  if (word("nan")) return neg ? -NAN : NAN;
-  // [digits][.digits][(e|E)[sign]digits], at least one digit in the mantissa; '_' only between two digits
-  std::string t;
-  if (neg) t += '-';
-  bool any = false, prev_digit = false;
-  auto digits = [&]() {
-    bool got = false;
-    while (p < s.e) {
-      if (*p >= '0' && *p <= '9') { t += *p; got = true; prev_digit = true; ++p; }
-      else if (*p == '_' && prev_digit && p + 1 < s.e && p[1] >= '0' && p[1] <= '9') { prev_digit = false; ++p; }
-      else break;
-    }
-    prev_digit = false;
-    return got;
-  };
-  any |= digits();
-  if (p < s.e && *p == '.') { t += '.'; ++p; any |= digits(); }
-  if (!any) return bad();
-  if (p < s.e && (*p == 'e' || *p == 'E')) {
-    t += 'e'; ++p;
-    if (p < s.e && (*p == '+' || *p == '-')) { t += *p; ++p; }
-    if (!digits()) return bad();
-  }
-  if (p != s.e) return bad();
-  return strtod(t.c_str(), nullptr);
+  double v;
+  if (!parse_py_float(s0, v)) throw Fail{"ValueError", "could not convert string to float: '" + std::string(s0.b, s0.size()) + "'"};
+  return v;
 }
 
 // first '|'-separated name whose last '_' piece starts with R; empty Span{nullptr} = "?"  (remap.py:21-26)
@@ -446,33 +405,56 @@ void remap_run(const std::string& csv_path, const std::string& gtf_path, int64_t
   if (err.row != UINT64_MAX) throw Error(err.kind, "GTF byte " + std::to_string(err.row) + ": " + err.what);
   for (auto& kv : wanted) std::sort(kv.second.begin(), kv.second.end());
   pt.lap("exon table");
-  // ---- pass 2
-  std::vector<std::string> outs(chunks.size());
-  parallel_chunks(chunks.size(), unsigned(std::max<size_t>(1, chunks.size())), [&](unsigned, size_t cb, size_t ce) {
-    for (size_t c = cb; c < ce; ++c) {
-      std::string& out = outs[c];
-      out.reserve(size_t(chunks[c].second - chunks[c].first) + (size_t(chunks[c].second - chunks[c].first) >> 2));
-      each_line(chunks[c].first, chunks[c].second, [&](Span line) {
-        if (starts(line, "etype")) return;
-        const uint64_t key = uint64_t(line.b - csv.b);
-        if (first_bad.load(std::memory_order_relaxed) < key) return;
-        try {
-          remap_row(line, wanted, min_intron, out);
-        } catch (const Fail& x) {
-          std::lock_guard<std::mutex> lk(mu);
-          err.take(key, x.kind, x.what);
-          first_bad.store(err.row, std::memory_order_relaxed);
-        }
-      });
+  // ---- pass 2, streamed: pieces of ~32 MB of rows, a wave of `threads` pieces at a time, each wave written in row order and dropped
+  // (the whole output of a whole-genome quantification is tens of GB).  Pass 1 and the GTF have succeeded, so from here
+  // on the output is the reference's also when a row fails: the header and every row in front of the failing one are out, as
+  // remap.py has printed them when it dies (:131-195 print row by row).
+  const size_t PIECE = size_t(32) << 20;
+  const unsigned P = unsigned(std::max<size_t>(C, std::min<size_t>(1u << 20, size_t(csv.e - csv.b) / PIECE + 1)));
+  const auto pieces = P == C ? chunks : cut_lines(csv.b, csv.e, P);
+  if (fd_out >= 0) write_all(fd_out, HEADER, sizeof HEADER - 1);
+  double t_rows = 0, t_write = 0;
+  for (size_t w0 = 0; w0 < pieces.size(); w0 += threads) {
+    const size_t w1 = std::min(pieces.size(), w0 + threads);
+    std::vector<std::string> outs(w1 - w0);
+    const double ta = now_s();
+    parallel_chunks(w1 - w0, unsigned(w1 - w0), [&](unsigned, size_t cb, size_t ce) {
+      for (size_t c = cb; c < ce; ++c) {
+        std::string& out = outs[c];
+        const auto& pc = pieces[w0 + c];
+        out.reserve(size_t(pc.second - pc.first) + (size_t(pc.second - pc.first) >> 2));
+        each_line(pc.first, pc.second, [&](Span line) {
+          if (starts(line, "etype")) return;
+          const uint64_t key = uint64_t(line.b - csv.b);
+          if (first_bad.load(std::memory_order_relaxed) < key) return;
+          try {
+            remap_row(line, wanted, min_intron, out);
+          } catch (const Fail& x) {
+            std::lock_guard<std::mutex> lk(mu);
+            err.take(key, x.kind, x.what);
+            first_bad.store(err.row, std::memory_order_relaxed);
+          }
+        });
+      }
+    });
+    const double tb = now_s();
+    t_rows += tb - ta;
+    const bool bad = err.row != UINT64_MAX;
+    for (size_t c = 0; c < outs.size(); ++c) {
+      const auto& pc = pieces[w0 + c];
+      if (bad && uint64_t(pc.first - csv.b) > err.row) break;          // pieces behind the failing row: not printed
+      std::string& o = outs[c];
+      // (the piece of the failing row: a piece is one thread's, walked in row order, so `o` ends in front of that row)
+      if (fd_out >= 0) write_all(fd_out, o.data(), o.size());
     }
-  });
-  if (err.row != UINT64_MAX) throw Error(err.kind, "quantification CSV byte " + std::to_string(err.row) + ": " + err.what);
-  pt.lap("rows");
-  if (fd_out >= 0) {
-    write_all(fd_out, HEADER, sizeof HEADER - 1);
-    for (const std::string& o : outs) write_all(fd_out, o.data(), o.size());
+    t_write += now_s() - tb;
+    if (bad) throw Error(err.kind, "quantification CSV byte " + std::to_string(err.row) + ": " + err.what);
   }
-  pt.lap("written");
+  {
+    char buf[96];
+    snprintf(buf, sizeof buf, "rows %.3f s + writing %.3f s, in waves", t_rows, t_write);
+    pt.lap(buf);
+  }
 }
 
 }  // namespace pantas

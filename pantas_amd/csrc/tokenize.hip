@@ -725,7 +725,7 @@ TextPrefetcherPtr make_text_prefetcher(DeviceGraph& dg, size_t max_bytes) {
   p->device = gi.device;
   p->cap = text_padded_bytes(max_bytes);
   p->stream = take_stream(gi.device);
-  for (int k = 0; k < 2; ++k) HIP_OK(hipMalloc(&p->buf[k], p->cap));
+  for (int k = 0; k < 2; ++k) HIP_OK(dmalloc(&p->buf[k], p->cap));
   return p;
 }
 
@@ -813,7 +813,12 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
                      uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), key.as<uint32_t>(), val.as<unsigned long long>(),
                      partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1, 0u, align_min);
   HIP_OK(hipGetLastError());
+#ifndef PANTAS_EXPERIMENTS
+  if (getenv("PANTAS_TOK_STOP"))
+    throw Error("Unsupported", "PANTAS_TOK_STOP is a timing experiment of builds made with `make EXPERIMENTS=1`; this library does not have it");
+#else
   if (const char* ab = getenv("PANTAS_TOK_STOP")) {
+    fprintf(stderr, "pantas: PANTAS_TOK_STOP=%s -- timing experiment (the relaunches write into the live buffers), THE RESULTS OF THIS RUN ARE INVALID\n", ab);
     // timing-only ablation of the parse (tools/tok_ablate.py): the kernel again, leaving every line after the named stage;
     // its outputs are garbage, the real launch above has already written the batch's
     hipEvent_t e0, e1;
@@ -834,6 +839,7 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }
+#endif
   hipLaunchKernelGGL(totals_kernel, dim3(std::min<uint32_t>(blocks_for(waves), 1024)), dim3(TPB), 0, s, partial.as<uint32_t>(), waves, small.as<unsigned long long>() + 1);
   HIP_OK(hipGetLastError());
   unsigned long long hs[SMALL_WORDS64];
@@ -904,7 +910,7 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   DevBuf hdr1(pool), nodes1(pool), ops1(pool), del(pool);
   hdr1.alloc((n_rec + 1) * sizeof(LineHdr)); nodes1.alloc((n_nodes + 1) * 4); ops1.alloc((n_ops + 1) * 4);
   del.alloc((size_t(out->n_del) + 1) * 4);
-  HIP_OK(hipMalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
+  HIP_OK(dmalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
   HIP_OK(hipStreamSynchronize(s));
   pt.lap("  sizes + scans; batch arrays allocated");
   hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, val.as<unsigned long long>(), prov.as<uint32_t>(), node_off1.as<uint32_t>(),
@@ -1517,6 +1523,19 @@ void scan_u32(DevMem& m, const uint32_t* in, uint32_t* out, size_t n_plus_1, hip
 }
 
 }  // namespace
+
+size_t parked_device_bytes() {
+  std::lock_guard<std::mutex> lk(g_park_mu);
+  return g_parked_bytes;
+}
+
+hipError_t device_malloc_retry(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess || parked_device_bytes() == 0) return e;
+  (void)hipGetLastError();
+  release_parked_device_memory();
+  return hipMalloc(p, bytes);
+}
 
 void release_parked_device_memory() {
   std::vector<void*> todo;

@@ -33,29 +33,58 @@ class LibBackend:
         from .engine import Graph, graph_cache_path
         self.device = device
         cache = graph_cache_path(gfa_path)
-        shared = None
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1 and not os.environ.get("PANTAS_EVERY_RANK_PARSES"):
-            if cache is None:       # no cache asked for: one for the length of this run, in memory-backed storage when there is any
-                import hashlib
-                tag = hashlib.sha1(f"{os.path.abspath(gfa_path)}:{os.path.getsize(gfa_path)}:{os.stat(gfa_path).st_mtime_ns}".encode()).hexdigest()[:16]
-                where = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else os.environ.get("TMPDIR", "/tmp")
-                cache = shared = os.path.join(where, f"pantas_{os.getuid()}_{tag}.pgc")
-            if dist.get_rank() == 0:
-                self.g = Graph(gfa_path, cache=cache)
-            dist.barrier()
-            if dist.get_rank() != 0:
-                self.g = Graph(gfa_path, cache=cache)       # (a graph the cache cannot hold -- names that are no decimals -- is parsed)
-            dist.barrier()
-            if shared and dist.get_rank() == 0:
-                try:
-                    os.unlink(shared)
-                except OSError:
-                    pass
+            self.g = self._load_shared(Graph, gfa_path, cache, dist)
             self.g.to_device(device)
         else:
             self.g = Graph(gfa_path, cache=cache).to_device(device)
         self.g.augment_reset()
         self.batch = None
+
+    @staticmethod
+    def _load_shared(Graph, gfa_path, cache, dist):
+        """Rank 0 parses and writes the cache, the others load it.  With no cache asked for, the cache of this run lives in a
+        directory only this user can enter (mkdtemp, mode 0700: nobody else can plant a file there), its path goes to the others by
+        broadcast, and a rank that does not find the file (another node) parses the GFA itself WITHOUT leaving a cache of its own.
+        A failure of rank 0 is broadcast in the place of the path, so that the others raise instead of waiting in a barrier."""
+        import shutil
+        import tempfile
+        rank0 = dist.get_rank() == 0
+        tmpdir, g, msg = None, None, [None, None]        # [cache path of the run, error of rank 0]
+        if rank0:
+            try:
+                path = cache
+                if path is None:
+                    where = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+                    tmpdir = tempfile.mkdtemp(prefix="pantas_pgc_", dir=where)
+                    path = os.path.join(tmpdir, "graph.pgc")
+                g = Graph(gfa_path, cache=path)
+                msg[0] = path
+            except BaseException as e:       # the others must hear of it before it is raised here
+                msg[1] = f"{type(e).__name__}: {e}"
+                err = e
+        dist.broadcast_object_list(msg, src=0)
+        try:
+            if msg[1] is not None:
+                if rank0:
+                    raise err
+                raise RuntimeError(f"rank 0 could not load {gfa_path}: {msg[1]}")
+            if not rank0:
+                path = msg[0]
+                mine = cache is not None and path == cache      # a cache the user asked for: every rank may use and write it
+                if not mine:
+                    try:
+                        st = os.stat(path)
+                        ok = st.st_uid == os.getuid()           # ours, in a directory only we can enter
+                    except OSError:
+                        ok = False                              # another node: parse, leave nothing behind
+                    path = path if ok else None
+                g = Graph(gfa_path, cache=path) if path is not None else Graph(gfa_path)
+        finally:
+            dist.barrier()                   # every rank has loaded (or failed): the cache of the run can go
+            if tmpdir is not None:
+                shutil.rmtree(tmpdir, ignore_errors=True)
+        return g
 
     def split(self, gaf_path, rank, world):
         from ._lib import check, lib

@@ -122,8 +122,7 @@ def remap(csv_path: str, gtf_path: str, min_intron_size: int = 100, out=sys.stdo
         with tempfile.TemporaryFile() as f:
             rc = lib.pantas_remap_run(os.fsencode(csv_path), os.fsencode(gtf_path), int(min_intron_size), f.fileno())
             f.seek(0)
-            if rc == 0:
-                out.write(f.read().decode())
+            out.write(f.read().decode())      # (also of a failed run: the rows in front of the failing one, as the script prints them)
     if rc != 0:
         kind = (lib.pantas_last_error_kind() or b"").decode()
         msg = (lib.pantas_last_error() or b"").decode()

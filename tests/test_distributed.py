@@ -208,3 +208,56 @@ def test_sharded_call_gloo(tmp_path, case, world):
     rows = open(out).read().splitlines()
     assert rows[0] == call_oracle.HEADER
     check_rows(rows[1:], gc)
+
+
+SHARED_WORKER = r'''
+import os, sys, stat
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pantas_amd.distributed import LibBackend
+mode, log = sys.argv[2], sys.argv[3]
+dist.init_process_group(backend="gloo")
+rank = dist.get_rank()
+
+class FakeGraph:                     # stands in for engine.Graph: records how each rank was asked to load
+    def __init__(self, gfa, cache=None):
+        if mode == "fail" and rank == 0:
+            raise ValueError("no such graph")
+        if cache is not None and rank == 0:
+            st = os.stat(os.path.dirname(cache))
+            assert stat.S_IMODE(st.st_mode) == 0o700 and st.st_uid == os.getuid()
+            open(cache, "w").write("x")
+        with open(f"{log}.{rank}", "w") as f:
+            f.write(f"{cache} {cache is not None and os.path.exists(cache)}")
+
+try:
+    LibBackend._load_shared(FakeGraph, "some.gfa", None, dist)
+    out = "ok"
+except Exception as e:
+    out = f"{type(e).__name__}: {e}"
+with open(f"{log}.{rank}.result", "w") as f:
+    f.write(out)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("mode", ["ok", "fail"])
+def test_one_rank_parses_private_cache_and_failure_reaches_every_rank(tmp_path, mode):
+    """ADVICE r3: the cache of a multi-rank run lives in a 0700 directory made by rank 0 (path broadcast, removed after the load), and a
+    rank 0 that cannot load the graph makes every rank raise instead of leaving them in a barrier"""
+    w = tmp_path / "w.py"
+    w.write_text(SHARED_WORKER)
+    log = str(tmp_path / "log")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), str(w), ROOT, mode, log], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [open(f"{log}.{k}.result").read() for k in range(2)]
+    if mode == "ok":
+        assert res == ["ok", "ok"]
+        p0, e0 = open(f"{log}.0").read().rsplit(" ", 1)
+        p1, e1 = open(f"{log}.1").read().rsplit(" ", 1)
+        assert p0 == p1 and e1 == "True" and "pantas_pgc_" in p0        # rank 1 was pointed at rank 0's file, and it was there
+        assert not os.path.exists(os.path.dirname(p0))                  # ... and nothing is left behind
+    else:
+        assert res[0] == "ValueError: no such graph"
+        assert res[1].startswith("RuntimeError: rank 0 could not load") and "no such graph" in res[1]

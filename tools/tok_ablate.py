@@ -3,6 +3,8 @@
 leaving after a named stage (PANTAS_TOK_STOP digits: 9 staging only, 1 columns, 2 integers, 3 tag search, 4 cs, 5 dv, 0 all).
 
     python tools/tok_ablate.py [--scale s3] [--stops 912345 0]
+
+Needs a library built with `make -C pantas_amd/csrc EXPERIMENTS=1` (the shipped build refuses PANTAS_TOK_STOP).
 """
 import argparse
 import os

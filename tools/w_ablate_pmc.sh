@@ -1,4 +1,6 @@
 #!/bin/bash
+# Needs a library built with the timing-only instances: make -C pantas_amd/csrc clean && make -C pantas_amd/csrc -j8 EXPERIMENTS=1
+# (the shipped build refuses PANTAS_ABLATE); build the plain library again afterwards.
 # Instruction counts and time of the wide-record kernel (augment_short_w_kernel, ABL instance) with parts switched off, one --pmc pass each
 # (PANTAS_ABLATE bits: 32 nothing queued, 512 a kept node is one probe and one atomic, 256 a kept node is nothing; 288 = the bare walk).
 # Timing only: results are wrong by construction.  Run on the GPU box: bash tools/w_ablate_pmc.sh
