@@ -347,8 +347,12 @@ def emit(out: dict, args) -> None:
     line["reads_per_s_incl_bucket"] = _sig(out["reads_per_s_incl_bucket"])
     line["reads_per_s_text_to_counters"] = _sig(out["reads_per_s_text_to_counters"])
     if out.get("allreduce_ms"):
+        ex = out.get("allreduce") or {}
         line["allreduce_ms"] = _sig(out["allreduce_ms"])
+        line["allreduce"] = {k: _sig(v) for k, v in ex.items() if isinstance(v, (int, float, str, bool)) and k in
+                             ("mode", "block_words", "counter_bytes", "exchanged_bytes")}
         line["world_size_seen_by_process_group"] = out["ranks"]["world_size_seen_by_process_group"]
+        line["backend"] = out["ranks"]["backend"]
     if e2e:
         line["e2e_wall_s"] = ({"augment": _sig(e2e["augment"]["wall_s"]), "call": _sig(e2e["call"]["wall_s"]),
                                "call_events": e2e["call"]["events"]} if "call" in e2e else

@@ -847,6 +847,247 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphVie
   }
 }
 
+// ---- the short walk with one lane per path position (round 4; walk.h "one lane per path POSITION") --------------------------
+struct TileView {
+  const TileDesc* desc;          // [tiles]
+  const uint32_t* pnodes;        // [64 x tiles] node of every position; lanes behind a tile's last record hold a valid node
+  const PosRec* prec;            // [n_short]
+  const uint32_t* chunk_tile;    // [chunks + 1] first tile of every chunk of CHUNK records
+  uint32_t n_chunks, n_tiles;
+};
+
+// inclusive sum over the wave's 64 lanes (DPP: four row shifts, two row broadcasts)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));      // row_shr:1
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));      // row_shr:2
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));      // row_shr:4
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));      // row_shr:8
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));      // row_bcast:15 into rows 1 and 3
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));      // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t from_lane) {
+  return uint32_t(__builtin_amdgcn_ds_bpermute(int(from_lane << 2), int(v)));
+}
+
+template <class Sink>
+__device__ __forceinline__ void chunk_tables_clear(const Sink& k, uint32_t threads) {
+  constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS;
+  for (uint32_t i = threadIdx.x; i < CN; i += threads) {
+    k.omin[i] = ~0u; k.omin[CN + i] = ~0u;
+    k.nkey[i] = LDS_EMPTY;
+    k.ncnt[i] = 0u; k.ncnt[CN + i] = 0u; k.ncnt2[i] = 0u;
+  }
+  for (uint32_t i = threadIdx.x; i < CF; i += threads) { k.fkey[i] = LDS_EMPTY; k.fmin[i] = ~0ull; k.vkey[i] = EMPTY_KEY; k.vmin[i] = ~0ull; k.vcnt[i] = 0u; }
+  for (uint32_t i = threadIdx.x; i < CS; i += threads) { k.skey[i] = LDS_EMPTY; k.scnt[i] = 0u; }
+  if (threadIdx.x == 0) *k.lq_n = 0u;
+}
+// queued links looked up, then every table of the chunk added to memory (the two barriers inside; none behind)
+template <class Sink>
+__device__ __forceinline__ void chunk_tables_flush(const GraphView& g, const Sink& k, uint32_t threads) {
+  constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS;
+  __syncthreads();
+  {
+    const uint32_t m = min(*k.lq_n, Sink::LQ_CAP);
+    for (uint32_t i = threadIdx.x; i < m; i += threads) {
+      const uint4 e = k.lq[i];
+      k.link_direct(e.x, e.y, (static_cast<uint64_t>(e.w) << 32) | e.z);
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < CN; i += threads) {
+    const uint32_t n = k.nkey[i];
+    if (n == LDS_EMPTY) continue;
+    const unsigned long long v = reinterpret_cast<const unsigned long long*>(k.ncnt)[i];
+    add_node4(g, n, uint32_t(v) & 0xFFFFu, uint32_t(v >> 16) & 0xFFFFu, uint32_t(v >> 32) & 0xFFFFu, uint32_t(v >> 48));
+    const uint32_t v2 = k.ncnt2[i];
+    if (v2) {
+      const uint32_t row = g.row_ptr[n];
+      if (v2 & 0xFFFFu) atomicAdd(&g.rc[row + 1u], v2 & 0xFFFFu);
+      if (v2 >> 16) atomicAdd(&g.rc[row + 2u], v2 >> 16);
+    }
+    if (k.omin[2 * i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(k.omin[2 * i], 0, 1));
+    if (k.omin[2 * i + 1] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(k.omin[2 * i + 1], 0, 1));
+  }
+  for (uint32_t i = threadIdx.x; i < CS; i += threads) {
+    const uint32_t sl = k.skey[i];
+    if (sl != LDS_EMPTY && k.scnt[i]) atomicAdd(&g.rc[sl], k.scnt[i]);
+  }
+  for (uint32_t i = threadIdx.x; i < CF; i += threads) {
+    const uint32_t kk = k.fkey[i];
+    if (kk != LDS_EMPTY && k.fmin[i] != ~0ull) table_update(g.slow->hist, hist_key(kk >> 1, kk & 1u, COMMON_POS), 0u, k.fmin[i]);
+    if (k.vkey[i] != EMPTY_KEY) table_update(g.slow->novel, k.vkey[i], k.vcnt[i], k.vmin[i]);
+  }
+}
+
+template <class Agg>
+struct TileSinkDev {
+  const Agg& s;
+  __device__ __forceinline__ void kept(uint32_t node, uint32_t flags, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
+    s.bump_w(node, flags, line_id, a_il, a_ol, code, exact_order);
+  }
+  // (a lane queues for its own record: the order of a link inside its line is the path index handed in)
+  uint32_t line_id;
+  __device__ __forceinline__ void later(uint32_t a, uint32_t b, uint32_t idx) const { s.link_later(a, b, event_order(line_id, idx, 0)); }
+};
+
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint32_t MINW>
+__global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphView g, BatchView b, const TileDesc* __restrict__ t_desc,
+                                                                        const uint32_t* __restrict__ t_pnodes, const PosRec* __restrict__ t_prec,
+                                                                        const uint32_t* __restrict__ t_chunk_tile, uint32_t n_chunks_in) {
+  // (the tile arrays as restrict pointers of their own: nothing the kernel writes aliases them, so the compiler may read the
+  // wave-uniform descriptors with scalar loads)
+  const TileView tv{t_desc, t_pnodes, t_prec, t_chunk_tile, n_chunks_in, 0u};
+  constexpr uint32_t LOG_S = 8;
+  using Sink = AggSink<LOG_N, LOG_S, LOG_F, true>;
+  constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS, NW = THREADS / 64u;
+  static_assert(CHUNK * PACKED_MAX_PATH < 65536u && CHUNK * (SHORT_MAX_PATH_INDEL + 2u) < 65536u, "a 16-bit field could overflow");
+  __shared__ uint32_t skey[CS];
+  __shared__ uint32_t scnt[CS];
+  __shared__ unsigned long long fmin[CF];
+  __shared__ unsigned long long vkey[CF];
+  __shared__ unsigned long long vmin[CF];
+  __shared__ uint32_t vcnt[CF];
+  __shared__ uint32_t fkey[CF];
+  __shared__ uint32_t nkey[CN];
+  __shared__ __attribute__((aligned(8))) uint32_t ncnt[2 * CN];
+  __shared__ uint32_t ncnt2[CN];
+  __shared__ __attribute__((aligned(8))) uint32_t omin[2 * CN];
+  __shared__ uint4 lq[Sink::LQ_CAP];
+  __shared__ uint32_t lq_n;
+  g.ablate = 0u;
+  const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_chunks = tv.n_chunks;
+  const uint32_t per_xcd = (n_chunks + 7u) / 8u;       // workgroup w takes chunk (w % 8) * n/8 + w / 8: an XCD walks one contiguous eighth
+  const NodeInfo3* info3 = reinterpret_cast<const NodeInfo3*>(g.info3);
+  const uint64_t le = tile_lanes_le(lane);
+  for (uint32_t c0 = blockIdx.x; c0 < 8u * per_xcd; c0 += gridDim.x) {
+    const uint32_t c = (c0 & 7u) * per_xcd + (c0 >> 3);
+    if (c >= n_chunks) continue;
+    Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin, nullptr, nullptr};
+    sink.ncnt2 = ncnt2; sink.lq = lq; sink.lq_n = &lq_n;
+    chunk_tables_clear(sink, THREADS);
+    const uint32_t t_begin = tv.chunk_tile[c], t_end = tv.chunk_tile[c + 1];      // (t_end > t_begin: a chunk has records)
+    const uint32_t t_last = t_end - 1u;
+    // pipeline: while tile t is worked on, the node ids and the descriptor of tile t + 2 NW and the node records and line records
+    // of tile t + NW are in flight; every load is issued unconditionally (tile index clamped to the chunk).  Descriptors are the
+    // same for the whole wave: they live in scalar registers.
+    uint32_t t = t_begin + wave;
+    auto load_desc = [&](uint32_t tt) { return tv.desc[tt]; };
+    TileDesc d_c = load_desc(min(t, t_last)), d_n = load_desc(min(t + NW, t_last));
+    uint32_t node_c = tv.pnodes[size_t(min(t, t_last)) * 64u + lane];
+    uint32_t node_n = tv.pnodes[size_t(min(t + NW, t_last)) * 64u + lane];
+    NodeInfo3 inf_c = info3[node_c];
+    // a lane behind the tile's last record reads the line record of the last one (and does nothing with it)
+    auto rec_of = [&](const TileDesc& dd) { return dd.first_rec + tile_rec_ordinal(tile_heads(dd), le & tile_lanes_le((dd.meta & 0x7Fu) - 1u)); };
+    uint32_t rec_c = rec_of(d_c);
+    PosRec pr_c = tv.prec[rec_c];
+    __syncthreads();
+    for (; t < t_end; t += NW) {
+      const TileDesc d = d_c;
+      const uint32_t node = node_c, rec = rec_c;
+      const NodeInfo3 inf = inf_c;
+      const PosRec pr = pr_c;
+      ShortOps so;
+      const bool tile_plain = (d.meta & TILE_PLAIN) != 0u;      // (wave-uniform)
+      uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
+      if (!tile_plain) r3 = b.rec[REC_QUADS * size_t(rec) + 2];      // a '*' or an indel somewhere in the tile: the lines' op summaries
+      // requests for the wave's next tiles (behind the load above: waiting for it leaves these in flight)
+      {
+        const uint32_t t2 = min(t + 2u * NW, t_last);
+        const TileDesc d_nn = load_desc(t2);
+        const uint32_t node_nn = tv.pnodes[size_t(t2) * 64u + lane];
+        inf_c = info3[node_n];
+        rec_c = rec_of(d_n);
+        pr_c = tv.prec[rec_c];
+        d_c = d_n; d_n = d_nn;
+        node_c = node_n; node_n = node_nn;
+      }
+      const uint32_t used = d.meta & 0x7Fu;
+      const bool active = lane < used;
+      const TileLane tl = tile_lane(tile_heads(d), used, le);
+      const uint32_t room = active ? tile_room(inf.word, lane == tl.seg_start, lane == tl.seg_end, pr) : 0u;
+      const uint32_t incl = wave_inclusive_sum(room);
+      const uint32_t base = lane_read(incl, tl.seg_start - 1u);           // (lane 63 for a record at lane 0: not used)
+      const uint32_t in_front = incl - room - (tl.seg_start ? base : 0u);
+      bool keep, exhausted;
+      uint32_t plain = 1u;
+      if (tile_plain) {
+        const uint32_t T = pr.tw & 0xFFFFu;
+        exhausted = room != 0u && in_front >= T;
+        keep = room != 0u && in_front < T;
+      } else {
+        so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
+        tile_keep(pr, so, room, in_front, keep, plain, exhausted);
+      }
+      if (__ballot(exhausted) != 0ull) { if (exhausted) report_status(g, pr.line_id, WALK_OPS_EXHAUSTED); }
+      const uint64_t kept = __ballot(keep);
+      const TileNeighbour nb = tile_neighbour(kept, tl, lane, le, (pr.tw & POS_REV) != 0);
+      const uint32_t tnode = lane_read(node, nb.lane);
+      uint32_t q = 0u;
+      if (!tile_plain) q = tile_kept_index(kept, tl, le);
+      if (keep) {
+        const TileSinkDev<Sink> ts{sink, pr.line_id};
+        tile_emit(ts, node, inf, plain, pr, tl, nb, lane, tnode, q);
+      }
+    }
+    chunk_tables_flush(g, sink, THREADS);
+    __syncthreads();
+  }
+}
+
+// -- tiles of a batch's short-walk class, from the batch's own arrays (both tokenisers end here) --
+// pass 1, one wave per chunk: greedy packing in record order; place[r] = tile within the chunk << 8 | first lane
+template <uint32_t CHUNK>
+__global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const uint4* rec, uint32_t* place, uint32_t* chunk_tiles) {
+  __shared__ uint8_t ks[CHUNK];
+  const uint32_t c = blockIdx.x, lo = c * CHUNK, hi = min(n_short, lo + CHUNK);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 64u) ks[i - lo] = uint8_t(rec[REC_QUADS * size_t(i)].z & 0xFFu);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t fill = 0, tile = 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+      const uint32_t k = max(1u, uint32_t(ks[i - lo]));      // (a record without path nodes -- none in the class -- would take a lane)
+      if (tile_pack(fill, k, i == lo) && i != lo) ++tile;
+      place[i] = (tile << 8) | (fill - k);
+    }
+    chunk_tiles[c] = tile + 1u;
+  }
+}
+// pass 2, a thread per record: its positions, its line record, and -- the first record of a tile -- the tile's descriptor and padding
+template <uint32_t CHUNK>
+__global__ void tile_fill_kernel(uint32_t n_short, const LineHdr* hdr, const uint4* rec, const uint32_t* nodes, const uint32_t* place,
+                                 const uint32_t* chunk_tile, TileDesc* desc, uint32_t* pnodes, PosRec* prec) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_short; i += gridDim.x * 256u) {
+    const uint32_t c = i / CHUNK, pl = place[i], tile = chunk_tile[c] + (pl >> 8), l0 = pl & 0xFFu;
+    const uint4 r = rec[REC_QUADS * size_t(i)], r3 = rec[REC_QUADS * size_t(i) + 2];
+    const uint32_t k = r.z & 0xFFu;
+    ShortOps so;
+    so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
+    prec[i] = make_pos_rec(hdr[i], so);
+    uint32_t* out = pnodes + size_t(tile) * 64u;
+    for (uint32_t j = 0; j < k; ++j) out[l0 + j] = nodes[r.x + j];
+    if (l0 == 0u) {
+      uint64_t heads = 1ull;
+      uint32_t used = max(1u, k);
+      bool plain = (so.ns | so.x) == 0u;
+      const uint32_t hi = min(n_short, (c + 1u) * CHUNK);
+      for (uint32_t j = i + 1u; j < hi; ++j) {
+        const uint32_t pj = place[j];
+        if ((pj >> 8) != (pl >> 8)) break;
+        const uint4 q3 = rec[REC_QUADS * size_t(j) + 2];
+        heads |= 1ull << (pj & 0xFFu);
+        used = (pj & 0xFFu) + max(1u, rec[REC_QUADS * size_t(j)].z & 0xFFu);
+        plain = plain && ((q3.x >> 16) | q3.w) == 0u;
+      }
+      desc[tile] = TileDesc{i, uint32_t(heads), uint32_t(heads >> 32), used | (plain ? TILE_PLAIN : 0u)};
+      const uint32_t pad = nodes[r.x];
+      if (k == 0u) out[0] = 0u;
+      for (uint32_t l = used; l < 64u; ++l) out[l] = k ? pad : 0u;
+    }
+  }
+}
+
 __global__ void clear_flags_kernel(uint32_t* word, uint2* info, uint4* info3, uint32_t n) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { word[i] &= LEN_MASK; info[i].x &= LEN_MASK; info3[i].x &= LEN_MASK; }
 }
@@ -996,7 +1237,8 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
 
 void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   if (!b) return;
-  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx, (void*)b->rec})
+  for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx, (void*)b->rec,
+                  (void*)b->tile_desc, (void*)b->pnodes, (void*)b->prec, (void*)b->chunk_tile})
     if (p) (void)hipFree(p);
   delete b;
 }
@@ -1298,6 +1540,7 @@ __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uin
   }
 }
 
+int main_kernel_variant();
 void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
   if (b.rec) { (void)hipFree(b.rec); b.rec = nullptr; }
@@ -1308,6 +1551,45 @@ void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
+  if (main_kernel_variant() >= 120) build_batch_tiles(d, b);
+}
+
+// PANTAS_MAIN_KERNEL as the default of this build: 120 = one lane per path position (round 4), 110 = one lane per record
+// over 16-byte node records (round 3), 101 = round 2's, 0 = direct atomics
+int main_kernel_variant() { return getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 120; }
+
+constexpr uint32_t TILE_CHUNK = 2048;      // records per chunk of the aggregating kernels
+
+void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
+  HIP_OK(hipSetDevice(d.device));
+  for (void* p : {(void*)b.tile_desc, (void*)b.pnodes, (void*)b.prec, (void*)b.chunk_tile}) if (p) (void)hipFree(p);
+  b.tile_desc = nullptr; b.pnodes = nullptr; b.prec = nullptr; b.chunk_tile = nullptr; b.n_tiles = 0;
+  if (!b.n_short) return;
+  const uint32_t n_chunks = (b.n_short + TILE_CHUNK - 1u) / TILE_CHUNK;
+  ScratchPool& pool = scratch_pool(d);
+  uint32_t* place = static_cast<uint32_t*>(pool.take(size_t(b.n_short) * 4));
+  uint32_t* counts = static_cast<uint32_t*>(pool.take((size_t(n_chunks) + 1) * 4));
+  HIP_OK(dmalloc(&b.chunk_tile, (size_t(n_chunks) + 1) * 4));
+  HIP_OK(dmalloc(&b.prec, size_t(b.n_short) * sizeof(PosRec)));
+  HIP_OK(hipMemsetAsync(counts + n_chunks, 0, 4, d.stream));
+  hipLaunchKernelGGL((tile_place_kernel<TILE_CHUNK>), dim3(n_chunks), dim3(64), 0, d.stream, b.n_short, b.rec, place, counts);
+  HIP_OK(hipGetLastError());
+  size_t need = 0;
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, b.chunk_tile, int(n_chunks + 1), d.stream));
+  void* tmp = pool.take(need);
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp, need, counts, b.chunk_tile, int(n_chunks + 1), d.stream));
+  uint32_t n_tiles = 0;
+  HIP_OK(hipMemcpyAsync(&n_tiles, b.chunk_tile + n_chunks, 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  b.n_tiles = n_tiles;
+  HIP_OK(dmalloc(&b.tile_desc, size_t(n_tiles) * sizeof(TileDesc)));
+  HIP_OK(dmalloc(&b.pnodes, size_t(n_tiles) * 64 * 4));
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n_short) + 255) / 256, 1u << 16));
+  hipLaunchKernelGGL((tile_fill_kernel<TILE_CHUNK>), dim3(blocks), dim3(256), 0, d.stream, b.n_short, b.hdr, b.rec, b.nodes, place, b.chunk_tile,
+                     b.tile_desc, b.pnodes, b.prec);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(d.stream));
+  pool.give(place); pool.give(counts); pool.give(tmp);
 }
 
 DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {
@@ -1488,7 +1770,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     // others run the two record classes in kernels of their own -- the short-walk class [0, n_short) on the launch stream,
     // the rest with the general aggregating kernel beside it on a second stream: 101 = round 2's short walk, 110 = round 3's (default;
     // see the switch).  Every variant leaves the same counters (tools/ab_variants.py).
-    const int variant = getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 110;   // read per launch: tools/ab_variants.py switches it
+    const int variant = main_kernel_variant();   // read per launch: tools/ab_variants.py switches it
 #define PANTAS_AGG_RANGE(STREAM, BEGIN, END, T, CH, LN, LS, LF, MW, ...) \
     do { if ((END) > (BEGIN)) hipLaunchKernelGGL((augment_main_agg_kernel<T, CH, LN, LS, LF, MW, ##__VA_ARGS__>), \
                                                dim3(((END) - (BEGIN) + CH - 1) / CH), dim3(T), 0, STREAM, g, bv, BEGIN, END); } while (0)
@@ -1543,6 +1825,22 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
+        case 120: {
+          // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
+          // of 64 positions; same tables, same chunks of 2048 records dealt to the XCDs in eighths
+          if (b.n_short && !b.tile_desc) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
+          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          if (b.n_short) {
+            const TileView tv{b.tile_desc, b.pnodes, b.prec, b.chunk_tile, n_ch, b.n_tiles};
+            hipLaunchKernelGGL((augment_short_p_kernel<512, 2048, 10, 7, 8>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, tv.desc, tv.pnodes,
+                               tv.prec, tv.chunk_tile, tv.n_chunks);
+          }
+          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          break;
+        }
         default:
           // 110 (round 3): the short-walk class over 16-byte node records (walk.h walk_short_w, augment_short_w_kernel): a link is matched
           // against its node's first three out-targets where the node is visited and counted in the node's own table entry; same chunk

@@ -39,6 +39,12 @@ struct DeviceBatch {
                                  // star positions, the indel} -- with hdr[] everything the short-walk kernel needs to start a record
                                  // AND its gather pipeline, in four 16-byte loads (instead of hdr, two offset pairs, nodes[0..2], then
                                  // ops[] and a scan of it: three dependent load levels and a loop less per record)
+  // round 4, the short walk with one lane per path position (walk.h): the short-walk class laid out in tiles of 64 positions
+  TileDesc* tile_desc = nullptr;     // [n_tiles]
+  uint32_t* pnodes = nullptr;        // [64 x n_tiles]
+  PosRec* prec = nullptr;            // [n_short]
+  uint32_t* chunk_tile = nullptr;    // [ceil(n_short / 2048) + 1]
+  uint32_t n_tiles = 0;
   uint32_t n = 0, n_del = 0;
   uint32_t n_short = 0;          // records [0, n_short) are the short-walk class (walk.h), bucketed apart from the rest
   uint64_t n_nodes = 0, n_ops = 0, del_nodes = 0;
@@ -135,6 +141,9 @@ struct DeviceGraph;
 DeviceGraphInfo graph_info(DeviceGraph& dg);
 // fills db.rec from the batch's own arrays (augment.hip); both ways a batch comes to be call it last
 void build_batch_rec(DeviceGraph& dg, DeviceBatch& db);
+// the tiles of the short-walk class for the position-parallel kernel (augment.hip), from hdr / rec / nodes; after db.rec exists
+void build_batch_tiles(DeviceGraph& dg, DeviceBatch& db);
+int main_kernel_variant();      // PANTAS_MAIN_KERNEL, default 120 (augment.hip)
 struct Graph;
 // dense name table (id - base -> node) in HBM, uploaded on first use and owned by the DeviceGraph
 uint32_t* device_name_table(DeviceGraph& dg, const Graph& g);

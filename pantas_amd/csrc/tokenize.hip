@@ -1016,6 +1016,12 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
       DeviceBatchPtr one = tokenize_one_pass(gi, pool, scan, d_text, size, ls.as<uint64_t>(), n_lines, getenv("PANTAS_TOK_STAGE") ? uint32_t(atoi(getenv("PANTAS_TOK_STAGE"))) : stage_one,
                                              thr, check_cr, names, first_line_id, st, tm, pt);
       if (one) {
+        if (main_kernel_variant() >= 120) {        // the tiles of the position-parallel kernel: part of what a batch costs before its first launch
+          const double tt = now();
+          build_batch_tiles(dg, *one);
+          tm.bucket_s += now() - tt;
+          pt.lap("tiles of the short-walk class");
+        }
         tm.total_s = now() - t_begin;
         if (times) *times = tm;
         return one;

@@ -554,6 +554,141 @@ PANTAS_UNROLL
   return WALK_OK;
 }
 
+// ---- the short walk, one lane per path POSITION (round 4) ---------------------------------------------------------------
+// walk_short_w gives a record to a lane and loops over its path: 63 % of the lanes work in the walk, 31 % in the table code
+// behind it (lines of different lengths, kept / not kept, link found / not found), and the loop control is scalar work per pass.
+// Here the path nodes of the short-walk class are laid out in TILES of 64 positions (a record never straddles a tile; a tile
+// is padded behind its last record), a wave takes a tile, and every lane owns ONE path position: what the loop carried from
+// node to node -- the op-space position P, "is this the first / last kept node", the neighbour kept node -- becomes one wave
+// scan of the rooms and bit arithmetic on two 64-bit masks (where records start, which positions are kept).
+//   room_i   = len_i - (i == 0 ? start : 0) - (i == last ? tail - 1 : 0), counted when > 0                       (:213-216)
+//   P_i      = min(T, sum of the rooms in front of i); the line is refused when a node with room finds P_i >= T
+//   le_i     = min(room_i, T - P_i); kept / plain entries from (P_i, le_i) exactly as in walk_short_w
+//   link     = forward: to the NEXT kept position, counted in the node's own entry when that is the next path node and one of
+//              the node's first three out-targets, else handed to sink.later; reverse: to the PREVIOUS kept position, matched
+//              exactly -- the same calls with the same arguments as walk_short_w makes, in another order (all sums and minima).
+// The helpers below are what a lane computes for itself; the kernel (augment.hip augment_short_p_kernel) and the CPU harness
+// (tests/hostsim/short_walk_host.h, which loops over the 64 lanes) put the same ones around their cross-lane steps.
+constexpr uint32_t TILE_LANES = 64;
+struct alignas(16) TileDesc {
+  uint32_t first_rec;            // record (index in the batch) of the tile's first position
+  uint32_t heads_lo, heads_hi;   // bit l: a record starts at lane l (bit 0 always set)
+  uint32_t meta;                 // lanes in use (bits 0 .. 6) | TILE_PLAIN: every record of the tile is ':' runs only
+};
+constexpr uint32_t TILE_PLAIN = 1u << 8;
+// what a position needs of its record: 16 bytes instead of hdr + rec (64)
+struct alignas(16) PosRec {
+  int32_t start, tail;
+  uint32_t line_id;
+  uint32_t tw;                   // T (bits 0 .. 15) | POS_REV | POS_HAS_DEL | POS_NOT_PLAIN
+};
+constexpr uint32_t POS_REV = 1u << 16, POS_HAS_DEL = 1u << 17, POS_NOT_PLAIN = 1u << 18;
+constexpr uint32_t TILE_ROOM_CAP = 1u << 16;      // rooms only matter up to T < 2^16: capped so that 64 of them add up in 32 bits
+
+PANTAS_HD PosRec make_pos_rec(const LineHdr& h, const ShortOps& so) {
+  return PosRec{h.start, h.tail, h.line_id,
+                (so.T & 0xFFFFu) | ((h.flags & LINE_REV) ? POS_REV : 0u) | ((h.flags & LINE_HAS_DEL) ? POS_HAS_DEL : 0u) |
+                    ((so.ns | so.x) ? POS_NOT_PLAIN : 0u)};
+}
+// greedy packing of a chunk's records into tiles, in record order: `fill` = lanes taken in the open tile; true = the record of
+// k path nodes (1 <= k <= 64) opens a new tile.  Afterwards fill = lanes taken including this record, which starts at fill - k.
+PANTAS_HD bool tile_pack(uint32_t& fill, uint32_t k, bool first_of_chunk) {
+  const bool open = first_of_chunk || fill + k > TILE_LANES;
+  if (open) fill = 0;
+  fill += k;
+  return open;
+}
+
+PANTAS_HD uint32_t tile_clz64(uint64_t x) {      // x != 0
+#if defined(__HIPCC__) || defined(__GNUC__)
+  return uint32_t(__builtin_clzll(x));
+#else
+  uint32_t n = 0; while (!(x >> 63)) { x <<= 1; ++n; } return n;
+#endif
+}
+PANTAS_HD uint32_t tile_ctz64(uint64_t x) {      // x != 0
+#if defined(__HIPCC__) || defined(__GNUC__)
+  return uint32_t(__builtin_ctzll(x));
+#else
+  uint32_t n = 0; while (!(x & 1)) { x >>= 1; ++n; } return n;
+#endif
+}
+PANTAS_HD uint32_t tile_popc64(uint64_t x) {
+#if defined(__HIPCC__) || defined(__GNUC__)
+  return uint32_t(__builtin_popcountll(x));
+#else
+  uint32_t n = 0; while (x) { x &= x - 1; ++n; } return n;
+#endif
+}
+PANTAS_HD uint64_t tile_lanes_le(uint32_t lane) { return lane >= 63u ? ~0ull : ((2ull << lane) - 1ull); }      // lanes 0 .. lane
+PANTAS_HD uint64_t tile_lanes_lt(uint32_t lane) { return (1ull << lane) - 1ull; }                               // lanes 0 .. lane - 1
+
+struct TileLane {
+  uint32_t seg_start, seg_end;   // first / last lane of the lane's record
+};
+// the lane's record, counted from the tile's first (lane < used)
+PANTAS_HD uint32_t tile_rec_ordinal(uint64_t heads, uint64_t le) { return tile_popc64(heads & le) - 1u; }
+PANTAS_HD TileLane tile_lane(uint64_t heads, uint32_t used, uint64_t le) {
+  const uint64_t upto = heads & le, behind = heads & ~le;      // upto != 0 for every lane: lane 0 starts a record
+  TileLane t;
+  t.seg_start = 63u - tile_clz64(upto | 1ull);
+  t.seg_end = (behind ? tile_ctz64(behind) : used) - 1u;
+  return t;
+}
+PANTAS_HD uint64_t tile_heads(const TileDesc& d) { return (uint64_t(d.heads_hi) << 32) | d.heads_lo; }
+// room of the position (0: none), capped
+PANTAS_HD uint32_t tile_room(uint32_t word, bool first, bool last, const PosRec& pr) {
+  const int32_t r = int32_t(word & LEN_MASK) - (first ? pr.start : 0) - (last ? pr.tail - 1 : 0);
+  const int32_t c = r < int32_t(TILE_ROOM_CAP) ? r : int32_t(TILE_ROOM_CAP);
+  return uint32_t(c > 0 ? c : 0);
+}
+// from the sum of the rooms in front: kept?  plain entries?  refused?   (`so` is only read for a record with POS_NOT_PLAIN)
+PANTAS_HD void tile_keep(const PosRec& pr, const ShortOps& so, uint32_t room, uint32_t in_front, bool& keep, uint32_t& plain, bool& exhausted) {
+  const uint32_t T = pr.tw & 0xFFFFu;
+  exhausted = room != 0u && in_front >= T;
+  keep = room != 0u && in_front < T;
+  plain = 1u;
+  if (keep && (pr.tw & POS_NOT_PLAIN)) {
+    const uint32_t left = T - in_front, le = room < left ? room : left;
+    short_node_summary(so, in_front, le, keep, plain);
+  }
+}
+struct TileNeighbour {
+  bool is_first, is_last;        // no kept position of the record in front of / behind this one
+  bool has;                      // the link's other end exists (forward: a next kept node; reverse: a previous one)
+  uint32_t lane;                 // ... and stands at this lane (any lane when there is none)
+};
+// kept = the tile's kept positions; le = lanes 0 .. lane
+PANTAS_HD TileNeighbour tile_neighbour(uint64_t kept, const TileLane& tl, uint32_t lane, uint64_t le, bool rev) {
+  const uint64_t before = kept & (le >> 1), after = kept & ~le;      // (le >> 1 = lanes 0 .. lane - 1)
+  (void)lane;
+  const uint32_t pl = 63u - tile_clz64(before | 1ull), nl = after ? tile_ctz64(after) : 64u;
+  const bool has_prev = before != 0 && pl >= tl.seg_start, has_next = nl <= tl.seg_end;
+  TileNeighbour n;
+  n.is_first = !has_prev;
+  n.is_last = !has_next;
+  n.has = rev ? has_prev : has_next;
+  n.lane = (rev ? pl : nl) & 63u;
+  return n;
+}
+// index of a kept position among the kept positions of its record (only a line with a '-' asks)
+PANTAS_HD uint32_t tile_kept_index(uint64_t kept, const TileLane& tl, uint64_t le) {
+  return tile_popc64(kept & (le >> 1) & ~tile_lanes_lt(tl.seg_start));
+}
+// the calls of one kept position (tnode = the node at nb.lane, q = tile_kept_index when the line has a '-')
+template <class Sink>
+PANTAS_HD void tile_emit(const Sink& sink, uint32_t node, const NodeInfo3& info, uint32_t plain, const PosRec& pr, const TileLane& tl,
+                         const TileNeighbour& nb, uint32_t lane, uint32_t tnode, uint32_t q) {
+  const bool rev = (pr.tw & POS_REV) != 0;
+  // forward, a dropped node or one without room in between: the link's slot is not looked for here, as in walk_short_w
+  const bool look = nb.has && (rev || nb.lane == lane + 1u);
+  const uint32_t code = !look ? 0u : info.t0 == tnode ? 1u : info.t1 == tnode ? 2u : info.t2 == tnode ? 3u : 0u;
+  const bool enter = plain != 0u && !nb.is_first, leave = plain != 0u && !nb.is_last;
+  if (nb.has && code == 0u) sink.later(node, tnode, (rev ? nb.lane : lane) - tl.seg_start);
+  sink.kept(node, info.word & (FLAG_IL | FLAG_OL), pr.line_id, (rev ? leave : enter) ? plain : 0u, (rev ? enter : leave) ? plain : 0u, code,
+            (pr.tw & POS_HAS_DEL) ? event_order(pr.line_id, q, 1) : 0ull);
+}
+
 // The rare-key pass over a one-indel line: only the nodes that hold a piece of the '-' can own a deletion-derived key, so
 // every other kept node is just counted (its index orders the events) and the piece-by-piece compaction (PieceAcc, fed
 // exactly as walk_line feeds it) runs for those one or two nodes alone.  Sink: the walk_line sink concept (rare() matters).

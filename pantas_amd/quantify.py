@@ -153,7 +153,12 @@ def quantify(c1, c2, w: int = 0, both: bool = False, out=sys.stdout):
     import ctypes as C
     import os
     import tempfile
-    from ._lib import PantasError, lib
+    try:
+        from ._lib import PantasError, lib
+    except (ImportError, OSError) as e:
+        # pure host work, but the native form lives in libpantas_gpu.so (HIP-linked): say what the way out is instead of a bare
+        # loader error -- the interpreted form is an explicit choice, never a silent substitute
+        raise ImportError(f"{e}; this command is host-only: PANTAS_QUANT=python runs its interpreted form without the library") from e
     n = len(c1)
     if len(c2) != n:
         raise ValueError("the same number of replicates for each condition")

@@ -109,7 +109,12 @@ def remap(csv_path: str, gtf_path: str, min_intron_size: int = 100, out=sys.stdo
     if os.environ.get("PANTAS_REMAP") == "python":
         return remap_python(csv_path, gtf_path, min_intron_size, out)
     import tempfile
-    from ._lib import PantasError, lib
+    try:
+        from ._lib import PantasError, lib
+    except (ImportError, OSError) as e:
+        # pure host work, but the native form lives in libpantas_gpu.so (HIP-linked): say what the way out is instead of a bare
+        # loader error -- the interpreted form is an explicit choice, never a silent substitute
+        raise ImportError(f"{e}; this command is host-only: PANTAS_REMAP=python runs its interpreted form without the library") from e
     try:
         fd = out.fileno()
         direct = True

@@ -102,7 +102,8 @@ def test_kernel_variants_and_record_order_give_identical_gfa():
     base = _augmented_sha({})
     assert int(base[1]) > 5e8
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0"}) == base
-    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "101"}) == base     # round 2's short walk (8-byte node records, deferred link lookups); the default is round 3's
+    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "101"}) == base     # round 2's short walk (8-byte node records, deferred link lookups)
+    assert _augmented_sha({"PANTAS_MAIN_KERNEL": "110"}) == base     # round 3's (one lane per record over 16-byte node records); the default is round 4's, one lane per path position
     assert _augmented_sha({"PANTAS_NO_BUCKET": "1"}) == base
     assert _augmented_sha({"PANTAS_MAIN_KERNEL": "0", "PANTAS_NO_BUCKET": "1", "PANTAS_THREADS": "3"}) == base
 
