@@ -66,6 +66,66 @@ int main(int argc, char** argv) {
       P += le;
     }
   }
+  // ---- round 4: the tile geometry of the position-parallel walk (walk.h tile_*) against plain loops over random tiles
+  uint64_t tiles_checked = 0;
+  for (uint64_t c = 0; c < cases / 20; ++c) {
+    // records of random lengths packed greedily (tile_pack), as the batch builder does for a chunk
+    std::vector<uint32_t> ks;
+    for (uint32_t i = 0, n = rnd(1, 60); i < n; ++i) ks.push_back(rng() % 8 == 0 ? rnd(20, 31) : rnd(1, 9));
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> tiles;      // per tile: (first lane, k) of its records
+    uint32_t fill = 0;
+    for (size_t i = 0; i < ks.size(); ++i) {
+      if (tile_pack(fill, ks[i], i == 0)) tiles.emplace_back();
+      if (fill > TILE_LANES || fill < ks[i]) { fprintf(stderr, "tile_pack: fill %u after a record of %u\n", fill, ks[i]); return 1; }
+      tiles.back().emplace_back(fill - ks[i], ks[i]);
+    }
+    for (size_t t = 0; t + 1 < tiles.size(); ++t) {      // greedy: the next tile's first record did not fit
+      const auto& last = tiles[t].back();
+      if (last.first + last.second + tiles[t + 1][0].second <= TILE_LANES) { fprintf(stderr, "tile_pack: a tile was closed early\n"); return 1; }
+    }
+    for (const auto& tile : tiles) {
+      uint64_t heads = 0;
+      uint32_t used = 0;
+      int seg_of[64];
+      for (int& x : seg_of) x = -1;
+      for (size_t r = 0; r < tile.size(); ++r) {
+        heads |= 1ull << tile[r].first;
+        for (uint32_t j = 0; j < tile[r].second; ++j) seg_of[tile[r].first + j] = int(r);
+        used = tile[r].first + tile[r].second;
+      }
+      const uint64_t kept = rng() & rng() & (used == 64 ? ~0ull : ((1ull << used) - 1ull)) | (rng() % 4 == 0 ? 0ull : (rng() & ((used == 64) ? ~0ull : ((1ull << used) - 1ull))));
+      for (uint32_t l = 0; l < 64; ++l) {
+        const uint64_t le = tile_lanes_le(l);
+        const uint32_t ord = tile_rec_ordinal(heads, le & tile_lanes_le(used - 1u));
+        const int want_ord = l < used ? seg_of[l] : int(tile.size()) - 1;
+        if (int(ord) != want_ord) { fprintf(stderr, "tile_rec_ordinal lane %u: %u, want %d\n", l, ord, want_ord); return 1; }
+        if (l >= used) continue;
+        const TileLane tl = tile_lane(heads, used, le);
+        const auto& rec = tile[size_t(seg_of[l])];
+        if (tl.seg_start != rec.first || tl.seg_end != rec.first + rec.second - 1u) { fprintf(stderr, "tile_lane lane %u: [%u, %u]\n", l, tl.seg_start, tl.seg_end); return 1; }
+        if (!((kept >> l) & 1u)) continue;
+        for (int rev = 0; rev < 2; ++rev) {
+          const TileNeighbour nb = tile_neighbour(kept, tl, l, le, rev != 0);
+          int prev = -1, next = -1;
+          uint32_t q = 0;
+          for (uint32_t j = tl.seg_start; j <= tl.seg_end; ++j) {
+            if (!((kept >> j) & 1u)) continue;
+            if (j < l) { prev = int(j); ++q; }
+            if (j > l && next < 0) next = int(j);
+          }
+          const int other = rev ? prev : next;
+          if (nb.is_first != (prev < 0) || nb.is_last != (next < 0) || nb.has != (other >= 0) || (other >= 0 && int(nb.lane) != other) || nb.lane > 63u ||
+              tile_kept_index(kept, tl, le) != q) {
+            fprintf(stderr, "tile_neighbour lane %u rev %d: first %d last %d has %d lane %u q %u; want prev %d next %d q %u\n", l, rev, nb.is_first, nb.is_last,
+                    nb.has, nb.lane, tile_kept_index(kept, tl, le), prev, next, q);
+            return 1;
+          }
+        }
+      }
+      ++tiles_checked;
+    }
+  }
+  printf("ok %llu tiles\n", (unsigned long long)tiles_checked);
   printf("ok %llu nodes, %llu dropped, plain 0/1/2/3: %llu %llu %llu %llu\n", (unsigned long long)nodes_checked, (unsigned long long)dropped,
          (unsigned long long)plain_hist[0], (unsigned long long)plain_hist[1], (unsigned long long)plain_hist[2], (unsigned long long)plain_hist[3]);
   return 0;

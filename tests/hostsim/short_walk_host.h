@@ -64,6 +64,73 @@ struct ShortFromGeneral {
   }
 };
 
+// Round 4, one lane per path position (walk.h tile_*): the line stands in a tile of 64 lanes, alone or behind / in front of copies
+// of itself (the copies' calls are dropped: they are there so that records start at other lanes than 0, masks have several heads and
+// neighbours are looked for across record borders), and the 64 lanes are looped over where the kernel does its cross-lane steps --
+// the wave scan of the rooms, the two lane reads, the ballot of the kept positions.
+template <class GenSink>
+int tile_walk_host(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops,
+                   uint32_t c, GenSink& s) {
+  if (k == 0) return WALK_OK;
+  const HostInfo ga{g, word};
+  ShortOps so;
+  short_ops_scan(ops, c, so);
+  const PosRec pr = make_pos_rec(h, so);
+  // copies in front of / behind the line, by line id; greedy packing decides where records start (tile_pack)
+  const uint32_t want_front = (h.line_id >> 1) % 3u, want_back = (h.line_id >> 3) % 3u;
+  uint32_t fill = 0, n_rec = 0, mine = 0;
+  uint64_t heads = 0;
+  uint32_t start_of[8];
+  for (uint32_t r = 0; r < want_front + 1u + want_back; ++r) {
+    uint32_t f = fill;
+    if (tile_pack(f, k, r == 0) && r != 0) {
+      if (r <= want_front) { fill = 0; n_rec = 0; heads = 0; f = k; }      // the tile closes in front of the line: start over with it
+      else break;                                                         // ... behind it: done
+    }
+    start_of[n_rec] = f - k;
+    heads |= 1ull << (f - k);
+    if (r == want_front) mine = n_rec;
+    ++n_rec;
+    fill = f;
+  }
+  const uint32_t used = fill;
+  const TileDesc d{0u, uint32_t(heads), uint32_t(heads >> 32), used | ((so.ns | so.x) ? 0u : TILE_PLAIN)};
+  uint32_t node[64], room[64], incl[64], plain[64];
+  NodeInfo3 inf[64];
+  TileLane tl[64];
+  bool keep[64];
+  for (uint32_t l = 0; l < 64; ++l) {
+    const uint64_t le = tile_lanes_le(l);
+    const uint32_t rec = tile_rec_ordinal(tile_heads(d), le & tile_lanes_le(used - 1u));
+    tl[l] = tile_lane(tile_heads(d), used, le);
+    const bool active = l < used;
+    node[l] = active ? nodes[l - start_of[rec]] : nodes[0];
+    inf[l] = ga.info3(node[l]);
+    room[l] = active ? tile_room(inf[l].word, l == tl[l].seg_start, l == tl[l].seg_end, pr) : 0u;
+  }
+  uint32_t sum = 0;
+  for (uint32_t l = 0; l < 64; ++l) { sum += room[l]; incl[l] = sum; }
+  uint64_t kept = 0;
+  int st = WALK_OK;
+  for (uint32_t l = 0; l < 64; ++l) {
+    const uint32_t base = incl[(tl[l].seg_start - 1u) & 63u];
+    const uint32_t in_front = incl[l] - room[l] - (tl[l].seg_start ? base : 0u);
+    bool exhausted;
+    tile_keep(pr, so, room[l], in_front, keep[l], plain[l], exhausted);
+    if (exhausted) st = WALK_OPS_EXHAUSTED;
+    if (keep[l]) kept |= 1ull << l;
+  }
+  if (st != WALK_OK) return st;      // (walk_short_w has made the calls in front of the refused node by then; a refused line ends the run)
+  const ShortWFromGeneral<GenSink> sw{s, g, h.line_id};
+  for (uint32_t l = start_of[mine]; l < start_of[mine] + k; ++l) {
+    if (!keep[l]) continue;
+    const uint64_t le = tile_lanes_le(l);
+    const TileNeighbour nb = tile_neighbour(kept, tl[l], l, le, (pr.tw & POS_REV) != 0);
+    tile_emit(sw, node[l], inf[l], plain[l], pr, tl[l], nb, l, node[nb.lane], tile_kept_index(kept, tl[l], le));
+  }
+  return WALK_OK;
+}
+
 // main pass over one line, as augment.hip dispatches it
 template <class GenSink>
 int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& h, const uint32_t* nodes, uint32_t k, const uint32_t* ops,
@@ -76,8 +143,10 @@ int main_walk(const Graph& g, const std::vector<uint32_t>& word, const LineHdr& 
   // every instance the kernels use takes its turn: gathers one / two nodes ahead, deferred link lookups, the lean
   // instance for lines without an indel
   static const bool wide_only = getenv("HOSTSIM_WIDE_WALK") != nullptr;      // every short-walk line through walk_short_w
-  const uint32_t sel = wide_only ? 4u + (h.line_id & 1u) : h.line_id % 6u;
+  static const bool tile_only = getenv("HOSTSIM_TILE_WALK") != nullptr;      // ... through the position-parallel walk (round 4, the default kernel)
+  const uint32_t sel = tile_only ? 6u : wide_only ? 4u + (h.line_id & 1u) : h.line_id % 8u;
   switch (sel) {
+    case 6: case 7: return tile_walk_host(g, word, h, nodes, k, ops, c, s);
     case 4: case 5: {     // round 3: 16-byte node records, links matched against the first three out-slots where the node is visited
       const ShortWFromGeneral<GenSink> sw{s, g, h.line_id};
       ShortOps so;

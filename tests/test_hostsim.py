@@ -145,6 +145,28 @@ def test_wide_short_walk_source(hostsim, tmp_path):
         assert r.returncode == 0 and r.stdout == want.getvalue(), seed
 
 
+def test_position_parallel_short_walk_source(hostsim, tmp_path):
+    """walk.h tile_* (round 4's dominant kernel: one lane per path position, tiles of 64 lanes, the op-space position of a node from
+    a scan of the rooms, first / last / neighbour kept node from 64-bit masks) for EVERY short-walk line, the line standing alone or
+    among copies of itself in the tile: the goldens' bytes, the edge goldens the CPU harness takes, and the oracle on workloads with
+    many bubbles, links the graph does not have, indels (dropped nodes in between, exact within-line orders), long reads"""
+    env = {**os.environ, "HOSTSIM_TILE_WALK": "1"}
+    for case in CASES:
+        d = os.path.join(GOLDEN, case)
+        r = subprocess.run([hostsim["augment"], f"{d}/in.gaf", f"{d}/in.gfa"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == open(f"{d}/expected.aug.gfa").read(), case
+    from pantas_amd import synth
+    for seed, kw in ((41, dict(bubble_rate=0.3, p_novel_skip=0.15, p_novel_ce=0.1)), (42, dict(p_indel=0.4, p_sub=0.5, bubble_rate=0.2)),
+                     (43, dict(bubble_rate=0.5, p_novel_ss=0.2, p_intron=0.2)), (44, dict(read_len=400, p_indel=0.2, p_sub=0.3))):
+        pre = str(tmp_path / f"w{seed}")
+        synth.write_all(pre, seed=seed, n_genes=30, n_lines=8000, **kw)
+        want = io.StringIO()
+        augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+        r = subprocess.run([hostsim["augment"], pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and r.stdout == want.getvalue(), seed
+
+
 @pytest.mark.parametrize("fan,isw", [(10, 5), (40, 5), (300, 5), (40, 2)])
 def test_intronic_search_beyond_local_frontier(hostsim, tmp_path, fan, isw):
     from hub_case import write_hub_case
@@ -277,13 +299,15 @@ def test_graph_cache_round_trip(hostsim, tmp_path):
 def test_short_walk_node_summary_vs_piece_compaction():
     """walk.h short_node_summary (what the short-walk kernel makes of a path node: kept?, how many compacted entries are
     neither '-' nor '*') against PieceAcc, the piece-by-piece restatement of :63-107, on random cs strings of the
-    short-walk classes (':' runs, up to four '*', at most one '+' / '-') laid over random node lengths."""
+    short-walk classes (':' runs, up to four '*', at most one '+' / '-') laid over random node lengths.  Round 4: and the tile geometry
+    of the position-parallel walk (tile_pack, tile_rec_ordinal, tile_lane, tile_neighbour, tile_kept_index) against plain loops over
+    randomly packed tiles and random kept masks."""
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, "hostsim_shortwalk")
     subprocess.check_call(CXX + ["-o", exe, os.path.join(ROOT, "tests/hostsim/hostsim_shortwalk.cpp")])
     r = run([exe, "400000"])
     assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout.startswith("ok ")
+    assert r.stdout.startswith("ok ") and " tiles" in r.stdout.splitlines()[0]
 
 
 @pytest.mark.parametrize("seed", [5, 6])
