@@ -552,14 +552,15 @@ def main():
         alg_bytes, short_alg = tot("alg_bytes"), tot("short_alg_bytes")
         if avg_short > 0:
             # two main kernels: the short-walk kernel takes the records of its class -- the dominant one
-            variant = os.environ.get("PANTAS_MAIN_KERNEL", "110")
-            dom_name = "augment_short_w_kernel<512,2048,10,7,8,1>" if variant == "110" else f"augment_main_agg_kernel<short-walk class> (PANTAS_MAIN_KERNEL={variant})"
+            variant = os.environ.get("PANTAS_MAIN_KERNEL", "120")
+            dom_name = {"120": "augment_short_p_kernel<512,2048,10,7,8,0>", "110": "augment_short_w_kernel<512,2048,10,7,8,1>"}.get(
+                variant, f"augment_main_agg_kernel<short-walk class> (PANTAS_MAIN_KERNEL={variant})")
             dom_ms, dom_bytes, dom_recs = avg_short, short_alg, tot("short_records")
         else:
             dom_name, dom_ms, dom_bytes, dom_recs = "augment main kernels of all resident batches", avg_main, alg_bytes, records
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
-        for tf in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        for tf in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if scale in tj and not args.lines and not args.del_hot:

@@ -326,7 +326,7 @@ constexpr uint32_t PACKED_MAX_PATH = SHORT_MAX_PATH;
 
 template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, bool PACKED = false>
 struct AggSink {
-  static constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CF = 1u << LOG_F;
+  static constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CF = 1u << LOG_F, LOG_N_ = LOG_N;
   const GraphView& g;
   uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN | RC of the node's first out-slot CN]; PACKED: CN x u64 {NC, IL0, OLL, RC first slot}
   uint32_t* skey; uint32_t* scnt;
@@ -382,11 +382,14 @@ struct AggSink {
     novel(a, b, order);
   }
 
-  template <uint32_t LOG>
+  // HOME 1: the key's low bits as the home slot (the keys of a chunk are runs of consecutive ids: no two nodes of a run share a slot);
+  // in the record-per-lane kernels it measured no faster than the multiplicative hash (2.427 vs 2.411 ms).
+  // HOME 2: the table as buckets of four slots, a node's bucket from its low bits, linear probing from the bucket's first slot (the
+  // position-parallel kernel reads the four keys of a bucket at once)
+  template <uint32_t LOG, int HOME = 0>
   static __device__ __forceinline__ uint32_t probe(uint32_t* keys, uint32_t key) {
     constexpr uint32_t CAP = 1u << LOG;
-    // (the key's low bits as the slot -- the keys of a chunk are runs of consecutive ids -- measured no faster: 2.427 vs 2.411 ms)
-    uint32_t h = (key * 2654435761u) >> (32 - LOG);
+    uint32_t h = HOME == 2 ? ((key << 2) & (CAP - 1u)) : HOME == 1 ? (key & (CAP - 1u)) : ((key * 2654435761u) >> (32 - LOG));
     // nearly every probe finds its key in the home slot (a chunk revisits the same few hundred nodes): one read, one compare
     if (__atomic_load_n(&keys[h], __ATOMIC_RELAXED) == key) return h;
 #pragma unroll 1
@@ -523,13 +526,14 @@ struct AggSink {
     else link_direct(a, b, order);
   }
   // one kept node: NC + 1, IL[0] / OL[len] + steps, one hit on out-slot code - 1 (code 1 .. 3), first-seen order of a flagged side
+  template <int HOME = 0>
   __device__ __forceinline__ void bump_w(uint32_t n, uint32_t flags, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
     if (wab & 256u) { if ((n ^ flags ^ line_id ^ a_il ^ a_ol ^ code) == 0x12345677u) ncnt[0] = 1; return; }
     if (wab & 512u) { const uint32_t hh = probe<LOG_N>(nkey, n); if (hh != LDS_EMPTY) atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + hh, 1ull | (uint64_t(a_il) << 16) | (uint64_t(a_ol) << 32) | (uint64_t(code == 1u) << 48)); return; }
     // (most nodes carry no flag: one test in front of the two per side)
     bool f_il = false, f_ol = false;
     if (flags) { f_il = a_il && (flags & FLAG_IL); f_ol = a_ol && (flags & FLAG_OL); }
-    const uint32_t h = probe<LOG_N>(nkey, n);
+    const uint32_t h = probe<LOG_N, HOME>(nkey, n);
     if (h != LDS_EMPTY) {
       const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) | (static_cast<unsigned long long>(a_ol) << 32) |
                                      (static_cast<unsigned long long>(code == 1u ? 1u : 0u) << 48);
@@ -848,14 +852,6 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphVie
 }
 
 // ---- the short walk with one lane per path position (round 4; walk.h "one lane per path POSITION") --------------------------
-struct TileView {
-  const TileDesc* desc;          // [tiles]
-  const uint32_t* pnodes;        // [64 x tiles] node of every position; lanes behind a tile's last record hold a valid node
-  const PosRec* prec;            // [n_short]
-  const uint32_t* chunk_tile;    // [chunks + 1] first tile of every chunk of CHUNK records
-  uint32_t n_chunks, n_tiles;
-};
-
 // inclusive sum over the wave's 64 lanes (DPP: four row shifts, two row broadcasts)
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
   v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));      // row_shr:1
@@ -880,7 +876,7 @@ __device__ __forceinline__ void chunk_tables_clear(const Sink& k, uint32_t threa
   }
   for (uint32_t i = threadIdx.x; i < CF; i += threads) { k.fkey[i] = LDS_EMPTY; k.fmin[i] = ~0ull; k.vkey[i] = EMPTY_KEY; k.vmin[i] = ~0ull; k.vcnt[i] = 0u; }
   for (uint32_t i = threadIdx.x; i < CS; i += threads) { k.skey[i] = LDS_EMPTY; k.scnt[i] = 0u; }
-  if (threadIdx.x == 0) *k.lq_n = 0u;
+  if (threadIdx.x < 8u) k.lq_n[threadIdx.x] = 0u;      // (the position-parallel kernel: one count per wave)
 }
 // queued links looked up, then every table of the chunk added to memory (the two barriers inside; none behind)
 template <class Sink>
@@ -888,10 +884,13 @@ __device__ __forceinline__ void chunk_tables_flush(const GraphView& g, const Sin
   constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS;
   __syncthreads();
   {
-    const uint32_t m = min(*k.lq_n, Sink::LQ_CAP);
-    for (uint32_t i = threadIdx.x; i < m; i += threads) {
-      const uint4 e = k.lq[i];
-      k.link_direct(e.x, e.y, (static_cast<uint64_t>(e.w) << 32) | e.z);
+    // the queue is one region per wave (LQ_CAP / waves entries each, filled without atomics): entry i belongs to wave i / region
+    const uint32_t region = Sink::LQ_CAP / (threads / 64u);
+    for (uint32_t i = threadIdx.x; i < Sink::LQ_CAP; i += threads) {
+      if ((i % region) < k.lq_n[i / region]) {
+        const uint4 e = k.lq[i];
+        k.link_direct(e.x, e.y, (static_cast<uint64_t>(e.w) << 32) | e.z);
+      }
     }
     __syncthreads();
   }
@@ -920,24 +919,15 @@ __device__ __forceinline__ void chunk_tables_flush(const GraphView& g, const Sin
   }
 }
 
-template <class Agg>
-struct TileSinkDev {
-  const Agg& s;
-  __device__ __forceinline__ void kept(uint32_t node, uint32_t flags, uint32_t line_id, uint32_t a_il, uint32_t a_ol, uint32_t code, uint64_t exact_order) const {
-    s.bump_w(node, flags, line_id, a_il, a_ol, code, exact_order);
-  }
-  // (a lane queues for its own record: the order of a link inside its line is the path index handed in)
-  uint32_t line_id;
-  __device__ __forceinline__ void later(uint32_t a, uint32_t b, uint32_t idx) const { s.link_later(a, b, event_order(line_id, idx, 0)); }
-};
-
-template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint32_t MINW>
-__global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphView g, BatchView b, const TileDesc* __restrict__ t_desc,
-                                                                        const uint32_t* __restrict__ t_pnodes, const PosRec* __restrict__ t_prec,
-                                                                        const uint32_t* __restrict__ t_chunk_tile, uint32_t n_chunks_in) {
-  // (the tile arrays as restrict pointers of their own: nothing the kernel writes aliases them, so the compiler may read the
-  // wave-uniform descriptors with scalar loads)
-  const TileView tv{t_desc, t_pnodes, t_prec, t_chunk_tile, n_chunks_in, 0u};
+// OPT (timing-only instances, compiled with EXPERIMENTS=1; results wrong by construction): 16 = a kept position updates nothing,
+// 32 = nothing is queued, 64 = nothing happens behind the mask of kept positions
+template <uint32_t THREADS, uint32_t CHUNK, uint32_t LOG_N, uint32_t LOG_F, uint32_t MINW, uint32_t OPT>
+__global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphView g, BatchView b, const uint32_t* __restrict__ t_first,
+                                                                        const uint32_t* __restrict__ t_pnodes, const uint16_t* __restrict__ t_pmeta,
+                                                                        const PosRec* __restrict__ t_prec, const uint32_t* __restrict__ t_chunk_tile,
+                                                                        uint32_t n_chunks) {
+  // (the tile arrays are restrict pointers of their own: nothing the kernel writes aliases them, so the wave-uniform words are read
+  // with scalar loads)
   constexpr uint32_t LOG_S = 8;
   using Sink = AggSink<LOG_N, LOG_S, LOG_F, true>;
   constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS, NW = THREADS / 64u;
@@ -949,95 +939,192 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
   __shared__ unsigned long long vmin[CF];
   __shared__ uint32_t vcnt[CF];
   __shared__ uint32_t fkey[CF];
-  __shared__ uint32_t nkey[CN];
+  __shared__ __attribute__((aligned(16))) uint32_t nkey[CN];
   __shared__ __attribute__((aligned(8))) uint32_t ncnt[2 * CN];
   __shared__ uint32_t ncnt2[CN];
   __shared__ __attribute__((aligned(8))) uint32_t omin[2 * CN];
   __shared__ uint4 lq[Sink::LQ_CAP];
-  __shared__ uint32_t lq_n;
+  __shared__ uint32_t lq_n[8];
   g.ablate = 0u;
   const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t n_chunks = tv.n_chunks;
   const uint32_t per_xcd = (n_chunks + 7u) / 8u;       // workgroup w takes chunk (w % 8) * n/8 + w / 8: an XCD walks one contiguous eighth
   const NodeInfo3* info3 = reinterpret_cast<const NodeInfo3*>(g.info3);
-  const uint64_t le = tile_lanes_le(lane);
   for (uint32_t c0 = blockIdx.x; c0 < 8u * per_xcd; c0 += gridDim.x) {
     const uint32_t c = (c0 & 7u) * per_xcd + (c0 >> 3);
     if (c >= n_chunks) continue;
     Sink sink{g, nkey, ncnt, skey, scnt, fkey, fmin, vkey, vcnt, vmin, omin, nullptr, nullptr};
-    sink.ncnt2 = ncnt2; sink.lq = lq; sink.lq_n = &lq_n;
+    sink.ncnt2 = ncnt2; sink.lq = lq; sink.lq_n = lq_n;
     chunk_tables_clear(sink, THREADS);
-    const uint32_t t_begin = tv.chunk_tile[c], t_end = tv.chunk_tile[c + 1];      // (t_end > t_begin: a chunk has records)
+    const uint32_t t_begin = t_chunk_tile[c], t_end = t_chunk_tile[c + 1];      // (t_end > t_begin: a chunk has records)
     const uint32_t t_last = t_end - 1u;
-    // pipeline: while tile t is worked on, the node ids and the descriptor of tile t + 2 NW and the node records and line records
-    // of tile t + NW are in flight; every load is issued unconditionally (tile index clamped to the chunk).  Descriptors are the
-    // same for the whole wave: they live in scalar registers.
+    // Pipeline over the wave's tiles t, t + NW, ...: while tile t is worked on, {first-record word, node ids, position words} of tile
+    // t + 2 NW and {node records, line records, op summaries} of tile t + NW are in flight.  Every load is issued unconditionally
+    // (tile index clamped to the chunk): a load that may or may not have been issued turns every later wait into a full one.
     uint32_t t = t_begin + wave;
-    auto load_desc = [&](uint32_t tt) { return tv.desc[tt]; };
-    TileDesc d_c = load_desc(min(t, t_last)), d_n = load_desc(min(t + NW, t_last));
-    uint32_t node_c = tv.pnodes[size_t(min(t, t_last)) * 64u + lane];
-    uint32_t node_n = tv.pnodes[size_t(min(t + NW, t_last)) * 64u + lane];
+    uint32_t queued = 0u;                                                 // links this wave has queued in its region (wave-uniform)
+    constexpr uint32_t REGION = Sink::LQ_CAP / NW;
+    static_assert(REGION >= 64u, "a tile can queue 64 links at once");
+    auto drain_region = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");                // (the wave's own stores to its region are done)
+      for (uint32_t j = lane; j < queued; j += 64u) {
+        const uint4 e = lq[wave * REGION + j];
+        const uint64_t order = (static_cast<uint64_t>(e.w) << 32) | (e.z & ~1u);
+        // bit 0 of the entry's order word (its phase bits are 0): the node has at most two out-slots, both looked at where the link
+        // was met -- the graph does not have the link, no row has to be read (most queued links: 1.9 % of all against 0.4 % that
+        // take a fourth or later slot)
+        if (e.z & 1u) sink.novel(e.x, e.y, order); else sink.link_direct(e.x, e.y, order);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    };
+    auto line_of = [&](uint32_t first_word, uint32_t meta) {      // a lane behind the last record reads the tile's first line (and drops it)
+      return (first_word & ~TILE_NOT_PLAIN) + (meta == POS_INACTIVE ? 0u : pos_ordinal(meta));
+    };
+    const uint32_t ta = min(t, t_last), tb = min(t + NW, t_last);
+    uint32_t first_c = t_first[ta], first_n = t_first[tb];
+    uint32_t node_c = t_pnodes[size_t(ta) * 64u + lane], node_n = t_pnodes[size_t(tb) * 64u + lane];
+    uint32_t meta_c = t_pmeta[size_t(ta) * 64u + lane], meta_n = t_pmeta[size_t(tb) * 64u + lane];
     NodeInfo3 inf_c = info3[node_c];
-    // a lane behind the tile's last record reads the line record of the last one (and does nothing with it)
-    auto rec_of = [&](const TileDesc& dd) { return dd.first_rec + tile_rec_ordinal(tile_heads(dd), le & tile_lanes_le((dd.meta & 0x7Fu) - 1u)); };
-    uint32_t rec_c = rec_of(d_c);
-    PosRec pr_c = tv.prec[rec_c];
+    uint32_t rec_c = line_of(first_c, meta_c);
+    PosRec pr_c = t_prec[rec_c];
+    uint4 so_c = make_uint4(0u, 0u, 0u, 0u);
+    if (first_c & TILE_NOT_PLAIN) so_c = b.rec[REC_QUADS * size_t(rec_c) + 2];
     __syncthreads();
     for (; t < t_end; t += NW) {
-      const TileDesc d = d_c;
-      const uint32_t node = node_c, rec = rec_c;
+      const uint32_t first_word = first_c, node = node_c, meta = meta_c;
       const NodeInfo3 inf = inf_c;
       const PosRec pr = pr_c;
-      ShortOps so;
-      const bool tile_plain = (d.meta & TILE_PLAIN) != 0u;      // (wave-uniform)
-      uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
-      if (!tile_plain) r3 = b.rec[REC_QUADS * size_t(rec) + 2];      // a '*' or an indel somewhere in the tile: the lines' op summaries
-      // requests for the wave's next tiles (behind the load above: waiting for it leaves these in flight)
+      const uint4 r3 = so_c;
       {
         const uint32_t t2 = min(t + 2u * NW, t_last);
-        const TileDesc d_nn = load_desc(t2);
-        const uint32_t node_nn = tv.pnodes[size_t(t2) * 64u + lane];
+        const uint32_t first_nn = t_first[t2];
+        const uint32_t node_nn = t_pnodes[size_t(t2) * 64u + lane];
+        const uint32_t meta_nn = t_pmeta[size_t(t2) * 64u + lane];
         inf_c = info3[node_n];
-        rec_c = rec_of(d_n);
-        pr_c = tv.prec[rec_c];
-        d_c = d_n; d_n = d_nn;
+        rec_c = line_of(first_n, meta_n);
+        pr_c = t_prec[rec_c];
+        if (first_n & TILE_NOT_PLAIN) so_c = b.rec[REC_QUADS * size_t(rec_c) + 2];      // (wave-uniform)
+        first_c = first_n; first_n = first_nn;
         node_c = node_n; node_n = node_nn;
+        meta_c = meta_n; meta_n = meta_nn;
       }
-      const uint32_t used = d.meta & 0x7Fu;
-      const bool active = lane < used;
-      const TileLane tl = tile_lane(tile_heads(d), used, le);
-      const uint32_t room = active ? tile_room(inf.word, lane == tl.seg_start, lane == tl.seg_end, pr) : 0u;
+      // ---- the position's room and what stands in front of it in its record
+      const uint32_t i = meta & 31u, rem = (meta >> 5) & 31u;
+      const bool first = i == 0u, last = rem == 0u;
+      const int32_t r = int32_t(inf.word & LEN_MASK) - (first ? pr.start : 0) - (last ? pr.tail - 1 : 0);
+      const int32_t rc = r < int32_t(TILE_ROOM_CAP) ? r : int32_t(TILE_ROOM_CAP);
+      const uint32_t room = (meta != POS_INACTIVE && rc > 0) ? uint32_t(rc) : 0u;
       const uint32_t incl = wave_inclusive_sum(room);
-      const uint32_t base = lane_read(incl, tl.seg_start - 1u);           // (lane 63 for a record at lane 0: not used)
-      const uint32_t in_front = incl - room - (tl.seg_start ? base : 0u);
-      bool keep, exhausted;
+      const uint32_t base = lane_read(incl, lane - i - 1u);               // the sum up to the lane in front of the record (not used at lane 0)
+      const uint32_t in_front = incl - room - (i == lane ? 0u : base);
+      const uint32_t T = pr.tw & 0xFFFFu;
+      bool keep = room != 0u && in_front < T;
       uint32_t plain = 1u;
-      if (tile_plain) {
-        const uint32_t T = pr.tw & 0xFFFFu;
-        exhausted = room != 0u && in_front >= T;
-        keep = room != 0u && in_front < T;
-      } else {
-        so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
-        tile_keep(pr, so, room, in_front, keep, plain, exhausted);
+      if (__ballot(room != 0u && in_front >= T) != 0ull) {                // (never, in a run that is not about to fail)
+        if (room != 0u && in_front >= T) report_status(g, pr.line_id, WALK_OPS_EXHAUSTED);
       }
-      if (__ballot(exhausted) != 0ull) { if (exhausted) report_status(g, pr.line_id, WALK_OPS_EXHAUSTED); }
-      const uint64_t kept = __ballot(keep);
-      const TileNeighbour nb = tile_neighbour(kept, tl, lane, le, (pr.tw & POS_REV) != 0);
-      const uint32_t tnode = lane_read(node, nb.lane);
-      uint32_t q = 0u;
-      if (!tile_plain) q = tile_kept_index(kept, tl, le);
+      if (first_word & TILE_NOT_PLAIN) {                                  // (wave-uniform) a '*' or an indel somewhere in the tile
+        if (keep && (pr.tw & POS_NOT_PLAIN)) {
+          ShortOps so;
+          so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
+          const uint32_t left = T - in_front, le = room < left ? room : left, end = in_front + le;
+          const bool indel_here = so.x_len() != 0u && so.x_pos() < end && so.x_pos() + so.x_len() > in_front;
+          if (indel_here || le <= so.n_stars()) short_node_summary(so, in_front, le, keep, plain);
+        }
+      }
+      // ---- first / last kept position of the record, the neighbour kept position
+      const unsigned long long kept = __ballot(keep);
+      const bool rev = (pr.tw & POS_REV) != 0u;
+      bool is_first = first, is_last = last;
+      uint32_t nb_lane = rev ? lane - 1u : lane + 1u, q = i;
+      uint32_t tnode;
+      if (kept == __ballot(meta != POS_INACTIVE)) {
+        // (wave-uniform) every position of the tile is kept -- nearly every tile: the neighbours are the lanes next door
+        const uint32_t prev = uint32_t(__builtin_amdgcn_update_dpp(0, int(node), 0x138, 0xf, 0xf, false));      // wave_shr:1: from lane - 1
+        const uint32_t next = uint32_t(__builtin_amdgcn_update_dpp(0, int(node), 0x130, 0xf, 0xf, false));      // wave_shl:1: from lane + 1
+        tnode = rev ? prev : next;
+      } else {
+        unsigned long long k2 = kept;
+        asm volatile("; a tile with positions that are not kept" : "+s"(k2));      // (keeps the mask arithmetic out of the path above)
+        const TileNeighbour nb = tile_neighbour(k2, tile_lane(meta, lane), lane, tile_lanes_le(lane), rev);
+        is_first = nb.is_first; is_last = nb.is_last;
+        nb_lane = nb.has ? nb.lane : (rev ? lane - i - 1u : lane + rem + 1u);      // (none: a lane outside the record)
+        tnode = lane_read(node, nb.lane);
+        q = tile_kept_index(k2, tile_lane(meta, lane), tile_lanes_le(lane));
+      }
+      if constexpr ((OPT & 64u) != 0u) {      // (timing-only instance)
+        if (keep && (uint32_t(kept >> 7) ^ node ^ tnode ^ q ^ uint32_t(is_first) ^ nb_lane) == 0x12345677u) ncnt[0] = 1u;
+        continue;
+      }
+      // the link to the neighbour: forward to the next kept position, reverse to the previous one; its slot is looked for among
+      // the node's first three out-targets -- forward only when the neighbour is the next path node, as in walk_short_w
+      const bool has = keep && (rev ? !is_first : !is_last);
+      const bool look = has && (rev || nb_lane == lane + 1u);
+      const uint32_t code = !look ? 0u : inf.t0 == tnode ? 1u : inf.t1 == tnode ? 2u : inf.t2 == tnode ? 3u : 0u;
+      const bool enter = plain != 0u && !is_first, leave = plain != 0u && !is_last;
+      const uint32_t a_il = (rev ? leave : enter) ? plain : 0u, a_ol = (rev ? enter : leave) ? plain : 0u;
+      // a link whose slot is not among the node's first three out-targets (or that the graph does not have): into the wave's own
+      // region of the workgroup queue -- slots from a ballot, no atomic, no wait -- and looked up at the end of the chunk
+      if constexpr ((OPT & 32u) == 0u) {
+        const bool later = has && code == 0u;
+        const unsigned long long lm = __ballot(later);
+        if (lm != 0ull) {                                                   // (wave-uniform)
+          const uint32_t more = uint32_t(__builtin_popcountll(lm));
+          if (queued + more > REGION) { drain_region(); queued = 0u; }      // (wave-uniform) the region is full: its links looked up now, a lane each
+          if (later) {
+            const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi(uint32_t(lm >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(lm), 0u));
+            const uint64_t order = event_order(pr.line_id, (rev ? nb_lane : lane) - (lane - i), 0);
+            lq[wave * REGION + slot] = make_uint4(node, tnode, uint32_t(order) | ((look && inf.t2 == NO_TARGET) ? 1u : 0u), uint32_t(order >> 32));
+          }
+          queued += more;
+        }
+      }
       if (keep) {
-        const TileSinkDev<Sink> ts{sink, pr.line_id};
-        tile_emit(ts, node, inf, plain, pr, tl, nb, lane, tnode, q);
+        if constexpr ((OPT & 16u) != 0u) {    // (timing-only instance)
+          if ((node ^ a_il ^ a_ol ^ code) == 0x12345677u) ncnt[0] = 1u;
+          continue;
+        }
+        // the table update.  The node table is 256 buckets of four slots, a node's bucket from its low bits (the nodes of a chunk
+        // are runs of consecutive ids): ONE 16-byte read finds the node -- or an empty slot to put it in -- for all but a node whose
+        // bucket is full; then one 64-bit add (one more for a hit on the second / third out-slot).  A flagged node, a full bucket,
+        // a lost race for an empty slot: through bump_w, which probes on from the bucket's first slot.
+        const uint32_t flags = inf.word & (FLAG_IL | FLAG_OL);
+        const uint32_t h0 = (node << 2) & (CN - 1u);
+        const uint4 k4 = *reinterpret_cast<const uint4*>(&nkey[h0]);
+        uint32_t slot = k4.x == node ? 0u : k4.y == node ? 1u : k4.z == node ? 2u : k4.w == node ? 3u : 4u;
+        if (slot == 4u) {
+          const uint32_t e = k4.x == LDS_EMPTY ? 0u : k4.y == LDS_EMPTY ? 1u : k4.z == LDS_EMPTY ? 2u : k4.w == LDS_EMPTY ? 3u : 4u;
+          if (e < 4u) {
+            const uint32_t old = atomicCAS(&nkey[h0 + e], LDS_EMPTY, node);
+            if (old == LDS_EMPTY || old == node) slot = e;
+          }
+        }
+        // (a flagged side of a node -- every node of an expressed gene is flagged before long -- asks for the first line that touched
+        // its common key: a running minimum per slot, read before it is lowered; only a line with a '-' needs its exact order)
+        const bool f_il = a_il != 0u && (flags & FLAG_IL) != 0u, f_ol = a_ol != 0u && (flags & FLAG_OL) != 0u;
+        if (slot < 4u && !((f_il || f_ol) && (pr.tw & POS_HAS_DEL))) {
+          const uint32_t h = h0 + slot;
+          const unsigned long long inc = 1ull | (static_cast<unsigned long long>(a_il) << 16) | (static_cast<unsigned long long>(a_ol) << 32) |
+                                         (static_cast<unsigned long long>(code == 1u ? 1u : 0u) << 48);
+          atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
+          if (code >= 2u) __hip_atomic_fetch_add(&ncnt2[h], code == 2u ? 1u : 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (f_il || f_ol) {
+            const unsigned long long cur = __atomic_load_n(reinterpret_cast<const unsigned long long*>(__builtin_assume_aligned(omin, 8)) + h, __ATOMIC_RELAXED);
+            if (f_il && pr.line_id < uint32_t(cur)) atomicMin(&omin[2u * h], pr.line_id);
+            if (f_ol && pr.line_id < uint32_t(cur >> 32)) atomicMin(&omin[2u * h + 1u], pr.line_id);
+          }
+        } else {
+          sink.template bump_w<2>(node, flags, pr.line_id, a_il, a_ol, code, (pr.tw & POS_HAS_DEL) ? event_order(pr.line_id, q, 1) : 0ull);
+        }
       }
     }
+    drain_region();                          // what is left in the wave's region (lq_n stays 0: the flush below finds nothing queued)
     chunk_tables_flush(g, sink, THREADS);
     __syncthreads();
   }
 }
 
 // -- tiles of a batch's short-walk class, from the batch's own arrays (both tokenisers end here) --
-// pass 1, one wave per chunk: greedy packing in record order; place[r] = tile within the chunk << 8 | first lane
+// pass 1, one wave per chunk: greedy packing in record order; place[r] = tile within the chunk << 14 | record within the tile << 8 | first lane
 template <uint32_t CHUNK>
 __global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const uint4* rec, uint32_t* place, uint32_t* chunk_tiles) {
   __shared__ uint8_t ks[CHUNK];
@@ -1045,45 +1132,45 @@ __global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const 
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 64u) ks[i - lo] = uint8_t(rec[REC_QUADS * size_t(i)].z & 0xFFu);
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t fill = 0, tile = 0;
+    uint32_t fill = 0, tile = 0, ord = 0;
     for (uint32_t i = lo; i < hi; ++i) {
       const uint32_t k = max(1u, uint32_t(ks[i - lo]));      // (a record without path nodes -- none in the class -- would take a lane)
-      if (tile_pack(fill, k, i == lo) && i != lo) ++tile;
-      place[i] = (tile << 8) | (fill - k);
+      if (tile_pack(fill, k, i == lo)) { if (i != lo) ++tile; ord = 0; }
+      place[i] = (tile << 14) | (ord << 8) | (fill - k);
+      ++ord;
     }
     chunk_tiles[c] = tile + 1u;
   }
 }
-// pass 2, a thread per record: its positions, its line record, and -- the first record of a tile -- the tile's descriptor and padding
+// pass 2, a thread per record: its positions, its line record, and -- the first record of a tile -- the tile's word and padding
 template <uint32_t CHUNK>
 __global__ void tile_fill_kernel(uint32_t n_short, const LineHdr* hdr, const uint4* rec, const uint32_t* nodes, const uint32_t* place,
-                                 const uint32_t* chunk_tile, TileDesc* desc, uint32_t* pnodes, PosRec* prec) {
+                                 const uint32_t* chunk_tile, uint32_t* tile_first, uint32_t* pnodes, uint16_t* pmeta, PosRec* prec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_short; i += gridDim.x * 256u) {
-    const uint32_t c = i / CHUNK, pl = place[i], tile = chunk_tile[c] + (pl >> 8), l0 = pl & 0xFFu;
+    const uint32_t c = i / CHUNK, pl = place[i], tile = chunk_tile[c] + (pl >> 14), ord = (pl >> 8) & 63u, l0 = pl & 0xFFu;
     const uint4 r = rec[REC_QUADS * size_t(i)], r3 = rec[REC_QUADS * size_t(i) + 2];
     const uint32_t k = r.z & 0xFFu;
     ShortOps so;
     so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
     prec[i] = make_pos_rec(hdr[i], so);
     uint32_t* out = pnodes + size_t(tile) * 64u;
-    for (uint32_t j = 0; j < k; ++j) out[l0 + j] = nodes[r.x + j];
+    uint16_t* om = pmeta + size_t(tile) * 64u;
+    for (uint32_t j = 0; j < k; ++j) { out[l0 + j] = nodes[r.x + j]; om[l0 + j] = uint16_t(pos_meta(j, k, ord)); }
     if (l0 == 0u) {
-      uint64_t heads = 1ull;
       uint32_t used = max(1u, k);
       bool plain = (so.ns | so.x) == 0u;
       const uint32_t hi = min(n_short, (c + 1u) * CHUNK);
       for (uint32_t j = i + 1u; j < hi; ++j) {
         const uint32_t pj = place[j];
-        if ((pj >> 8) != (pl >> 8)) break;
+        if ((pj >> 14) != (pl >> 14)) break;
         const uint4 q3 = rec[REC_QUADS * size_t(j) + 2];
-        heads |= 1ull << (pj & 0xFFu);
         used = (pj & 0xFFu) + max(1u, rec[REC_QUADS * size_t(j)].z & 0xFFu);
         plain = plain && ((q3.x >> 16) | q3.w) == 0u;
       }
-      desc[tile] = TileDesc{i, uint32_t(heads), uint32_t(heads >> 32), used | (plain ? TILE_PLAIN : 0u)};
-      const uint32_t pad = nodes[r.x];
-      if (k == 0u) out[0] = 0u;
-      for (uint32_t l = used; l < 64u; ++l) out[l] = k ? pad : 0u;
+      tile_first[tile] = i | (plain ? 0u : TILE_NOT_PLAIN);
+      const uint32_t pad = k ? nodes[r.x] : 0u;
+      if (k == 0u) { out[0] = 0u; om[0] = uint16_t(POS_INACTIVE); }
+      for (uint32_t l = used; l < 64u; ++l) { out[l] = pad; om[l] = uint16_t(POS_INACTIVE); }
     }
   }
 }
@@ -1238,7 +1325,7 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
 void DeviceBatchDeleter::operator()(DeviceBatch* b) const {
   if (!b) return;
   for (void* p : {(void*)b->hdr, (void*)b->node_off, (void*)b->op_off, (void*)b->nodes, (void*)b->ops, (void*)b->del_idx, (void*)b->rec,
-                  (void*)b->tile_desc, (void*)b->pnodes, (void*)b->prec, (void*)b->chunk_tile})
+                  (void*)b->tile_first, (void*)b->pnodes, (void*)b->pmeta, (void*)b->prec, (void*)b->chunk_tile})
     if (p) (void)hipFree(p);
   delete b;
 }
@@ -1562,9 +1649,10 @@ constexpr uint32_t TILE_CHUNK = 2048;      // records per chunk of the aggregati
 
 void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipSetDevice(d.device));
-  for (void* p : {(void*)b.tile_desc, (void*)b.pnodes, (void*)b.prec, (void*)b.chunk_tile}) if (p) (void)hipFree(p);
-  b.tile_desc = nullptr; b.pnodes = nullptr; b.prec = nullptr; b.chunk_tile = nullptr; b.n_tiles = 0;
+  for (void* p : {(void*)b.tile_first, (void*)b.pnodes, (void*)b.pmeta, (void*)b.prec, (void*)b.chunk_tile}) if (p) (void)hipFree(p);
+  b.tile_first = nullptr; b.pnodes = nullptr; b.pmeta = nullptr; b.prec = nullptr; b.chunk_tile = nullptr; b.n_tiles = 0;
   if (!b.n_short) return;
+  if (b.n_short >= (1u << 31)) throw Error("Unsupported", "more than 2^31 - 1 short-walk records in one batch");
   const uint32_t n_chunks = (b.n_short + TILE_CHUNK - 1u) / TILE_CHUNK;
   ScratchPool& pool = scratch_pool(d);
   uint32_t* place = static_cast<uint32_t*>(pool.take(size_t(b.n_short) * 4));
@@ -1582,11 +1670,12 @@ void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
   HIP_OK(hipMemcpyAsync(&n_tiles, b.chunk_tile + n_chunks, 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
   b.n_tiles = n_tiles;
-  HIP_OK(dmalloc(&b.tile_desc, size_t(n_tiles) * sizeof(TileDesc)));
+  HIP_OK(dmalloc(&b.tile_first, size_t(n_tiles) * 4));
   HIP_OK(dmalloc(&b.pnodes, size_t(n_tiles) * 64 * 4));
+  HIP_OK(dmalloc(&b.pmeta, size_t(n_tiles) * 64 * 2));
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n_short) + 255) / 256, 1u << 16));
   hipLaunchKernelGGL((tile_fill_kernel<TILE_CHUNK>), dim3(blocks), dim3(256), 0, d.stream, b.n_short, b.hdr, b.rec, b.nodes, place, b.chunk_tile,
-                     b.tile_desc, b.pnodes, b.prec);
+                     b.tile_first, b.pnodes, b.pmeta, b.prec);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(d.stream));
   pool.give(place); pool.give(counts); pool.give(tmp);
@@ -1825,17 +1914,25 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
-        case 120: {
+        case 120: case 124: case 125: case 126: {
           // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
           // of 64 positions; same tables, same chunks of 2048 records dealt to the XCDs in eighths
-          if (b.n_short && !b.tile_desc) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
+          if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
           HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.ev[4], d.stream2));
           if (b.n_short) {
-            const TileView tv{b.tile_desc, b.pnodes, b.prec, b.chunk_tile, n_ch, b.n_tiles};
-            hipLaunchKernelGGL((augment_short_p_kernel<512, 2048, 10, 7, 8>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, tv.desc, tv.pnodes,
-                               tv.prec, tv.chunk_tile, tv.n_chunks);
+#define PANTAS_P(OPT) hipLaunchKernelGGL((augment_short_p_kernel<512, 2048, 10, 7, 8, OPT>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, \
+                                         b.tile_first, b.pnodes, b.pmeta, b.prec, b.chunk_tile, n_ch)
+            switch (variant - 120) {
+#ifdef PANTAS_EXPERIMENTS
+              // timing-only instances (results wrong by construction): 124 a kept position updates nothing, 125 ... and nothing is queued,
+              // 126 nothing behind the mask of kept positions
+              case 4: PANTAS_P(16); break; case 5: PANTAS_P(48); break; case 6: PANTAS_P(64); break;
+#endif
+              default: PANTAS_P(0); break;
+            }
+#undef PANTAS_P
           }
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));

@@ -40,8 +40,9 @@ struct DeviceBatch {
                                  // AND its gather pipeline, in four 16-byte loads (instead of hdr, two offset pairs, nodes[0..2], then
                                  // ops[] and a scan of it: three dependent load levels and a loop less per record)
   // round 4, the short walk with one lane per path position (walk.h): the short-walk class laid out in tiles of 64 positions
-  TileDesc* tile_desc = nullptr;     // [n_tiles]
+  uint32_t* tile_first = nullptr;    // [n_tiles] first record | TILE_NOT_PLAIN
   uint32_t* pnodes = nullptr;        // [64 x n_tiles]
+  uint16_t* pmeta = nullptr;         // [64 x n_tiles] walk.h pos_meta
   PosRec* prec = nullptr;            // [n_short]
   uint32_t* chunk_tile = nullptr;    // [ceil(n_short / 2048) + 1]
   uint32_t n_tiles = 0;

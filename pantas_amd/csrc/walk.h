@@ -570,12 +570,14 @@ PANTAS_UNROLL
 // The helpers below are what a lane computes for itself; the kernel (augment.hip augment_short_p_kernel) and the CPU harness
 // (tests/hostsim/short_walk_host.h, which loops over the 64 lanes) put the same ones around their cross-lane steps.
 constexpr uint32_t TILE_LANES = 64;
-struct alignas(16) TileDesc {
-  uint32_t first_rec;            // record (index in the batch) of the tile's first position
-  uint32_t heads_lo, heads_hi;   // bit l: a record starts at lane l (bit 0 always set)
-  uint32_t meta;                 // lanes in use (bits 0 .. 6) | TILE_PLAIN: every record of the tile is ':' runs only
-};
-constexpr uint32_t TILE_PLAIN = 1u << 8;
+// Layout of a tile: for every lane its node (pnodes), and pmeta = where the lane stands in its record and which record that is,
+// counted from the tile's first: i | (k - 1 - i) << 5 | ordinal << 10 (k <= 31 path nodes, at most 64 records).  A lane behind the
+// tile's last record has POS_INACTIVE (and a valid node, so that its gather is harmless).  Per tile one word: the batch index of its
+// first record, TILE_NOT_PLAIN set when a record of the tile has a '*' or an indel.
+constexpr uint32_t POS_INACTIVE = 0xFFFFu;
+constexpr uint32_t TILE_NOT_PLAIN = 1u << 31;
+PANTAS_HD uint32_t pos_meta(uint32_t i, uint32_t k, uint32_t ordinal) { return i | ((k - 1u - i) << 5) | (ordinal << 10); }
+PANTAS_HD uint32_t pos_ordinal(uint32_t meta) { return meta >> 10; }
 // what a position needs of its record: 16 bytes instead of hdr + rec (64)
 struct alignas(16) PosRec {
   int32_t start, tail;
@@ -626,16 +628,7 @@ PANTAS_HD uint64_t tile_lanes_lt(uint32_t lane) { return (1ull << lane) - 1ull; 
 struct TileLane {
   uint32_t seg_start, seg_end;   // first / last lane of the lane's record
 };
-// the lane's record, counted from the tile's first (lane < used)
-PANTAS_HD uint32_t tile_rec_ordinal(uint64_t heads, uint64_t le) { return tile_popc64(heads & le) - 1u; }
-PANTAS_HD TileLane tile_lane(uint64_t heads, uint32_t used, uint64_t le) {
-  const uint64_t upto = heads & le, behind = heads & ~le;      // upto != 0 for every lane: lane 0 starts a record
-  TileLane t;
-  t.seg_start = 63u - tile_clz64(upto | 1ull);
-  t.seg_end = (behind ? tile_ctz64(behind) : used) - 1u;
-  return t;
-}
-PANTAS_HD uint64_t tile_heads(const TileDesc& d) { return (uint64_t(d.heads_hi) << 32) | d.heads_lo; }
+PANTAS_HD TileLane tile_lane(uint32_t meta, uint32_t lane) { return TileLane{lane - (meta & 31u), lane + ((meta >> 5) & 31u)}; }
 // room of the position (0: none), capped
 PANTAS_HD uint32_t tile_room(uint32_t word, bool first, bool last, const PosRec& pr) {
   const int32_t r = int32_t(word & LEN_MASK) - (first ? pr.start : 0) - (last ? pr.tail - 1 : 0);
@@ -649,8 +642,10 @@ PANTAS_HD void tile_keep(const PosRec& pr, const ShortOps& so, uint32_t room, ui
   keep = room != 0u && in_front < T;
   plain = 1u;
   if (keep && (pr.tw & POS_NOT_PLAIN)) {
-    const uint32_t left = T - in_front, le = room < left ? room : left;
-    short_node_summary(so, in_front, le, keep, plain);
+    // a line with '*' or an indel: still one plain entry on every node longer than the line has '*' that holds no piece of the indel
+    const uint32_t left = T - in_front, le = room < left ? room : left, end = in_front + le;
+    const bool indel_here = so.x_len() != 0u && so.x_pos() < end && so.x_pos() + so.x_len() > in_front;
+    if (indel_here || le <= so.n_stars()) short_node_summary(so, in_front, le, keep, plain);
   }
 }
 struct TileNeighbour {

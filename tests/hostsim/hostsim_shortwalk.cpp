@@ -96,12 +96,11 @@ int main(int argc, char** argv) {
       const uint64_t kept = rng() & rng() & (used == 64 ? ~0ull : ((1ull << used) - 1ull)) | (rng() % 4 == 0 ? 0ull : (rng() & ((used == 64) ? ~0ull : ((1ull << used) - 1ull))));
       for (uint32_t l = 0; l < 64; ++l) {
         const uint64_t le = tile_lanes_le(l);
-        const uint32_t ord = tile_rec_ordinal(heads, le & tile_lanes_le(used - 1u));
-        const int want_ord = l < used ? seg_of[l] : int(tile.size()) - 1;
-        if (int(ord) != want_ord) { fprintf(stderr, "tile_rec_ordinal lane %u: %u, want %d\n", l, ord, want_ord); return 1; }
         if (l >= used) continue;
-        const TileLane tl = tile_lane(heads, used, le);
         const auto& rec = tile[size_t(seg_of[l])];
+        const uint32_t meta = pos_meta(l - rec.first, rec.second, uint32_t(seg_of[l]));
+        if (meta >= POS_INACTIVE || pos_ordinal(meta) != uint32_t(seg_of[l])) { fprintf(stderr, "pos_meta lane %u: %x\n", l, meta); return 1; }
+        const TileLane tl = tile_lane(meta, l);
         if (tl.seg_start != rec.first || tl.seg_end != rec.first + rec.second - 1u) { fprintf(stderr, "tile_lane lane %u: [%u, %u]\n", l, tl.seg_start, tl.seg_end); return 1; }
         if (!((kept >> l) & 1u)) continue;
         for (int rev = 0; rev < 2; ++rev) {

@@ -79,34 +79,34 @@ int tile_walk_host(const Graph& g, const std::vector<uint32_t>& word, const Line
   // copies in front of / behind the line, by line id; greedy packing decides where records start (tile_pack)
   const uint32_t want_front = (h.line_id >> 1) % 3u, want_back = (h.line_id >> 3) % 3u;
   uint32_t fill = 0, n_rec = 0, mine = 0;
-  uint64_t heads = 0;
   uint32_t start_of[8];
   for (uint32_t r = 0; r < want_front + 1u + want_back; ++r) {
     uint32_t f = fill;
     if (tile_pack(f, k, r == 0) && r != 0) {
-      if (r <= want_front) { fill = 0; n_rec = 0; heads = 0; f = k; }      // the tile closes in front of the line: start over with it
-      else break;                                                         // ... behind it: done
+      if (r <= want_front) { fill = 0; n_rec = 0; f = k; }      // the tile closes in front of the line: start over with it
+      else break;                                              // ... behind it: done
     }
     start_of[n_rec] = f - k;
-    heads |= 1ull << (f - k);
     if (r == want_front) mine = n_rec;
     ++n_rec;
     fill = f;
   }
   const uint32_t used = fill;
-  const TileDesc d{0u, uint32_t(heads), uint32_t(heads >> 32), used | ((so.ns | so.x) ? 0u : TILE_PLAIN)};
-  uint32_t node[64], room[64], incl[64], plain[64];
+  uint32_t node[64], meta[64], room[64], incl[64], plain[64];
   NodeInfo3 inf[64];
   TileLane tl[64];
   bool keep[64];
+  for (uint32_t l = 0; l < 64; ++l) meta[l] = POS_INACTIVE;
+  for (uint32_t r = 0; r < n_rec; ++r)
+    for (uint32_t j = 0; j < k; ++j) meta[start_of[r] + j] = pos_meta(j, k, r);
   for (uint32_t l = 0; l < 64; ++l) {
-    const uint64_t le = tile_lanes_le(l);
-    const uint32_t rec = tile_rec_ordinal(tile_heads(d), le & tile_lanes_le(used - 1u));
-    tl[l] = tile_lane(tile_heads(d), used, le);
-    const bool active = l < used;
-    node[l] = active ? nodes[l - start_of[rec]] : nodes[0];
+    const bool active = meta[l] != POS_INACTIVE;
+    tl[l] = tile_lane(meta[l], l);
+    node[l] = active ? nodes[meta[l] & 31u] : nodes[0];
     inf[l] = ga.info3(node[l]);
-    room[l] = active ? tile_room(inf[l].word, l == tl[l].seg_start, l == tl[l].seg_end, pr) : 0u;
+    room[l] = active ? tile_room(inf[l].word, (meta[l] & 31u) == 0u, ((meta[l] >> 5) & 31u) == 0u, pr) : 0u;
+    if (active && (l < used) != true) return -1;
+    if (active && (pos_ordinal(meta[l]) >= n_rec || tl[l].seg_start != start_of[pos_ordinal(meta[l])])) return -1;
   }
   uint32_t sum = 0;
   for (uint32_t l = 0; l < 64; ++l) { sum += room[l]; incl[l] = sum; }
