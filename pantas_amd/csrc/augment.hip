@@ -1123,54 +1123,57 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
   }
 }
 
-// -- tiles of a batch's short-walk class, from the batch's own arrays (both tokenisers end here) --
-// pass 1, one wave per chunk: greedy packing in record order; place[r] = tile within the chunk << 14 | record within the tile << 8 | first lane
+// -- tiles of a batch's short-walk class --
+// pass 1: greedy packing of every chunk's records in record order (walk.h tile_pack).  A packing is a chain from record to record, so
+// a lane takes a CHUNK: a workgroup of 64 lanes stages the path lengths of 64 chunks in LDS (coalesced) and every lane walks its own.
 template <uint32_t CHUNK>
-__global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const uint4* rec, uint32_t* place, uint32_t* chunk_tiles) {
-  __shared__ uint8_t ks[CHUNK];
-  const uint32_t c = blockIdx.x, lo = c * CHUNK, hi = min(n_short, lo + CHUNK);
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 64u) ks[i - lo] = uint8_t(rec[REC_QUADS * size_t(i)].z & 0xFFu);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t fill = 0, tile = 0, ord = 0;
-    for (uint32_t i = lo; i < hi; ++i) {
-      const uint32_t k = max(1u, uint32_t(ks[i - lo]));      // (a record without path nodes -- none in the class -- would take a lane)
-      if (tile_pack(fill, k, i == lo)) { if (i != lo) ++tile; ord = 0; }
-      place[i] = (tile << 14) | (ord << 8) | (fill - k);
-      ++ord;
-    }
-    chunk_tiles[c] = tile + 1u;
+__global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const uint32_t* node_off, uint32_t* place, uint32_t* chunk_tiles) {
+  constexpr uint32_t STRIDE = CHUNK + 4u;      // (lanes read different banks)
+  __shared__ uint8_t ks[64u * STRIDE];
+  const uint32_t c0 = blockIdx.x * 64u, n_chunks = (n_short + CHUNK - 1u) / CHUNK;
+  for (uint32_t cc = 0; cc < 64u && c0 + cc < n_chunks; ++cc) {
+    const uint32_t lo = (c0 + cc) * CHUNK, hi = min(n_short, lo + CHUNK);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 64u) ks[cc * STRIDE + (i - lo)] = uint8_t(min(node_off[i + 1] - node_off[i], 255u));
   }
+  __syncthreads();
+  const uint32_t c = c0 + threadIdx.x;
+  if (c >= n_chunks) return;
+  const uint32_t lo = c * CHUNK, hi = min(n_short, lo + CHUNK);
+  const uint8_t* mine = ks + threadIdx.x * STRIDE;
+  uint32_t fill = 0, tile = 0, ord = 0, head = lo, head_word = 0;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t k = max(1u, uint32_t(mine[i - lo]));      // (a record without path nodes -- none in the class -- would take a lane)
+    uint32_t f = fill;
+    if (tile_pack(f, k, i == lo)) {
+      if (i != lo) { place[head] = head_word | ((fill - 1u) << 23); ++tile; }
+      ord = 0; head = i; head_word = tile << 12;
+    } else {
+      place[i] = (tile << 12) | (ord << 6) | (f - k);
+    }
+    fill = f;
+    ++ord;
+  }
+  place[head] = head_word | ((fill - 1u) << 23);
+  chunk_tiles[c] = tile + 1u;
 }
-// pass 2, a thread per record: its positions, its line record, and -- the first record of a tile -- the tile's word and padding
+// pass 2 for a batch whose arrays exist (the host tokeniser's upload, a batch made under another default kernel), a thread per record:
+// its positions, its line record, and -- the first record of a tile -- what tile_head adds.  (The GPU tokeniser's gather writes the same.)
 template <uint32_t CHUNK>
 __global__ void tile_fill_kernel(uint32_t n_short, const LineHdr* hdr, const uint4* rec, const uint32_t* nodes, const uint32_t* place,
                                  const uint32_t* chunk_tile, uint32_t* tile_first, uint32_t* pnodes, uint16_t* pmeta, PosRec* prec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_short; i += gridDim.x * 256u) {
-    const uint32_t c = i / CHUNK, pl = place[i], tile = chunk_tile[c] + (pl >> 14), ord = (pl >> 8) & 63u, l0 = pl & 0xFFu;
+    const uint32_t pl = place[i], tile = chunk_tile[i / CHUNK] + place_tile(pl), ord = place_ord(pl), l0 = place_lane(pl);
     const uint4 r = rec[REC_QUADS * size_t(i)], r3 = rec[REC_QUADS * size_t(i) + 2];
     const uint32_t k = r.z & 0xFFu;
     ShortOps so;
     so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
-    prec[i] = make_pos_rec(hdr[i], so);
-    uint32_t* out = pnodes + size_t(tile) * 64u;
-    uint16_t* om = pmeta + size_t(tile) * 64u;
-    for (uint32_t j = 0; j < k; ++j) { out[l0 + j] = nodes[r.x + j]; om[l0 + j] = uint16_t(pos_meta(j, k, ord)); }
+    const PosRec pr = make_pos_rec(hdr[i], so);
+    prec[i] = pr;
+    if (pr.tw & POS_NOT_PLAIN) atomicOr(&tile_first[tile], TILE_NOT_PLAIN);
+    for (uint32_t j = 0; j < k; ++j) { pnodes[size_t(tile) * 64u + l0 + j] = nodes[r.x + j]; pmeta[size_t(tile) * 64u + l0 + j] = uint16_t(pos_meta(j, k, ord)); }
     if (l0 == 0u) {
-      uint32_t used = max(1u, k);
-      bool plain = (so.ns | so.x) == 0u;
-      const uint32_t hi = min(n_short, (c + 1u) * CHUNK);
-      for (uint32_t j = i + 1u; j < hi; ++j) {
-        const uint32_t pj = place[j];
-        if ((pj >> 14) != (pl >> 14)) break;
-        const uint4 q3 = rec[REC_QUADS * size_t(j) + 2];
-        used = (pj & 0xFFu) + max(1u, rec[REC_QUADS * size_t(j)].z & 0xFFu);
-        plain = plain && ((q3.x >> 16) | q3.w) == 0u;
-      }
-      tile_first[tile] = i | (plain ? 0u : TILE_NOT_PLAIN);
-      const uint32_t pad = k ? nodes[r.x] : 0u;
-      if (k == 0u) { out[0] = 0u; om[0] = uint16_t(POS_INACTIVE); }
-      for (uint32_t l = used; l < 64u; ++l) { out[l] = pad; om[l] = uint16_t(POS_INACTIVE); }
+      if (k == 0u) { pnodes[size_t(tile) * 64u] = 0u; pmeta[size_t(tile) * 64u] = uint16_t(POS_INACTIVE); }
+      tile_head(tile, i, place_used(pl), k ? nodes[r.x] : 0u, tile_first, pnodes, pmeta);
     }
   }
 }
@@ -1645,22 +1648,20 @@ void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
 // over 16-byte node records (round 3), 101 = round 2's, 0 = direct atomics
 int main_kernel_variant() { return getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 120; }
 
-constexpr uint32_t TILE_CHUNK = 2048;      // records per chunk of the aggregating kernels
-
-void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
+uint32_t* place_batch_tiles(int device, hipStream_t stream, ScratchPool& pool, DeviceBatch& b, const uint32_t* node_off) {
+  struct { int device; hipStream_t stream; } d{device, stream};
   HIP_OK(hipSetDevice(d.device));
   for (void* p : {(void*)b.tile_first, (void*)b.pnodes, (void*)b.pmeta, (void*)b.prec, (void*)b.chunk_tile}) if (p) (void)hipFree(p);
   b.tile_first = nullptr; b.pnodes = nullptr; b.pmeta = nullptr; b.prec = nullptr; b.chunk_tile = nullptr; b.n_tiles = 0;
-  if (!b.n_short) return;
+  if (!b.n_short) return nullptr;
   if (b.n_short >= (1u << 31)) throw Error("Unsupported", "more than 2^31 - 1 short-walk records in one batch");
   const uint32_t n_chunks = (b.n_short + TILE_CHUNK - 1u) / TILE_CHUNK;
-  ScratchPool& pool = scratch_pool(d);
   uint32_t* place = static_cast<uint32_t*>(pool.take(size_t(b.n_short) * 4));
   uint32_t* counts = static_cast<uint32_t*>(pool.take((size_t(n_chunks) + 1) * 4));
   HIP_OK(dmalloc(&b.chunk_tile, (size_t(n_chunks) + 1) * 4));
   HIP_OK(dmalloc(&b.prec, size_t(b.n_short) * sizeof(PosRec)));
   HIP_OK(hipMemsetAsync(counts + n_chunks, 0, 4, d.stream));
-  hipLaunchKernelGGL((tile_place_kernel<TILE_CHUNK>), dim3(n_chunks), dim3(64), 0, d.stream, b.n_short, b.rec, place, counts);
+  hipLaunchKernelGGL((tile_place_kernel<TILE_CHUNK>), dim3((n_chunks + 63u) / 64u), dim3(64), 0, d.stream, b.n_short, node_off, place, counts);
   HIP_OK(hipGetLastError());
   size_t need = 0;
   HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, counts, b.chunk_tile, int(n_chunks + 1), d.stream));
@@ -1669,16 +1670,24 @@ void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
   uint32_t n_tiles = 0;
   HIP_OK(hipMemcpyAsync(&n_tiles, b.chunk_tile + n_chunks, 4, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
+  pool.give(counts); pool.give(tmp);
   b.n_tiles = n_tiles;
   HIP_OK(dmalloc(&b.tile_first, size_t(n_tiles) * 4));
   HIP_OK(dmalloc(&b.pnodes, size_t(n_tiles) * 64 * 4));
   HIP_OK(dmalloc(&b.pmeta, size_t(n_tiles) * 64 * 2));
+  HIP_OK(hipMemsetAsync(b.tile_first, 0, size_t(n_tiles) * 4, d.stream));
+  return place;
+}
+
+void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
+  uint32_t* place = place_batch_tiles(d.device, d.stream, scratch_pool(d), b, b.node_off);
+  if (!place) return;
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n_short) + 255) / 256, 1u << 16));
   hipLaunchKernelGGL((tile_fill_kernel<TILE_CHUNK>), dim3(blocks), dim3(256), 0, d.stream, b.n_short, b.hdr, b.rec, b.nodes, place, b.chunk_tile,
                      b.tile_first, b.pnodes, b.pmeta, b.prec);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(d.stream));
-  pool.give(place); pool.give(counts); pool.give(tmp);
+  scratch_pool(d).give(place);
 }
 
 DeviceBatchPtr upload_batch(DeviceGraph& d, const GafBatch& b) {

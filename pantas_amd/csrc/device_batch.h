@@ -58,7 +58,7 @@ constexpr uint32_t REC_OPS_MAX = SHORT_MAX_OPS - 1u;     // rec holds the op cou
 // rec[i] of a record whose k path nodes will stand at nodes[n0 ..] and whose c cs ops at ops[o0 ..] of the batch (see DeviceBatch::rec);
 // `nodes` / `ops` point at the record's first node / first op, wherever they are read from
 __device__ __forceinline__ void make_rec_entry(uint4* rec, size_t i, uint32_t n0, uint32_t k, uint32_t o0, uint32_t c, const uint32_t* nodes,
-                                               const uint32_t* ops) {
+                                               const uint32_t* ops, ShortOps* so_out = nullptr) {
   const uint32_t last = k ? k - 1u : 0u;
   auto id = [&](uint32_t j) { return k ? nodes[j < last ? j : last] : 0u; };
   rec[REC_QUADS * i] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
@@ -68,6 +68,22 @@ __device__ __forceinline__ void make_rec_entry(uint4* rec, size_t i, uint32_t n0
   ShortOps so;
   if (c < SHORT_MAX_OPS) short_ops_scan(ops, c, so);
   rec[REC_QUADS * i + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
+  if (so_out) *so_out = so;
+}
+
+// ---- tiles of the short-walk class (walk.h "one lane per path POSITION") ------------------------------------------------------
+// place[r] of record r: tile within its chunk (bits 12 ..) | record within the tile (bits 6 .. 11) | first lane (bits 0 .. 5); the
+// first record of a tile also holds the tile's lanes in use - 1 in bits 23 .. 28
+constexpr uint32_t TILE_CHUNK = 2048;      // records per chunk of the aggregating kernels
+__device__ __forceinline__ uint32_t place_tile(uint32_t pl) { return (pl >> 12) & 0x7FFu; }
+__device__ __forceinline__ uint32_t place_ord(uint32_t pl) { return (pl >> 6) & 63u; }
+__device__ __forceinline__ uint32_t place_lane(uint32_t pl) { return pl & 63u; }
+__device__ __forceinline__ uint32_t place_used(uint32_t pl) { return ((pl >> 23) & 63u) + 1u; }
+// what the first record of a tile adds to the tile: its word and the lanes behind the last record
+__device__ __forceinline__ void tile_head(uint32_t tile, uint32_t rec_index, uint32_t used, uint32_t pad_node, uint32_t* tile_first, uint32_t* pnodes,
+                                          uint16_t* pmeta) {
+  atomicOr(&tile_first[tile], rec_index);                    // (the records of the tile OR TILE_NOT_PLAIN into the same word: zeroed beforehand)
+  for (uint32_t l = used; l < 64u; ++l) { pnodes[size_t(tile) * 64u + l] = pad_node; pmeta[size_t(tile) * 64u + l] = uint16_t(POS_INACTIVE); }
 }
 
 // the GPU GFA loader parks its device memory instead of freeing it (tokenize.hip); no allocation may fail while blocks are parked
@@ -144,6 +160,10 @@ DeviceGraphInfo graph_info(DeviceGraph& dg);
 void build_batch_rec(DeviceGraph& dg, DeviceBatch& db);
 // the tiles of the short-walk class for the position-parallel kernel (augment.hip), from hdr / rec / nodes; after db.rec exists
 void build_batch_tiles(DeviceGraph& dg, DeviceBatch& db);
+// ... in two steps for a builder that writes the tile arrays itself (the GPU tokeniser's gather): place the records (db.chunk_tile and
+// db.n_tiles are set, the tile arrays allocated, tile_first zeroed; returns the placement words, scratch of the pool: give it back)
+struct ScratchPool;
+uint32_t* place_batch_tiles(int device, hipStream_t stream, ScratchPool& pool, DeviceBatch& db, const uint32_t* node_off);
 int main_kernel_variant();      // PANTAS_MAIN_KERNEL, default 120 (augment.hip)
 struct Graph;
 // dense name table (id - base -> node) in HBM, uploaded on first use and owned by the DeviceGraph

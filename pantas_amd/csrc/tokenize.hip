@@ -485,10 +485,25 @@ __global__ void __launch_bounds__(TPB) sizes2_kernel(uint32_t n, const unsigned 
 // of the workgroup's contiguous stretch of nodes[] / ops[] and finds the record a word belongs to by a binary search in the 256
 // offsets (LDS): coalesced stores, and every load of a lane is independent of its other loads, so a lane keeps several trips
 // to memory in flight (one lane per record made fifteen dependent ones).
+// Round 4: with `place` (device_batch.h; null = no tiles) the same pass writes the tiles of the short-walk class (records below
+// n_short) for the position-parallel kernel: every node word goes out a second time, to its lane of its tile, with its position word;
+// a thread per record writes the 16-byte line record, ORs TILE_NOT_PLAIN into its tile's word and, for the first record of a tile,
+// does what tile_head does.  (tile_fill_kernel of augment.hip makes the same arrays from a finished batch.)
+struct TileOut {
+  const uint32_t* place;
+  const uint32_t* chunk_tile;
+  uint32_t* tile_first;
+  uint32_t* pnodes;
+  uint16_t* pmeta;
+  PosRec* prec;
+  uint32_t n_short;
+};
 __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned long long* val, const uint32_t* prov, const uint32_t* node_off,
                                                       const uint32_t* op_off, const uint32_t* del_scan, LineHdr* hdr, uint32_t* nodes, uint32_t* ops,
-                                                      uint32_t* del_idx, uint4* rec) {
+                                                      uint32_t* del_idx, uint4* rec, TileOut to) {
   __shared__ uint32_t s_slot[TPB], s_k[TPB], s_noff[TPB + 1], s_ooff[TPB + 1];
+  __shared__ uint32_t s_tpos[TPB];       // tile * 64 + first lane of the record (0xFFFFFFFF: no tile)
+  __shared__ uint8_t s_ord[TPB];         // the record's ordinal in its tile
   const uint32_t r0 = blockIdx.x * TPB, t = threadIdx.x, i = r0 + t;
   const uint32_t cnt = min(TPB, n - r0);
   uint32_t slot = 0, k = 0, c = 0, flags = 0;
@@ -502,6 +517,14 @@ __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned
     s_k[t] = k;
     s_noff[t] = node_off[i];
     s_ooff[t] = op_off[i];
+    uint32_t tpos = 0xFFFFFFFFu, ord = 0;
+    if (to.place && i < to.n_short) {
+      const uint32_t pl = to.place[i];
+      tpos = (to.chunk_tile[i / TILE_CHUNK] + place_tile(pl)) * 64u + place_lane(pl);
+      ord = place_ord(pl);
+    }
+    s_tpos[t] = tpos;
+    s_ord[t] = uint8_t(ord);
   }
   if (t == 0) { s_noff[cnt] = node_off[r0 + cnt]; s_ooff[cnt] = op_off[r0 + cnt]; }
   __syncthreads();
@@ -515,8 +538,11 @@ __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned
     return lo;
   };
   for (uint32_t p = s_noff[0] + t; p < s_noff[cnt]; p += TPB) {
-    const uint32_t r = owner(s_noff, p);
-    nodes[p] = prov[s_slot[r] + PROV_HDR + (p - s_noff[r])];
+    const uint32_t r = owner(s_noff, p), j = p - s_noff[r];
+    const uint32_t id = prov[s_slot[r] + PROV_HDR + j];
+    nodes[p] = id;
+    const uint32_t tpos = s_tpos[r];
+    if (tpos != 0xFFFFFFFFu) { to.pnodes[size_t(tpos) + j] = id; to.pmeta[size_t(tpos) + j] = uint16_t(pos_meta(j, s_k[r], s_ord[r])); }
   }
   for (uint32_t p = s_ooff[0] + t; p < s_ooff[cnt]; p += TPB) {
     const uint32_t r = owner(s_ooff, p);
@@ -525,7 +551,19 @@ __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned
   if (t < cnt) {
     if (flags & LINE_HAS_DEL) del_idx[del_scan[i]] = i;
     const uint32_t* w = prov + slot;
-    make_rec_entry(rec, i, s_noff[t], k, s_ooff[t], c, w + PROV_HDR, w + PROV_HDR + k);
+    ShortOps so;
+    make_rec_entry(rec, i, s_noff[t], k, s_ooff[t], c, w + PROV_HDR, w + PROV_HDR + k, &so);
+    const uint32_t tpos = s_tpos[t];
+    if (tpos != 0xFFFFFFFFu) {
+      const PosRec pr = make_pos_rec(LineHdr{int32_t(w[0]), int32_t(w[1]), w[2], flags}, so);
+      to.prec[i] = pr;
+      const uint32_t tile = tpos >> 6;
+      if (pr.tw & POS_NOT_PLAIN) atomicOr(&to.tile_first[tile], TILE_NOT_PLAIN);
+      if ((tpos & 63u) == 0u) {
+        if (k == 0u) { to.pnodes[tpos] = 0u; to.pmeta[tpos] = uint16_t(POS_INACTIVE); }
+        tile_head(tile, i, place_used(to.place[i]), k ? w[PROV_HDR] : 0u, to.tile_first, to.pnodes, to.pmeta);
+      }
+    }
   }
 }
 
@@ -913,10 +951,19 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   HIP_OK(dmalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
   HIP_OK(hipStreamSynchronize(s));
   pt.lap("  sizes + scans; batch arrays allocated");
+  // the tiles of the position-parallel kernel (the default main kernel) come out of the same gather: records placed first
+  TileOut to{};
+  uint32_t* place = nullptr;
+  if (main_kernel_variant() >= 120 && n_short) {
+    place = place_batch_tiles(gi.device, s, pool, *out, node_off1.as<uint32_t>());
+    to = TileOut{place, out->chunk_tile, out->tile_first, out->pnodes, out->pmeta, out->prec, n_short};
+    pt.lap("  records placed in tiles");
+  }
   hipLaunchKernelGGL(gather2_kernel, dim3(blocks_for(n)), dim3(TPB), 0, s, n, val.as<unsigned long long>(), prov.as<uint32_t>(), node_off1.as<uint32_t>(),
-                     op_off1.as<uint32_t>(), dscan.as<uint32_t>(), hdr1.as<LineHdr>(), nodes1.as<uint32_t>(), ops1.as<uint32_t>(), del.as<uint32_t>(), out->rec);
+                     op_off1.as<uint32_t>(), dscan.as<uint32_t>(), hdr1.as<LineHdr>(), nodes1.as<uint32_t>(), ops1.as<uint32_t>(), del.as<uint32_t>(), out->rec, to);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(s));
+  if (place) pool.give(place);
   out->hdr = hdr1.hand_over<LineHdr>();
   out->node_off = node_off1.hand_over<uint32_t>();
   out->op_off = op_off1.hand_over<uint32_t>();
@@ -1016,12 +1063,6 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
       DeviceBatchPtr one = tokenize_one_pass(gi, pool, scan, d_text, size, ls.as<uint64_t>(), n_lines, getenv("PANTAS_TOK_STAGE") ? uint32_t(atoi(getenv("PANTAS_TOK_STAGE"))) : stage_one,
                                              thr, check_cr, names, first_line_id, st, tm, pt);
       if (one) {
-        if (main_kernel_variant() >= 120) {        // the tiles of the position-parallel kernel: part of what a batch costs before its first launch
-          const double tt = now();
-          build_batch_tiles(dg, *one);
-          tm.bucket_s += now() - tt;
-          pt.lap("tiles of the short-walk class");
-        }
         tm.total_s = now() - t_begin;
         if (times) *times = tm;
         return one;
