@@ -1007,6 +1007,19 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
         node_c = node_n; node_n = node_nn;
         meta_c = meta_n; meta_n = meta_nn;
       }
+      if constexpr ((OPT & 384u) != 0u) {     // (timing-only instances: 128 = 32 more vector instructions per tile, 256 = 32 more scalar ones)
+        uint32_t x = node, y = meta;
+        int sx = int(t);
+        if constexpr ((OPT & 128u) != 0u) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 3" : "+v"(x), "+v"(y));
+        }
+        if constexpr ((OPT & 256u) != 0u) {
+#pragma unroll
+          for (int u = 0; u < 32; ++u) asm volatile("s_add_i32 %0, %0, 1" : "+s"(sx) : : "scc");
+        }
+        if ((x ^ y ^ uint32_t(sx)) == 0x12345677u) ncnt[0] = 1u;
+      }
       // ---- the position's room and what stands in front of it in its record
       const uint32_t i = meta & 31u, rem = (meta >> 5) & 31u;
       const bool first = i == 0u, last = rem == 0u;
@@ -1923,7 +1936,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
-        case 120: case 124: case 125: case 126: {
+        case 120: case 124: case 125: case 126: case 127: case 128: {
           // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
           // of 64 positions; same tables, same chunks of 2048 records dealt to the XCDs in eighths
           if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
@@ -1938,6 +1951,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
               // timing-only instances (results wrong by construction): 124 a kept position updates nothing, 125 ... and nothing is queued,
               // 126 nothing behind the mask of kept positions
               case 4: PANTAS_P(16); break; case 5: PANTAS_P(48); break; case 6: PANTAS_P(64); break;
+              case 7: PANTAS_P(128); break; case 8: PANTAS_P(256); break;      // 127 / 128: 32 more vector / scalar instructions per tile
 #endif
               default: PANTAS_P(0); break;
             }
