@@ -962,6 +962,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
     // (tile index clamped to the chunk): a load that may or may not have been issued turns every later wait into a full one.
     uint32_t t = t_begin + wave;
     uint32_t queued = 0u;                                                 // links this wave has queued in its region (wave-uniform)
+    uint32_t refused = 0xFFFFFFFFu;                                       // the lowest line of this lane's that the walk refuses
     constexpr uint32_t REGION = Sink::LQ_CAP / NW;
     static_assert(REGION >= 64u, "a tile can queue 64 links at once");
     auto drain_region = [&]() {
@@ -989,6 +990,11 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
     uint4 so_c = make_uint4(0u, 0u, 0u, 0u);
     if (first_c & TILE_NOT_PLAIN) so_c = b.rec[REC_QUADS * size_t(rec_c) + 2];
     __syncthreads();
+    [[maybe_unused]] unsigned long long st_last = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+    // (timing-only instance 130: shader-clock stamps between the parts of a tile's work, summed per wave; shares, not durations)
+#define PANTAS_STAMP(K, DEP) do { if constexpr ((OPT & 1024u) != 0u) { asm volatile("" :: "v"(DEP)); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                                  st_acc[K] += now_ - st_last; st_last = now_; } } while (0)
+    if constexpr ((OPT & 1024u) != 0u) st_last = __builtin_amdgcn_s_memtime();
     for (; t < t_end; t += NW) {
       const uint32_t first_word = first_c, node = node_c, meta = meta_c;
       const NodeInfo3 inf = inf_c;
@@ -1026,15 +1032,19 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
       const int32_t r = int32_t(inf.word & LEN_MASK) - (first ? pr.start : 0) - (last ? pr.tail - 1 : 0);
       const int32_t rc = r < int32_t(TILE_ROOM_CAP) ? r : int32_t(TILE_ROOM_CAP);
       const uint32_t room = (meta != POS_INACTIVE && rc > 0) ? uint32_t(rc) : 0u;
+      PANTAS_STAMP(0, room);            // requests issued, this tile's node and line records arrived, room computed
       const uint32_t incl = wave_inclusive_sum(room);
       const uint32_t base = lane_read(incl, lane - i - 1u);               // the sum up to the lane in front of the record (not used at lane 0)
       const uint32_t in_front = incl - room - (i == lane ? 0u : base);
+      PANTAS_STAMP(1, in_front);        // scan + lane read
       const uint32_t T = pr.tw & 0xFFFFu;
       bool keep = room != 0u && in_front < T;
       uint32_t plain = 1u;
-      if (__ballot(room != 0u && in_front >= T) != 0ull) {                // (never, in a run that is not about to fail)
-        if (room != 0u && in_front >= T) report_status(g, pr.line_id, WALK_OPS_EXHAUSTED);
-      }
+      // a node with room behind the line's last op: the line is refused.  Remembered here and reported behind the chunk's tiles: a
+      // report needs g.slow->status, and with the report in this loop the compiler loads that pointer in EVERY pass and waits for
+      // it with vmcnt(0) -- the wait that also covers the requests just made for the next tiles (found by the stamps of instance
+      // 130: 59 % of a wave's clocks stood there)
+      if (room != 0u && in_front >= T) refused = min(refused, pr.line_id);
       if (first_word & TILE_NOT_PLAIN) {                                  // (wave-uniform) a '*' or an indel somewhere in the tile
         if (keep && (pr.tw & POS_NOT_PLAIN)) {
           ShortOps so;
@@ -1068,6 +1078,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
         if (keep && (uint32_t(kept >> 7) ^ node ^ tnode ^ q ^ uint32_t(is_first) ^ nb_lane) == 0x12345677u) ncnt[0] = 1u;
         continue;
       }
+      PANTAS_STAMP(2, tnode);           // kept / plain, ballot, neighbours
       // the link to the neighbour: forward to the next kept position, reverse to the previous one; its slot is looked for among
       // the node's first three out-targets -- forward only when the neighbour is the next path node, as in walk_short_w
       const bool has = keep && (rev ? !is_first : !is_last);
@@ -1091,6 +1102,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
           queued += more;
         }
       }
+      PANTAS_STAMP(3, code);            // link matching, queue
       if (keep) {
         if constexpr ((OPT & 16u) != 0u) {    // (timing-only instance)
           if ((node ^ a_il ^ a_ol ^ code) == 0x12345677u) ncnt[0] = 1u;
@@ -1129,8 +1141,15 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
           sink.template bump_w<2>(node, flags, pr.line_id, a_il, a_ol, code, (pr.tw & POS_HAS_DEL) ? event_order(pr.line_id, q, 1) : 0ull);
         }
       }
+      PANTAS_STAMP(4, node);              // table update (issue: the adds themselves are not waited for)
     }
+    if (refused != 0xFFFFFFFFu) report_status(g, refused, WALK_OPS_EXHAUSTED);
     drain_region();                          // what is left in the wave's region (lq_n stays 0: the flush below finds nothing queued)
+    if constexpr ((OPT & 1024u) != 0u) {
+      PANTAS_STAMP(5, lane);
+      if (lane == 0u) for (int u = 0; u < 6; ++u) atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(b.del_idx)) + u, st_acc[u]);
+    }
+#undef PANTAS_STAMP
     chunk_tables_flush(g, sink, THREADS);
     __syncthreads();
   }
@@ -1936,7 +1955,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
           HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
-        case 120: case 124: case 125: case 126: case 127: case 128: {
+        case 120: case 124: case 125: case 126: case 127: case 128: case 130: {
           // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
           // of 64 positions; same tables, same chunks of 2048 records dealt to the XCDs in eighths
           if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
@@ -1952,6 +1971,23 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
               // 126 nothing behind the mask of kept positions
               case 4: PANTAS_P(16); break; case 5: PANTAS_P(48); break; case 6: PANTAS_P(64); break;
               case 7: PANTAS_P(128); break; case 8: PANTAS_P(256); break;      // 127 / 128: 32 more vector / scalar instructions per tile
+              case 10: {                                                        // 130: shader-clock stamps between the parts of a tile's work
+                static unsigned long long* stamps = nullptr;
+                if (!stamps) HIP_OK(hipMalloc(&stamps, 64));
+                HIP_OK(hipMemsetAsync(stamps, 0, 64, d.stream));
+                BatchView bs = bv;
+                bs.del_idx = reinterpret_cast<const uint32_t*>(stamps);
+                hipLaunchKernelGGL((augment_short_p_kernel<512, 2048, 10, 7, 8, 1024>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bs, b.tile_first, b.pnodes,
+                                   b.pmeta, b.prec, b.chunk_tile, n_ch);
+                unsigned long long hs[6];
+                HIP_OK(hipMemcpyAsync(hs, stamps, 48, hipMemcpyDeviceToHost, d.stream));
+                HIP_OK(hipStreamSynchronize(d.stream));
+                double tot = 0;
+                for (double x : hs) tot += x;
+                fprintf(stderr, "[stamps] loads+room %.1f %%, scan+lane read %.1f %%, kept+neighbours %.1f %%, links+queue %.1f %%, table update %.1f %%, drain %.1f %% of %.3g wave-clocks\n",
+                        100 * hs[0] / tot, 100 * hs[1] / tot, 100 * hs[2] / tot, 100 * hs[3] / tot, 100 * hs[4] / tot, 100 * hs[5] / tot, tot);
+                break;
+              }
 #endif
               default: PANTAS_P(0); break;
             }

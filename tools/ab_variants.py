@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--env", default="", help="extra NAME=VALUE pairs applied to every variant, comma separated")
     ap.add_argument("--del-hot", type=float, default=0.0, help="synthetic deletion skew (bench.py --del-hot)")
     ap.add_argument("--hot-sites", type=int, default=1000)
+    ap.add_argument("--no-check", action="store_true", help="timing-only instances among the variants (results wrong by construction): digests are printed, not compared")
     ap.add_argument("--p-indel", type=float, default=-1.0, help="indel rate of the synthetic reads (default: the scale's own, 0.05)")
     args = ap.parse_args()
     from bench import SCALES
@@ -69,7 +70,13 @@ def main():
             ms.append(ls.main_ms)
             short.append(ls.main_short_ms)
             rare.append(ls.rare_ms)
-        g.finish()
+        try:
+            g.finish()
+        except Exception as e:      # a timing-only instance may leave a line flagged: its times are what is asked for
+            if not args.no_check:
+                raise
+            print(json.dumps({"variant": int(v), "main_ms": round(sum(ms) / len(ms), 4), "short_ms": round(sum(short) / len(short), 4), "finish": str(e)[:80]}), flush=True)
+            continue
         h = hashlib.sha256()
         for a in g.read_counters():
             h.update(np.ascontiguousarray(a).tobytes())
@@ -86,7 +93,7 @@ def main():
                           "short_ms": round(avg_s, 4), "rare_ms": round(sum(rare) / len(rare), 4), "short_frac_of_8TBps": round(bs.short_alg_bytes / (avg_s * 1e-3) / 8e12, 4) if avg_s else None,
                           "whole_frac": round(bs.alg_bytes / (sum(ms) / len(ms) * 1e-3) / 8e12, 4),
                           "digest": dig, "same_as_first": dig == ref}), flush=True)
-        assert dig == ref, "variant changed the result"
+        assert args.no_check or dig == ref, "variant changed the result"
 
 
 if __name__ == "__main__":

@@ -6,5 +6,5 @@ scale=${1:-s4}
 make -C pantas_amd/csrc -j16 EXPERIMENTS=1 OUT=/tmp/libpantas_exp.so OBJDIR=/tmp/obj_exp > /tmp/exp_build.log 2>&1 || { tail -20 /tmp/exp_build.log; exit 1; }
 cp pantas_amd/libpantas_gpu.so /tmp/libpantas_plain.so
 cp /tmp/libpantas_exp.so pantas_amd/libpantas_gpu.so
-python3 tools/ab_variants.py --scale $scale --variants 120,127,128,120,127,128 --steps 8 | cut -c1-200
+python3 tools/ab_variants.py --scale $scale --variants ${VARIANTS:-120,127,128,120,127,128} --steps 8 ${NOCHECK:+--no-check} | cut -c1-200
 cp /tmp/libpantas_plain.so pantas_amd/libpantas_gpu.so
