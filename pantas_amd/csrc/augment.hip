@@ -982,13 +982,18 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
     };
     const uint32_t ta = min(t, t_last), tb = min(t + NW, t_last);
     uint32_t first_c = t_first[ta], first_n = t_first[tb];
-    uint32_t node_c = t_pnodes[size_t(ta) * 64u + lane], node_n = t_pnodes[size_t(tb) * 64u + lane];
-    uint32_t meta_c = t_pmeta[size_t(ta) * 64u + lane], meta_n = t_pmeta[size_t(tb) * 64u + lane];
+    // (32-bit byte offsets on the arrays' scalar bases: the host has checked that tiles, line records and op summaries end below 4 GB)
+    auto node_at = [&](uint32_t tt) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t_pnodes) + ((tt << 8) + (lane << 2))); };
+    auto meta_at = [&](uint32_t tt) { return uint32_t(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t_pmeta) + ((tt << 7) + (lane << 1)))); };
+    auto line_at = [&](uint32_t rec) { return *reinterpret_cast<const PosRec*>(reinterpret_cast<const char*>(t_prec) + (rec << 4)); };
+    auto ops_at = [&](uint32_t rec) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(b.rec) + (rec * 48u + 32u)); };
+    uint32_t node_c = node_at(ta), node_n = node_at(tb);
+    uint32_t meta_c = meta_at(ta), meta_n = meta_at(tb);
     NodeInfo3 inf_c = info3[node_c];
     uint32_t rec_c = line_of(first_c, meta_c);
-    PosRec pr_c = t_prec[rec_c];
+    PosRec pr_c = line_at(rec_c);
     uint4 so_c = make_uint4(0u, 0u, 0u, 0u);
-    if (first_c & TILE_NOT_PLAIN) so_c = b.rec[REC_QUADS * size_t(rec_c) + 2];
+    if (first_c & TILE_NOT_PLAIN) so_c = ops_at(rec_c);
     __syncthreads();
     [[maybe_unused]] unsigned long long st_last = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
     // (timing-only instance 130: shader-clock stamps between the parts of a tile's work, summed per wave; shares, not durations)
@@ -1003,12 +1008,12 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
       {
         const uint32_t t2 = min(t + 2u * NW, t_last);
         const uint32_t first_nn = t_first[t2];
-        const uint32_t node_nn = t_pnodes[size_t(t2) * 64u + lane];
-        const uint32_t meta_nn = t_pmeta[size_t(t2) * 64u + lane];
+        const uint32_t node_nn = node_at(t2);
+        const uint32_t meta_nn = meta_at(t2);
         inf_c = info3[node_n];
         rec_c = line_of(first_n, meta_n);
-        pr_c = t_prec[rec_c];
-        if (first_n & TILE_NOT_PLAIN) so_c = b.rec[REC_QUADS * size_t(rec_c) + 2];      // (wave-uniform)
+        pr_c = line_at(rec_c);
+        if (first_n & TILE_NOT_PLAIN) so_c = ops_at(rec_c);      // (wave-uniform)
         first_c = first_n; first_n = first_nn;
         node_c = node_n; node_n = node_nn;
         meta_c = meta_n; meta_n = meta_nn;
@@ -1940,7 +1945,15 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
       } else
 #endif
-      switch (variant) {
+      int variant_run = variant;
+      if (variant >= 120) {
+        // the position-parallel kernel addresses its tiles, line records and op summaries with 32-bit byte offsets: a batch beyond that
+        // (more than 16.7 M tiles = a billion path positions, or 89 M short-walk records; the tokeniser's 8 GiB of text per batch stay
+        // below) is walked by the record-per-lane kernel
+        if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
+        if (b.n_tiles >= (1u << 24) || b.n_short >= 89000000u) variant_run = 110;
+      }
+      switch (variant_run) {
         // (variants 73 / 80 / 85 / 97 / 100 -- round 1's short walk and round 2's steps towards 101 -- were retired in round 3; their
         // measurements are in DESIGN.md section 3 and profiles/r2_ab_s4_*.txt)
         case 101:
@@ -1958,7 +1971,6 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         case 120: case 124: case 125: case 126: case 127: case 128: case 130: {
           // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
           // of 64 positions; same tables, same chunks of 2048 records dealt to the XCDs in eighths
-          if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
           HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.ev[4], d.stream2));
