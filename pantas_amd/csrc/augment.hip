@@ -1930,6 +1930,14 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 20));
       hipLaunchKernelGGL(augment_main_kernel, dim3(blocks), dim3(256), 0, d.stream, g, bv);
     } else {
+      int variant_run = variant;
+      if (variant >= 120) {
+        // the position-parallel kernel addresses its tiles, line records and op summaries with 32-bit byte offsets: a batch beyond that
+        // (more than 16.7 M tiles = a billion path positions, or 89 M short-walk records; the tokeniser's 8 GiB of text per batch stay
+        // below) is walked by the record-per-lane kernel
+        if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
+        if (b.n_tiles >= (1u << 24) || b.n_short >= 89000000u) variant_run = 110;
+      }
 #ifdef PANTAS_EXPERIMENTS
       if (g.ablate) fprintf(stderr, "pantas: PANTAS_ABLATE=%u -- timing experiment, THE RESULTS OF THIS RUN ARE INVALID\n", g.ablate);
       if (g.ablate && variant >= 110) {
@@ -1945,14 +1953,6 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
       } else
 #endif
-      int variant_run = variant;
-      if (variant >= 120) {
-        // the position-parallel kernel addresses its tiles, line records and op summaries with 32-bit byte offsets: a batch beyond that
-        // (more than 16.7 M tiles = a billion path positions, or 89 M short-walk records; the tokeniser's 8 GiB of text per batch stay
-        // below) is walked by the record-per-lane kernel
-        if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
-        if (b.n_tiles >= (1u << 24) || b.n_short >= 89000000u) variant_run = 110;
-      }
       switch (variant_run) {
         // (variants 73 / 80 / 85 / 97 / 100 -- round 1's short walk and round 2's steps towards 101 -- were retired in round 3; their
         // measurements are in DESIGN.md section 3 and profiles/r2_ab_s4_*.txt)
