@@ -33,10 +33,19 @@ namespace pantas {
 constexpr uint64_t EMPTY_KEY = ~0ull;
 constexpr uint32_t COMMON_POS = 0x7FFFFFFFu;
 
+// One slot of a global hash table: key, first-seen order and count side by side.  The tables are sized for what a run might hold (a
+// quarter of a batch's links: gigabytes) and hold a sliver of it, so every access is a miss in the caches and in the TLB -- one
+// 32-byte sector per update here, three lines of three arrays in the planar form of rounds 1-3 (S4: 1.725 -> 1.69 ms).
+struct __attribute__((aligned(32))) TableSlot {
+  unsigned long long key;     // EMPTY_KEY: free
+  unsigned long long first;   // min over the key's events of their order word
+  uint32_t cnt;
+  uint32_t pad[3];
+};
+static_assert(sizeof(TableSlot) == 32, "one sector");
+
 struct TableView {
-  uint64_t* keys;
-  uint32_t* cnt;
-  uint64_t* first;
+  TableSlot* slots;
   uint32_t mask;        // capacity - 1 (capacity is a power of two)
   uint32_t* n_keys;     // distinct keys inserted
   uint32_t* overflow;   // set when an insert found no free slot
@@ -114,17 +123,17 @@ __device__ __forceinline__ uint32_t mix64(uint64_t k) {
 
 // count += add, first = min(first, order) for `key`; inserts the key if absent.
 __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, uint32_t add, uint64_t order) {
-  PANTAS_GLOBAL_AS unsigned long long* keys = (PANTAS_GLOBAL_AS unsigned long long*)t.keys;
-  PANTAS_GLOBAL_AS uint32_t* cnt = (PANTAS_GLOBAL_AS uint32_t*)t.cnt;
-  PANTAS_GLOBAL_AS unsigned long long* first = (PANTAS_GLOBAL_AS unsigned long long*)t.first;
+  PANTAS_GLOBAL_AS TableSlot* slots = (PANTAS_GLOBAL_AS TableSlot*)t.slots;
+  typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
   uint32_t h = mix64(key) & t.mask;
   for (uint32_t probe = 0; probe <= t.mask && probe < 8192u; ++probe) {
     // plain loads (an agent-scope atomic load is an sc1 load that goes past the caches): a stale EMPTY is settled by the
-    // compare-and-swap, and a key never changes once it is set
-    unsigned long long cur = keys[h];
+    // compare-and-swap, and a key never changes once it is set.  Key and first-seen order come in one 16-byte load.
+    const ull2 kf = *reinterpret_cast<PANTAS_GLOBAL_AS const ull2*>(&slots[h]);
+    unsigned long long cur = kf.x;
     if (cur == EMPTY_KEY) {
       unsigned long long expected = EMPTY_KEY;
-      if (__hip_atomic_compare_exchange_strong(&keys[h], &expected, static_cast<unsigned long long>(key), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+      if (__hip_atomic_compare_exchange_strong(&slots[h].key, &expected, static_cast<unsigned long long>(key), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT)) {
         __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)t.n_keys, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cur = key;
@@ -133,11 +142,11 @@ __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, u
       }
     }
     if (cur == key) {
-      if (add) __hip_atomic_fetch_add(&cnt[h], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (add) __hip_atomic_fetch_add(&slots[h].cnt, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // first-seen is a running minimum: once the early lines have landed nearly every later
       // candidate loses, and a (possibly stale, hence too large) read is enough to know it
-      if (order < first[h])
-        __hip_atomic_fetch_min(&first[h], static_cast<unsigned long long>(order), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (order < kf.y)
+        __hip_atomic_fetch_min(&slots[h].first, static_cast<unsigned long long>(order), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return;
     }
     h = (h + 1) & t.mask;
@@ -1231,12 +1240,12 @@ __global__ void build_info_kernel(const uint32_t* word, const uint32_t* row_ptr,
 __global__ void compact_table_kernel(TableView t, uint64_t* keys, uint32_t* cnt, uint64_t* first, uint32_t* cursor) {
   const uint32_t cap = t.mask + 1u;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cap; i += gridDim.x * 256u) {
-    const uint64_t k = t.keys[i];
-    if (k != EMPTY_KEY) {
+    const TableSlot sl = t.slots[i];
+    if (sl.key != EMPTY_KEY) {
       const uint32_t o = atomicAdd(cursor, 1u);
-      keys[o] = k;
-      cnt[o] = t.cnt[i];
-      first[o] = t.first[i];
+      keys[o] = sl.key;
+      cnt[o] = sl.cnt;
+      first[o] = sl.first;
     }
   }
 }
@@ -1248,10 +1257,8 @@ struct Table {
   TableView v{};
   uint32_t cap = 0;
   void free_all() {
-    if (v.keys) (void)hipFree(v.keys);
-    if (v.cnt) (void)hipFree(v.cnt);
-    if (v.first) (void)hipFree(v.first);
-    v.keys = nullptr; v.cnt = nullptr; v.first = nullptr; cap = 0;
+    if (v.slots) (void)hipFree(v.slots);
+    v.slots = nullptr; cap = 0;
   }
 };
 
@@ -1526,20 +1533,23 @@ static uint32_t pow2_at_least(uint64_t x) {
 static void table_alloc(Table& t, uint32_t cap, uint32_t* n_keys, uint32_t* overflow) {
   if (t.cap >= cap) { t.v.n_keys = n_keys; t.v.overflow = overflow; return; }
   t.free_all();
-  HIP_OK(dmalloc(&t.v.keys, size_t(cap) * 8));
-  HIP_OK(dmalloc(&t.v.cnt, size_t(cap) * 4));
-  HIP_OK(dmalloc(&t.v.first, size_t(cap) * 8));
+  HIP_OK(dmalloc(&t.v.slots, size_t(cap) * sizeof(TableSlot)));
   t.cap = cap;
   t.v.mask = cap - 1;
   t.v.n_keys = n_keys;
   t.v.overflow = overflow;
 }
 
+__global__ void table_clear_kernel(TableSlot* slots, uint32_t cap) {
+  uint4* w = reinterpret_cast<uint4*>(slots);      // two 16-byte stores per slot: {key, first} = all ones, {cnt, pad} = 0
+  for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < 2u * size_t(cap); i += size_t(gridDim.x) * 256u)
+    w[i] = (i & 1u) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+
 static void table_clear(Table& t, hipStream_t s) {
   if (!t.cap) return;
-  HIP_OK(hipMemsetAsync(t.v.keys, 0xFF, size_t(t.cap) * 8, s));
-  HIP_OK(hipMemsetAsync(t.v.cnt, 0, size_t(t.cap) * 4, s));
-  HIP_OK(hipMemsetAsync(t.v.first, 0xFF, size_t(t.cap) * 8, s));
+  hipLaunchKernelGGL(table_clear_kernel, dim3(uint32_t(std::min<uint64_t>((2ull * t.cap + 255) / 256, 1u << 16))), dim3(256), 0, s, t.v.slots, t.cap);
+  HIP_OK(hipGetLastError());
 }
 
 DeviceGraphPtr upload_graph(const Graph& g, int device) {
@@ -1635,8 +1645,8 @@ static T* to_device(const std::vector<T>& v, hipStream_t s) {
 __global__ void rehash_kernel(TableView from, TableView to) {
   const uint32_t cap = from.mask + 1u;
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cap; i += gridDim.x * 256u) {
-    const uint64_t k = from.keys[i];
-    if (k != EMPTY_KEY) table_update(to, k, from.cnt[i], from.first[i]);
+    const TableSlot sl = from.slots[i];
+    if (sl.key != EMPTY_KEY) table_update(to, sl.key, sl.cnt, sl.first);
   }
 }
 
