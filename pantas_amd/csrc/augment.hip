@@ -994,13 +994,14 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
     // (32-bit byte offsets on the arrays' scalar bases: the host has checked that tiles, line records and op summaries end below 4 GB)
     auto node_at = [&](uint32_t tt) { return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(t_pnodes) + ((tt << 8) + (lane << 2))); };
     auto meta_at = [&](uint32_t tt) { return uint32_t(*reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(t_pmeta) + ((tt << 7) + (lane << 1)))); };
-    auto line_at = [&](uint32_t rec) { return *reinterpret_cast<const PosRec*>(reinterpret_cast<const char*>(t_prec) + (rec << 4)); };
-    auto ops_at = [&](uint32_t rec) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(b.rec) + (rec * 48u + 32u)); };
+    // (the two halves of the line's 32-byte record: one sector)
+    auto line_at = [&](uint32_t rec) { return *reinterpret_cast<const PosLine*>(reinterpret_cast<const char*>(t_prec) + (rec << 5)); };
+    auto ops_at = [&](uint32_t rec) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(t_prec) + ((rec << 5) + 16u)); };
     uint32_t node_c = node_at(ta), node_n = node_at(tb);
     uint32_t meta_c = meta_at(ta), meta_n = meta_at(tb);
     NodeInfo3 inf_c = info3[node_c];
     uint32_t rec_c = line_of(first_c, meta_c);
-    PosRec pr_c = line_at(rec_c);
+    PosLine pr_c = line_at(rec_c);
     uint4 so_c = make_uint4(0u, 0u, 0u, 0u);
     if (first_c & TILE_NOT_PLAIN) so_c = ops_at(rec_c);
     __syncthreads();
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
     for (; t < t_end; t += NW) {
       const uint32_t first_word = first_c, node = node_c, meta = meta_c;
       const NodeInfo3 inf = inf_c;
-      const PosRec pr = pr_c;
+      const PosLine pr = pr_c;
       const uint4 r3 = so_c;
       {
         const uint32_t t2 = min(t + 2u * NW, t_last);
@@ -1205,21 +1206,20 @@ __global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const 
 // pass 2 for a batch whose arrays exist (the host tokeniser's upload, a batch made under another default kernel), a thread per record:
 // its positions, its line record, and -- the first record of a tile -- what tile_head adds.  (The GPU tokeniser's gather writes the same.)
 template <uint32_t CHUNK>
-__global__ void tile_fill_kernel(uint32_t n_short, const LineHdr* hdr, const uint4* rec, const uint32_t* nodes, const uint32_t* place,
-                                 const uint32_t* chunk_tile, uint32_t* tile_first, uint32_t* pnodes, uint16_t* pmeta, PosRec* prec) {
+__global__ void tile_fill_kernel(uint32_t n_short, const LineHdr* hdr, const uint32_t* node_off, const uint32_t* op_off, const uint32_t* nodes, const uint32_t* ops,
+                                 const uint32_t* place, const uint32_t* chunk_tile, uint32_t* tile_first, uint32_t* pnodes, uint16_t* pmeta, PosRec* prec) {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_short; i += gridDim.x * 256u) {
     const uint32_t pl = place[i], tile = chunk_tile[i / CHUNK] + place_tile(pl), ord = place_ord(pl), l0 = place_lane(pl);
-    const uint4 r = rec[REC_QUADS * size_t(i)], r3 = rec[REC_QUADS * size_t(i) + 2];
-    const uint32_t k = r.z & 0xFFu;
+    const uint32_t n0 = node_off[i], k = node_off[i + 1] - n0, o0 = op_off[i], c = op_off[i + 1] - o0;
     ShortOps so;
-    so.T = r3.x & 0xFFFFu; so.ns = r3.x >> 16; so.star01 = r3.y; so.star23 = r3.z; so.x = r3.w;
+    if (c < SHORT_MAX_OPS) short_ops_scan(ops + o0, c, so);      // (as make_rec_entry)
     const PosRec pr = make_pos_rec(hdr[i], so);
     prec[i] = pr;
-    if (pr.tw & POS_NOT_PLAIN) atomicOr(&tile_first[tile], TILE_NOT_PLAIN);
-    for (uint32_t j = 0; j < k; ++j) { pnodes[size_t(tile) * 64u + l0 + j] = nodes[r.x + j]; pmeta[size_t(tile) * 64u + l0 + j] = uint16_t(pos_meta(j, k, ord)); }
+    if (pr.line.tw & POS_NOT_PLAIN) atomicOr(&tile_first[tile], TILE_NOT_PLAIN);
+    for (uint32_t j = 0; j < k; ++j) { pnodes[size_t(tile) * 64u + l0 + j] = nodes[n0 + j]; pmeta[size_t(tile) * 64u + l0 + j] = uint16_t(pos_meta(j, k, ord)); }
     if (l0 == 0u) {
       if (k == 0u) { pnodes[size_t(tile) * 64u] = 0u; pmeta[size_t(tile) * 64u] = uint16_t(POS_INACTIVE); }
-      tile_head(tile, i, place_used(pl), k ? nodes[r.x] : 0u, tile_first, pnodes, pmeta);
+      tile_head(tile, i, place_used(pl), k ? nodes[n0] : 0u, tile_first, pnodes, pmeta);
     }
   }
 }
@@ -1678,9 +1678,9 @@ __global__ void build_rec_kernel(uint32_t n, const uint32_t* node_off, const uin
 }
 
 int main_kernel_variant();
-void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
+void ensure_batch_rec(DeviceGraph& d, DeviceBatch& b) {
+  if (b.rec) return;
   HIP_OK(hipSetDevice(d.device));
-  if (b.rec) { (void)hipFree(b.rec); b.rec = nullptr; }
   HIP_OK(dmalloc(&b.rec, std::max<size_t>(1, b.n) * REC_QUADS * sizeof(uint4)));
   if (b.n) {
     const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n) + 255) / 256, 1u << 16));
@@ -1688,7 +1688,14 @@ void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
-  if (main_kernel_variant() >= 120) build_batch_tiles(d, b);
+}
+
+// Since the line records of the tiles hold the op summaries (late round 4), the position-parallel kernel reads nothing of rec: a
+// batch made while it is the default has tiles and no rec (48 bytes per record less to write and to keep); ensure_batch_rec makes
+// it when a record-per-lane kernel is asked for.
+void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
+  if (main_kernel_variant() >= 120) { if (b.n_short && !b.tile_first) build_batch_tiles(d, b); }
+  else ensure_batch_rec(d, b);
 }
 
 // PANTAS_MAIN_KERNEL as the default of this build: 120 = one lane per path position (round 4), 110 = one lane per record
@@ -1730,8 +1737,8 @@ void build_batch_tiles(DeviceGraph& d, DeviceBatch& b) {
   uint32_t* place = place_batch_tiles(d.device, d.stream, scratch_pool(d), b, b.node_off);
   if (!place) return;
   const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(b.n_short) + 255) / 256, 1u << 16));
-  hipLaunchKernelGGL((tile_fill_kernel<TILE_CHUNK>), dim3(blocks), dim3(256), 0, d.stream, b.n_short, b.hdr, b.rec, b.nodes, place, b.chunk_tile,
-                     b.tile_first, b.pnodes, b.pmeta, b.prec);
+  hipLaunchKernelGGL((tile_fill_kernel<TILE_CHUNK>), dim3(blocks), dim3(256), 0, d.stream, b.n_short, b.hdr, b.node_off, b.op_off, b.nodes, b.ops, place,
+                     b.chunk_tile, b.tile_first, b.pnodes, b.pmeta, b.prec);
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(d.stream));
   scratch_pool(d).give(place);
@@ -1907,7 +1914,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   pt.lap("tables sized");
   d.sync_slow();
   const GraphView g = d.view();
-  const BatchView bv = batch_view(b);
+  BatchView bv = batch_view(b);
   HIP_OK(hipEventRecord(d.ev[1], d.stream));
   d.last_short_ms = 0.f;
   if (b.n) {
@@ -1942,12 +1949,14 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
     } else {
       int variant_run = variant;
       if (variant >= 120) {
-        // the position-parallel kernel addresses its tiles, line records and op summaries with 32-bit byte offsets: a batch beyond that
-        // (more than 16.7 M tiles = a billion path positions, or 89 M short-walk records; the tokeniser's 8 GiB of text per batch stay
-        // below) is walked by the record-per-lane kernel
+        // the position-parallel kernel addresses its tiles and line records with 32-bit byte offsets: a batch beyond that (more than
+        // 16.7 M tiles = a billion path positions, or 134 M short-walk records; the tokeniser's 8 GiB of text per batch stay below) is
+        // walked by the record-per-lane kernel
         if (b.n_short && !b.tile_first) build_batch_tiles(d, b);       // (a batch made while another variant was the default)
-        if (b.n_tiles >= (1u << 24) || b.n_short >= 89000000u) variant_run = 110;
+        if (b.n_tiles >= (1u << 24) || b.n_short >= (1u << 27)) variant_run = 110;
       }
+      // the record-per-lane kernels read rec, which a batch made for the position-parallel kernel does not have
+      if ((variant_run < 120 || g.ablate) && !b.rec) { ensure_batch_rec(d, b); bv.rec = b.rec; }
 #ifdef PANTAS_EXPERIMENTS
       if (g.ablate) fprintf(stderr, "pantas: PANTAS_ABLATE=%u -- timing experiment, THE RESULTS OF THIS RUN ARE INVALID\n", g.ablate);
       if (g.ablate && variant >= 110) {

@@ -792,10 +792,11 @@ static uint64_t cut_at_line_start(const MappedFile& f, uint64_t want, uint64_t e
 }
 
 static uint64_t batch_device_bytes(const pantas_batch_stats& s) {
-  // hdr 16 + offsets 8 + rec 48 per record, 4 per path node and cs op, 4 per record with a '-'; round 4, the tiles of the
-  // position-parallel kernel: a 16-byte line record per record, node + position word (6 bytes) per lane of a tile -- the tiles
-  // hold the path nodes of the short-walk class (nearly all of them) with about 5 % of padding
-  return 72 * s.records + 4 * (s.path_nodes + s.cs_ops) + 4 * s.del_records + 16 * s.records + 7 * s.path_nodes + 4096;
+  // hdr 16 + offsets 8 per record, 4 per path node and cs op, 4 per record with a '-'; the tiles of the position-parallel kernel: a
+  // 32-byte line record (with the op summary) per record, node + position word (6 bytes) per lane of a tile -- the tiles hold the path
+  // nodes of the short-walk class (nearly all of them) with about 5 % of padding.  (rec, 48 bytes per record, only exists for a batch
+  // walked by a record-per-lane kernel; it is counted: the bound must hold for the fallback too.)
+  return 72 * s.records + 4 * (s.path_nodes + s.cs_ops) + 4 * s.del_records + 32 * s.records + 7 * s.path_nodes + 4096;
 }
 
 static void stream_rare_pass(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end, uint64_t first_line,

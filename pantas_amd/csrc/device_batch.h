@@ -43,7 +43,7 @@ struct DeviceBatch {
   uint32_t* tile_first = nullptr;    // [n_tiles] first record | TILE_NOT_PLAIN
   uint32_t* pnodes = nullptr;        // [64 x n_tiles]
   uint16_t* pmeta = nullptr;         // [64 x n_tiles] walk.h pos_meta
-  PosRec* prec = nullptr;            // [n_short]
+  PosRec* prec = nullptr;            // [n_short] 32 bytes: line record + op summary
   uint32_t* chunk_tile = nullptr;    // [ceil(n_short / 2048) + 1]
   uint32_t n_tiles = 0;
   uint32_t n = 0, n_del = 0;
@@ -57,18 +57,21 @@ constexpr uint32_t REC_OPS_MAX = SHORT_MAX_OPS - 1u;     // rec holds the op cou
 
 // rec[i] of a record whose k path nodes will stand at nodes[n0 ..] and whose c cs ops at ops[o0 ..] of the batch (see DeviceBatch::rec);
 // `nodes` / `ops` point at the record's first node / first op, wherever they are read from
+// (rec == nullptr: only the op summary is wanted -- a batch made for the position-parallel kernel keeps it in its line records and
+// builds rec when a record-per-lane kernel is asked for)
 __device__ __forceinline__ void make_rec_entry(uint4* rec, size_t i, uint32_t n0, uint32_t k, uint32_t o0, uint32_t c, const uint32_t* nodes,
                                                const uint32_t* ops, ShortOps* so_out = nullptr) {
-  const uint32_t last = k ? k - 1u : 0u;
-  auto id = [&](uint32_t j) { return k ? nodes[j < last ? j : last] : 0u; };
-  rec[REC_QUADS * i] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
-  rec[REC_QUADS * i + 1] = make_uint4(id(1), id(2), id(3), id(4));
   // the short walk's view of the cs (walk.h ShortOps), so that the dominant kernel neither reads ops[] nor scans it; only read for
   // records of the short-walk class (fewer than SHORT_MAX_OPS ops, total below 2^16)
   ShortOps so;
   if (c < SHORT_MAX_OPS) short_ops_scan(ops, c, so);
-  rec[REC_QUADS * i + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
   if (so_out) *so_out = so;
+  if (!rec) return;
+  const uint32_t last = k ? k - 1u : 0u;
+  auto id = [&](uint32_t j) { return k ? nodes[j < last ? j : last] : 0u; };
+  rec[REC_QUADS * i] = make_uint4(n0, o0, (k < 255u ? k : 255u) | ((c < REC_OPS_MAX ? c : REC_OPS_MAX) << 8), id(0));
+  rec[REC_QUADS * i + 1] = make_uint4(id(1), id(2), id(3), id(4));
+  rec[REC_QUADS * i + 2] = make_uint4((so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x);
 }
 
 // ---- tiles of the short-walk class (walk.h "one lane per path POSITION") ------------------------------------------------------
@@ -156,8 +159,11 @@ struct DeviceGraphInfo {
 };
 struct DeviceGraph;
 DeviceGraphInfo graph_info(DeviceGraph& dg);
-// fills db.rec from the batch's own arrays (augment.hip); both ways a batch comes to be call it last
+// what the default main kernel reads beside the batch's own arrays (augment.hip): the tiles of the position-parallel kernel, or db.rec
+// for a record-per-lane default; both ways a batch comes to be call it last.  ensure_batch_rec: db.rec for a batch that has none (a
+// record-per-lane kernel asked for by PANTAS_MAIN_KERNEL or taken because the batch is beyond the tiles' 32-bit offsets)
 void build_batch_rec(DeviceGraph& dg, DeviceBatch& db);
+void ensure_batch_rec(DeviceGraph& dg, DeviceBatch& db);
 // the tiles of the short-walk class for the position-parallel kernel (augment.hip), from hdr / rec / nodes; after db.rec exists
 void build_batch_tiles(DeviceGraph& dg, DeviceBatch& db);
 // ... in two steps for a builder that writes the tile arrays itself (the GPU tokeniser's gather): place the records (db.chunk_tile and

@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned
       const PosRec pr = make_pos_rec(LineHdr{int32_t(w[0]), int32_t(w[1]), w[2], flags}, so);
       to.prec[i] = pr;
       const uint32_t tile = tpos >> 6;
-      if (pr.tw & POS_NOT_PLAIN) atomicOr(&to.tile_first[tile], TILE_NOT_PLAIN);
+      if (pr.line.tw & POS_NOT_PLAIN) atomicOr(&to.tile_first[tile], TILE_NOT_PLAIN);
       if ((tpos & 63u) == 0u) {
         if (k == 0u) { to.pnodes[tpos] = 0u; to.pmeta[tpos] = uint16_t(POS_INACTIVE); }
         tile_head(tile, i, place_used(to.place[i]), k ? w[PROV_HDR] : 0u, to.tile_first, to.pnodes, to.pmeta);
@@ -948,7 +948,8 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   DevBuf hdr1(pool), nodes1(pool), ops1(pool), del(pool);
   hdr1.alloc((n_rec + 1) * sizeof(LineHdr)); nodes1.alloc((n_nodes + 1) * 4); ops1.alloc((n_ops + 1) * 4);
   del.alloc((size_t(out->n_del) + 1) * 4);
-  HIP_OK(dmalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
+  // (rec: only for a record-per-lane default kernel; the position-parallel one reads the op summaries out of its line records)
+  if (main_kernel_variant() < 120) HIP_OK(dmalloc(&out->rec, size_t(n) * REC_QUADS * sizeof(uint4)));
   HIP_OK(hipStreamSynchronize(s));
   pt.lap("  sizes + scans; batch arrays allocated");
   // the tiles of the position-parallel kernel (the default main kernel) come out of the same gather: records placed first

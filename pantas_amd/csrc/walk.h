@@ -578,19 +578,27 @@ constexpr uint32_t POS_INACTIVE = 0xFFFFu;
 constexpr uint32_t TILE_NOT_PLAIN = 1u << 31;
 PANTAS_HD uint32_t pos_meta(uint32_t i, uint32_t k, uint32_t ordinal) { return i | ((k - 1u - i) << 5) | (ordinal << 10); }
 PANTAS_HD uint32_t pos_ordinal(uint32_t meta) { return meta >> 10; }
-// what a position needs of its record: 16 bytes instead of hdr + rec (64)
-struct alignas(16) PosRec {
+// what a position needs of its record: ONE 32-byte sector instead of hdr + rec (64 bytes of two arrays) -- the line's start / tail /
+// id / flags and, in the second half, the short walk's view of its cs (ShortOps as DeviceBatch::rec packs it; only read for a tile
+// that holds a record with a '*' or an indel)
+struct alignas(16) PosLine {
   int32_t start, tail;
   uint32_t line_id;
   uint32_t tw;                   // T (bits 0 .. 15) | POS_REV | POS_HAS_DEL | POS_NOT_PLAIN
 };
+struct alignas(32) PosRec {
+  PosLine line;
+  uint32_t so_tn, so_star01, so_star23, so_x;      // T | ns << 16, star01, star23, x
+};
+static_assert(sizeof(PosRec) == 32, "one sector");
 constexpr uint32_t POS_REV = 1u << 16, POS_HAS_DEL = 1u << 17, POS_NOT_PLAIN = 1u << 18;
 constexpr uint32_t TILE_ROOM_CAP = 1u << 16;      // rooms only matter up to T < 2^16: capped so that 64 of them add up in 32 bits
 
 PANTAS_HD PosRec make_pos_rec(const LineHdr& h, const ShortOps& so) {
-  return PosRec{h.start, h.tail, h.line_id,
-                (so.T & 0xFFFFu) | ((h.flags & LINE_REV) ? POS_REV : 0u) | ((h.flags & LINE_HAS_DEL) ? POS_HAS_DEL : 0u) |
-                    ((so.ns | so.x) ? POS_NOT_PLAIN : 0u)};
+  return PosRec{PosLine{h.start, h.tail, h.line_id,
+                        (so.T & 0xFFFFu) | ((h.flags & LINE_REV) ? POS_REV : 0u) | ((h.flags & LINE_HAS_DEL) ? POS_HAS_DEL : 0u) |
+                            ((so.ns | so.x) ? POS_NOT_PLAIN : 0u)},
+                (so.T & 0xFFFFu) | (so.ns << 16), so.star01, so.star23, so.x};
 }
 // greedy packing of a chunk's records into tiles, in record order: `fill` = lanes taken in the open tile; true = the record of
 // k path nodes (1 <= k <= 64) opens a new tile.  Afterwards fill = lanes taken including this record, which starts at fill - k.
@@ -630,13 +638,13 @@ struct TileLane {
 };
 PANTAS_HD TileLane tile_lane(uint32_t meta, uint32_t lane) { return TileLane{lane - (meta & 31u), lane + ((meta >> 5) & 31u)}; }
 // room of the position (0: none), capped
-PANTAS_HD uint32_t tile_room(uint32_t word, bool first, bool last, const PosRec& pr) {
+PANTAS_HD uint32_t tile_room(uint32_t word, bool first, bool last, const PosLine& pr) {
   const int32_t r = int32_t(word & LEN_MASK) - (first ? pr.start : 0) - (last ? pr.tail - 1 : 0);
   const int32_t c = r < int32_t(TILE_ROOM_CAP) ? r : int32_t(TILE_ROOM_CAP);
   return uint32_t(c > 0 ? c : 0);
 }
 // from the sum of the rooms in front: kept?  plain entries?  refused?   (`so` is only read for a record with POS_NOT_PLAIN)
-PANTAS_HD void tile_keep(const PosRec& pr, const ShortOps& so, uint32_t room, uint32_t in_front, bool& keep, uint32_t& plain, bool& exhausted) {
+PANTAS_HD void tile_keep(const PosLine& pr, const ShortOps& so, uint32_t room, uint32_t in_front, bool& keep, uint32_t& plain, bool& exhausted) {
   const uint32_t T = pr.tw & 0xFFFFu;
   exhausted = room != 0u && in_front >= T;
   keep = room != 0u && in_front < T;
@@ -672,7 +680,7 @@ PANTAS_HD uint32_t tile_kept_index(uint64_t kept, const TileLane& tl, uint64_t l
 }
 // the calls of one kept position (tnode = the node at nb.lane, q = tile_kept_index when the line has a '-')
 template <class Sink>
-PANTAS_HD void tile_emit(const Sink& sink, uint32_t node, const NodeInfo3& info, uint32_t plain, const PosRec& pr, const TileLane& tl,
+PANTAS_HD void tile_emit(const Sink& sink, uint32_t node, const NodeInfo3& info, uint32_t plain, const PosLine& pr, const TileLane& tl,
                          const TileNeighbour& nb, uint32_t lane, uint32_t tnode, uint32_t q) {
   const bool rev = (pr.tw & POS_REV) != 0;
   // forward, a dropped node or one without room in between: the link's slot is not looked for here, as in walk_short_w

@@ -75,7 +75,7 @@ int tile_walk_host(const Graph& g, const std::vector<uint32_t>& word, const Line
   const HostInfo ga{g, word};
   ShortOps so;
   short_ops_scan(ops, c, so);
-  const PosRec pr = make_pos_rec(h, so);
+  const PosLine pr = make_pos_rec(h, so).line;
   // copies in front of / behind the line, by line id; greedy packing decides where records start (tile_pack)
   const uint32_t want_front = (h.line_id >> 1) % 3u, want_back = (h.line_id >> 3) % 3u;
   uint32_t fill = 0, n_rec = 0, mine = 0;
