@@ -1837,8 +1837,15 @@ static void register_batch_main(DeviceGraph& d, const DeviceBatch& b) {
 // Tables large enough for everything registered so far; growing keeps their contents (rehash on the device).
 static void ensure_tables(DeviceGraph& d) {
   const uint64_t hist_keys = std::max<uint64_t>(d.hist_bound, d.reserved_hist) * d.hist_boost;
-  const uint32_t hc = pow2_at_least(2 * hist_keys + 1024);
-  const uint32_t nc = pow2_at_least(2 * d.novel_room + 1024);
+  uint32_t hc = pow2_at_least(2 * hist_keys + 1024);
+  uint32_t nc = pow2_at_least(2 * d.novel_room + 1024);
+  // (tests: tables that start with PANTAS_TABLE_SLOTS_FIRST slots, so that a small workload overflows them and the run is redone
+  // with four times the room -- pantas_augment_run's TableOverflow loop, tests/test_gpu_stream.py)
+  static const uint64_t slots_first = getenv("PANTAS_TABLE_SLOTS_FIRST") ? strtoull(getenv("PANTAS_TABLE_SLOTS_FIRST"), nullptr, 10) : 0;
+  if (slots_first) {
+    hc = std::min<uint64_t>(hc, pow2_at_least(slots_first * d.hist_boost));
+    nc = std::min<uint64_t>(nc, pow2_at_least(slots_first * d.novel_boost));
+  }
   if (hc > d.hist.cap) table_grow(d, d.hist, hc, d.small + 2, d.small + 3);
   if (nc > d.novel.cap) table_grow(d, d.novel, nc, d.small + 4, d.small + 5);
 }

@@ -103,6 +103,27 @@ def test_cli_streams_in_batches(tmp_path):
     assert r.stderr.splitlines() == json.load(open(f"{d}/expected.json"))["stderr"]
 
 
+def test_tables_that_overflow_are_enlarged_and_the_run_redone(tmp_path):
+    """The novel-link table and the IL/OL key table are sized from guesses; a run that fills one is redone with four times the room
+    (pantas_augment_run, TableOverflow).  PANTAS_TABLE_SLOTS_FIRST (tests only) starts both with 1024 slots on a workload that has more
+    keys than that: the bytes must be the oracle's, which they can only be after at least one redo."""
+    from pantas_amd import synth
+    pre = str(tmp_path / "s")
+    synth.write_all(pre, seed=31, n_genes=40, n_lines=30000, p_indel=0.3, p_sub=0.5, bubble_rate=0.15, p_novel_skip=0.1, p_novel_ce=0.05,
+                    p_novel_ss=0.1)
+    want = io.StringIO()
+    augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    text = want.getvalue()
+    novel = text.count("\tID:Z:N")
+    rare = sum(f.count(",") + 1 for ln in text.splitlines() if ln.startswith("S") for f in ln.split("\t") if f.startswith(("IL:Z:", "OL:Z:")))
+    assert novel > 1024 or rare > 1024, (novel, rare)      # (else the workload does not overflow 1024 slots: enlarge it)
+    env = {**os.environ, "PANTAS_TABLE_SLOTS_FIRST": "1024", "PANTAS_BATCH_BYTES": str(os.path.getsize(pre + ".gaf") // 5)}
+    r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "the run is redone with four times its room" in r.stderr, r.stderr[-2000:]
+    assert r.stdout == text
+
+
 def test_stream_api_protocol(monkeypatch):
     from pantas_amd.engine import Graph, PantasError
     d = os.path.join(GOLDEN, "synth_b")
