@@ -1997,9 +1997,14 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
         case 120: case 124: case 125: case 126: case 127: case 128: case 130: {
           // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
           // of 64 positions; same tables, same chunks of 2048 records dealt to the XCDs in eighths
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
-          PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
-          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          // (the general-walk kernel beside it on the second stream -- when the batch has such records: two cross-stream waits cost a
+          // small batch a tenth of its step)
+          const bool general = b.n > b.n_short;
+          if (general) {
+            HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+            PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
+            HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          }
           if (b.n_short) {
 #define PANTAS_P(OPT) hipLaunchKernelGGL((augment_short_p_kernel<512, 2048, 10, 7, 8, OPT>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, \
                                          b.tile_first, b.pnodes, b.pmeta, b.prec, b.chunk_tile, n_ch)
@@ -2032,7 +2037,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
 #undef PANTAS_P
           }
           HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
-          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          if (general) HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
           break;
         }
         default:
