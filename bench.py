@@ -329,7 +329,8 @@ def emit(out: dict, args) -> None:
         line[k] = _sig(out[k], 6)
     line["config"] = {"workload": wl.split(";")[0] + f"; {out['gaf_lines_per_step'] // out['n_gpus']} GAF lines per GPU per step, "
                                                       f"{out['walked_records_per_step'] // out['n_gpus']} walked",
-                      "parallelism": f"read shards x{out['n_gpus']}, graph replicated, one block-sparse RCCL all-reduce of the counters"}
+                      "parallelism": f"read shards x{out['n_gpus']}, graph replicated, one block-sparse RCCL all-reduce of the counters",
+                      "steps": "enqueued back to back, collected" if str(out.get("step_mode", "")).startswith("the steps") else "each waited for"}
     line["roofline"] = {k: _sig(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
     line["roofline"]["kernel_ms"] = _sig(out["kernel_ms"]["augment_main_short_walk"] or out["kernel_ms"]["augment_main"])
     if cb is not None:
@@ -376,6 +377,9 @@ def main():
     ap.add_argument("--full-line", action="store_true",
                     help="print the whole details object as the line (tools/*.sh read phase times from it); the default line is the "
                          "short one of the contract, with the details in gpurun_out/bench_details_n<N>.json")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="one host round trip per step (pantas_augment_launch) instead of steps enqueued back to back "
+                         "(pantas_augment_launch_async, at most 64 in flight) and collected")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-call", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -483,12 +487,27 @@ def main():
         del bm, allbm, st
     sync()
     main_ms, rare_ms, short_ms = [], [], []
+    # One resident batch: the K steps are enqueued back to back on the graph's stream (a streamed run launches batch after batch the
+    # same way) and their HIP-event times read afterwards; with --sync-steps, or several resident batches, every launch is waited for.
+    pipelined = len(batches) == 1 and not args.sync_steps
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r, m, s = step()
-        rare_ms.append(r)
-        main_ms.append(m)
-        short_ms.append(s)
+    if pipelined:
+        done = 0
+        while done < args.steps:
+            k = min(64, args.steps - done)
+            for _ in range(k):
+                g.launch_async(batches[0])
+            for r, m, s in g.launch_collect():
+                rare_ms.append(r)
+                main_ms.append(m)
+                short_ms.append(s)
+            done += k
+    else:
+        for _ in range(args.steps):
+            r, m, s = step()
+            rare_ms.append(r)
+            main_ms.append(m)
+            short_ms.append(s)
     allreduce_ms = 0.0
     if dist is not None:
         # the ONE sum over the coverage arrays that ends a read-sharded replicate: bitmap of touched blocks ->
@@ -582,6 +601,8 @@ def main():
                                    + (f", {args.del_hot:.0%} of the deletion reads on 1000 fixed sites" if args.del_hot else ""),
                        "parallelism": f"read shards x{world}, graph replicated, one block-sparse all-reduce of the coverage counters per replicate"},
             "value_counts": "records walked by the kernels per second, summed over ranks (GAF lines filtered out by the tokeniser are not counted)",
+            "step_mode": ("the steps of the timed region are enqueued back to back on the stream (pantas_augment_launch_async, at most 64 in flight) "
+                          "and collected; --sync-steps waits for every step") if pipelined else "every launch waited for (pantas_augment_launch)",
             "walked_records_per_step": records_all, "gaf_lines_per_step": lines_all,
             # first-class companions of `value`: what a batch that is bucketed once and launched once sees
             "reads_per_s_kernels_only": records_all / step_s,

@@ -53,7 +53,7 @@ void pantas_device_init(int device);
  * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
  * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
  * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
-#define PANTAS_ABI_VERSION 6
+#define PANTAS_ABI_VERSION 7
 int pantas_abi_version(void);
 
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
@@ -151,6 +151,14 @@ int pantas_batch_download(pantas_graph* g, pantas_batch* b, int32_t* hdr, uint32
  * for every batch (a late rare-key kernel cannot flag nodes for batches already walked; PANTAS_E_ARG).
  * Relaunching a batch that was already launched in this run is allowed (benchmarks). */
 int pantas_augment_launch(pantas_graph* g, pantas_batch* b, pantas_launch_stats* out);
+/* ABI 7.  The same two kernels enqueued on the graph's stream and NOT waited for, so that a caller who launches batch after batch
+ * (or one resident batch again and again) keeps the GPU fed: pantas_augment_launch pays a host round trip -- launch, wake-up, event
+ * reads, about 50 microseconds -- per call.  At most 64 launches may be in flight (PANTAS_E_ARG beyond).  launch_collect waits for
+ * everything enqueued and returns the number of launches in *n, their kernel times oldest first as three floats per launch
+ * {rare_ms, main_ms, main_short_ms} (what pantas_launch_stats holds) in ms[0 .. 3 * min(*n, capacity)).  The staged rule above holds
+ * as for pantas_augment_launch; pantas_augment_finish and every download wait for the stream as before. */
+int pantas_augment_launch_async(pantas_graph* g, pantas_batch* b);
+int pantas_augment_launch_collect(pantas_graph* g, float* ms, uint64_t capacity, uint64_t* n);
 /* the two kernels separately, for runs sharded over several GPUs: after the rare-key kernel every
  * rank exports the node flags it set ((node << 1) | side, uint32), the ranks all-gather them, import
  * the union, and only then run the main kernel (it records the first-seen order of the common IL/OL

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 6      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
+ABI_VERSION = 7      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
 
@@ -130,6 +130,8 @@ def _load():
         "pantas_gaf_split": (i32, [C.c_char_p, i32, i32, P(u64), P(u64), P(u64)]),
         "pantas_batch_free": (None, [vp]),
         "pantas_augment_launch": (i32, [vp, vp, P(LaunchStats)]),
+        "pantas_augment_launch_async": (i32, [vp, vp]),
+        "pantas_augment_launch_collect": (i32, [vp, P(C.c_float), u64, P(u64)]),
         "pantas_augment_reserve": (i32, [vp, u64]),
         "pantas_augment_launch_rare": (i32, [vp, vp, P(C.c_float)]),
         "pantas_augment_launch_main": (i32, [vp, vp, P(C.c_float)]),

@@ -88,6 +88,11 @@ float launch_augment(DeviceGraph& dg, DeviceBatch& db, float* ms_rare = nullptr,
 // The two stages separately (multi-GPU: node flags are exchanged between them).
 float launch_rare(DeviceGraph& dg, DeviceBatch& db);
 float launch_main(DeviceGraph& dg, DeviceBatch& db);
+// launch_augment without the wait (several in flight on the graph's stream); launch_collect waits for all of them and returns how many
+// there were, their kernel times oldest first in out[0 .. min(n, capacity))
+struct LaunchTimes { float rare_ms = 0, main_ms = 0, main_short_ms = 0; };
+void launch_augment_async(DeviceGraph& dg, DeviceBatch& db);
+size_t launch_collect(DeviceGraph& dg, LaunchTimes* out, size_t capacity);
 void export_flags(DeviceGraph& dg, std::vector<uint32_t>& codes);          // (node << 1 | side), sorted
 void import_flags(DeviceGraph& dg, const uint32_t* codes, size_t n);
 // Raises Error if a kernel reported a line the reference would have died on (or one this engine refuses).

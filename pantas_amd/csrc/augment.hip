@@ -1266,6 +1266,12 @@ struct DeviceGraph {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t* evs = ev;           // the events the launch functions record: ev, or the slot of a launch that is not waited for
+  // launches enqueued without a wait (launch_augment_async): their events, read by launch_collect
+  struct InFlight { hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool split = false; };
+  std::vector<InFlight> ring;
+  std::vector<uint32_t> in_flight;      // ring slots, oldest first
+  bool last_split = false;
   hipStream_t stream2 = nullptr;  // the general-walk kernel runs here, beside the short-walk kernel on `stream`
   float last_short_ms = 0.f;      // duration of the short-walk kernel of the last launch_main (0 when one kernel did everything)
   uint32_t V = 0;
@@ -1364,6 +1370,7 @@ void DeviceGraphDeleter::operator()(DeviceGraph* d) const {
   d->hist.free_all();
   d->novel.free_all();
   for (auto& e : d->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& f : d->ring) for (auto& e : f.ev) if (e) (void)hipEventDestroy(e);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   if (d->stream2) (void)hipStreamDestroy(d->stream2);
   delete d;
@@ -1879,7 +1886,7 @@ static float launch_rare_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
   d.sync_slow();
   const GraphView g = d.view();
   const BatchView bv = batch_view(b);
-  HIP_OK(hipEventRecord(d.ev[0], d.stream));
+  HIP_OK(hipEventRecord(d.evs[0], d.stream));
   if (b.n_del) {
     // PANTAS_RARE_KERNEL (A/B): 0 = every line through the general walk, one global table update per key event; 1 = the
     // short walk for one-indel lines, same updates (round 1); 2 .. 5 = 1 with the workgroup-private LDS stage in front of the
@@ -1901,15 +1908,15 @@ static float launch_rare_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
     }
     HIP_OK(hipGetLastError());
   }
-  HIP_OK(hipEventRecord(d.ev[5], d.stream));
+  HIP_OK(hipEventRecord(d.evs[5], d.stream));
   if (!wait) return 0.f;
-  HIP_OK(hipEventSynchronize(d.ev[5]));
+  HIP_OK(hipEventSynchronize(d.evs[5]));
   float a = 0;
-  HIP_OK(hipEventElapsedTime(&a, d.ev[0], d.ev[5]));
+  HIP_OK(hipEventElapsedTime(&a, d.evs[0], d.evs[5]));
   return a;
 }
 
-float launch_main(DeviceGraph& d, DeviceBatch& b) {
+static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
   HIP_OK(hipSetDevice(d.device));
   if (std::find(d.rare_done.begin(), d.rare_done.end(), b.id) == d.rare_done.end())
     throw Error("ProtocolError", "main kernel of a batch whose rare-key kernel has not run");
@@ -1922,7 +1929,7 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
   d.sync_slow();
   const GraphView g = d.view();
   BatchView bv = batch_view(b);
-  HIP_OK(hipEventRecord(d.ev[1], d.stream));
+  HIP_OK(hipEventRecord(d.evs[1], d.stream));
   d.last_short_ms = 0.f;
   if (b.n) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
@@ -1939,14 +1946,14 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
 #define PANTAS_AGG(ID, ...) case ID: PANTAS_AGG_RANGE(d.stream, 0u, b.n, __VA_ARGS__); break;
     // one after the other on the launch stream
 #define PANTAS_SPLIT_SEQ(ID, SHORT_ARGS, GENERAL_ARGS) case ID: \
-      PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; PANTAS_AGG_RANGE GENERAL_ARGS; break;
+      PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true; PANTAS_AGG_RANGE GENERAL_ARGS; break;
     // side by side: the general-walk kernel (few records, slow waves, often too few workgroups to fill the chip) on a
     // second stream fills what the short-walk kernel leaves; both add to the same counters with atomics
 #define PANTAS_SPLIT(ID, SHORT_ARGS, GENERAL_ARGS) case ID: \
-      HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0)); \
-      PANTAS_AGG_RANGE GENERAL_ARGS; HIP_OK(hipEventRecord(d.ev[4], d.stream2)); \
-      PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true; \
-      HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0)); break;
+      HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0)); \
+      PANTAS_AGG_RANGE GENERAL_ARGS; HIP_OK(hipEventRecord(d.evs[4], d.stream2)); \
+      PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true; \
+      HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0)); break;
     bool split = false;
     const uint32_t n_ch = (b.n_short + 2047u) / 2048u;      // chunks of the short-walk class
     (void)n_ch;
@@ -1969,12 +1976,12 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
       if (g.ablate && variant >= 110) {
         // timing experiments on the round-3 kernel: its ABL instance (the general class is not launched: no such records in the workloads)
         if (b.n_short) hipLaunchKernelGGL((augment_short_w_kernel<512, 2048, 10, 7, 8, 1, true>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
-        HIP_OK(hipEventRecord(d.ev[3], d.stream));
+        HIP_OK(hipEventRecord(d.evs[3], d.stream));
         split = true;
       } else if (g.ablate) {
         // timing experiments: the default pair of kernels with the ablation switches compiled in, one after the other
         PANTAS_AGG_RANGE_ABL(d.stream, 0u, b.n_short, 512, 2048, 10, 10, 7, 8, true, 1, true, 2, true, true);
-        HIP_OK(hipEventRecord(d.ev[3], d.stream));
+        HIP_OK(hipEventRecord(d.evs[3], d.stream));
         split = true;
         PANTAS_AGG_RANGE_ABL(d.stream, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2, false, 1);
       } else
@@ -1986,13 +1993,13 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           // round 2's short walk over 8-byte node records {length, first out-target}: links off the first out-slot deferred per line and
           // looked up behind the node loop, links absent from the graph queued per workgroup; chunks dealt to the XCDs in eighths; the
           // line's ShortOps with the record; odd rounds of a chunk the other way round.  The A/B partner of the default.
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
-          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          HIP_OK(hipEventRecord(d.evs[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true, true>),
                                             dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
-          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
-          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0));
           break;
         case 120: case 124: case 125: case 126: case 127: case 128: case 130: {
           // round 4: the short-walk class with one lane per path POSITION (walk.h tile_*; augment_short_p_kernel) over the batch's tiles
@@ -2001,9 +2008,9 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           // small batch a tenth of its step)
           const bool general = b.n > b.n_short;
           if (general) {
-            HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+            HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0));
             PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
-            HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+            HIP_OK(hipEventRecord(d.evs[4], d.stream2));
           }
           if (b.n_short) {
 #define PANTAS_P(OPT) hipLaunchKernelGGL((augment_short_p_kernel<512, 2048, 10, 7, 8, OPT>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, \
@@ -2036,8 +2043,8 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
             }
 #undef PANTAS_P
           }
-          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
-          if (general) HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true;
+          if (general) HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0));
           break;
         }
         default:
@@ -2045,12 +2052,12 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
           // against its node's first three out-targets where the node is visited and counted in the node's own table entry; same chunk
           // order, record layout and round order as 101.  S4: 2.07 against 2.17 ms (profiles/r3_ab_s4_wide.txt); two nodes ahead instead
           // of one measured the same (2.11).
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.ev[1], 0));
+          HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
-          HIP_OK(hipEventRecord(d.ev[4], d.stream2));
+          HIP_OK(hipEventRecord(d.evs[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_short_w_kernel<512, 2048, 10, 7, 8, 1>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
-          HIP_OK(hipEventRecord(d.ev[3], d.stream)); split = true;
-          HIP_OK(hipStreamWaitEvent(d.stream, d.ev[4], 0));
+          HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true;
+          HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0));
           break;
       }
     }
@@ -2060,18 +2067,24 @@ float launch_main(DeviceGraph& d, DeviceBatch& b) {
 #undef PANTAS_AGG_RANGE
 #undef PANTAS_AGG_RANGE_ABL
     HIP_OK(hipGetLastError());
-    HIP_OK(hipEventRecord(d.ev[2], d.stream));
-    HIP_OK(hipEventSynchronize(d.ev[2]));
-    if (split) HIP_OK(hipEventElapsedTime(&d.last_short_ms, d.ev[1], d.ev[3]));
+    HIP_OK(hipEventRecord(d.evs[2], d.stream));
+    d.last_split = split;
+    if (!wait) return 0.f;
+    HIP_OK(hipEventSynchronize(d.evs[2]));
+    if (split) HIP_OK(hipEventElapsedTime(&d.last_short_ms, d.evs[1], d.evs[3]));
   } else {
-    HIP_OK(hipEventRecord(d.ev[2], d.stream));
-    HIP_OK(hipEventSynchronize(d.ev[2]));
+    HIP_OK(hipEventRecord(d.evs[2], d.stream));
+    d.last_split = false;
+    if (!wait) return 0.f;
+    HIP_OK(hipEventSynchronize(d.evs[2]));
   }
   float m = 0;
-  HIP_OK(hipEventElapsedTime(&m, d.ev[1], d.ev[2]));
+  HIP_OK(hipEventElapsedTime(&m, d.evs[1], d.evs[2]));
   pt.lap("kernels + wait");
   return m;
 }
+
+float launch_main(DeviceGraph& d, DeviceBatch& b) { return launch_main_impl(d, b, true); }
 
 float last_short_kernel_ms(const DeviceGraph& d) { return d.last_short_ms; }
 
@@ -2079,10 +2092,54 @@ float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_m
   (void)launch_rare_impl(d, b, false);
   const float m = launch_main(d, b);        // returns after everything enqueued so far has completed
   float a = 0;
-  HIP_OK(hipEventElapsedTime(&a, d.ev[0], d.ev[5]));
+  HIP_OK(hipEventElapsedTime(&a, d.evs[0], d.evs[5]));
   if (ms_rare) *ms_rare = a;
   if (ms_main) *ms_main = m;
   return a + m;
+}
+
+// The same two kernels enqueued and NOT waited for: a caller that launches batch after batch (or one batch again and again: a
+// benchmark) keeps the stream fed, where launch_augment pays a host round trip -- launch, wake-up, event reads, 50 microseconds --
+// per call, a quarter of a small batch's step.  The launch's events go into a slot of a ring; launch_collect waits for everything
+// enqueued and hands the times back, oldest first.
+constexpr size_t LAUNCH_RING = 64;
+void launch_augment_async(DeviceGraph& d, DeviceBatch& b) {
+  HIP_OK(hipSetDevice(d.device));
+  if (d.in_flight.size() >= LAUNCH_RING) throw Error("ProtocolError", "64 launches in flight: collect them (pantas_augment_launch_collect) before the next");
+  if (d.ring.empty()) {
+    d.ring.resize(LAUNCH_RING);
+    for (auto& f : d.ring) for (auto& e : f.ev) HIP_OK(hipEventCreate(&e));
+  }
+  uint32_t slot = 0;
+  while (std::find(d.in_flight.begin(), d.in_flight.end(), slot) != d.in_flight.end()) ++slot;
+  d.evs = d.ring[slot].ev;
+  try {
+    (void)launch_rare_impl(d, b, false);
+    (void)launch_main_impl(d, b, false);
+  } catch (...) {
+    d.evs = d.ev;
+    throw;
+  }
+  d.evs = d.ev;
+  d.ring[slot].split = d.last_split;
+  d.in_flight.push_back(slot);
+}
+
+size_t launch_collect(DeviceGraph& d, LaunchTimes* out, size_t capacity) {
+  HIP_OK(hipSetDevice(d.device));
+  HIP_OK(hipStreamSynchronize(d.stream));      // (the second stream's kernels are joined into it by every launch)
+  size_t n = 0;
+  for (uint32_t slot : d.in_flight) {
+    const auto& f = d.ring[slot];
+    LaunchTimes t{};
+    HIP_OK(hipEventElapsedTime(&t.rare_ms, f.ev[0], f.ev[5]));
+    HIP_OK(hipEventElapsedTime(&t.main_ms, f.ev[1], f.ev[2]));
+    if (f.split) HIP_OK(hipEventElapsedTime(&t.main_short_ms, f.ev[1], f.ev[3]));
+    if (n < capacity && out) out[n] = t;
+    ++n;
+  }
+  d.in_flight.clear();
+  return n;
 }
 
 // (node << 1 | side) of every node flag the rare kernel has set so far -- what other ranks need

@@ -471,6 +471,26 @@ __attribute__((visibility("default"))) int pantas_augment_launch(pantas_graph* g
   });
 }
 
+__attribute__((visibility("default"))) int pantas_augment_launch_async(pantas_graph* g, pantas_batch* b) {
+  return guarded([&] {
+    need_device(g);
+    need(b && b->dev, "null batch");
+    launch_augment_async(*g->dev, *b->dev);
+  });
+}
+
+__attribute__((visibility("default"))) int pantas_augment_launch_collect(pantas_graph* g, float* ms, uint64_t capacity, uint64_t* n) {
+  return guarded([&] {
+    need_device(g);
+    need(n, "null argument");
+    need(ms || capacity == 0, "null buffer");
+    std::vector<LaunchTimes> t(capacity);
+    const size_t got = launch_collect(*g->dev, t.data(), t.size());
+    *n = got;
+    for (size_t i = 0; i < std::min<size_t>(got, capacity); ++i) { ms[3 * i] = t[i].rare_ms; ms[3 * i + 1] = t[i].main_ms; ms[3 * i + 2] = t[i].main_short_ms; }
+  });
+}
+
 __attribute__((visibility("default"))) int pantas_augment_reserve(pantas_graph* g, uint64_t keys) {
   return guarded([&] {
     need_device(g);

@@ -122,6 +122,17 @@ class Graph:
         check(lib.pantas_augment_launch(self._h, batch._h, C.byref(st)))
         return st
 
+    def launch_async(self, batch: Batch):
+        """the two kernels enqueued, not waited for (at most 64 in flight); launch_collect() waits and returns their times"""
+        check(lib.pantas_augment_launch_async(self._h, batch._h))
+
+    def launch_collect(self):
+        """[(rare_ms, main_ms, main_short_ms)] of the launches enqueued by launch_async since the last collect, oldest first"""
+        ms = (C.c_float * (3 * 64))()
+        n = C.c_uint64()
+        check(lib.pantas_augment_launch_collect(self._h, ms, 64, C.byref(n)))
+        return [(ms[3 * i], ms[3 * i + 1], ms[3 * i + 2]) for i in range(min(n.value, 64))]
+
     def reserve(self, keys: int):
         check(lib.pantas_augment_reserve(self._h, keys))
 

@@ -124,6 +124,52 @@ def test_relaunch_is_linear():
         assert (2 * a.astype("int64") == c.astype("int64")).all()
 
 
+def test_launches_that_are_not_waited_for(tmp_path):
+    """pantas_augment_launch_async / _collect (ABI 7): launches enqueued back to back leave what the same number of waited-for launches
+    leaves -- counters, sparse tables, the written GFA --, the collect returns one triple of kernel times per launch, oldest first, and
+    the 65th launch in flight is refused."""
+    from pantas_amd import synth
+    from pantas_amd.engine import Graph, PantasError
+    pre = str(tmp_path / "s")
+    synth.write_all(pre, seed=77, n_genes=60, n_lines=40000, p_indel=0.2, p_sub=0.4, p_novel_skip=0.08, p_novel_ce=0.04)
+
+    def run(pipelined, launches):
+        g = Graph(pre + ".gfa").to_device(0)
+        g.augment_reset()
+        b = g.load_gaf(pre + ".gaf")
+        if pipelined:
+            for _ in range(launches):
+                g.launch_async(b)
+            times = g.launch_collect()
+            assert len(times) == launches and all(m > 0 and r >= 0 and 0 <= s <= m for r, m, s in times)
+            assert g.launch_collect() == []
+        else:
+            for _ in range(launches):
+                g.launch(b)
+        g.finish()
+        with tempfile.TemporaryFile() as f:
+            g.write_gfa(f.fileno())
+            f.seek(0)
+            return f.read()
+
+    assert run(True, 5) == run(False, 5)
+    # one launch through either door is the oracle's file
+    want = io.StringIO()
+    augment_oracle.augment(pre + ".gaf", pre + ".gfa", want)
+    assert run(True, 1).decode() == want.getvalue()
+    g = Graph(pre + ".gfa").to_device(0)
+    g.augment_reset()
+    b = g.load_gaf(pre + ".gaf")
+    for _ in range(64):
+        g.launch_async(b)
+    with pytest.raises(PantasError):
+        g.launch_async(b)
+    assert len(g.launch_collect()) == 64
+    g.launch_async(b)                      # room again
+    assert len(g.launch_collect()) == 1
+    g.finish()
+
+
 def test_sharded_driver_nccl_single_rank(tmp_path):
     """pantas_amd.distributed with the real library and the RCCL backend (one rank: the only GPU here).
     Exercises the zero-copy tensor view of the counters, the collectives and the rank-0 writer."""
