@@ -365,8 +365,10 @@ def emit(out: dict, args) -> None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (a step is milliseconds; the kernel's first launches after the set-up run 5 % longer than its tenth -- clocks, TLBs --, so the
+    # defaults are what the driver passes: 20 timed steps behind 5 warm-up steps)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", default=os.environ.get("PANTAS_BENCH_SCALE", "auto"))
     ap.add_argument("--lines", type=int, default=0, help="override the scale's GAF lines per GPU (per batch)")
     ap.add_argument("--blocks", type=int, default=0, help="override the number of resident batches per GPU")
