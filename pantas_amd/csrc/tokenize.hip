@@ -88,15 +88,43 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return base + inc - v;
 }
 
-// text is padded with zero bytes to a multiple of TILE, so the loads need no bound
-__global__ void __launch_bounds__(TPB) count_newlines_kernel(const uint4* text, uint32_t* tile_cnt) {
-  const uint4* p = text + (size_t(blockIdx.x) * TILE + threadIdx.x * 64u) / 16u;
+// 0x80 in every byte of w that equals '\r'
+__device__ __forceinline__ uint32_t cr_bits(uint32_t w) {
+  const uint32_t x = w ^ 0x0D0D0D0Du;
+  const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+  return ~(t | x | 0x7F7F7F7Fu);
+}
+
+// text is padded with zero bytes to a multiple of TILE plus one tile, so the loads (and the one word a lane reads behind its 64 bytes)
+// need no bound.  *lone_cr is set when the text holds a '\r' that is followed by a byte other than '\n' (the reference's universal
+// newlines end a line there; to the kernels it is whitespace: gaf_device.h TE_LONE_CR) -- found here, where every byte is read anyway,
+// since late round 4: the host looked for it in the pinned pieces on their way to HBM, and that scan, not PCIe, set the pace (40 GB/s
+// against 54 without it).
+__global__ void __launch_bounds__(TPB) count_newlines_kernel(const uint4* text, uint32_t* tile_cnt, uint32_t* lone_cr, uint64_t size) {
+  const size_t byte0 = size_t(blockIdx.x) * TILE + threadIdx.x * 64u;
+  const uint4* p = text + byte0 / 16u;
   uint32_t c = 0;
+  uint32_t w[17];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint4 v = p[j];
-    c += __popc(newline_bits(v.x)) + __popc(newline_bits(v.y)) + __popc(newline_bits(v.z)) + __popc(newline_bits(v.w));
+    w[4 * j] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
   }
+  w[16] = reinterpret_cast<const uint32_t*>(p + 4)[0];
+  bool lone = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t nl = newline_bits(w[j]);
+    c += __popc(nl);
+    // byte i of the word is a '\r' and byte i + 1 (of this word or the first of the next) is no '\n'
+    uint32_t m = cr_bits(w[j]) & ~((nl >> 8) | (newline_bits(w[j + 1]) << 24));
+    while (m) {      // (rare: a text with '\r' in it at all)
+      const uint32_t bit = uint32_t(__ffs(int(m))) - 1u;
+      if (byte0 + uint32_t(j) * 4u + (bit >> 3) + 1u < size) lone = true;      // (a '\r' as the text's last byte ends nothing)
+      m &= m - 1u;
+    }
+  }
+  if (lone) atomicOr(lone_cr, 1u);
   uint32_t total;
   (void)block_exclusive_scan(c, &total);
   if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
@@ -670,7 +698,8 @@ double now() { return now_s(); }
 // TE_LONE_CR), which costs a scan of every line, so the kernels only do it when told that there is something to find
 // fd >= 0: the bytes come from the FILE (pread into the pinned buffer) instead of from its mapping -- a 19 GB GFA that was never
 // touched through the mapping costs 4.7 M page faults to copy from (17 GB/s on the box's sixteen cores; pread: the page cache's speed)
-bool upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinned_bytes, const char* data, size_t size, uint8_t* dst, hipStream_t stream, int fd = -1) {
+bool upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinned_bytes, const char* data, size_t size, uint8_t* dst, hipStream_t stream, int fd = -1,
+                 bool scan_cr = true) {
   constexpr size_t STAGE = size_t(32) << 20;
   if (size == 0) return false;
   if (!pinned[0]) {
@@ -700,7 +729,7 @@ bool upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinne
       } else {
         memcpy(dstp + b, src + b, e - b);
       }
-      for (const char* q = dstp + b; q < dstp + e;) {
+      for (const char* q = dstp + b; scan_cr && q < dstp + e;) {      // (the GPU callers find it in count_newlines_kernel)
         q = static_cast<const char*>(memchr(q, '\r', size_t(dstp + e - q)));
         if (!q) break;
         const size_t at = off + size_t(q - dstp);     // position in the text
@@ -782,7 +811,7 @@ void prefetch_start(TextPrefetcher& p, const char* data, size_t size) {
     try {
       HIP_OK(hipSetDevice(pp->device));
       HIP_OK(hipMemsetAsync(pp->buf[k] + size, 0, text_padded_bytes(size) - size, pp->stream));
-      job.lone_cr = upload_text(pp->pinned, pp->pinned_done, pp->pinned_bytes, data, size, pp->buf[k], pp->stream);
+      job.lone_cr = upload_text(pp->pinned, pp->pinned_done, pp->pinned_bytes, data, size, pp->buf[k], pp->stream, -1, false);      // (false: the tokeniser's line index looks)
       HIP_OK(hipStreamSynchronize(pp->stream));
     } catch (const Error& e) {
       job.err = std::make_shared<Error>(e);
@@ -1002,11 +1031,11 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
     // the text is in HBM already (TextPrefetcher copied it while the batch before this one was being handled)
     if (resident->size != size || !resident->dev) throw Error("InternalError", "resident text does not match the range");
     d_text = resident->dev;
-    check_cr = resident->lone_cr ? 1u : 0u;
+    check_cr = 0u;      // (found by the line index below)
   } else {
     text.alloc(padded);
     HIP_OK(hipMemsetAsync(text.as<uint8_t>() + size, 0, padded - size, s));
-    check_cr = upload_text(pool.pinned, pool.pinned_done, pool.pinned_bytes, data, size, text.as<uint8_t>(), s) ? 1u : 0u;
+    (void)upload_text(pool.pinned, pool.pinned_done, pool.pinned_bytes, data, size, text.as<uint8_t>(), s, -1, false);
     d_text = text.as<uint8_t>();
   }
   const uint4* d_text4 = reinterpret_cast<const uint4*>(d_text);
@@ -1018,18 +1047,20 @@ DeviceBatchPtr tokenize_gaf_device(DeviceGraph& dg, const Graph& g, const char* 
   if (uint64_t(tiles) * TILE / 2 >= 0xFFFFFFFFull) throw Error("Unsupported", "GAF range too large for one batch");
   Scanner scan(pool);
   DevBuf tile_cnt(pool), tile_off(pool);
-  tile_cnt.alloc((size_t(tiles) + 1) * 4);
+  tile_cnt.alloc((size_t(tiles) + 2) * 4);      // (+ one word behind the counts: the lone-'\r' flag of the text)
   tile_off.alloc((size_t(tiles) + 1) * 4);
-  HIP_OK(hipMemsetAsync(tile_cnt.p, 0, (size_t(tiles) + 1) * 4, s));
+  HIP_OK(hipMemsetAsync(tile_cnt.p, 0, (size_t(tiles) + 2) * 4, s));
   t0 = now();
   if (tiles) {
-    hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, d_text4, tile_cnt.as<uint32_t>());
+    hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, d_text4, tile_cnt.as<uint32_t>(), tile_cnt.as<uint32_t>() + tiles + 1, uint64_t(size));
     HIP_OK(hipGetLastError());
   }
   scan.run(tile_cnt.as<uint32_t>(), tile_off.as<uint32_t>(), size_t(tiles) + 1, s);
-  uint32_t newlines = 0;
+  uint32_t newlines = 0, lone_cr = 0;
   HIP_OK(hipMemcpyAsync(&newlines, tile_off.as<uint32_t>() + tiles, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(&lone_cr, tile_cnt.as<uint32_t>() + tiles + 1, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
+  check_cr = lone_cr ? 1u : 0u;
   const bool open_tail = size > 0 && data[size - 1] != '\n';
   const uint64_t n_lines64 = uint64_t(newlines) + (open_tail ? 1 : 0);
   if (first_line_id + n_lines64 > uint64_t(0xFFFFFFFFu)) throw Error("Unsupported", "more than 2^32-1 GAF lines");
@@ -1624,23 +1655,24 @@ std::unique_ptr<Graph> load_graph_device(const char* path, int device, bool call
   hipEvent_t pinned_done[2] = {nullptr, nullptr};
   size_t pinned_bytes = 0;
   // (pread of the file into the pinned buffers instead of a copy out of the mapping was measured: 1.6 - 1.9 s against 1.1 s for 19 GB)
-  const bool lone_cr = upload_text(pinned, pinned_done, pinned_bytes, data, size, d_text, s, getenv("PANTAS_GFA_PREAD") ? g->text.fd : -1);
+  (void)upload_text(pinned, pinned_done, pinned_bytes, data, size, d_text, s, getenv("PANTAS_GFA_PREAD") ? g->text.fd : -1, false);
   for (int k = 0; k < 2; ++k) { if (pinned[k]) (void)hipHostFree(pinned[k]); if (pinned_done[k]) (void)hipEventDestroy(pinned_done[k]); }
-  if (lone_cr) return nullptr;                 // universal newlines: the host loader reads a copy with them applied
   pt.lap("text -> HBM");
   // ---- line index
   const uint32_t tiles = uint32_t((size + TILE - 1) / TILE);
   uint8_t* scan_tmp = nullptr;
   size_t scan_tmp_bytes = 0;
-  uint32_t* tile_cnt = m.get<uint32_t>(size_t(tiles) + 1);
+  uint32_t* tile_cnt = m.get<uint32_t>(size_t(tiles) + 2);      // (+ the lone-'\r' flag behind the counts)
   uint32_t* tile_off = m.get<uint32_t>(size_t(tiles) + 1);
-  HIP_OK(hipMemsetAsync(tile_cnt, 0, (size_t(tiles) + 1) * 4, s));
-  hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, reinterpret_cast<const uint4*>(d_text), tile_cnt);
+  HIP_OK(hipMemsetAsync(tile_cnt, 0, (size_t(tiles) + 2) * 4, s));
+  hipLaunchKernelGGL(count_newlines_kernel, dim3(tiles), dim3(TPB), 0, s, reinterpret_cast<const uint4*>(d_text), tile_cnt, tile_cnt + tiles + 1, uint64_t(size));
   HIP_OK(hipGetLastError());
   scan_u32(m, tile_cnt, tile_off, size_t(tiles) + 1, s, scan_tmp, scan_tmp_bytes);
-  uint32_t newlines = 0;
+  uint32_t newlines = 0, lone_cr = 0;
   HIP_OK(hipMemcpyAsync(&newlines, tile_off + tiles, 4, hipMemcpyDeviceToHost, s));
+  HIP_OK(hipMemcpyAsync(&lone_cr, tile_cnt + tiles + 1, 4, hipMemcpyDeviceToHost, s));
   HIP_OK(hipStreamSynchronize(s));
+  if (lone_cr) return nullptr;                 // universal newlines: the host loader reads a copy with them applied
   const bool open_tail = data[size - 1] != '\n';
   const uint64_t n_lines64 = uint64_t(newlines) + (open_tail ? 1 : 0);
   if (n_lines64 >= 0x7FFFFFFFull) return nullptr;

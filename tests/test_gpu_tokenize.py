@@ -200,6 +200,66 @@ def test_oracle_parity_behind_device_tokenizer(tmp_path):
     assert bs.tokenizer == 2 and bs.rejected == a.rejected and got == want.getvalue()
 
 
+def test_a_lone_carriage_return_is_found_wherever_it_stands(tmp_path):
+    """Python's universal newlines end a line at a '\\r' that no '\\n' follows; the kernels only look for one when the line index says
+    the text holds one (count_newlines_kernel, since late round 4: the host used to look while it staged the text).  The '\\r' is put at
+    byte offsets around the kernel's borders -- words, a lane's 64 bytes, the 16 KB tile, the text's last byte -- by lengthening the
+    first line's read name; both tokenisers must end alike (same bytes or the same refusal), and a '\\r\\n' or a '\\r' as the last
+    byte must change nothing."""
+    from pantas_amd.engine import Graph, PantasError
+    d = os.path.join(GOLDEN, "synth_a")
+    raw = open(f"{d}/in.gaf", "rb").read()
+    assert len(raw) > 40000
+    lines = raw.split(b"\n")
+    g = Graph(f"{d}/in.gfa").to_device(0)
+
+    def ends(text):
+        gaf = str(tmp_path / "r.gaf")
+        open(gaf, "wb").write(text)
+        out = []
+        for where in ("host", "device"):
+            g.set_tokenizer(where)
+            try:
+                with tempfile.TemporaryFile() as f:
+                    g.augment(gaf, 20, f.fileno())
+                    f.seek(0)
+                    out.append(("ok", f.read()))
+            except PantasError as e:
+                out.append(("err", e.kind, str(e)))
+        assert out[0] == out[1], (out[0][:2], out[1][:2])
+        return out[0]
+
+    plain = ends(raw)
+    assert plain[0] == "ok"
+    seen_change = 0
+    def with_cr_at(target):
+        """the text with one '\\r' inside a read name, at byte offset `target`"""
+        name0 = lines[0].split(b"\t")[0]
+        if target < 100:                                  # inside the first line's own name, grown to hold it
+            grown = name0 + b"x" * max(0, target + 3 - len(name0))
+            grown = grown[:target] + b"\r" + grown[target + 1:]
+            return b"\n".join([b"\t".join([grown] + lines[0].split(b"\t")[1:])] + lines[1:])
+        off = 0
+        for i, ln in enumerate(lines):
+            n = target - 1 - off                          # the first line's name grown by n puts byte 1 of line i's name at the target
+            if i > 0 and 0 <= n < 400 and len(ln.split(b"\t")[0]) >= 4:
+                mod = list(lines)
+                mod[0] = b"\t".join([name0 + b"x" * n] + lines[0].split(b"\t")[1:])
+                mod[i] = ln[:1] + b"\r" + ln[2:]
+                return b"\n".join(mod)
+            off += len(ln) + 1
+        raise AssertionError(f"no line for offset {target}")
+
+    for border in (16, 64, 4096, 16384, 32768):
+        for delta in (-2, -1, 0, 1):
+            text = with_cr_at(border + delta)
+            assert text[border + delta] == 13 and text.count(b"\r") == 1
+            seen_change += ends(text) != plain
+    assert seen_change >= 15                              # (a read name cut in two is two broken lines: the run ends differently)
+    assert ends(raw.replace(b"\n", b"\r\n")) == plain
+    assert ends(raw.rstrip(b"\n") + b"\r") == ends(raw.rstrip(b"\n"))
+
+
 def test_empty_and_unterminated_input(tmp_path):
     from pantas_amd.engine import Graph
     d = os.path.join(GOLDEN, "micro")
