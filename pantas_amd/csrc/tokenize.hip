@@ -693,9 +693,10 @@ double now() { return now_s(); }
 
 // host text -> HBM through two pinned staging buffers (kept with the graph); several host threads fill one buffer while
 // the other is in flight
-// returns true when the text holds a '\r' that no '\n' follows (looked for while each piece is in cache): the reference's
+// scan_cr: returns true when the text holds a '\r' that no '\n' follows (looked for while each piece is in cache): the reference's
 // universal newlines end a line there, to the kernels it is whitespace -- the line that holds it is refused (gaf_device.h
-// TE_LONE_CR), which costs a scan of every line, so the kernels only do it when told that there is something to find
+// TE_LONE_CR), which costs a scan of every line, so the kernels only do it when told that there is something to find.  The callers
+// in this file pass false since late round 4 (count_newlines_kernel finds it: the host scan held the copies to 40 GB/s)
 // fd >= 0: the bytes come from the FILE (pread into the pinned buffer) instead of from its mapping -- a 19 GB GFA that was never
 // touched through the mapping costs 4.7 M page faults to copy from (17 GB/s on the box's sixteen cores; pread: the page cache's speed)
 bool upload_text(void* (&pinned)[2], hipEvent_t (&pinned_done)[2], size_t& pinned_bytes, const char* data, size_t size, uint8_t* dst, hipStream_t stream, int fd = -1,
