@@ -10,11 +10,15 @@ import types
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_line_is_short_and_complete(capsys, monkeypatch, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("recorded", ["r3_bench_default_s4_final.json", "r4_bench_default_s4_details.json"])
+def test_bench_line_is_short_and_complete(capsys, monkeypatch, tmp_path, recorded):
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    full = json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_default_s4_final.json")).read())   # a recorded full result
+    full = json.loads(open(os.path.join(ROOT, "profiles", recorded)).read())   # a recorded full result
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     bench.emit(full, types.SimpleNamespace(cpu_sample=800000))
     out = capsys.readouterr().out.strip().splitlines()
