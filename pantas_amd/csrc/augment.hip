@@ -1268,10 +1268,11 @@ struct DeviceGraph {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t* evs = ev;           // the events the launch functions record: ev, or the slot of a launch that is not waited for
   // launches enqueued without a wait (launch_augment_async): their events, read by launch_collect
-  struct InFlight { hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool split = false; };
+  struct InFlight { hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool split = false, short_all = false; };
   std::vector<InFlight> ring;
   std::vector<uint32_t> in_flight;      // ring slots, oldest first
-  bool last_split = false;
+  bool last_split = false, last_short_all = false;
+  bool start_is_rare_end = false;      // set around launch_main_impl by the callers that have just enqueued the batch's rare-key kernel
   hipStream_t stream2 = nullptr;  // the general-walk kernel runs here, beside the short-walk kernel on `stream`
   float last_short_ms = 0.f;      // duration of the short-walk kernel of the last launch_main (0 when one kernel did everything)
   uint32_t V = 0;
@@ -1929,7 +1930,11 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
   d.sync_slow();
   const GraphView g = d.view();
   BatchView bv = batch_view(b);
-  HIP_OK(hipEventRecord(d.evs[1], d.stream));
+  // (behind the rare-key kernel of the same call the start of the main kernels is that kernel's end event: every event record is a
+  // barrier packet between two kernels)
+  const hipEvent_t ev_start = d.start_is_rare_end ? d.evs[5] : d.evs[1];
+  if (!d.start_is_rare_end) HIP_OK(hipEventRecord(ev_start, d.stream));
+  bool short_all = false;
   d.last_short_ms = 0.f;
   if (b.n) {
     // PANTAS_MAIN_KERNEL (A/B, profiles/README.md): 0 = the general walk with direct global atomics for every record; the
@@ -1950,7 +1955,7 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
     // side by side: the general-walk kernel (few records, slow waves, often too few workgroups to fill the chip) on a
     // second stream fills what the short-walk kernel leaves; both add to the same counters with atomics
 #define PANTAS_SPLIT(ID, SHORT_ARGS, GENERAL_ARGS) case ID: \
-      HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0)); \
+      HIP_OK(hipStreamWaitEvent(d.stream2, ev_start, 0)); \
       PANTAS_AGG_RANGE GENERAL_ARGS; HIP_OK(hipEventRecord(d.evs[4], d.stream2)); \
       PANTAS_AGG_RANGE SHORT_ARGS; HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true; \
       HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0)); break;
@@ -1993,7 +1998,7 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
           // round 2's short walk over 8-byte node records {length, first out-target}: links off the first out-slot deferred per line and
           // looked up behind the node loop, links absent from the graph queued per workgroup; chunks dealt to the XCDs in eighths; the
           // line's ShortOps with the record; odd rounds of a chunk the other way round.  The A/B partner of the default.
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0));
+          HIP_OK(hipStreamWaitEvent(d.stream2, ev_start, 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.evs[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_main_agg_kernel<512, 2048, 10, 10, 7, 8, true, 1, false, true, 2, true, true, 1, true, true>),
@@ -2008,7 +2013,7 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
           // small batch a tenth of its step)
           const bool general = b.n > b.n_short;
           if (general) {
-            HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0));
+            HIP_OK(hipStreamWaitEvent(d.stream2, ev_start, 0));
             PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
             HIP_OK(hipEventRecord(d.evs[4], d.stream2));
           }
@@ -2043,8 +2048,9 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
             }
 #undef PANTAS_P
           }
-          HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true;
-          if (general) HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0));
+          // (no general-class records: the short-walk kernel is the whole launch, its end the launch's end event)
+          if (general) { HIP_OK(hipEventRecord(d.evs[3], d.stream)); split = true; HIP_OK(hipStreamWaitEvent(d.stream, d.evs[4], 0)); }
+          else short_all = true;
           break;
         }
         default:
@@ -2052,7 +2058,7 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
           // against its node's first three out-targets where the node is visited and counted in the node's own table entry; same chunk
           // order, record layout and round order as 101.  S4: 2.07 against 2.17 ms (profiles/r3_ab_s4_wide.txt); two nodes ahead instead
           // of one measured the same (2.11).
-          HIP_OK(hipStreamWaitEvent(d.stream2, d.evs[1], 0));
+          HIP_OK(hipStreamWaitEvent(d.stream2, ev_start, 0));
           PANTAS_AGG_RANGE(d.stream2, b.n_short, b.n, 512, 2048, 10, 10, 7, 8, false, 2);
           HIP_OK(hipEventRecord(d.evs[4], d.stream2));
           if (b.n_short) hipLaunchKernelGGL((augment_short_w_kernel<512, 2048, 10, 7, 8, 1>), dim3(8u * ((n_ch + 7u) / 8u)), dim3(512), 0, d.stream, g, bv, 0u, b.n_short);
@@ -2069,17 +2075,20 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
     HIP_OK(hipGetLastError());
     HIP_OK(hipEventRecord(d.evs[2], d.stream));
     d.last_split = split;
+    d.last_short_all = short_all;
     if (!wait) return 0.f;
     HIP_OK(hipEventSynchronize(d.evs[2]));
-    if (split) HIP_OK(hipEventElapsedTime(&d.last_short_ms, d.evs[1], d.evs[3]));
+    if (split) HIP_OK(hipEventElapsedTime(&d.last_short_ms, ev_start, d.evs[3]));
+    else if (short_all) HIP_OK(hipEventElapsedTime(&d.last_short_ms, ev_start, d.evs[2]));
   } else {
     HIP_OK(hipEventRecord(d.evs[2], d.stream));
     d.last_split = false;
+    d.last_short_all = false;
     if (!wait) return 0.f;
     HIP_OK(hipEventSynchronize(d.evs[2]));
   }
   float m = 0;
-  HIP_OK(hipEventElapsedTime(&m, d.evs[1], d.evs[2]));
+  HIP_OK(hipEventElapsedTime(&m, ev_start, d.evs[2]));
   pt.lap("kernels + wait");
   return m;
 }
@@ -2090,7 +2099,10 @@ float last_short_kernel_ms(const DeviceGraph& d) { return d.last_short_ms; }
 
 float launch_augment(DeviceGraph& d, DeviceBatch& b, float* ms_rare, float* ms_main) {
   (void)launch_rare_impl(d, b, false);
-  const float m = launch_main(d, b);        // returns after everything enqueued so far has completed
+  d.start_is_rare_end = true;
+  float m = 0;
+  try { m = launch_main_impl(d, b, true); } catch (...) { d.start_is_rare_end = false; throw; }        // returns after everything enqueued so far has completed
+  d.start_is_rare_end = false;
   float a = 0;
   HIP_OK(hipEventElapsedTime(&a, d.evs[0], d.evs[5]));
   if (ms_rare) *ms_rare = a;
@@ -2115,13 +2127,17 @@ void launch_augment_async(DeviceGraph& d, DeviceBatch& b) {
   d.evs = d.ring[slot].ev;
   try {
     (void)launch_rare_impl(d, b, false);
+    d.start_is_rare_end = true;
     (void)launch_main_impl(d, b, false);
   } catch (...) {
     d.evs = d.ev;
+    d.start_is_rare_end = false;
     throw;
   }
   d.evs = d.ev;
+  d.start_is_rare_end = false;
   d.ring[slot].split = d.last_split;
+  d.ring[slot].short_all = d.last_short_all;
   d.in_flight.push_back(slot);
 }
 
@@ -2133,8 +2149,9 @@ size_t launch_collect(DeviceGraph& d, LaunchTimes* out, size_t capacity) {
     const auto& f = d.ring[slot];
     LaunchTimes t{};
     HIP_OK(hipEventElapsedTime(&t.rare_ms, f.ev[0], f.ev[5]));
-    HIP_OK(hipEventElapsedTime(&t.main_ms, f.ev[1], f.ev[2]));
-    if (f.split) HIP_OK(hipEventElapsedTime(&t.main_short_ms, f.ev[1], f.ev[3]));
+    HIP_OK(hipEventElapsedTime(&t.main_ms, f.ev[5], f.ev[2]));      // (the main kernels start at the rare-key kernel's end event)
+    if (f.split) HIP_OK(hipEventElapsedTime(&t.main_short_ms, f.ev[5], f.ev[3]));
+    else if (f.short_all) t.main_short_ms = t.main_ms;
     if (n < capacity && out) out[n] = t;
     ++n;
   }
