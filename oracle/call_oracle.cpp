@@ -4,7 +4,8 @@
 // lines) with the four fixed rules of oracle/call_oracle.py for what the reference leaves to Python's hash seed:
 //   R1  rows in (pass, junction in file order, emission order);
 //   R2  "any exon of the set" (:484-486) = the EX tag that appears first in the GFA;
-//   R3  set.pop() / "any hit" of the intronic search (:743, :752, :796, :805) = the segment whose S line comes first;
+//   R3  set.pop() of the intronic search (:743, :796) level by level: the members the set held when pvisitl was last set, in
+//       S-line order, before anything added since; "any hit" (:752, :805) = the segment whose S line comes first;
 //   R4  '|'-joined set contents (:876, :1072-1077) in first-appearance order.
 // Written for speed -- whole-genome graphs, 10^8 rows -- so that `pantas call` can be checked at BASELINE.json sizes and
 // bench.py's `cpu_baseline` leg can time "call on the host cores" (SURVEY.md 8-d rows 2a / 2b).  Only tests/,
@@ -122,7 +123,10 @@ inline bool parse_int(sv s, i64& v) {
   if (i < s.size() && (s[i] == '+' || s[i] == '-')) neg = s[i++] == '-';
   if (i == s.size()) return false;
   i64 x = 0;
+  // int() takes single '_' between digits ("1_0" == 10), not in front, at the end or doubled
+  if (s[i] == '_' || s.back() == '_') return false;
   for (; i < s.size(); ++i) {
+    if (s[i] == '_') { if (s[i - 1] == '_') return false; continue; }
     if (s[i] < '0' || s[i] > '9') return false;
     if (x > (INT64_MAX - 9) / 10) crash("Unsupported", "integer beyond 64 bits");
     x = x * 10 + (s[i] - '0');
@@ -937,26 +941,33 @@ struct Caller {
     }
   }
 
-  // the level-bounded frontier search [:734-750, :787-803] with rule R3 for pop() and for the hit
+  // the level-bounded frontier search [:734-750, :787-803] with rule R3 for pop() and for the hit: `visit` is the reference's set,
+  // `level_nodes` the pvisitl members it held when the level began, by S-line position -- popped before anything added since
   u32 search(u32 start, const std::vector<u32>& targets, bool forward) const {
-    std::vector<u32> visit{start};
+    std::vector<u32> visit{start}, level_nodes{start};
+    size_t next = 0;
+    auto first_of = [&](u32 a, u32 b) { return g.seg[a].first_off < g.seg[b].first_off; };
     auto hits = [&] {
       u32 best = NONE;
       for (u32 x : visit)
-        if (std::find(targets.begin(), targets.end(), x) != targets.end() && (best == NONE || g.seg[x].first_off < g.seg[best].first_off)) best = x;
+        if (std::find(targets.begin(), targets.end(), x) != targets.end() && (best == NONE || first_of(x, best))) best = x;
       return best;
     };
     i64 left = 1, level = 0;
     while (hits() == NONE && level < o.isw) {
       if (visit.empty()) return NONE;
-      size_t k = 0;
-      for (size_t i = 1; i < visit.size(); ++i) if (g.seg[visit[i]].first_off < g.seg[visit[k]].first_off) k = i;
-      const u32 n = visit[k];
-      visit.erase(visit.begin() + long(k));
+      const u32 n = level_nodes[next++];
+      visit.erase(std::find(visit.begin(), visit.end(), n));
       --left;
       auto push = [&](u32 x) { if (std::find(visit.begin(), visit.end(), x) == visit.end()) visit.push_back(x); };
       if (forward) g.outs(n, push); else g.ins(n, push);
-      if (left == 0) { ++level; left = i64(visit.size()); }
+      if (left == 0) {
+        ++level;
+        left = i64(visit.size());
+        level_nodes = visit;
+        std::sort(level_nodes.begin(), level_nodes.end(), first_of);
+        next = 0;
+      }
     }
     return level < o.isw ? hits() : NONE;
   }

@@ -14,8 +14,12 @@ possible behaviours:
 
   R1  rows are emitted in a fixed order (pass, then junction in file order);
   R2  "pick any exon of a set" (:484-486) picks the tag that appears first in the GFA;
-  R3  ``set.pop()`` in the intronic search (:743, :796) pops the node that appears first
-      in the GFA; "any node of visit & targets" (:752, :805) likewise;
+  R3  ``set.pop()`` in the intronic search (:743, :796) works level by level -- the members
+      the set held when ``pvisitl`` was last set are popped, in GFA order, before anything
+      added since (round 5; until round 4: always the member that appears first in the GFA,
+      which spends the ``--isw`` budget on the lowest branch and misses rows the reference
+      prints under 61 of 64 hash seeds); "any node of visit & targets" (:752, :805) is the
+      one that appears first in the GFA;
   R4  '|'-joined set contents (:876, :1072-1077) are listed in first-appearance order.
 
 Differences from the reference by design: junctions sharing a head/tail are found through
@@ -69,6 +73,34 @@ class Graph:
         self.nov_by_tail = {}
 
 
+def _position_clusters_raise(v, ctx):
+    """What is left of the IL/OL clustering [:37-66, collapse_linkcounts :15-21]: the exceptions.
+
+    One entry: only ``max(_v, key=x[1])`` [:66] looks at it.  Several: one cluster when first minimum and first maximum
+    position are closer than 3 [:43-45], else a low and a high cluster [:47-61] seeded with those two; entries whose whole
+    list equals one of the seeds are left out [:49-50].  Every cluster reads x[1] of its members, then divides by their sum;
+    the low cluster is summed first.
+    """
+    def total(members):
+        if any(len(x) < 2 for x in members):
+            raise ReferenceCrash("IndexError", f"{ctx}: entry without a count")
+        if sum(x[1] for x in members) == 0:
+            raise ReferenceCrash("ZeroDivisionError", f"{ctx}: counts of a cluster sum to 0")
+
+    if len(v) == 1:
+        if len(v[0]) < 2:
+            raise ReferenceCrash("IndexError", f"{ctx}: entry without a count")
+        return
+    lo = min(v, key=lambda x: x[0])
+    hi = max(v, key=lambda x: x[0])
+    if hi[0] - lo[0] < 3:
+        total(v)
+        return
+    rest = [x for x in v if x != lo and x != hi]
+    total([lo] + [x for x in rest if x[0] - lo[0] < hi[0] - x[0]])
+    total([hi] + [x for x in rest if not x[0] - lo[0] < hi[0] - x[0]])
+
+
 def _attrs(fields, crash_ctx):
     """[:25-69] tag list -> dict."""
     out = {}
@@ -83,11 +115,12 @@ def _attrs(fields, crash_ctx):
             except ValueError:
                 raise ReferenceCrash("ValueError", f"{crash_ctx}: {f!r}") from None
         elif name in ("IL", "OL"):
-            # parsed (and collapsed) by the reference but never read afterwards
+            # parsed and clustered by the reference [:33-66]; nothing reads the result, but the clustering can raise
             try:
                 out[name] = [list(map(int, x.split("."))) for x in value.split(",")]
             except ValueError:
                 raise ReferenceCrash("ValueError", f"{crash_ctx}: {f!r}") from None
+            _position_clusters_raise(out[name], f"{crash_ctx}: {f!r}")
         else:
             out[name] = value.split(",")
     return out
@@ -346,20 +379,27 @@ class Caller:
 
     # ---- novel links ---------------------------------------------------------------------
     def search(self, start, targets, key):
-        """[:734-750, :787-803] the level-bounded frontier search, with rule R3 for pop()."""
+        """[:734-750, :787-803] the level-bounded frontier search, with rule R3 for pop().
+
+        `visit` is the reference's set; `level_nodes` are the `pvisitl` members it held when the level began, in GFA order --
+        they are popped before anything the level adds (a node popped and added again belongs to the next level).  The loop
+        condition is looked at before every pop, as there: a hit on the level's LAST pop is seen with the level already counted.
+        """
         visit = {start}
+        level_nodes = [start]
         left = 1
         level = 0
         while not (visit & targets) and level < self.isw:
             if not visit:
                 return None
-            n = self.first_node(visit)
+            n = level_nodes.pop(0)
             visit.discard(n)
             left -= 1
             visit |= set(self.g.seg[n][key])
             if left == 0:
                 level += 1
                 left = len(visit)
+                level_nodes = sorted(visit, key=lambda x: self.g.seg[x]["rank"])
         if level < self.isw:
             return self.first_node(visit & targets)
         return None

@@ -253,8 +253,8 @@ PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit
   }
 }
 
-// [:734-750, :787-803] level-bounded frontier search; pop() takes the node that comes first in
-// the GFA (rule R3).  dir 0: follow out-links from `start`, targets = {n : (anchor, n) junction};
+// [:734-750, :787-803] level-bounded frontier search; pop() takes the members of a level, in GFA order, before anything the
+// level adds, the hit is the target that comes first in the GFA (rule R3).  dir 0: follow out-links from `start`, targets = {n : (anchor, n) junction};
 // dir 1: follow in-links, targets = {p : (p, anchor) junction}.
 constexpr uint32_t FRONTIER_LOCAL = 24;
 constexpr uint32_t FRONTIER_TARGETS = 8;
@@ -287,18 +287,24 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
   uint32_t* vis = local;      // sorted set of node indices; moves to an arena slice when it outgrows `local`
   uint32_t cap = FRONTIER_LOCAL;
   uint32_t n = 1;
-  vis[0] = start;
+  // Rule R3 (round 5: level order): the members the set held when the level began -- the reference's `pvisitl` of them --
+  // carry FRONTIER_LEVEL and are popped in ascending order before anything added since (a node popped and added again comes
+  // back without the bit: it belongs to the next level).  Node indices stay below 2^31 (the loader refuses more).
+  constexpr uint32_t FRONTIER_LEVEL = 0x80000000u;
+  vis[0] = start | FRONTIER_LEVEL;
   // the first member of the (sorted) set that is a target = the smallest target in it; members only leave by the pop below,
   // which is not reached while there is one
   uint32_t tmin = is_target(start) ? start : CNONE;
-  int32_t left = 1;
+  int32_t left = 1;          // members with the bit
   int32_t level = 0;
+  uint32_t cur = 0;          // nothing in front of `cur` carries the bit
   for (;;) {
     if (tmin != CNONE) return level < c.isw ? tmin : CNONE;
     if (level >= c.isw) return CNONE;
     if (n == 0) return CNONE;
-    const uint32_t x = vis[0];
-    for (uint32_t i = 1; i < n; ++i) vis[i - 1] = vis[i];
+    while (!(vis[cur] & FRONTIER_LEVEL)) ++cur;
+    const uint32_t x = vis[cur] & ~FRONTIER_LEVEL;
+    for (uint32_t i = cur + 1; i < n; ++i) vis[i - 1] = vis[i];
     --n;
     --left;
     const uint32_t b = dir == 0 ? c.row_ptr[x] : c.irow_ptr[x];
@@ -309,9 +315,9 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
       uint32_t lo = 0, hi = n;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (vis[mid] < y) lo = mid + 1; else hi = mid;
+        if ((vis[mid] & ~FRONTIER_LEVEL) < y) lo = mid + 1; else hi = mid;
       }
-      if (lo < n && vis[lo] == y) continue;
+      if (lo < n && (vis[lo] & ~FRONTIER_LEVEL) == y) continue;
       if (n == cap) {
         if (vis != local || c.arena == nullptr) { f.raise(CE_FRONTIER); return CNONE; }
         const uint32_t slice = claim_slice(c.arena_next);
@@ -324,9 +330,15 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
       for (uint32_t i = n; i > lo; --i) vis[i] = vis[i - 1];
       vis[lo] = y;
       ++n;
+      if (lo <= cur) ++cur;
       if (y < tmin && is_target(y)) tmin = y;
     }
-    if (left == 0) { ++level; left = int32_t(n); }
+    if (left == 0) {
+      ++level;
+      left = int32_t(n);
+      cur = 0;
+      for (uint32_t i = 0; i < n; ++i) vis[i] |= FRONTIER_LEVEL;
+    }
   }
 }
 

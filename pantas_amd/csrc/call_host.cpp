@@ -78,21 +78,66 @@ int32_t tag_int(Span v, uint64_t off) {
   return int32_t(x);
 }
 
-// IL/OL values are parsed (ints around '.') by the reference although never used (:33-66)
+// IL/OL values go through build_attrs' position clustering (scripts/call.py:33-66) although nothing reads the result: what is
+// left of it is where it raises.  Entries are int lists split on '.' (extra fields are carried along and only matter for the
+// list equality of :49); one entry skips the clustering and meets `max(_v, key=x[1])` (:66, IndexError without a second int);
+// two or more are summed in one group (positions within d = 3 of each other, :43-45) or in two around the first minimum / first
+// maximum (:47-61) -- `collapse_linkcounts` (:15-21) reads x[1] of every member (IndexError) and divides by the sum of the
+// counts (ZeroDivisionError), the low group in front of the high one.
 void check_hist_value(Span v, uint64_t off) {
+  struct Ent { uint32_t first, n; };            // pieces [first, first + n) of `ints`
+  std::vector<int64_t> ints;
+  std::vector<Ent> ent;
   const char* p = v.b;
   while (p <= v.e) {
     const char* q = static_cast<const char*>(memchr(p, ',', size_t(v.e - p)));
     if (!q) q = v.e;
+    Ent en{uint32_t(ints.size()), 0};
     const char* a = p;
     while (a <= q) {
       const char* d = static_cast<const char*>(memchr(a, '.', size_t(q - a)));
       if (!d) d = q;
       int64_t x;
-      if (!parse_py_int(Span{a, d}, x)) throw Error("ValueError", "GFA byte " + std::to_string(off) + ": IL/OL value is not 'int.int'");
+      if (!parse_py_int(Span{a, d}, x)) {
+        int64_t big;
+        if (parse_py_int(Span{a, d}, big, true)) throw Error("Unsupported", "GFA byte " + std::to_string(off) + ": IL/OL integer beyond 2^60");
+        throw Error("ValueError", "GFA byte " + std::to_string(off) + ": IL/OL value is not 'int.int'");
+      }
+      ints.push_back(x);
+      ++en.n;
       a = d + 1;
     }
+    ent.push_back(en);
     p = q + 1;
+  }
+  auto no_count = [&]() { throw Error("IndexError", "GFA byte " + std::to_string(off) + ": list index out of range (IL/OL entry without a count)"); };
+  if (ent.size() == 1) {
+    if (ent[0].n < 2) no_count();
+    return;
+  }
+  size_t lo = 0, hi = 0;                          // min() / max() keep the first of equals
+  for (size_t i = 1; i < ent.size(); ++i) {
+    if (ints[ent[i].first] < ints[ent[lo].first]) lo = i;
+    if (ints[ent[i].first] > ints[ent[hi].first]) hi = i;
+  }
+  auto same_list = [&](const Ent& a, const Ent& b) {
+    return a.n == b.n && std::equal(ints.begin() + a.first, ints.begin() + a.first + a.n, ints.begin() + b.first);
+  };
+  // group of an entry: 0 = low, 1 = high, 2 = in neither (a list equal to the minimum's or the maximum's, :49-50)
+  const bool one_group = ints[ent[hi].first] - ints[ent[lo].first] < 3;
+  auto group_of = [&](size_t i) -> int {
+    if (one_group) return 0;
+    if (same_list(ent[i], ent[lo]) || same_list(ent[i], ent[hi])) return 2;
+    const int64_t x = ints[ent[i].first];
+    return x - ints[ent[lo].first] < ints[ent[hi].first] - x ? 0 : 1;
+  };
+  for (int grp = 0; grp < (one_group ? 1 : 2); ++grp) {
+    __int128 count = 0;
+    auto take = [&](const Ent& e) { if (e.n < 2) no_count(); count += ints[e.first + 1]; };
+    if (!one_group) take(ent[grp == 0 ? lo : hi]);   // k1 = [minv], k2 = [maxv] (:40-42)
+    for (size_t i = 0; i < ent.size(); ++i)
+      if (group_of(i) == grp) take(ent[i]);
+    if (count == 0) throw Error("ZeroDivisionError", "GFA byte " + std::to_string(off) + ": division by zero (IL/OL counts of a cluster sum to 0)");
   }
 }
 
@@ -357,6 +402,7 @@ void build_call_tables_mem(const Graph& g, const char* gtf_data, size_t gtf_size
   if (g.dup_names && g.dup_ws)
     throw Error("Unsupported", "several S lines for one segment name, one of them behind leading whitespace (call)");
   const uint32_t V = g.V;
+  if (V >= 0x80000000u) throw Error("Unsupported", "more than 2^31 segments (call: the frontier search keeps a bit beside a node index)");
   // ---- link layout -------------------------------------------------------------------------------
   RawVector<uint32_t> old_slot;     // fused: slot of the graph behind each slot of the layout (NONE32 = added link)
   std::vector<uint32_t> slot_of_added;   // fused: slot of the i-th added link (first-seen order) in the layout

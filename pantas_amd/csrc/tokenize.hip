@@ -1377,8 +1377,8 @@ __global__ void __launch_bounds__(LPB) gfa_lines_kernel(const uint8_t* text, con
 // :145-181), for the command line that goes on to call: a second staged pass over the text, once the S / L ordinals are known.
 // A tag is name:type:value with exactly two ':'; NC / LN / RC values are ints, IL / OL values lists of int.int; the value of EX
 // (S lines) and JN (L lines) is kept as a span of the text, the presence of ID (L lines) as a flag; a later tag of a name
-// overrides an earlier one.  Only the plain form is taken -- digits without sign or '_' for the ints (an optional '-' inside
-// IL / OL), a value below 2^31 -- anything else sets `odd` and the host scans the lines itself (and words the error).
+// overrides an earlier one.  Only the plain form is taken -- digits without sign or '_' for the ints (IL / OL: `tag_plain_hist`),
+// a value below 2^31 -- anything else sets `odd` and the host scans the lines itself (and words the error).
 constexpr uint32_t TAG_HAS_NC = 1u, TAG_HAS_EX = 2u;      // nflags: bit 0 = call_device.h N_HAS_NC
 __device__ __forceinline__ bool tag_plain_int(TextWords& T, uint32_t b, uint32_t e, uint32_t& v) {
   const uint32_t n = e - b;
@@ -1394,14 +1394,22 @@ __device__ __forceinline__ bool tag_plain_int(TextWords& T, uint32_t b, uint32_t
   return true;
 }
 __device__ __forceinline__ bool tag_plain_hist(TextWords& T, uint32_t b, uint32_t e) {
-  // pieces between ',' and '.': an optional '-' and 1 .. 18 digits each
-  uint32_t digits = 0;
-  bool minus = false;
+  // entries between ',', pieces between '.': 1 .. 18 digits each, at least two pieces per entry and a second piece that is
+  // not zero -- what `pantas augment` writes.  build_attrs clusters the entries and divides by the sum of a cluster's counts
+  // (scripts/call.py:15-21, :37-66): with every count positive nothing there can raise; an entry without a count, a sign or
+  // a zero count goes to the host's scan, which follows the clustering and words the IndexError / ZeroDivisionError.
+  uint32_t digits = 0, piece = 0;
+  bool nonzero = false, count_ok = false;
   for (uint32_t c = b; c <= e; ++c) {
     const uint32_t ch = c < e ? T.at(c) : uint32_t(',');
-    if (ch == ',' || ch == '.') { if (digits == 0) return false; digits = 0; minus = false; }
-    else if (ch == '-') { if (digits != 0 || minus) return false; minus = true; }
-    else if (ch - '0' <= 9u) { if (++digits > 18u) return false; }
+    if (ch == ',' || ch == '.') {
+      if (digits == 0) return false;
+      if (piece == 1u) count_ok = nonzero;
+      if (ch == ',') { if (piece == 0u || !count_ok) return false; piece = 0; }
+      else ++piece;
+      digits = 0; nonzero = false;
+    }
+    else if (ch - '0' <= 9u) { if (++digits > 18u) return false; nonzero |= ch != '0'; }
     else return false;
   }
   return true;

@@ -65,13 +65,11 @@ def test_oracle_on_edge_inputs(c):
 
 
 @pytest.mark.parametrize("c", CASES, ids=IDS)
-def test_device_sources_on_edge_inputs(c):
+def test_device_sources_on_edge_inputs(hostsim, c):
     """the kernels' walk / call sources compiled for the CPU (tests/hostsim): same verdicts as the GPU test below"""
-    from test_hostsim import BUILD
+    from conftest import BUILD
     n = c["name"]
     exe = os.path.join(BUILD, "hostsim_augment" if c["stage"] == "augment" else "hostsim_call")
-    if not os.path.exists(exe):
-        pytest.skip("hostsim not built (tests/test_hostsim.py builds it)")
     if c["stage"] == "augment":
         r = subprocess.run([exe, f"{EDGE}/{n}.gaf", f"{EDGE}/{n}.gfa"], capture_output=True, text=True)
     else:
@@ -134,13 +132,11 @@ DEBUG_CASES = [(case, i) for case, sets in DEBUG.items() for i in range(len(sets
 
 
 @pytest.mark.parametrize("case,i", DEBUG_CASES)
-def test_device_sources_debug_lines(case, i):
+def test_device_sources_debug_lines(hostsim, case, i):
     """--debug: the reference's "Checking ..." / "Skipping ..." stderr lines (scripts/call.py:254 ... :1002) as a
     multiset -- the reference visits junctions in the order of a Python set -- and rows unchanged by the option."""
-    from test_hostsim import BUILD
+    from conftest import BUILD
     exe = os.path.join(BUILD, "hostsim_call")
-    if not os.path.exists(exe):
-        pytest.skip("hostsim not built (tests/test_hostsim.py builds it)")
     d = os.path.join(GOLDEN, case)
     want = DEBUG[case][i]
     r = subprocess.run([exe, "--debug", *want["flags"], f"{d}/expected.aug.gfa", f"{d}/in.gtf"], capture_output=True, text=True)
@@ -205,13 +201,11 @@ def _same_verdict(mine_rc, mine_rows, mine_kind, ref):
 
 
 @pytest.mark.parametrize("case", ["synth_a", "synth_b", "quirks", "micro"])
-def test_duplicate_s_lines_device_sources_vs_cpp_oracle(case, tmp_path):
+def test_duplicate_s_lines_device_sources_vs_cpp_oracle(hostsim, case, tmp_path):
     """runs without --novel on graphs with repeated S lines: the kernels' sources (CPU build) print what oracle/call_oracle.cpp
     prints -- which restates the reference's dict semantics and is pinned to `dup_s_call_annotated` -- or die of the same class"""
-    from test_hostsim import BUILD
+    from conftest import BUILD
     exe = os.path.join(BUILD, "hostsim_call")
-    if not os.path.exists(exe):
-        pytest.skip("hostsim not built (tests/test_hostsim.py builds it)")
     gtf = os.path.join(GOLDEN, case, "in.gtf")
     for trial, text in _dup_s_variants(case, 12):
         gfa = str(tmp_path / f"d{trial}.gfa")

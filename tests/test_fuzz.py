@@ -10,7 +10,6 @@ import pytest
 
 import augment_oracle
 import fuzz_gaf
-from test_hostsim import hostsim  # noqa: F401  (fixture)
 
 
 def oracle_result(gaf, gfa):

@@ -17,23 +17,7 @@ import call_oracle
 from conftest import CASES, GOLDEN, ROOT
 from test_oracle_golden import _flags_to_opts, check_rows
 
-BUILD = os.path.join(ROOT, "build", "hostsim")
-CSRC = os.path.join(ROOT, "pantas_amd", "csrc")
-CXX = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-       "-fno-omit-frame-pointer", "-I", CSRC]
-
-
-@pytest.fixture(scope="session")
-def hostsim():
-    os.makedirs(BUILD, exist_ok=True)
-    common = [os.path.join(CSRC, f) for f in ("graph.cpp", "graph_cache.cpp", "common.cpp")]
-    aug = os.path.join(BUILD, "hostsim_augment")
-    call = os.path.join(BUILD, "hostsim_call")
-    subprocess.check_call(CXX + ["-o", aug, os.path.join(ROOT, "tests/hostsim/hostsim_augment.cpp"), *common,
-                                 os.path.join(CSRC, "gaf.cpp"), os.path.join(CSRC, "augment_host.cpp"), "-lpthread"])
-    subprocess.check_call(CXX + ["-o", call, os.path.join(ROOT, "tests/hostsim/hostsim_call.cpp"), *common,
-                                 os.path.join(CSRC, "call_host.cpp"), "-lpthread"])
-    return {"augment": aug, "call": call}
+from conftest import BUILD, CSRC, CXX  # noqa: E402,F401  (the `hostsim` fixture lives in conftest.py: every test file builds it once per session)
 
 
 def run(cmd):

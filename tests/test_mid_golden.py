@@ -1,0 +1,152 @@
+"""The mid-size golden (tests/golden/mid, tools/make_golden_r5.py): 700 genes, 120 k GAF lines, SNP bubbles and novel links
+turned up, run through the REAL reference -- augment once, `call` under 32 PYTHONHASHSEEDs per flag set.  Stored per flag
+set: the rows every seed prints and, for each seed-dependent row, the number of seeds that print it.
+
+What a restatement must do (check_mid_rows): print every row all seeds print, nothing the reference never prints, and --
+round 5 -- not miss a row the reference prints under >= 90 % of the seeds: the fixed rules R2 / R3 pick ONE of the reference's
+behaviours where it has several, and a pick that systematically lands on a rare one under-reports events (round 4's R3 did:
+depth-first pops spent the --isw budget on the lowest branch)."""
+import collections
+import io
+import json
+import lzma
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+import augment_oracle
+import call_oracle
+from conftest import GOLDEN, ROOT
+from test_oracle_golden import _flags_to_opts
+
+MID = os.path.join(GOLDEN, "mid")
+META = json.load(open(os.path.join(MID, "meta.json")))
+CALLS = list(range(len(META["calls"])))
+
+
+@pytest.fixture(scope="module")
+def mid(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mid")
+    for n in ("in.gfa", "in.gaf", "in.gtf", "expected.aug.gfa"):
+        with lzma.open(os.path.join(MID, n + ".xz"), "rb") as f, open(d / n, "wb") as g:
+            shutil.copyfileobj(f, g)
+    return str(d)
+
+
+def golden_call(k):
+    with lzma.open(os.path.join(MID, META["calls"][k]["file"]), "rt") as f:
+        return json.load(f)
+
+
+def check_mid_rows(rows, gc):
+    mine = collections.Counter(call_oracle.normalise_row(r) for r in rows)
+    stable = collections.Counter(gc["stable"])
+    missing = stable - mine
+    assert not missing, f"rows every seed prints are missing: {list(missing)[:3]}"
+    extra = mine - stable
+    never = [r for r in extra if r not in gc["unstable"]]
+    assert not never, f"rows the reference never prints: {never[:3]}"
+    likely = [r for r, n in gc["unstable"].items() if n >= 0.9 * gc["seeds"] and extra[r] == 0]
+    assert not likely, f"rows the reference prints under >= 90 % of its hash seeds are missing: {likely[:3]}"
+
+
+def test_fixture_is_what_the_header_says():
+    assert META["seeds"] >= 32 and META["params"]["n_genes"] == 700 and META["params"]["n_lines"] == 120000
+    for k in CALLS:
+        gc = golden_call(k)
+        assert gc["flags"] == META["calls"][k]["flags"] and gc["seeds"] == META["seeds"]
+        assert len(gc["stable"]) == META["calls"][k]["stable"] > 7000
+        kinds = {tuple(r.split(",")[:2]) for r in gc["stable"]}
+        assert kinds >= {(t, a) for t in ("ES", "A3", "A5", "IR") for a in ("annotated", "novel")} | {("CE", "novel")}
+    assert any(n >= 0.9 * META["seeds"] for n in golden_call(1)["unstable"].values())     # the check above has something to bite on
+
+
+def test_augment_python_oracle(mid):
+    out = io.StringIO()
+    a = augment_oracle.augment(f"{mid}/in.gaf", f"{mid}/in.gfa", out)
+    assert out.getvalue() == open(f"{mid}/expected.aug.gfa").read()
+    assert a.rejected == META["rejected"]
+
+
+@pytest.mark.parametrize("k", CALLS)
+def test_call_python_oracle(mid, k):
+    gc = golden_call(k)
+    check_mid_rows(call_oracle.call(f"{mid}/expected.aug.gfa", f"{mid}/in.gtf", None, **_flags_to_opts(gc["flags"])), gc)
+
+
+@pytest.fixture(scope="module")
+def cpp():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return os.path.join(ROOT, "oracle", "bin")
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+def test_augment_cpp_oracle(cpp, mid, threads):
+    r = subprocess.run([f"{cpp}/augment_oracle_cpp", "--threads", str(threads), f"{mid}/in.gaf", f"{mid}/in.gfa"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == open(f"{mid}/expected.aug.gfa", "rb").read()
+    assert f"Rejected alignments: {META['rejected']}\n".encode() in r.stderr
+
+
+@pytest.mark.parametrize("k", CALLS)
+def test_call_cpp_oracle(cpp, mid, k):
+    gc = golden_call(k)
+    want = call_oracle.call(f"{mid}/expected.aug.gfa", f"{mid}/in.gtf", None, **_flags_to_opts(gc["flags"]))
+    for threads in (1, 8):
+        r = subprocess.run([f"{cpp}/call_oracle_cpp", "--threads", str(threads), *gc["flags"], f"{mid}/expected.aug.gfa", f"{mid}/in.gtf"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = r.stdout.splitlines()
+        assert rows[0] == call_oracle.HEADER
+        check_mid_rows(rows[1:], gc)
+        assert rows[1:] == want       # (same rules, same order: the two oracles print the same file)
+
+
+def test_device_sources(hostsim, mid):
+    """the product's host code and kernel sources compiled for the CPU (tests/hostsim), both command lines"""
+    from conftest import BUILD
+    aug, call = os.path.join(BUILD, "hostsim_augment"), os.path.join(BUILD, "hostsim_call")
+    r = subprocess.run([aug, f"{mid}/in.gaf", f"{mid}/in.gfa"], capture_output=True)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout == open(f"{mid}/expected.aug.gfa", "rb").read()
+    for k in CALLS:
+        gc = golden_call(k)
+        r = subprocess.run([call, *gc["flags"], f"{mid}/expected.aug.gfa", f"{mid}/in.gtf"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        check_mid_rows(r.stdout.splitlines()[1:], gc)
+
+
+@pytest.mark.gpu
+def test_engine_command_lines(mid, tmp_path):
+    out = str(tmp_path / "aug.gfa")
+    with open(out, "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", f"{mid}/in.gaf", f"{mid}/in.gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()
+    assert open(out, "rb").read() == open(f"{mid}/expected.aug.gfa", "rb").read()
+    assert f"Rejected alignments: {META['rejected']}" in r.stderr.decode()
+    for k in CALLS:
+        gc = golden_call(k)
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.call", *gc["flags"], out, f"{mid}/in.gtf"], capture_output=True, text=True, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        rows = r.stdout.splitlines()
+        assert rows[0] == call_oracle.HEADER
+        check_mid_rows(rows[1:], gc)
+
+
+@pytest.mark.gpu
+def test_engine_fused(mid):
+    """augment and call in one process, counters handed over in HBM (no GFA text in between)"""
+    from pantas_amd.engine import Graph
+    g = Graph(f"{mid}/in.gfa").to_device(0)
+    g.augment(f"{mid}/in.gaf", 20, -1)
+    g.call_prepare_fused(f"{mid}/in.gtf")
+    for k in CALLS:
+        gc = golden_call(k)
+        with tempfile.TemporaryFile() as f:
+            g.call(f.fileno(), -1, **_flags_to_opts(gc["flags"]))
+            f.seek(0)
+            check_mid_rows(f.read().decode().splitlines()[1:], gc)

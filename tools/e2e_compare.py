@@ -62,9 +62,18 @@ def main():
         t_aug = timed([py, os.path.join(a.ref, "scripts", "alignments_augmentation_from_gaf.py"), pre + ".gaf", pre + ".gfa"], pre + ".ref.gfa")
         t_call = timed([py, os.path.join(a.ref, "scripts", "call.py"), *flags, pre + ".ref.gfa", pre + ".gtf"], pre + ".ref.csv",
                        env={**os.environ, "PYTHONHASHSEED": "0"})
+        # the reference's rows against the oracle's as multisets (after the one normalisation of SURVEY 8-P #2): the oracle fixes one
+        # of the reference's hash-seed-dependent behaviours, so rows may differ -- they are counted and shown, not hidden
+        norm = call_oracle.normalise_row
+        ref_rows = collections.Counter(map(norm, open(pre + ".ref.csv").read().splitlines()[1:]))
+        or_rows = collections.Counter(map(norm, open(pre + ".or.csv").read().splitlines()[1:]))
+        only_ref, only_or = ref_rows - or_rows, or_rows - ref_rows
         res["reference"] = {"augment_s": t_aug, "call_s": t_call, "total_s": t_aug + t_call,
                             "gfa_equals_oracle": open(pre + ".ref.gfa", "rb").read() == open(pre + ".or.gfa", "rb").read(),
-                            "csv_rows": sum(1 for _ in open(pre + ".ref.csv")) - 1}
+                            "csv_rows": sum(ref_rows.values()), "oracle_csv_rows": sum(or_rows.values()),
+                            "csv_equals_oracle_multiset": not only_ref and not only_or,
+                            "rows_only_reference_seed0": sum(only_ref.values()), "rows_only_oracle": sum(only_or.values()),
+                            "variants": {"only_reference_seed0": sorted(only_ref.elements())[:20], "only_oracle": sorted(only_or.elements())[:20]}}
     # ---- the engine
     if _lib.device_count() > 0:
         runs = []
