@@ -59,61 +59,100 @@ def gfa_lines():
     return exe
 
 
-def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads, check_augment=True):
+def _heartbeat(label):
+    """a line every 30 s under gpurun_out/ (a silent GPU-box command is taken for hung after 7 minutes)"""
+    import threading
+    import time
+    beat = os.path.join(ROOT, "gpurun_out", "heartbeat.txt")
+    stop = threading.Event()
+
+    def run():
+        while not stop.wait(30):
+            if os.path.isdir(os.path.dirname(beat)):
+                with open(beat, "a") as f:
+                    f.write(f"{label} parity {time.strftime('%H:%M:%S')}\n")
+    threading.Thread(target=run, daemon=True).start()
+    return stop
+
+
+def _append_read_blocks(pre, kw, first, last):
+    """blocks [first, last) of the scale's read stream behind the GAF that is there (s5: four blocks of 50 M lines in ONE file)"""
+    from pantas_amd.engine import Synth
+    for b in range(first, last):
+        Synth(seed=5, line_offset=b * kw["n_lines"], gaf_only=1, **kw).write(pre + f".b{b}")
+        with open(pre + ".gaf", "ab") as out, open(pre + f".b{b}.gaf", "rb") as src:
+            shutil.copyfileobj(src, out, 1 << 26)
+        for ext in (".gaf", ".gfa", ".gtf"):
+            if os.path.exists(pre + f".b{b}" + ext):
+                os.unlink(pre + f".b{b}" + ext)
+
+
+def _augment_vs_cpp_oracle(pre, oracle_threads, by_digest):
+    """`pantas augment` on pre.gaf / pre.gfa -> pre.gpu.gfa, against oracle/augment_oracle.cpp on the host cores: the same file --
+    byte by byte, or (whole-genome sizes: 23 GB) through the oracle's order-dependent digest of the bytes it WOULD write and the same
+    digest of the engine's file (`--digest` / `--digest-file`; the oracle then formats its pieces on every core and prints nothing)"""
+    import json
+    import time
+    exe = os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp")
+    threads = str(min(os.cpu_count() or 1, oracle_threads))
+    t0 = time.perf_counter()
+    with open(pre + ".gpu.gfa", "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    t1 = time.perf_counter()
+    size = os.path.getsize(pre + ".gpu.gfa")
+    res = {"gaf_bytes": os.path.getsize(pre + ".gaf"), "engine_augment_wall_s": t1 - t0, "bytes": size}
+    if by_digest:
+        o = subprocess.run([exe, "--threads", threads, "--digest", pre + ".gaf", pre + ".gfa"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        assert o.returncode == 0, o.stderr.decode()[-2000:]
+        t2 = time.perf_counter()
+        stats = json.loads(o.stderr.decode().strip().splitlines()[-1])
+        got = json.loads(subprocess.run([exe, "--threads", threads, "--digest-file", pre + ".gpu.gfa"], capture_output=True, check=True).stdout)
+        assert size > 10**9 and got == stats["digest"], (got, stats["digest"])
+        res.update({"aug_gfa_equals_cpp_oracle": True, "compared": "digest of the bytes (oracle --digest, engine file --digest-file)", "digest": got,
+                    "digest_file_s": time.perf_counter() - t2})
+    else:
+        with open(pre + ".or.gfa", "wb") as f:
+            o = subprocess.run([exe, "--threads", threads, pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
+        assert o.returncode == 0, o.stderr.decode()[-2000:]
+        t2 = time.perf_counter()
+        stats = json.loads(o.stderr.decode().strip().splitlines()[-1])
+        assert size == os.path.getsize(pre + ".or.gfa") > 10**9
+        with open(pre + ".gpu.gfa", "rb") as x, open(pre + ".or.gfa", "rb") as y:
+            while True:
+                a, b = x.read(1 << 26), y.read(1 << 26)
+                assert a == b
+                if not a:
+                    break
+        os.unlink(pre + ".or.gfa")
+        res.update({"aug_gfa_equals_cpp_oracle": True, "compared": "bytes"})
+    rej = [l for l in o.stderr.decode().splitlines() if l.startswith("Rejected alignments:")]
+    assert rej and rej[0] in r.stderr.decode()
+    res.update({"cpp_oracle_wall_s": t2 - t1, "cpp_oracle_stats": stats})
+    return res
+
+
+def _whole_workload_vs_cpp_oracle(scale, need_gb, oracle_threads, check_augment=True, by_digest=False):
     """`pantas augment` on the whole workload of a BASELINE scale against oracle/augment_oracle.cpp on the host cores: one file;
     then `pantas call --rca 3 --novel` on it against oracle/call_oracle.cpp: the same rows."""
     import json
-    import threading
-    import time
     import bench
     from pantas_amd.engine import Synth
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     tmp = workdir(need_gb)
-    beat = os.path.join(ROOT, "gpurun_out", "heartbeat.txt")       # (a silent GPU-box command is taken for hung after 7 minutes)
-    stop = threading.Event()
-
-    def heartbeat():
-        while not stop.wait(30):
-            if os.path.isdir(os.path.dirname(beat)):
-                with open(beat, "a") as f:
-                    f.write(f"{scale} parity {time.strftime('%H:%M:%S')}\n")
-    threading.Thread(target=heartbeat, daemon=True).start()
+    stop = _heartbeat(scale)
     try:
         pre = os.path.join(tmp, scale)
         desc, kw, *rest = bench.SCALES[scale]
         Synth(seed=5, **kw).write(pre)
-        for b in range(1, rest[0] if rest else 1):          # (s5: four blocks of the read stream in ONE GAF file)
-            Synth(seed=5, line_offset=b * kw["n_lines"], gaf_only=1, **kw).write(pre + f".b{b}")
-            with open(pre + ".gaf", "ab") as out, open(pre + f".b{b}.gaf", "rb") as src:
-                shutil.copyfileobj(src, out, 1 << 26)
-            for ext in (".gaf", ".gfa", ".gtf"):
-                if os.path.exists(pre + f".b{b}" + ext):
-                    os.unlink(pre + f".b{b}" + ext)
-        t0 = time.perf_counter()
-        with open(pre + ".gpu.gfa", "wb") as f:
-            r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
-        t1 = time.perf_counter()
-        res = {"scale": scale, "workload": desc, "gaf_bytes": os.path.getsize(pre + ".gaf"), "engine_augment_wall_s": t1 - t0}
+        _append_read_blocks(pre, kw, 1, rest[0] if rest else 1)
+        res = {"scale": scale, "workload": desc}
         if check_augment:
-            with open(pre + ".or.gfa", "wb") as f:
-                o = subprocess.run([os.path.join(ROOT, "oracle", "bin", "augment_oracle_cpp"), "--threads", str(min(os.cpu_count() or 1, oracle_threads)),
-                                    pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE)
-            assert o.returncode == 0, o.stderr.decode()[-2000:]
-            t2 = time.perf_counter()
-            size = os.path.getsize(pre + ".gpu.gfa")
-            assert size == os.path.getsize(pre + ".or.gfa") > 10**9
-            with open(pre + ".gpu.gfa", "rb") as x, open(pre + ".or.gfa", "rb") as y:
-                while True:
-                    a, b = x.read(1 << 26), y.read(1 << 26)
-                    assert a == b
-                    if not a:
-                        break
-            rej = [l for l in o.stderr.decode().splitlines() if l.startswith("Rejected alignments:")]
-            assert rej and rej[0] in r.stderr.decode()
-            res.update({"aug_gfa_equals_cpp_oracle": True, "bytes": size, "cpp_oracle_wall_s": t2 - t1,
-                        "cpp_oracle_stats": json.loads(o.stderr.decode().strip().splitlines()[-1])})
-            os.unlink(pre + ".or.gfa")
+            res.update(_augment_vs_cpp_oracle(pre, oracle_threads, by_digest))
+        else:
+            with open(pre + ".gpu.gfa", "wb") as f:
+                r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+            assert r.returncode == 0, r.stderr.decode()[-2000:]
         os.unlink(pre + ".gaf")
         res["call"] = _call_vs_cpp_oracle(pre, pre + ".gpu.gfa", oracle_threads)
         if os.environ.get("PANTAS_PARITY_JSON"):
@@ -170,26 +209,64 @@ def test_whole_s3_vs_cpp_oracle():
     _whole_workload_vs_cpp_oracle("s3", 12, 32)
 
 
-@pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S4"),
-                    reason="11 minutes (the augment oracle hashes 2.5e8 segment names on one thread and prints 23 GB on one): PANTAS_WHOLE_S4=1; "
-                           "the round's run is profiles/r3_parity_s4_cpp_oracles.json")
-def test_whole_s4_vs_cpp_oracle():
-    _whole_workload_vs_cpp_oracle("s4", 120, 64)
+# the S5 leg below runs in the default suite when the S4 leg in front of it was done within this many seconds (a GPU box of
+# ordinary speed: about 230; the driver gives the whole `-m gpu` run 900 s); PANTAS_WHOLE_S5=1 runs it whatever the clock says,
+# PANTAS_WHOLE_S5=0 never
+S5_IF_S4_WITHIN_S = 300.0
 
 
-@pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S4_CALL"),
-                    reason="the call half of the S4 check alone (68 M rows; minutes): PANTAS_WHOLE_S4_CALL=1; profiles/r3_parity_s4_call.json")
-def test_whole_s4_call_vs_cpp_oracle():
-    _whole_workload_vs_cpp_oracle("s4", 120, 64, check_augment=False)
+def test_whole_s4_and_s5_vs_cpp_oracles():
+    """BASELINE.json configs[3] (one replicate) and configs[4] AT THEIR SIZES, in the default `-m gpu` run since round 5.
 
-
-@pytest.mark.skipif(not os.environ.get("PANTAS_WHOLE_S5"),
-                    reason="200 M reads, annotated + novel search, 276 M rows / 52 GB of CSV: PANTAS_WHOLE_S5=1; the round's run is "
-                           "profiles/r3_parity_s5_call.json")
-def test_whole_s5_call_vs_cpp_oracle():
-    """BASELINE.json configs[4] at its size: `pantas augment` over 200 M reads, `pantas call --rca 3 --novel` on the result against
-    oracle/call_oracle.cpp (the augment half at this graph size is test_whole_s4_vs_cpp_oracle's)"""
-    _whole_workload_vs_cpp_oracle("s5", 220, 64, check_augment=False)
+    S4 -- the human whole-genome graph (2.5e8 segments, 19 GB of GFA) and one replicate of 50 M reads: `pantas augment`, its 23 GB
+    file against oracle/augment_oracle.cpp through the byte digest (the oracle formats on every core and writes nothing: 10 minutes
+    became 2), then `pantas call --rca 3 --novel` on it against oracle/call_oracle.cpp (44.6 M rows, multiset digest).
+    S5 -- the same graph, 200 M reads (three more blocks of the read stream behind the first): `pantas augment` again (four
+    resident batches), `pantas call --rca 3 --novel` against oracle/call_oracle.cpp (241 M rows); the augment kernels at this
+    graph size are what the S4 leg checked byte for byte."""
+    import json
+    import time
+    import bench
+    from pantas_amd.engine import Synth
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    tmp = workdir(130)
+    stop = _heartbeat("s4+s5")
+    t_start = time.perf_counter()
+    try:
+        pre = os.path.join(tmp, "s4")
+        desc, kw = bench.SCALES["s4"][:2]
+        Synth(seed=5, **kw).write(pre)
+        res = {"scale": "s4", "workload": desc, "generate_s": time.perf_counter() - t_start}
+        res.update(_augment_vs_cpp_oracle(pre, 64, by_digest=True))
+        res["call"] = _call_vs_cpp_oracle(pre, pre + ".gpu.gfa", 64)
+        res["leg_s"] = time.perf_counter() - t_start
+        if os.environ.get("PANTAS_PARITY_JSON"):
+            json.dump(res, open(os.environ["PANTAS_PARITY_JSON"].format(scale="s4"), "w"), indent=1)
+        want_s5 = os.environ.get("PANTAS_WHOLE_S5")
+        if want_s5 == "0" or (want_s5 is None and res["leg_s"] > S5_IF_S4_WITHIN_S):
+            pytest.skip(f"S4 checked (GFA digest and {res['call']['rows']} rows equal) in {res['leg_s']:.0f} s; the S5 leg is left out on "
+                        f"this box to keep the run inside the driver's limit (PANTAS_WHOLE_S5=1 runs it)")
+        t5 = time.perf_counter()
+        os.unlink(pre + ".gpu.gfa")
+        if shutil.disk_usage(tmp).free < 110e9:       # 30 GB of reads + 23 GB of GFA + 44 GB of rows beside the graph
+            pytest.skip(f"S4 checked in {res['leg_s']:.0f} s; no room for the S5 leg's files in {tmp}")
+        desc5, kw5, blocks = bench.SCALES["s5"]
+        assert kw5 == kw
+        _append_read_blocks(pre, kw, 1, blocks)
+        res5 = {"scale": "s5", "workload": desc5, "generate_s": time.perf_counter() - t5, "gaf_bytes": os.path.getsize(pre + ".gaf")}
+        t0 = time.perf_counter()
+        with open(pre + ".gpu.gfa", "wb") as f:
+            r = subprocess.run([sys.executable, "-m", "pantas_amd.augment", pre + ".gaf", pre + ".gfa"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        res5["engine_augment_wall_s"] = time.perf_counter() - t0
+        os.unlink(pre + ".gaf")
+        res5["call"] = _call_vs_cpp_oracle(pre, pre + ".gpu.gfa", 64)
+        res5["leg_s"] = time.perf_counter() - t5
+        if os.environ.get("PANTAS_PARITY_JSON"):
+            json.dump(res5, open(os.environ["PANTAS_PARITY_JSON"].format(scale="s5"), "w"), indent=1)
+    finally:
+        stop.set()
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def test_e2e_command_lines_vs_oracle():
