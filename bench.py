@@ -315,7 +315,7 @@ def emit(out: dict, args) -> None:
             with open(path, "w") as f:
                 json.dump(out, f)
                 f.write("\n")
-            details_path = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+            details_path = os.path.relpath(path, ROOT) if os.path.commonpath([os.path.abspath(path), ROOT]) == ROOT else path
             break
         except OSError:
             pass
@@ -331,7 +331,7 @@ def emit(out: dict, args) -> None:
                                                       f"{out['walked_records_per_step'] // out['n_gpus']} walked",
                       "parallelism": f"read shards x{out['n_gpus']}, graph replicated, one block-sparse RCCL all-reduce of the counters",
                       "steps": "enqueued back to back, collected" if str(out.get("step_mode", "")).startswith("the steps") else "each waited for"}
-    line["roofline"] = {k: _sig(rf[k]) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
+    line["roofline"] = {k: _sig(rf.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm_frac_physical", "kernel")}
     line["roofline"]["kernel_ms"] = _sig(out["kernel_ms"]["augment_main_short_walk"] or out["kernel_ms"]["augment_main"])
     if cb is not None:
         c = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -376,6 +376,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=800_000)
     ap.add_argument("--del-hot", type=float, default=0.0,
                     help="share of the deletion reads aimed at 1 000 fixed (node, position) sites: the skew of real indel variants")
+    ap.add_argument("--p-general", type=float, default=0.0,
+                    help="share of the mapped reads with TWO indels in their cs (synth p_two_indels): records of the general-walk class, "
+                         "which the plain recipe never writes -- what an indel-rich GAF costs (kernel_ms.augment_main_general)")
     ap.add_argument("--full-line", action="store_true",
                     help="print the whole details object as the line (tools/*.sh read phase times from it); the default line is the "
                          "short one of the contract, with the details in gpurun_out/bench_details_n<N>.json")
@@ -419,6 +422,8 @@ def main():
         kw["n_lines"] = args.lines
     if args.del_hot:
         kw["p_del_hot"] = args.del_hot
+    if args.p_general:
+        kw["p_two_indels"] = args.p_general
     n_lines = kw["n_lines"]
     t_gen = time.perf_counter()
     # every rank: the same graph (same seed), its own blocks of the read stream
@@ -580,12 +585,14 @@ def main():
         else:
             dom_name, dom_ms, dom_bytes, dom_recs = "augment main kernels of all resident batches", avg_main, alg_bytes, records
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        for tf in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
+        traffic, traffic_file, traffic_rule = None, None, None
+        for tf in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-                if scale in tj and not args.lines and not args.del_hot:
-                    traffic = tj[scale]["traffic_bytes"]     # measured in a separate --pmc run of this workload
+                if scale in tj and not args.lines and not args.del_hot and not args.p_general:
+                    traffic = tj[scale]["traffic_bytes"]     # measured in separate --pmc runs of this workload
+                    traffic_file = tf
+                    traffic_rule = tj[scale].get("traffic_rule", "2 * FETCH_SIZE + WRITE_SIZE")
                     break
             except (OSError, ValueError):
                 pass
@@ -600,7 +607,9 @@ def main():
                                    f"{kw['n_genes']} genes; {lines} GAF lines per GPU per step in {len(batches)} resident batch(es) "
                                    f"({records} walked, {tot('path_nodes') / max(1, records):.2f} nodes/line, "
                                    f"{tot('cs_ops') / max(1, records):.2f} cs ops/line), gene expression Zipf a={kw.get('zipf_a', 1.2)}"
-                                   + (f", {args.del_hot:.0%} of the deletion reads on 1000 fixed sites" if args.del_hot else ""),
+                                   + (f", {args.del_hot:.0%} of the deletion reads on 1000 fixed sites" if args.del_hot else "")
+                                   + (f", {args.p_general:.0%} of the mapped reads with two indels ({records - tot('short_records')} records of the "
+                                      f"general-walk class per step)" if args.p_general else ""),
                        "parallelism": f"read shards x{world}, graph replicated, one block-sparse all-reduce of the coverage counters per replicate"},
             "value_counts": "records walked by the kernels per second, summed over ranks (GAF lines filtered out by the tokeniser are not counted)",
             "step_mode": ("the steps of the timed region are enqueued back to back on the stream (pantas_augment_launch_async, at most 64 in flight) "
@@ -629,6 +638,9 @@ def main():
                       "backend": dist.get_backend() if dist is not None else None, "per_rank": ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # what the memory system moved / (this run's kernel time) / peak: the physical fraction next to the nominal one
+                         "hbm_frac_physical": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "traffic_source": f"profiles/{traffic_file}: {traffic_rule}" if traffic_file else None,
                          "kernel": dom_name, "alg_bytes_per_launch": dom_bytes, "records_per_launch": dom_recs,
                          "whole_main_step": {"ms": avg_main, "alg_bytes": alg_bytes, "achieved_GBps": alg_bytes / (avg_main * 1e-3) / 1e9},
                          "traffic_note": "HBM bytes per launch from profiles/r*_traffic.json (separate rocprofv3 --pmc passes "

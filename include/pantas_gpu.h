@@ -53,7 +53,7 @@ void pantas_device_init(int device);
  * with before every call: the library reads / writes that many bytes and never more, so an older, shorter declaration
  * keeps working and a forgotten one is refused (PANTAS_E_ARG) instead of overrunning the caller's buffer.  Fields are only
  * ever appended.  PANTAS_ABI_VERSION counts such appends; pantas_abi_version() is what the loaded library was built with. */
-#define PANTAS_ABI_VERSION 7
+#define PANTAS_ABI_VERSION 8
 int pantas_abi_version(void);
 
 /* ---- graph: replaces the GFA readers of both scripts and scripts/gfautils.py:92-128 ------ */
@@ -317,6 +317,9 @@ typedef struct {
   int32_t gaf_only;        /* 1: no GFA / GTF text (further blocks of the read stream of a graph generated before) */
   uint32_t hot_sites;      /* with p_del_hot > 0: that share of the deletion reads is aimed at hot_sites fixed */
   double p_del_hot;        /* (node, position) sites on the most expressed genes -- the skew of real indel variants */
+  double p_two_indels;     /* ABI 8: share of the mapped reads whose cs holds TWO indels (an insertion and a deletion) -- reads outside
+                              the short-walk class of the augment kernels, which the plain recipe never writes; 0 leaves every
+                              other draw of the stream as it was */
 } pantas_synth_params;
 typedef struct {
   uint32_t struct_size, reserved0_;

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 7      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
+ABI_VERSION = 8      # PANTAS_ABI_VERSION of include/pantas_gpu.h this file mirrors
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpantas_gpu.so")
 
@@ -95,7 +95,7 @@ class SynthParams(_Sized):
                 ("p_lowmapq", C.c_double), ("p_unmapped", C.c_double), ("p_sub", C.c_double), ("p_indel", C.c_double),
                 ("p_highdv", C.c_double), ("p_novel_skip", C.c_double), ("p_novel_ce", C.c_double),
                 ("p_intron", C.c_double), ("p_novel_ss", C.c_double), ("p_clip", C.c_double),
-                ("line_offset", C.c_uint64), ("gaf_only", C.c_int32), ("hot_sites", C.c_uint32), ("p_del_hot", C.c_double)]
+                ("line_offset", C.c_uint64), ("gaf_only", C.c_int32), ("hot_sites", C.c_uint32), ("p_del_hot", C.c_double), ("p_two_indels", C.c_double)]
 
 
 class SynthStats(_Sized):

@@ -1177,6 +1177,8 @@ template <uint32_t CHUNK>
 __global__ __launch_bounds__(64) void tile_place_kernel(uint32_t n_short, const uint32_t* node_off, uint32_t* place, uint32_t* chunk_tiles) {
   constexpr uint32_t STRIDE = CHUNK + 4u;      // (lanes read different banks)
   __shared__ uint8_t ks[64u * STRIDE];
+  static_assert(sizeof(ks) <= 160u * 1024u, "tile_place_kernel stages 64 chunks of path lengths: 128 KB of the 160 KB of LDS a gfx950 CU has "
+                                            "(this library is built for gfx950 only; an architecture with 64 KB of LDS needs 16 chunks per workgroup)");
   const uint32_t c0 = blockIdx.x * 64u, n_chunks = (n_short + CHUNK - 1u) / CHUNK;
   for (uint32_t cc = 0; cc < 64u && c0 + cc < n_chunks; ++cc) {
     const uint32_t lo = (c0 + cc) * CHUNK, hi = min(n_short, lo + CHUNK);
@@ -1632,6 +1634,7 @@ void reset_counters(DeviceGraph& d) {
     HIP_OK(hipGetLastError());
   }
   HIP_OK(hipStreamSynchronize(d.stream));
+  d.in_flight.clear();          // (launches enqueued and never collected: their times go with the counters)
   d.imported_flags = 0;
   d.reserved_hist = 0;
   d.rare_done.clear();
@@ -1708,7 +1711,20 @@ void build_batch_rec(DeviceGraph& d, DeviceBatch& b) {
 
 // PANTAS_MAIN_KERNEL as the default of this build: 120 = one lane per path position (round 4), 110 = one lane per record
 // over 16-byte node records (round 3), 101 = round 2's, 0 = direct atomics
-int main_kernel_variant() { return getenv("PANTAS_MAIN_KERNEL") ? atoi(getenv("PANTAS_MAIN_KERNEL")) : 120; }
+// (anything else is refused here, where every user of the switch reads it: a mistyped value used to count as "position-parallel"
+// when the batch was built -- no rec -- and fall to the record-per-lane kernel at launch, which reads rec)
+int main_kernel_variant() {
+  const char* e = getenv("PANTAS_MAIN_KERNEL");
+  if (!e || !*e) return 120;
+  char* end = nullptr;
+  const long v = strtol(e, &end, 10);
+  bool known = v == 0 || v == 101 || v == 110 || v == 120;
+#ifdef PANTAS_EXPERIMENTS
+  known = known || (v >= 124 && v <= 128) || v == 130;
+#endif
+  if (*end || !known) throw Error("ValueError", std::string("PANTAS_MAIN_KERNEL=") + e + ": not a kernel of this build (0, 101, 110, 120)");
+  return int(v);
+}
 
 uint32_t* place_batch_tiles(int device, hipStream_t stream, ScratchPool& pool, DeviceBatch& b, const uint32_t* node_off) {
   struct { int device; hipStream_t stream; } d{device, stream};
@@ -2142,10 +2158,14 @@ void launch_augment_async(DeviceGraph& d, DeviceBatch& b) {
 }
 
 size_t launch_collect(DeviceGraph& d, LaunchTimes* out, size_t capacity) {
+  // whatever happens below, the ring is free again afterwards: a failed wait used to leave its slots taken for good
+  // ("64 launches in flight" from every later launch)
+  std::vector<uint32_t> slots;
+  slots.swap(d.in_flight);
   HIP_OK(hipSetDevice(d.device));
   HIP_OK(hipStreamSynchronize(d.stream));      // (the second stream's kernels are joined into it by every launch)
   size_t n = 0;
-  for (uint32_t slot : d.in_flight) {
+  for (uint32_t slot : slots) {
     const auto& f = d.ring[slot];
     LaunchTimes t{};
     HIP_OK(hipEventElapsedTime(&t.rare_ms, f.ev[0], f.ev[5]));
@@ -2155,7 +2175,6 @@ size_t launch_collect(DeviceGraph& d, LaunchTimes* out, size_t capacity) {
     if (n < capacity && out) out[n] = t;
     ++n;
   }
-  d.in_flight.clear();
   return n;
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void walk_once_kernel(CallView c, const EventR
     }
     o.path_off = bound_off[i];
     out[i] = o;
-    over[i] = (o.status == 1 && o.np > be.cap) ? o.np : 0u;
+    over[i] = (o.status == 1 && be.n > be.cap) ? be.n : 0u;       // (words of the path: runs of consecutive segments take two)
   }
 }
 
@@ -264,6 +264,58 @@ static T* dalloc(DeviceCall& d, size_t n) {
   return static_cast<T*>(p);
 }
 
+// ---- the intron walks' runs (call_device.h CallView::run_end_rev / pl / pnc), made on the device from the arrays that are there:
+// a whole-genome graph has 2.5e8 segments, and the host has the command line's wall time to lose
+__global__ __launch_bounds__(256) void run_breaks_kernel(uint32_t V, const uint32_t* nxt1, const uint32_t* nflags, uint32_t* key_rev, uint32_t* no_nc) {
+  uint32_t missing = 0;
+  for (uint32_t n = blockIdx.x * 256u + threadIdx.x; n < V; n += gridDim.x * 256u) {
+    key_rev[V - 1u - n] = nxt1[n] != n + 1u ? n : 0xFFFFFFFFu;        // (the last segment always ends its run: nxt1 < V)
+    missing += (nflags[n] & N_HAS_NC) ? 0u : 1u;
+  }
+  if (__ballot(missing != 0u) && missing) atomicAdd(no_nc, missing);
+}
+__global__ void run_totals_kernel(uint32_t V, const uint32_t* ln, const int32_t* nc, uint64_t* pl, uint64_t* pnc) {
+  pl[V] = pl[V - 1u] + ln[V - 1u];
+  pnc[V] = pnc[V - 1u] + uint64_t(uint32_t(nc[V - 1u]));
+}
+struct U32To64 { __host__ __device__ uint64_t operator()(uint32_t x) const { return x; } };
+struct I32To64 { __host__ __device__ uint64_t operator()(int32_t x) const { return uint64_t(uint32_t(x)); } };    // (counts are below 2^31)
+
+static void build_walk_runs(DeviceCall& d, CallView& c) {
+  c.run_end_rev = nullptr; c.pl = nullptr; c.pnc = nullptr;
+  const uint32_t V = c.V;
+  if (V == 0 || getenv("PANTAS_CALL_NO_RUNS")) return;
+  uint32_t* key = dalloc<uint32_t>(d, V);
+  uint32_t* no_nc = dalloc<uint32_t>(d, 1);
+  HIP_OK(hipMemsetAsync(no_nc, 0, 4, d.stream));
+  hipLaunchKernelGGL(run_breaks_kernel, dim3(uint32_t(std::min<uint64_t>((uint64_t(V) + 255) / 256, 1u << 16))), dim3(256), 0, d.stream, V, c.nxt1, c.nflags, key, no_nc);
+  HIP_OK(hipGetLastError());
+  uint32_t missing = 0;
+  HIP_OK(hipMemcpyAsync(&missing, no_nc, 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  if (missing) return;         // a segment without NC: the walks step through it one by one (and raise KeyError when a row needs its NC)
+  uint64_t* pl = dalloc<uint64_t>(d, size_t(V) + 1);
+  uint64_t* pnc = dalloc<uint64_t>(d, size_t(V) + 1);
+  hipcub::TransformInputIterator<uint64_t, U32To64, const uint32_t*> ln_it(c.ln, U32To64());
+  hipcub::TransformInputIterator<uint64_t, I32To64, const int32_t*> nc_it(c.nc, I32To64());
+  size_t need = 0, need2 = 0, need3 = 0;
+  // (exclusive sums over the V items; entry V, the total, is written by a one-thread kernel behind them)
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, ln_it, pl, int(V), d.stream));
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, need2, nc_it, pnc, int(V), d.stream));
+  HIP_OK(hipcub::DeviceScan::InclusiveScan(nullptr, need3, key, key, hipcub::Min(), int(V), d.stream));
+  need = std::max(need, std::max(need2, need3));
+  void* tmp = nullptr;
+  HIP_OK(dmalloc(&tmp, std::max<size_t>(need, 4)));
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp, need, ln_it, pl, int(V), d.stream));
+  HIP_OK(hipcub::DeviceScan::ExclusiveSum(tmp, need, nc_it, pnc, int(V), d.stream));
+  HIP_OK(hipcub::DeviceScan::InclusiveScan(tmp, need, key, key, hipcub::Min(), int(V), d.stream));      // nearest break at or behind, in reversed order
+  hipLaunchKernelGGL(run_totals_kernel, dim3(1), dim3(1), 0, d.stream, V, c.ln, c.nc, pl, pnc);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(d.stream));
+  (void)hipFree(tmp);
+  c.run_end_rev = key; c.pl = pl; c.pnc = pnc;
+}
+
 DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device)
@@ -299,6 +351,8 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   d->arena = dalloc<uint32_t>(*d, size_t(ARENA_SLOTS) * ARENA_CAP);
   d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
+  build_walk_runs(*d, c);
+  pt.lap("walk runs (device)");
   if (pt.on) fprintf(stderr, "[timing] upload_call: %.2f GB: hipMalloc %.3f s, copies %.3f s (%.1f GB/s)\n", g_up_bytes / 1e9, g_up_malloc_s, g_up_copy_s,
                      g_up_copy_s > 0 ? g_up_bytes / 1e9 / g_up_copy_s : 0.0);
   pt.lap("tables in HBM");

@@ -77,6 +77,11 @@ struct CallView {
   const uint32_t* ln;           // [V] len(sequence)
   const uint32_t* rank;         // [V] lexicographic rank of the segment name
   const uint32_t* nxt1;         // [V] the one out-neighbour of a segment, CNONE when it has none or several
+  // Round 5, the intron walks by RUNS (nullptr: none, the walk steps segment by segment): a run is a stretch of segments
+  // n, n + 1, ... whose one out-neighbour is the next index -- where "first out-neighbour that ..., else the last" has no choice.
+  const uint32_t* run_end_rev;  // [V] at V - 1 - n: the first segment m >= n with nxt1[m] != m + 1 (n .. m is walked in one step)
+  const uint64_t* pl;           // [V + 1] sums of ln[0 .. n)
+  const uint64_t* pnc;          // [V + 1] sums of nc[0 .. n); the three are only offered when EVERY segment has an NC tag
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
   // JN data hangs off the junction links only (5e5 of 2.6e8 slots at whole-genome scale): jrow[s] = ordinal of slot s
   // among the junction slots or CNONE, the four offset arrays are per junction ordinal (+ 1)
@@ -187,6 +192,23 @@ PANTAS_HD bool walk_exon(const CallView& c, uint32_t start, uint32_t goal, Ok ok
   nc_ok = true;
   uint32_t guard = c.V + 2;
   for (;;) {
+    if (c.run_end_rev) {
+      // the run that begins at cur in ONE step: its segments are consecutive indices, each the only out-neighbour of the one in
+      // front (a walk through an intron is a chain of trips to memory, one per segment: per run it is two -- where the run ends,
+      // then the prefix sums at both ends beside the next step's row).  The goal inside the run ends the walk there.
+      const uint32_t m = c.run_end_rev[c.V - 1u - cur];
+      const uint32_t last = (goal >= cur && goal <= m) ? goal : m;
+      if (last > cur) {
+        const uint32_t k = last - cur;                 // segments cur .. last - 1, then the step below handles `last`
+        if (emit) emit->push_range(cur, last - 1u);
+        n_path += k;
+        nc_sum += c.pnc[last] - c.pnc[cur];
+        ln_sum += c.pl[last] - c.pl[cur];
+        if (guard <= k) { f.raise(CE_HANG); return false; }
+        guard -= k;
+        cur = last;
+      }
+    }
     if (emit) emit->push(cur);
     ++n_path;
     if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;   // read only when a row is printed
@@ -827,18 +849,23 @@ struct TaskOut {
   uint32_t path_off;  // filled by the scan
 };
 
+// A path is a list of words: a segment index, or PATH_RANGE | first followed by last for a run of consecutive indices
+// (walk_exon; segment indices stay below 2^31).  TaskOut.np counts SEGMENTS; the words of a path are never more.
+constexpr uint32_t PATH_RANGE = 0x80000000u;
 struct PathEmit {
   uint32_t* out;
   uint32_t i;
   PANTAS_HD void push(uint32_t w) { out[i++] = w; }
+  PANTAS_HD void push_range(uint32_t a, uint32_t b) { if (a == b) out[i++] = a; else { out[i++] = PATH_RANGE | a; out[i++] = b; } }
 };
 // A walk that writes its path while it decides: room for `cap` segments (an upper bound known before the walk, walk_bound); a path
 // that outgrows it is counted to its end and written by a second walk.
 struct BoundEmit {
   uint32_t* out;
   uint32_t cap;
-  uint32_t n = 0;
+  uint32_t n = 0;            // words the path takes
   PANTAS_HD void push(uint32_t w) { if (n < cap) out[n] = w; ++n; }
+  PANTAS_HD void push_range(uint32_t a, uint32_t b) { if (a == b) push(a); else { push(PATH_RANGE | a); push(b); } }
 };
 // Upper bound of a walk's path: it runs from `start` to `goal` through segments whose names sort at or below the goal's, and in a
 // graph whose names follow its topological order (every graph vg writes) each step moves up: at most rank(goal) - rank(start) + 1

@@ -1076,6 +1076,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
   c.hid = t.hidden.empty() ? nullptr : t.hidden.data();
   c.nxt1 = t.nxt1.data();
+  c.run_end_rev = nullptr; c.pl = nullptr; c.pnc = nullptr;      // (made on the device, call.hip build_walk_runs; the CPU harness makes its own)
   c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
   c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
   c.jrow = t.jrow.data();
@@ -1180,8 +1181,14 @@ struct Renderer {
     }
     return p + n;
   }
+  // n segments: a word is a segment, or PATH_RANGE | first with last behind it (call_device.h: the walks write a run of
+  // consecutive segments as its two ends)
   void path(const uint32_t* p, uint32_t n) {
-    for (uint32_t i = 0; i < n; ++i) { if (i) out.push_back('>'); name(p[i]); }
+    for (uint32_t done = 0; done < n; ++p) {
+      uint32_t a = *p, b = a;
+      if (a & PATH_RANGE) { a &= ~PATH_RANGE; b = *++p; }
+      for (uint32_t x = a; x <= b; ++x, ++done) { if (done) out.push_back('>'); name(x); }
+    }
   }
   void extag(uint32_t id) { out.append(base + t.extag_span[id].off, t.extag_span[id].len); }
   void head(const char* type, const char* kind, uint32_t gene, const char* strand_plus, const char* strand_other) {

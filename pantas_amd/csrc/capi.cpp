@@ -484,10 +484,10 @@ __attribute__((visibility("default"))) int pantas_augment_launch_collect(pantas_
     need_device(g);
     need(n, "null argument");
     need(ms || capacity == 0, "null buffer");
-    std::vector<LaunchTimes> t(capacity);
+    std::vector<LaunchTimes> t(std::min<uint64_t>(capacity, 64));      // (at most 64 launches are ever in flight)
     const size_t got = launch_collect(*g->dev, t.data(), t.size());
     *n = got;
-    for (size_t i = 0; i < std::min<size_t>(got, capacity); ++i) { ms[3 * i] = t[i].rare_ms; ms[3 * i + 1] = t[i].main_ms; ms[3 * i + 2] = t[i].main_short_ms; }
+    for (size_t i = 0; i < std::min<size_t>(got, t.size()); ++i) { ms[3 * i] = t[i].rare_ms; ms[3 * i + 1] = t[i].main_ms; ms[3 * i + 2] = t[i].main_short_ms; }
   });
 }
 
@@ -813,10 +813,12 @@ static uint64_t cut_at_line_start(const MappedFile& f, uint64_t want, uint64_t e
 
 static uint64_t batch_device_bytes(const pantas_batch_stats& s) {
   // hdr 16 + offsets 8 per record, 4 per path node and cs op, 4 per record with a '-'; the tiles of the position-parallel kernel: a
-  // 32-byte line record (with the op summary) per record, node + position word (6 bytes) per lane of a tile -- the tiles hold the path
-  // nodes of the short-walk class (nearly all of them) with about 5 % of padding.  (rec, 48 bytes per record, only exists for a batch
-  // walked by a record-per-lane kernel; it is counted: the bound must hold for the fallback too.)
-  return 72 * s.records + 4 * (s.path_nodes + s.cs_ops) + 4 * s.del_records + 32 * s.records + 7 * s.path_nodes + 4096;
+  // 32-byte line record (with the op summary) per record, node + position word (6 bytes) per lane of a tile.  A record never
+  // straddles a tile, so the worst packing is records of 33 positions, one per tile of 64: 64 / 33 * 6 = 11.7 bytes per path node --
+  // that bound, not the 5 % of padding the synthetic reads (6 nodes) show, is what is budgeted: reads of 17 .. 31 nodes leave 13 .. 20
+  // lanes of a tile empty.  (rec, 48 bytes per record, only exists for a batch walked by a record-per-lane kernel; it is counted:
+  // the bound holds for the fallback too.)
+  return 72 * s.records + 4 * (s.path_nodes + s.cs_ops) + 4 * s.del_records + 32 * s.records + 12 * s.path_nodes + 4096;
 }
 
 static void stream_rare_pass(pantas_graph* g, const char* gaf_path, int thr, uint64_t begin, uint64_t end, uint64_t first_line,
@@ -1122,7 +1124,7 @@ __attribute__((visibility("default"))) void pantas_synth_defaults(pantas_synth_p
   p->p_novel_skip = d.p_novel_skip; p->p_novel_ce = d.p_novel_ce; p->p_intron = d.p_intron; p->p_novel_ss = d.p_novel_ss;
   p->p_clip = d.p_clip;
   p->line_offset = 0;
-  p->gaf_only = d.gaf_only; p->hot_sites = d.hot_sites; p->p_del_hot = d.p_del_hot;
+  p->gaf_only = d.gaf_only; p->hot_sites = d.hot_sites; p->p_del_hot = d.p_del_hot; p->p_two_indels = d.p_two_indels;
   (void)guarded([&] { put_out(out, v, "pantas_synth_params"); });   // a declaration without struct_size is left untouched
 }
 
@@ -1141,7 +1143,7 @@ __attribute__((visibility("default"))) int pantas_synth_generate(const pantas_sy
     d.p_novel_skip = p->p_novel_skip; d.p_novel_ce = p->p_novel_ce; d.p_intron = p->p_intron; d.p_novel_ss = p->p_novel_ss;
     d.p_clip = p->p_clip;
     d.line_offset = p->line_offset;
-    d.gaf_only = p->gaf_only; d.p_del_hot = p->p_del_hot;
+    d.gaf_only = p->gaf_only; d.p_del_hot = p->p_del_hot; d.p_two_indels = p->p_two_indels;
     if (p->hot_sites) d.hot_sites = p->hot_sites;
     auto h = std::make_unique<pantas_synth>();
     double t0 = now_s();

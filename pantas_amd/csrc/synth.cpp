@@ -434,6 +434,27 @@ void emit_gaf_line(const Model& m, const std::vector<double>& cdf, const std::ve
   const bool rev = r.next() & 1;
   const int mapq = (r.prob() < p.p_lowmapq && !hot) ? int(r.range(0, 19)) : 60;
   cs_for_span(r, p, span, cs);
+  if (p.p_two_indels > 0 && !hot && span >= 40) {
+    // (a stream of its own: p_two_indels = 0 leaves every other draw as it was)
+    Rng t(p.seed * 104729ull + li * 0x9E3779B97F4A7C15ull + 211);
+    if (t.prob() < p.p_two_indels) {
+      static const char B[4] = {'a', 'c', 'g', 't'};
+      const uint32_t c1 = uint32_t(t.range(3, int64_t(span) / 2 - 8)), n1 = uint32_t(t.range(1, 4));
+      const uint32_t c2 = uint32_t(t.range(3, int64_t(span) - c1 - 12)), n2 = uint32_t(t.range(1, 4));
+      const bool ins_first = t.next() & 1;
+      cs.clear();
+      cs += ':'; put_u(cs, c1);
+      cs += ins_first ? '+' : '-';
+      for (uint32_t i = 0; i < n1; ++i) cs += B[t.next() & 3];
+      cs += ':'; put_u(cs, c2);
+      cs += ins_first ? '-' : '+';
+      for (uint32_t i = 0; i < n2; ++i) cs += B[t.next() & 3];
+      // what the two '-' pieces take off the span; an insertion adds nothing to it (its letters are consumed like any op:
+      // alignments_augmentation_from_gaf.py:209-255, and the ops may outlast the path)
+      const uint32_t del = ins_first ? n2 : n1;
+      cs += ':'; put_u(cs, span - c1 - c2 - del);
+    }
+  }
   if (hot) {
     // the deletion in READ order: a reverse read runs down the path, so the site is met from the other end
     const uint32_t c = rev ? span - hot_c - hot_n : hot_c;

@@ -32,6 +32,9 @@ struct SynthParams {
   // reads stay random).
   double p_del_hot = 0.0;
   uint32_t hot_sites = 1000;
+  // share of the mapped reads with TWO indels in their cs (":a+xx:b-yy:c"): what the short-walk class of the augment kernels
+  // does not take (walk.h line_class_flags) -- the recipe's own reads carry one indel at most
+  double p_two_indels = 0.0;
 };
 
 // text buffer without the zero-fill of std::string::resize (the GFA is ~12 GB at the human scale)

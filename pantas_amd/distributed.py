@@ -46,7 +46,9 @@ class LibBackend:
         """Rank 0 parses and writes the cache, the others load it.  With no cache asked for, the cache of this run lives in a
         directory only this user can enter (mkdtemp, mode 0700: nobody else can plant a file there), its path goes to the others by
         broadcast, and a rank that does not find the file (another node) parses the GFA itself WITHOUT leaving a cache of its own.
-        A failure of rank 0 is broadcast in the place of the path, so that the others raise instead of waiting in a barrier."""
+        A failure of rank 0 is broadcast in the place of the path, so that the others raise instead of waiting in a barrier; a
+        failure of ANY rank reaches every rank the same way (the verdicts are all-gathered where a bare barrier stood): a rank
+        that raised alone used to leave the others waiting in their next collective until the process group timed out."""
         import shutil
         import tempfile
         rank0 = dist.get_rank() == 0
@@ -80,10 +82,20 @@ class LibBackend:
                         ok = False                              # another node: parse, leave nothing behind
                     path = path if ok else None
                 g = Graph(gfa_path, cache=path) if path is not None else Graph(gfa_path)
-        finally:
-            dist.barrier()                   # every rank has loaded (or failed): the cache of the run can go
-            if tmpdir is not None:
-                shutil.rmtree(tmpdir, ignore_errors=True)
+        except BaseException as e:
+            mine_err = e
+        else:
+            mine_err = None
+        # every rank has loaded (or failed): the cache of the run can go, and every rank hears of every failure
+        verdicts = [None] * dist.get_world_size()
+        dist.all_gather_object(verdicts, None if mine_err is None else f"{type(mine_err).__name__}: {mine_err}")
+        if tmpdir is not None:
+            shutil.rmtree(tmpdir, ignore_errors=True)
+        if mine_err is not None:
+            raise mine_err
+        failed = [(r, v) for r, v in enumerate(verdicts) if v is not None]
+        if failed:
+            raise RuntimeError(f"rank {failed[0][0]} could not load {gfa_path}: {failed[0][1]}")
         return g
 
     def split(self, gaf_path, rank, world):
