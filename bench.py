@@ -344,14 +344,17 @@ def emit(out: dict, args) -> None:
                     c[f"{name}_{leg}"] = {"threads": row[leg]["threads"], key: _sig(row[leg][key])}
         line["cpu_baseline"] = c
     if call:
-        line["call"] = {"events": call["events"], "events_per_s": _sig(call["events_per_s"]), "kernel_ms": _sig(call["kernel_ms"])}
+        line["call"] = {"events": call["events"], "events_per_s": _sig(call["events_per_s"]), "kernel_ms": _sig(call["kernel_ms"]),
+                        "achieved_GBps": _sig(call.get("achieved_GBps"))}
     line["reads_per_s_incl_bucket"] = _sig(out["reads_per_s_incl_bucket"])
     line["reads_per_s_text_to_counters"] = _sig(out["reads_per_s_text_to_counters"])
     if out.get("allreduce_ms"):
         ex = out.get("allreduce") or {}
         line["allreduce_ms"] = _sig(out["allreduce_ms"])
         line["allreduce"] = {k: _sig(v) for k, v in ex.items() if isinstance(v, (int, float, str, bool)) and k in
-                             ("mode", "block_words", "counter_bytes", "exchanged_bytes")}
+                             ("mode", "block_words", "counter_bytes", "exchanged_bytes", "bitmap_kernel_ms", "pack_ms", "unpack_ms")}
+        # per collective: [op, bytes (per rank for the all-gather), ms] -- rank 0's clock around each, inside allreduce_ms
+        line["allreduce"]["collectives"] = [[c["op"], c.get("bytes", c.get("bytes_per_rank")), _sig(c["ms"], 4)] for c in ex.get("collectives", [])]
         line["world_size_seen_by_process_group"] = out["ranks"]["world_size_seen_by_process_group"]
         line["backend"] = out["ranks"]["backend"]
     if e2e:
@@ -567,6 +570,11 @@ def main():
                 "events_per_s": cs.events / wall, "wall_s": wall, "kernel_ms": k_ms,
                 "kernel_ms_by_pass": {"annotated": cs.annotated_ms, "novel_links": cs.novel_ms, "novel_around": cs.around_ms},
                 "junction_evals_per_s_kernel": cs.evaluated / (k_ms * 1e-3) if k_ms else None,
+                # SURVEY 8-d "achieved bytes for completeness": one pass over the link flags and the CSR rows, 4 (V + A), plus a nominal
+                # 64 bytes per evaluated item (a row of up to eight neighbours and four tag triples); the kernels are chains of dependent
+                # loads over a few 10^5 items -- latency-bound, as the survey says: a fraction of a percent of the HBM roofline
+                "alg_bytes": 4 * (gs.segments + gs.link_slots) + 64 * cs.evaluated,
+                "achieved_GBps": (4 * (gs.segments + gs.link_slots) + 64 * cs.evaluated) / (k_ms * 1e-3) / 1e9 if k_ms else None,
                 "prepare_s": t_prep, "tag_parse_s": cs.parse_seconds, "render_s": cs.render_seconds}
 
     if rank == 0:

@@ -191,44 +191,51 @@ PANTAS_HD bool walk_exon(const CallView& c, uint32_t start, uint32_t goal, Ok ok
   ln_sum = 0;
   nc_ok = true;
   uint32_t guard = c.V + 2;
+  const uint32_t goal_rank = c.rank[goal];
   for (;;) {
-    if (c.run_end_rev) {
-      // the run that begins at cur in ONE step: its segments are consecutive indices, each the only out-neighbour of the one in
-      // front (a walk through an intron is a chain of trips to memory, one per segment: per run it is two -- where the run ends,
-      // then the prefix sums at both ends beside the next step's row).  The goal inside the run ends the walk there.
-      const uint32_t m = c.run_end_rev[c.V - 1u - cur];
-      const uint32_t last = (goal >= cur && goal <= m) ? goal : m;
-      if (last > cur) {
-        const uint32_t k = last - cur;                 // segments cur .. last - 1, then the step below handles `last`
-        if (emit) emit->push_range(cur, last - 1u);
-        n_path += k;
-        nc_sum += c.pnc[last] - c.pnc[cur];
-        ln_sum += c.pl[last] - c.pl[cur];
-        if (guard <= k) { f.raise(CE_HANG); return false; }
-        guard -= k;
-        cur = last;
-      }
+    // A walk through an intron is a chain of trips to memory -- its length is its time -- so everything that hangs on `cur` alone
+    // is asked for at once: where the run that begins here ends (round 5), the segment's own numbers, its one out-neighbour
+    // and the bounds of its row.
+    const uint32_t m = c.run_end_rev ? c.run_end_rev[c.V - 1u - cur] : cur;
+    const uint32_t fl = c.nflags[cur], lnv = c.ln[cur];
+    const int32_t ncv = c.nc[cur];
+    uint32_t one = c.nxt1[cur];
+    uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
+    const uint32_t last = (goal >= cur && goal <= m) ? goal : m;
+    if (last > cur) {
+      // the run cur .. last in ONE step: consecutive indices, each the only out-neighbour of the one in front ("first
+      // out-neighbour that ..., else the last" has no choice there).  The goal inside the run ends the walk.  A second trip
+      // brings the prefix sums at both ends and what the last segment needs for the step behind the run.
+      const uint32_t k = last - cur;
+      if (emit) emit->push_range(cur, last);
+      n_path += k + 1u;
+      nc_sum += c.pnc[last + 1u] - c.pnc[cur];             // (run arrays are only offered when every segment has an NC tag)
+      ln_sum += c.pl[last + 1u] - c.pl[cur];
+      if (guard <= k) { f.raise(CE_HANG); return false; }
+      guard -= k;
+      cur = last;
+      if (cur == goal) return true;
+      one = c.nxt1[cur];
+      b = c.row_ptr[cur]; e = c.row_ptr[cur + 1];
+    } else {
+      if (emit) emit->push(cur);
+      ++n_path;
+      if (fl & N_HAS_NC) nc_sum += uint64_t(int64_t(ncv)); else nc_ok = false;   // read only when a row is printed
+      ln_sum += lnv;
+      if (cur == goal) return true;
     }
-    if (emit) emit->push(cur);
-    ++n_path;
-    if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;   // read only when a row is printed
-    ln_sum += c.ln[cur];
-    if (cur == goal) return true;
-    // one out-neighbour: it is taken whether it passes the test or not ("first that ..., else the last") -- one load per step
-    // where the general step makes five dependent ones (the walk is a chain of trips to memory: its length is its time)
-    const uint32_t one = c.nxt1[cur];
+    // one out-neighbour: it is taken whether it passes the test or not ("first that ..., else the last")
     if (one != CNONE) {
       cur = one;
       if (--guard == 0) { f.raise(CE_HANG); return false; }
       continue;
     }
-    const uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
     uint32_t nxt = CNONE;
     for (uint32_t s = b; s < e; ++s) {
       if (!in_out_list(c, s)) continue;
       const uint32_t nn = c.col[s];
       nxt = nn;                                     // (the loop variable stays on the last out-neighbour)
-      if (c.rank[nn] <= c.rank[goal] && ok(nn)) break;
+      if (c.rank[nn] <= goal_rank && ok(nn)) break;
     }
     if (nxt == CNONE) { f.raise(CE_ASSERT_PATH); return false; }
     cur = nxt;

@@ -177,11 +177,17 @@ def allreduce_counters(backend, dist, block_words=None) -> dict:
             torch.cuda.synchronize()
     t0 = time.perf_counter()
     if block_words and ct.numel():
-        bm = backend.touched_bitmap(block_words)
+        bm = backend.touched_bitmap(block_words)          # (returns when the kernel is done)
+        info["bitmap_kernel_ms"] = (time.perf_counter() - t0) * 1e3
+        t1 = time.perf_counter()
         allbm = torch.empty(world * bm.numel(), dtype=bm.dtype, device=bm.device)
         dist.all_gather_into_tensor(allbm, bm)
         wait()
+        info["bitmap_allgather_ms"] = (time.perf_counter() - t1) * 1e3
         info["bitmap_ms"] = (time.perf_counter() - t0) * 1e3
+        # every collective of the exchange with its message size, so that a run on N GPUs explains itself
+        info["collectives"] = [{"op": "all_gather", "what": "bitmaps of touched blocks", "bytes_per_rank": bm.numel() * 4,
+                                "bytes_gathered": allbm.numel() * 4, "ms": info["bitmap_allgather_ms"]}]
         t1 = time.perf_counter()
         staging = backend.counters_pack(allbm, world)
         info["pack_ms"] = (time.perf_counter() - t1) * 1e3
@@ -191,6 +197,8 @@ def allreduce_counters(backend, dist, block_words=None) -> dict:
                 dist.all_reduce(staging)
                 wait()
             info["allreduce_ms"] = (time.perf_counter() - t1) * 1e3
+            info["collectives"].append({"op": "all_reduce", "what": "blocks of the union (staging buffer)", "bytes": staging.numel() * 4,
+                                        "ms": info["allreduce_ms"]})
             t1 = time.perf_counter()
             backend.counters_unpack()
             info["unpack_ms"] = (time.perf_counter() - t1) * 1e3
@@ -201,6 +209,7 @@ def allreduce_counters(backend, dist, block_words=None) -> dict:
     dist.all_reduce(ct)
     wait()
     info["allreduce_ms"] = (time.perf_counter() - t1) * 1e3
+    info.setdefault("collectives", []).append({"op": "all_reduce", "what": "the dense counter array", "bytes": ct.numel() * 4, "ms": info["allreduce_ms"]})
     info["total_ms"] = (time.perf_counter() - t0) * 1e3
     return info
 

@@ -150,3 +150,24 @@ def test_engine_fused(mid):
             g.call(f.fileno(), -1, **_flags_to_opts(gc["flags"]))
             f.seek(0)
             check_mid_rows(f.read().decode().splitlines()[1:], gc)
+
+
+def test_walks_by_runs_equal_walks_by_steps(hostsim, mid):
+    """the intron walks jump over runs of consecutive single-out segments (call_device.h walk_exon, round 5): the same bytes as the
+    walk that steps segment by segment (HOSTSIM_CALL_NO_RUNS=1) -- IR rows carry the whole path and its mean coverage"""
+    flags = META["calls"][1]["flags"]
+    cmd = [hostsim["call"], *flags, f"{mid}/expected.aug.gfa", f"{mid}/in.gtf"]
+    runs = subprocess.run(cmd, capture_output=True, text=True)
+    steps = subprocess.run(cmd, capture_output=True, text=True, env={**os.environ, "HOSTSIM_CALL_NO_RUNS": "1"})
+    assert runs.returncode == 0 and steps.returncode == 0, runs.stderr + steps.stderr
+    assert runs.stdout == steps.stdout
+    assert sum(1 for l in runs.stdout.splitlines() if l.startswith("IR,")) > 500
+
+
+@pytest.mark.gpu
+def test_engine_walks_by_runs_equal_walks_by_steps(mid):
+    cmd = [sys.executable, "-m", "pantas_amd.call", *META["calls"][1]["flags"], f"{mid}/expected.aug.gfa", f"{mid}/in.gtf"]
+    runs = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
+    steps = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env={**os.environ, "PANTAS_CALL_NO_RUNS": "1"})
+    assert runs.returncode == 0 and steps.returncode == 0, runs.stderr + steps.stderr
+    assert runs.stdout == steps.stdout and runs.stdout.count("\nIR,") > 500
