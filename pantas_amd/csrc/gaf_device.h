@@ -755,6 +755,285 @@ PANTAS_UNROLL
   r.tail = int32_t(tail);
 }
 
+// ---- the PLAIN line, fast (round 5) ----------------------------------------------------------------------------------------
+// parse_gaf_line_words above takes every line the reference takes -- any Python whitespace between columns, signed and
+// underscored integers, "cs:Z:" more than once, '=' and '~' ops, names of any width -- and pays for it on every line: 107 vector
+// instructions per line and lane at whole-genome scale, a kernel at half the chip's vector-issue peak (profiles/r5_tok_*).
+// A mapper writes ONE form: columns separated by single tabs and no other control character or space anywhere, a path of
+// '>' (or '<') and decimal names of at most twelve digits without leading zeros, plain unsigned integers of at most nine digits,
+// a cs of "cs:Z:" once with ':' '*' '+' '-' ops of at most 60 bytes, "dv:f:<digits>".  parse_gaf_line_fast takes that form and
+// nothing else: it returns false -- having written nothing that matters: the caller hands the line to the general parser -- the
+// moment a line is anything else (including every line the reference would raise on).  What it returns true on, it decides and
+// emits exactly as parse_gaf_line_words does; tests/hostsim/hostsim_tokenize.cpp holds the two to the same summaries, nodes and
+// ops on every line the fast form accepts (goldens, crash inputs, fuzzed files).
+//
+// Structure: no byte-wise scans.  Tabs, control characters, digits and op characters are found a word at a time (SWAR masks);
+// a name's end is the first non-digit of the four words that hold it, its value three groups of up to four digits read from those
+// same words; the node lookups of up to eight names are issued together.
+
+// 0x80 in every byte of w below 0x21 (control characters and the space); bytes from 0x80 up are not
+PANTAS_HD uint32_t sw_ctrl(uint32_t w) { return ~(((w & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | w) & 0x80808080u; }
+// 0x80 in every byte of w that is no ASCII digit
+PANTAS_HD uint32_t sw_nondigit(uint32_t w) {
+  const uint32_t d = w ^ 0x30303030u;
+  return (((d & 0x7F7F7F7Fu) + 0x76767676u) | d) & 0x80808080u;
+}
+// 0x80 in every byte of w outside '`' .. 'z' (0x60 .. 0x7A)
+PANTAS_HD uint32_t sw_nonlower(uint32_t w) {
+  const uint32_t l = w ^ 0x60606060u;
+  return (((l & 0x7F7F7F7Fu) + 0x65656565u) | l) & 0x80808080u;
+}
+// bits 7, 15, 23, 31 of m as bits 0 .. 3
+PANTAS_HD uint32_t sw_nibble(uint32_t m) { return ((m >> 7) * 0x00204081u >> 21) & 0xFu; }
+// the n (0 .. 4) ASCII digits in the low bytes of x (first digit in byte 0) as a number; the bytes ARE digits
+PANTAS_HD uint32_t sw_digits4_known(uint32_t x, uint32_t n) {
+  const uint32_t y = uint32_t(((uint64_t(x) << 32) | 0x30303030ull) >> (8u * n));
+  uint32_t d = y & 0x0F0F0F0Fu;
+  d = d * 10u + (d >> 8);
+  return (d & 0xFFu) * 100u + ((d >> 16) & 0xFFu);
+}
+PANTAS_HD uint32_t sw_pow10(uint32_t n) { return n == 4u ? 10000u : uint32_t(0x03E80064000A0001ull >> (16u * n)) & 0xFFFFu; }   // n = 0 .. 4
+
+template <class Out>
+PANTAS_HD bool parse_gaf_line_fast(TextWords& T, const uint32_t b, const uint32_t e, int thr, const DenseNames& names, Out& out, LineSummary& r, bool check_cr,
+                                   uint32_t stop = 0) {       // stop: timing-only ablation (tools/tok_ablate.py letters a .. f): leave after that stage
+  r.status = TOK_ERROR; r.err = TE_NONE; r.n_nodes = 0; r.n_ops = 0; r.flags = 0; r.start = 0; r.tail = 0;
+  // check_cr: the text holds a '\r' that no '\n' follows somewhere (the line index looked): such a line is refused whatever else
+  // it holds, before the mapping quality is looked at -- every line of such a text goes to the parser that looks for it
+  if (e <= b || check_cr) return false;
+  const uint32_t we = e >> 2;                                   // the word that holds byte e (the '\n', or padding behind the text)
+  const uint32_t ebits = 0x80808080u << (8u * (e & 3u));        // its bytes from e on
+  auto word_at = [&](uint32_t i) { return T.w[i < we ? i : we]; };                       // (never read behind the line's own end)
+  auto beyond = [&](uint32_t i) { return i < we ? 0u : i == we ? ebits : 0x80808080u; };  // bytes of word i at or behind e
+
+  // ---- columns 0 .. 4: five tabs, and no other control character or space in front of them
+  uint32_t p5b = TK_NONE32;
+  {
+    uint32_t seen = 0;
+    uint32_t front = ~(0xFFFFFFFFu << (8u * (b & 3u)));        // bytes of the first word in front of b
+    uint32_t carry = 0x80u << (8u * (b & 3u));                 // "a tab stands in front of this byte": the line's start counts as one
+    for (uint32_t i = b >> 2; i <= we; ++i) {
+      const uint32_t w = T.w[i];
+      const uint32_t keep = 0x80808080u & ~front & ~beyond(i);
+      front = 0u;
+      const uint32_t tab = sw_eq(w, 0x09090909u) & keep, ctl = sw_ctrl(w) & keep;
+      if (tab != ctl) return false;
+      if (tab & ((tab << 8) | carry)) return false;            // an empty column: str.split() would close the gap
+      carry = tab >> 31 ? 0x80u : 0u;
+      const uint32_t n = uint32_t(__builtin_popcount(tab));
+      if (seen + n >= 5u) {
+        uint32_t s = tab;
+        for (uint32_t k = 4u - seen; k > 0u; --k) s &= s - 1u;
+        p5b = (i << 2) + (sw_ctz(s) >> 3) + 1u;
+        break;
+      }
+      seen += n;
+    }
+  }
+  if (p5b == TK_NONE32 || p5b >= e) return false;
+  if (stop == 1u) { r.start = int32_t(p5b); return true; }
+
+  // ---- column 5, the path
+  const uint32_t c5 = T.at(p5b);
+  uint32_t p5e, n_nodes = 0;
+  bool star_path = false;
+  if (c5 == '*') {
+    p5e = p5b + 1u;
+    star_path = true;
+  } else {
+    if (c5 != '>' && c5 != '<') return false;
+    uint32_t t = p5b + 1u;
+    // name -> node lookups are gathers from a table of graph size (a gigabyte for a whole genome: every one a trip to memory of
+    // microseconds under load): the table indices of up to FAST_BATCH names wait in registers and are asked for TOGETHER -- looked
+    // up one by one, even a name ahead, a line of six nodes was six trips long and the kernel waited 85 % of its time
+    constexpr uint32_t FAST_BATCH = 8;
+    uint32_t R[FAST_BATCH];
+PANTAS_UNROLL
+    for (uint32_t j = 0; j < FAST_BATCH; ++j) R[j] = 0u;
+    uint32_t cnt = 0, last = TK_NONE32;
+    bool unknown = false;
+    auto flush = [&]() {
+      uint32_t idx[FAST_BATCH];
+PANTAS_UNROLL
+      for (uint32_t j = 0; j < FAST_BATCH; ++j) idx[j] = tk_node_of(names, R[j]);      // (slots beyond cnt hold an index that was valid: loads without a condition)
+PANTAS_UNROLL
+      for (uint32_t j = 0; j < FAST_BATCH; ++j) {
+        if (j < cnt) {
+          if (idx[j] == TK_NONE32) unknown = true;
+          else if (!unknown && (n_nodes == 0u || idx[j] != last)) { out.node(n_nodes++, idx[j]); last = idx[j]; }
+        }
+      }
+      cnt = 0;
+    };
+    for (;;) {
+      // the four words that hold a name of up to twelve digits from byte t on
+      const uint32_t i = t >> 2, o8 = (t & 3u) << 3;
+      const uint32_t w0 = word_at(i), w1 = word_at(i + 1u), w2 = word_at(i + 2u), w3 = word_at(i + 3u);
+      // its end: the first byte at or behind t that is no digit (a byte at or behind e never is)
+      uint32_t nd = sw_nibble(sw_nondigit(w0) | beyond(i)) | (sw_nibble(sw_nondigit(w1) | beyond(i + 1u)) << 4) |
+                    (sw_nibble(sw_nondigit(w2) | beyond(i + 2u)) << 8) | (sw_nibble(sw_nondigit(w3) | beyond(i + 3u)) << 12);
+      nd &= 0xFFFFu << (t & 3u);
+      if (nd == 0u) return false;                              // thirteen digits or more
+      const uint32_t q = (i << 2) + sw_ctz(nd), n = q - t;
+      if (n == 0u || n > 12u || q >= e) return false;          // (an empty name; a line that ends inside its path)
+      const uint32_t g0 = uint32_t((uint64_t(w0) | (uint64_t(w1) << 32)) >> o8);
+      const uint32_t g1 = uint32_t((uint64_t(w1) | (uint64_t(w2) << 32)) >> o8);
+      const uint32_t g2 = uint32_t((uint64_t(w2) | (uint64_t(w3) << 32)) >> o8);
+      if (n > 1u && (g0 & 0xFFu) == '0') return false;         // a leading zero names no segment
+      const uint32_t k0 = n < 4u ? n : 4u, k1 = n > 4u ? (n - 4u < 4u ? n - 4u : 4u) : 0u, k2 = n > 8u ? n - 8u : 0u;
+      const uint64_t val = (uint64_t(sw_digits4_known(g0, k0)) * sw_pow10(k1) + sw_digits4_known(g1, k1)) * sw_pow10(k2) + sw_digits4_known(g2, k2);
+      const uint64_t off = val - names.base;
+      if (off >= names.size) return false;
+PANTAS_UNROLL
+      for (uint32_t j = 0; j < FAST_BATCH; ++j) R[j] = j == cnt ? uint32_t(off) : R[j];
+      ++cnt;
+      const uint32_t delim = T.at(q);
+      if (delim == c5) {
+        t = q + 1u;
+        if (cnt == FAST_BATCH) { flush(); if (unknown) return false; }
+        continue;
+      }
+      if (delim != '\t') return false;                         // the other orientation character, a letter, ...
+      p5e = q;
+      break;
+    }
+    flush();
+    if (unknown) return false;
+  }
+  if (p5e >= e || T.at(p5e) != '\t') return false;
+  out.nodes_done(n_nodes);
+  if (stop == 2u) { r.start = int32_t(p5e + n_nodes); return true; }
+
+  // ---- columns 6 .. 11: the seven tabs from the one behind the path on (the last may be the line's end), nothing else below 0x21
+  uint32_t tp[7];
+  {
+    uint32_t found = 0;
+    uint32_t front = ~(0xFFFFFFFFu << (8u * (p5e & 3u)));
+    for (uint32_t i = p5e >> 2, j = 0; j < 14u && found < 7u; ++i, ++j) {
+      const uint32_t w = word_at(i);
+      const uint32_t keep = 0x80808080u & ~front & ~beyond(i);
+      front = 0u;
+      uint32_t tab = sw_eq(w, 0x09090909u) & keep;
+      if (tab != (sw_ctrl(w) & keep)) return false;
+      if (i >= we) tab |= i == we ? (0x80u << (8u * (e & 3u))) : 0u;       // the line's end closes column 11 like a tab
+      while (tab && found < 7u) {
+        const uint32_t at = (i << 2) + (sw_ctz(tab) >> 3);
+        tab &= tab - 1u;
+PANTAS_UNROLL
+        for (uint32_t k = 0; k < 7u; ++k) tp[k] = k == found ? at : tp[k];
+        ++found;
+      }
+      if (i >= we) break;
+    }
+    if (found < 7u) return false;                              // fewer than twelve columns, or columns wider than the window
+    bool gap = false;                                          // an empty column: str.split() would close the gap and shift the rest
+PANTAS_UNROLL
+    for (uint32_t k = 0; k < 6u; ++k) gap |= tp[k + 1u] == tp[k] + 1u;
+    if (gap) return false;
+  }
+  const uint32_t opt = tp[6];                                   // end of column 11: a tab, or e
+  if (stop == 3u) { r.start = int32_t(opt + tp[0] + tp[1] + tp[2] + tp[3] + tp[5]); return true; }
+  int64_t mapq, path_len, start, endpos;
+  if (!sw_uint9(T, tp[5] + 1u, tp[6], mapq)) return false;
+  if (mapq < int64_t(thr)) { r.status = TOK_REJECT; return true; }
+  if (star_path) { r.status = TOK_SKIP; return true; }
+  if (!sw_uint9(T, tp[0] + 1u, tp[1], path_len) || !sw_uint9(T, tp[1] + 1u, tp[2], start) || !sw_uint9(T, tp[2] + 1u, tp[3], endpos)) return false;
+
+  // ---- the optional fields: tabs and nothing else below 0x21; the first "cs:" and the first "dv:f:<digit>"
+  uint32_t cs_at = TK_NONE32, dv_at = TK_NONE32;
+  if (opt < e) {
+    uint32_t front = ~(0xFFFFFFFFu << (8u * (opt & 3u)));
+    for (uint32_t i = opt >> 2; i <= we; ++i) {
+      const uint32_t w = T.w[i];
+      const uint32_t keep = 0x80808080u & ~front & ~beyond(i);
+      front = 0u;
+      if ((sw_eq(w, 0x09090909u) & keep) != (sw_ctrl(w) & keep)) return false;
+      uint32_t cm = cs_at == TK_NONE32 ? (sw_eq(w, 0x63636363u) & keep) : 0u;
+      uint32_t dm = dv_at == TK_NONE32 ? (sw_eq(w, 0x64646464u) & keep) : 0u;
+      while (cm) {
+        const uint32_t pos = (i << 2) + (sw_ctz(cm) >> 3);
+        cm &= cm - 1u;
+        if (pos + 3u <= e && T.at(pos + 1u) == 's' && T.at(pos + 2u) == ':') { cs_at = pos; break; }
+      }
+      while (dm) {
+        const uint32_t pos = (i << 2) + (sw_ctz(dm) >> 3);
+        dm &= dm - 1u;
+        if (pos + 6u <= e && T.at(pos + 1u) == 'v' && T.at(pos + 2u) == ':' && T.at(pos + 3u) == 'f' && T.at(pos + 4u) == ':' && tk_digit(T.at(pos + 5u))) { dv_at = pos; break; }
+      }
+    }
+  }
+  if (dv_at == TK_NONE32) return false;                         // (the reference raises: the general parser words it)
+  if (stop == 4u) { r.start = int32_t(cs_at + dv_at + path_len + start + endpos); return true; }
+
+  // ---- cs: "cs:Z:" once, then ':' '*' '+' '-' ops over at most 60 bytes
+  OpList<Out> em(out);
+  if (cs_at != TK_NONE32) {
+    if (cs_at + 5u > e || sw_bytes4(T, cs_at + 1u) != 0x3A5A3A73u /* "s:Z:" */) return false;
+    const uint32_t s0 = cs_at + 5u, base = s0 & ~3u;
+    // op candidates (neither digit nor '`' .. 'z'), digits, and the field's end (the first tab, or e), one bit per byte
+    uint64_t opbits = 0, digbits = 0;
+    uint32_t fe = TK_NONE32;
+    for (uint32_t i = base >> 2, j = 0; j < 16u; ++i, ++j) {
+      const uint32_t w = word_at(i);
+      const uint32_t keep = 0x80808080u & ~(i == (base >> 2) ? ~(0xFFFFFFFFu << (8u * (s0 & 3u))) : 0u);
+      const uint32_t endm = (sw_eq(w, 0x09090909u) | beyond(i)) & keep;
+      const uint32_t nd = sw_nondigit(w);
+      if (sw_eq(w, 0x73737373u) & keep & ~(endm ? (0xFFFFFFFFu << sw_ctz(endm)) : 0u)) return false;      // an 's': there may be another "cs:Z:" to step over
+      opbits |= uint64_t(sw_nibble(nd & sw_nonlower(w) & keep)) << (4u * j);
+      digbits |= uint64_t(sw_nibble(~nd & keep)) << (4u * j);
+      if (endm) { fe = (i << 2) + (sw_ctz(endm) >> 3); break; }
+    }
+    if (fe == TK_NONE32) return false;                          // a cs of more than 60 bytes
+    const uint32_t len = fe - base;                             // bits at and behind len are not the field's
+    const uint64_t inside = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
+    opbits &= inside;
+    digbits &= inside;
+    // nothing behind "cs:Z:", or bytes in front of the first op character (the reference drops them): the general parser's business
+    if (opbits == 0ull || uint32_t(__builtin_ctzll(opbits)) != s0 - base) return false;
+    while (opbits) {
+      const uint32_t pb = uint32_t(__builtin_ctzll(opbits));
+      opbits &= opbits - 1ull;
+      const uint32_t nxt = opbits ? uint32_t(__builtin_ctzll(opbits)) : len;
+      const uint32_t at = base + pb, run = nxt - pb - 1u;
+      const uint32_t op = T.at(at);
+      if (op != ':' && op != '*' && op != '+' && op != '-') return false;      // '=' and '~' (and any other byte that is no run content)
+      uint32_t v = run;
+      if (op == '*') v = 1u;
+      else if (run > 0u) {
+        const uint64_t runmask = ((1ull << run) - 1ull) << (pb + 1u);          // (run <= 59)
+        if ((digbits & runmask) == runmask) {                                   // all digits: the number
+          if (run > 9u) return false;
+          int64_t num;
+          if (!sw_uint9(T, at + 1u, base + nxt, num)) return false;
+          v = uint32_t(num);
+        }
+      }
+      if (v > OP_MAX_LEN) return false;
+      em.push((v << 3) | tk_opcode(op));
+    }
+  } else {
+    em.push((1u << 3) | OP_STAR);
+  }
+  em.finish(start);
+  if (stop == 5u) { r.start = int32_t(start + em.n); return true; }
+
+  // ---- dv, then what the general parser decides last
+  if (tk_dv_above_tenth(T, dv_at + 5u, e)) { r.status = TOK_SKIP; return true; }
+  const int64_t tail = path_len - endpos;
+  if (start < -2147483648ll || start > 2147483647ll || tail < -2147483648ll || tail > 2147483647ll) return false;
+  uint32_t flags = c5 != '>' ? LINE_REV : 0u;
+  if (em.slow) flags |= LINE_SLOW;
+  flags |= line_class_flags(em.n, em.stars, em.indels, em.others, em.slow, em.total, start, tail);
+  if (em.has_del) flags |= LINE_HAS_DEL;
+  r.status = TOK_KEEP;
+  r.n_nodes = n_nodes;
+  r.n_ops = em.n;
+  r.flags = flags;
+  r.start = int32_t(start);
+  r.tail = int32_t(tail);
+  return true;
+}
+
 // the same for a line given by pointers: [b, e) plus up to three bytes on either side must be readable
 template <class Out>
 PANTAS_HD void parse_gaf_line(const uint8_t* b, const uint8_t* e, int thr, const DenseNames& names, Out& out, LineSummary& r, bool check_cr = true) {

@@ -359,7 +359,7 @@ struct ProvOut {
 __global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))) parse_once_kernel(const uint8_t* text, const uint64_t* ls, uint32_t n_lines, uint32_t stage_bytes, int thr, uint32_t check_cr,
                                                          DenseNames names, uint32_t first_line, uint32_t bits, uint32_t* prov, uint64_t prov_words,
                                                          uint32_t* arena_next, uint32_t arena_words, uint32_t* key, unsigned long long* val, uint32_t* partial,
-                                                         unsigned long long* err, uint32_t* fallback, uint32_t stop, uint32_t align_min) {
+                                                         unsigned long long* err, uint32_t* fallback, uint32_t stop, uint32_t align_min, uint32_t fast) {
   uint32_t t[N_TOTALS];
 #pragma unroll
   for (uint32_t j = 0; j < N_TOTALS; ++j) t[j] = 0;
@@ -390,7 +390,17 @@ __global__ void __launch_bounds__(LPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (uint32_t pass = 0; pass < 2u; ++pass) {
       ProvOut po{prov + at, cap};
       TextWords T(words);
-      parse_gaf_line_words(T, b, e, thr, names, po, r, check_cr != 0u && pass == 0u, stop);
+      // round 5: the form a mapper writes is taken by the lean parser (gaf_device.h parse_gaf_line_fast: a third of the vector
+      // instructions); whatever it refuses -- other whitespace, signed integers, '=' / '~' ops, a line the reference raises on ...
+      // -- is parsed by the general one, in this lane, as before (`fast` = 0: every line by the general parser, the A/B partner)
+#ifdef PANTAS_EXPERIMENTS
+      if (stop >= 10u) { (void)parse_gaf_line_fast(T, b, e, thr, names, po, r, false, stop - 10u); break; }      // (timing only: stages of the lean parser)
+#endif
+      if (!(fast && parse_gaf_line_fast(T, b, e, thr, names, po, r, check_cr != 0u))) {
+        po = ProvOut{prov + at, cap};
+        T = TextWords(words);
+        parse_gaf_line_words(T, b, e, thr, names, po, r, check_cr != 0u && pass == 0u, stop);
+      }
       first_node = po.first; last_node = po.last;
       if (pass == 1u || r.status != TOK_KEEP || !(po.ovf || cur < PROV_HDR)) break;
       const uint32_t need = PROV_HDR + r.n_ops + r.n_nodes;
@@ -877,9 +887,11 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   uint32_t align_min = 0;
   if (const char* a = getenv("PANTAS_TOK_ALIGN_MIN")) align_min = uint32_t(atoi(a));
   if (align_min == 0) align_min = 0xFFFFFFFFu;
+  // PANTAS_TOK_FAST=0: every line through the general parser (the A/B partner of the lean parser for plain lines; same arrays)
+  const uint32_t tok_fast = (getenv("PANTAS_TOK_FAST") && atoi(getenv("PANTAS_TOK_FAST")) == 0) ? 0u : 1u;
   hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
                      uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), key.as<uint32_t>(), val.as<unsigned long long>(),
-                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1, 0u, align_min);
+                     partial.as<uint32_t>(), small.as<unsigned long long>(), d_arena_next + 1, 0u, align_min, tok_fast);
   HIP_OK(hipGetLastError());
 #ifndef PANTAS_EXPERIMENTS
   if (getenv("PANTAS_TOK_STOP"))
@@ -892,13 +904,14 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     for (const char* p = ab; *p; ++p) {
-      if (*p < '0' || *p > '9') continue;
+      if (!((*p >= '0' && *p <= '9') || (*p >= 'a' && *p <= 'f'))) continue;
+      const uint32_t stop_code = *p <= '9' ? uint32_t(*p - '0') : 10u + uint32_t(*p - 'a');      // a .. f: stages 0 .. 5 of the lean parser (a = all of it)
       DevBuf junk(pool);
       junk.alloc(size_t(n_lines) * 4);
       HIP_OK(hipEventRecord(e0, s));
       hipLaunchKernelGGL(parse_once_kernel, dim3(waves), dim3(LPB), stage_bytes, s, d_text, d_ls, n_lines, stage_bytes, thr, check_cr, names, uint32_t(first_line_id),
                          uint32_t(bits), prov.as<uint32_t>(), prov_words, d_arena_next, uint32_t(arena_words), junk.as<uint32_t>(), val.as<unsigned long long>(),
-                         partial.as<uint32_t>(), small.as<unsigned long long>() + N_TOTALS + 2 /* (never written in this mode) */, d_arena_next + 1, uint32_t(*p - '0'), align_min);
+                         partial.as<uint32_t>(), small.as<unsigned long long>() + N_TOTALS + 2 /* (never written in this mode) */, d_arena_next + 1, stop_code, align_min, *p == '0' ? tok_fast : 0u);
       HIP_OK(hipEventRecord(e1, s));
       HIP_OK(hipEventSynchronize(e1));
       float ms = 0;

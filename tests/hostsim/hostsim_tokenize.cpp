@@ -108,6 +108,32 @@ int main(int argc, char** argv) {
         return 1;
       }
     }
+    // ---- the fast form for plain lines (parse_gaf_line_fast): whatever it accepts, it decides and emits as the general parser does
+    size_t fast_taken = 0;
+    bool lone_cr = false;         // what tokenize.hip's line index reports for the text: a '\r' that no '\n' follows
+    for (size_t i = 0; i < f.size; ++i) lone_cr = lone_cr || (text[i] == '\r' && !(i + 1 < f.size && text[i + 1] == '\n'));
+    for (size_t i = 0; i < n_lines; ++i) {
+      const uint8_t* lb = text + ls[i];
+      const uintptr_t a = reinterpret_cast<uintptr_t>(lb) & ~uintptr_t(3);
+      const uint32_t off = uint32_t(reinterpret_cast<uintptr_t>(lb) - a), len = uint32_t(ls[i + 1] - 1 - ls[i]);
+      std::vector<uint32_t> fn(len + 2, 0xDEADBEEFu), fo(len + 2, 0xDEADBEEFu), gn(len + 2, 0xDEADBEEFu), go(len + 2, 0xDEADBEEFu);
+      WriteOut fw{fn.data(), fo.data()}, gw{gn.data(), go.data()};
+      LineSummary fs, gs;
+      TextWords TF(reinterpret_cast<const uint32_t*>(a));
+      if (!parse_gaf_line_fast(TF, off, off + len, thr, names, fw, fs, lone_cr)) continue;
+      ++fast_taken;
+      TextWords TG(reinterpret_cast<const uint32_t*>(a));
+      parse_gaf_line_words(TG, off, off + len, thr, names, gw, gs);
+      if (memcmp(&fs, &gs, sizeof fs) != 0) {
+        printf("MISMATCH line %zu: fast parse (status %u err %u nodes %u ops %u flags %u start %d tail %d) differs from the general one (%u %u %u %u %u %d %d)\n", i + 1,
+               fs.status, fs.err, fs.n_nodes, fs.n_ops, fs.flags, fs.start, fs.tail, gs.status, gs.err, gs.n_nodes, gs.n_ops, gs.flags, gs.start, gs.tail);
+        return 1;
+      }
+      if (fs.status == TOK_KEEP && (memcmp(fn.data(), gn.data(), (fs.n_nodes + 1) * 4) != 0 || memcmp(fo.data(), go.data(), (fs.n_ops + 1) * 4) != 0)) {
+        printf("MISMATCH line %zu: fast parse emits other nodes / ops than the general one\n", i + 1);
+        return 1;
+      }
+    }
     GafBatch dev;
     dev.node_off.push_back(0);
     dev.op_off.push_back(0);
@@ -168,8 +194,8 @@ int main(int argc, char** argv) {
     }
     if (host.node_off != dev.node_off || host.nodes != dev.nodes) { printf("MISMATCH path nodes\n"); return 1; }
     if (host.op_off != dev.op_off || host.ops != dev.ops) { printf("MISMATCH cs ops\n"); return 1; }
-    printf("OK lines=%zu records=%zu rejected=%llu skipped=%llu error=%s\n", n_lines, dev.size(), (unsigned long long)dev.rejected,
-           (unsigned long long)dev.skipped, host_err ? host.deferred->kind.c_str() : "none");
+    printf("OK lines=%zu records=%zu rejected=%llu skipped=%llu error=%s fast=%zu\n", n_lines, dev.size(), (unsigned long long)dev.rejected,
+           (unsigned long long)dev.skipped, host_err ? host.deferred->kind.c_str() : "none", fast_taken);
     return 0;
   } catch (const Error& e) {
     // the graph itself is refused (both tokenisers are behind the same loader)

@@ -272,3 +272,54 @@ def test_empty_and_unterminated_input(tmp_path):
     for path in (empty, cut):
         h, dv = both(g, path)
         assert_same(h, dv)
+
+
+def test_lean_parser_for_plain_lines_equals_general_parser(tmp_path):
+    """round 5: plain lines go through parse_gaf_line_fast inside parse_once_kernel, everything else through the general parser
+    in the same lane (PANTAS_TOK_FAST=0: all of them through the general one).  Same arrays either way and as the host tokeniser's --
+    on the synthetic recipe (all plain, two-indel reads among them) and on a file where every fifth line is mutated (other
+    whitespace, signs, '=' ops, doubled tabs, cut columns: lines the lean parser must hand over)."""
+    from pantas_amd.engine import Graph, Synth
+    pre = str(tmp_path / "s")
+    Synth(seed=47, n_genes=200, n_lines=120000, p_indel=0.2, p_sub=0.4, p_novel_skip=0.05, p_two_indels=0.1).write(pre)
+    g = Graph(pre + ".gfa").to_device(0)
+    h, fast = both(g, pre + ".gaf")
+    assert_same(h, fast)
+    with _with_env(PANTAS_TOK_FAST=0):
+        _, general = both(g, pre + ".gaf")
+    assert_same(h, general)
+    # mutations that keep a line acceptable to the reference (no raise): the two parsers and the host must agree line by line
+    rng = random.Random(9)
+    lines = open(pre + ".gaf").read().splitlines()[:40000]
+
+    def mutate(l):
+        t = l.split("\t")
+        if len(t) < 14:              # (an unmapped read: twelve columns)
+            return l
+        k = rng.randrange(8)
+        if k == 0:
+            return l.replace("\t", " ", 1)                        # a space where a tab stood
+        if k == 1:
+            return l.replace("\t", "\t\t", 1)                     # an empty column: split() closes the gap
+        if k == 2:
+            t[11] = "+" + t[11]
+        elif k == 3:
+            t[7] = "0" + t[7] if t[5] != "*" else t[7]           # a leading zero in an integer
+        elif k == 4:
+            t[12] = t[12] + " "                                   # a space behind a tag (still the same tokens)
+        elif k == 5:
+            t = [x.replace("cs:Z::", "cs:Z:=ACGT:") if x.startswith("cs:Z::") else x for x in t]
+        elif k == 6:
+            t.append("zz:Z:cs:x dv:f:1")
+        else:
+            t = t[:12] + t[13:]                                   # a tag dropped
+        return "\t".join(t)
+    with open(pre + ".m.gaf", "w") as f:
+        for i, l in enumerate(lines):
+            f.write((mutate(l) if i % 5 == 0 else l) + "\n")
+    h, fast = both(g, pre + ".m.gaf")
+    assert_same(h, fast)
+    with _with_env(PANTAS_TOK_FAST=0):
+        _, general = both(g, pre + ".m.gaf")
+    for x, y in zip(fast[1], general[1]):
+        assert np.array_equal(x, y)

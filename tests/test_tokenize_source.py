@@ -49,7 +49,7 @@ def test_crash_inputs_same_class_same_line(tokenize_sim):
         if c["stage"] != "augment":
             continue
         out = run(tokenize_sim, f"{cd}/{c['name']}.gaf", f"{cd}/{c['name']}.gfa")
-        seen.add(out.strip().split("error=")[-1])
+        seen.add(out.strip().split("error=")[-1].split()[0])
     assert {"IndexError", "ValueError", "KeyError", "AssertionError"} <= seen, seen
 
 
@@ -67,7 +67,7 @@ def test_fuzzed_text(tokenize_sim, tmp_path, seed):
                 if rng.random() < (0.6 if nl < 10 else 0.02):
                     l = fuzz_gaf.mutate_text(rng, l)
                 f.write(l + ("\n" if (i < nl - 1 or rng.random() < 0.9) else ""))
-        k = run(tokenize_sim, gaf, gfa).strip().split("error=")[-1]
+        k = run(tokenize_sim, gaf, gfa).strip().split("error=")[-1].split()[0]
         kinds[k] = kinds.get(k, 0) + 1
     assert kinds.get("none", 0) > 50 and len(kinds) >= 4, kinds
 
@@ -77,4 +77,40 @@ def test_multithreaded_host_tokeniser_same_records(tokenize_sim, tmp_path):
     from pantas_amd.engine import Synth
     pre = str(tmp_path / "s")
     Synth(seed=41, n_genes=50, n_lines=60000, p_indel=0.2, p_novel_skip=0.05).write(pre)
-    assert run(tokenize_sim, pre + ".gaf", pre + ".gfa", "20", "4").startswith("OK lines=60000")
+    out = run(tokenize_sim, pre + ".gaf", pre + ".gfa", "20", "4")
+    assert out.startswith("OK lines=60000")
+    # the fast form for plain lines (parse_gaf_line_fast) takes what a mapper writes: every line of the synthetic recipe
+    assert int(out.split("fast=")[1]) >= 59990, out
+
+
+def test_fast_form_on_mutated_plain_lines(tokenize_sim, tmp_path):
+    """parse_gaf_line_fast must either refuse a line or agree with the general parser: plain synthetic lines with one byte
+    changed, inserted or dropped at a random place (tabs doubled, digits turned into letters, names cut, tags renamed ...)"""
+    from pantas_amd.engine import Synth
+    pre = str(tmp_path / "s")
+    Synth(seed=43, n_genes=30, n_lines=3000, p_indel=0.3, p_sub=0.4, p_novel_skip=0.05, p_two_indels=0.1).write(pre)
+    lines = open(pre + ".gaf").read().splitlines()
+    rng = random.Random(5)
+    alphabet = "\t\t\t  >><<**::++--==~~0123456789acgtZsdvf.c_"
+    taken = 0
+    for trial in range(40):
+        out_lines = []
+        for l in rng.sample(lines, 120):
+            for _ in range(rng.choice([1, 1, 2])):
+                at = rng.randrange(len(l) + 1)
+                kind = rng.random()
+                if kind < 0.4 and at < len(l):
+                    l = l[:at] + rng.choice(alphabet) + l[at + 1:]
+                elif kind < 0.7:
+                    l = l[:at] + rng.choice(alphabet) + l[at:]
+                elif at < len(l):
+                    l = l[:at] + l[at + 1:]
+            out_lines.append(l)
+        # one mutated line per file in front of plain ones: a line the reference dies on ends the comparison of a file
+        for k, l in enumerate(out_lines):
+            with open(pre + ".m.gaf", "w") as f:
+                f.write(l + "\n" + "\n".join(lines[k * 3:k * 3 + 3]) + "\n")
+            out = run(tokenize_sim, pre + ".m.gaf", pre + ".gfa")
+            taken += int(out.split("fast=")[1])
+    assert taken > 10000        # (most mutations leave a line plain, or touch a free-text column)
+
