@@ -435,6 +435,8 @@ def main():
     t_gen = time.perf_counter() - t_gen
     g = Graph(text=syn.gfa).to_device(local_rank)
     gs = g.stats
+    if world > 1 and os.environ.get("PANTAS_TRACK_TOUCHED", "1") != "0":
+        g.track_touched(True)        # (the exchange that ends the replicate folds the kernels' own bitmap of touched blocks)
     g.augment_reset()
     keep_for_e2e = rank == 0 and world == 1 and not args.no_e2e
     syns = [syn]

@@ -183,6 +183,12 @@ int pantas_augment_counters(pantas_graph* g, void** dev_ptr, uint64_t* words);
  *      (same layout on every rank); the caller all-reduces staging_words uint32 sums (staging_words may be 0);
  *   3. pantas_counters_unpack: staging -> counters.  Skipping 3 leaves the counters as they were. */
 int pantas_counters_bitmap(pantas_graph* g, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words);
+/* ABI 8.  on != 0: from the next pantas_augment_reset on, the augment kernels keep the bitmap of step 1 themselves (every site that
+ * adds to a counter sets its block's bit), and pantas_counters_bitmap / pantas_counters_allreduce only fold it to block_words instead
+ * of reading all 4V + A counters (5 GB at whole-genome scale).  For callers that will exchange: a run on one GPU leaves it off (the
+ * kernels then carry one never-taken branch per flushed counter).  With PANTAS_EXCHANGE_VERIFY=1 in the environment step 1 also
+ * reads the counters and fails (PANTAS_E_INTERNAL) when a block that holds a count is missing from the kept bitmap. */
+int pantas_augment_track_touched(pantas_graph* g, int on);
 int pantas_counters_pack(pantas_graph* g, const void* dev_bitmaps, uint32_t n_bitmaps, void** dev_staging, uint64_t* staging_words);
 int pantas_counters_unpack(pantas_graph* g);
 /* THE data-path collective of a read-sharded replicate behind the C ABI (round 3; north_star: "a single RCCL all-reduce over the

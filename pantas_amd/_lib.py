@@ -139,6 +139,7 @@ def _load():
         "pantas_augment_flags_import": (i32, [vp, vp, u64]),
         "pantas_augment_counters": (i32, [vp, P(vp), P(u64)]),
         "pantas_counters_bitmap": (i32, [vp, C.c_uint32, P(vp), P(u64)]),
+        "pantas_augment_track_touched": (i32, [vp, i32]),
         "pantas_counters_pack": (i32, [vp, vp, C.c_uint32, P(vp), P(u64)]),
         "pantas_counters_unpack": (i32, [vp]),
         "pantas_quant_run": (i32, [P(C.c_char_p), P(C.c_char_p), C.c_uint32, i32, i32, i32]),

@@ -112,6 +112,12 @@ void download_result(DeviceGraph& dg, const Graph& g, AugmentResult& r);
 // Any elementwise sum over ranks is a valid merge; the planar arrays only exist on the host (download_result).
 struct CounterPtrs { void* base; uint64_t words; uint64_t V, A; };
 CounterPtrs counter_ptrs(DeviceGraph& dg);
+// Round 5: the kernels can keep the bitmap of touched counter blocks themselves (one bit per block_words counters, set by every
+// site that adds to a counter), so that the exchange does not read the whole counter array to find them.  Asked for by a caller
+// that will exchange (read-sharded runs); kept from the next zeroing of the counters on.  bits == nullptr: not kept (this run).
+void set_track_touched(DeviceGraph& dg, bool on);
+struct TouchedBitmap { const uint32_t* bits; uint64_t words; uint32_t block_words; };
+TouchedBitmap touched_bitmap_of(DeviceGraph& dg);
 // Block-sparse exchange of the counters between ranks (exchange.hip): bitmap of touched blocks -> (caller all-gathers)
 // -> pack the union's blocks into a staging buffer -> (caller all-reduces it) -> unpack.  The allocation behind
 // counter_ptrs is zero-padded to a multiple of COUNTER_PAD_WORDS so that whole blocks can be read.

@@ -56,7 +56,12 @@ struct SlowTables {
   TableView hist, novel;
   unsigned long long* status; // min over failing lines of (line_id << 8 | code)
   TildeCarry tilde;           // lengths that leak into lines whose first op is '~' (walk.h); empty unless the run found such lines
+  // Round 5: one bit per block of TOUCHED_BLOCK_WORDS counters that an update has reached, or nullptr (a run on one GPU never
+  // asks).  Read-sharded runs exchange only touched blocks (exchange.hip); with the bitmap kept here, by every site that adds to a
+  // counter, the exchange no longer reads the 5 GB of counters to find them.
+  uint32_t* touched;
 };
+constexpr uint32_t TOUCHED_BLOCK_WORDS = 8;    // the finest block of the exchange; coarser ones are ORs of neighbouring bits
 
 struct GraphView {
   uint32_t* word;             // [V] segment length | FLAG_IL | FLAG_OL
@@ -86,17 +91,41 @@ struct BatchView {
   uint32_t n, n_del;
 };
 
+#define PANTAS_GLOBAL_AS __attribute__((address_space(1)))
+// counter word `w` (index into [4 V | A]) has been added to: its block's bit in the run's bitmap, when one is kept.  The bit is
+// looked at first -- an expressed gene's counters are reached by every chunk that holds its reads, and an atomic per visit on the
+// same word would serialise -- and set by a fire-and-forget atomic.
+typedef PANTAS_GLOBAL_AS uint32_t* TouchedPtr;
+// the run's bitmap, or nullptr.  A flush loads it ONCE in front of its loops (a scalar load inside them would make every pass
+// wait for the LDS reads in flight as well: lgkmcnt counts both); the rare paths inside the walk loops load it where they stand.
+__device__ __forceinline__ TouchedPtr touched_of(const GraphView& g) { return (TouchedPtr)g.slow->touched; }
+__device__ __forceinline__ void mark_touched(TouchedPtr t, uint64_t w) {
+#ifdef PANTAS_NO_TOUCHED_MARKS      // (A/B builds only: what the marking costs the kernels of a run that does not ask for the bitmap)
+  (void)t; (void)w;
+  return;
+#endif
+  if (t == nullptr) return;
+  const uint64_t blk = w / TOUCHED_BLOCK_WORDS;
+  const uint32_t bit = 1u << (uint32_t(blk) & 31u);
+  if (!(t[blk >> 5] & bit)) __hip_atomic_fetch_or(t + (blk >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t* nc_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n); }
 __device__ __forceinline__ uint32_t* il0_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n) + 1; }
 __device__ __forceinline__ uint32_t* oll_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n) + 2; }
 __device__ __forceinline__ uint32_t* rc0_of(const GraphView& g, uint32_t n) { return g.cnt4 + 4 * size_t(n) + 3; }
 // the four counters of node n as two 64-bit adds (counts stay below 2^31, so the low half never carries)
-__device__ __forceinline__ void add_node4(const GraphView& g, uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol, uint32_t a_r0) {
+__device__ __forceinline__ void add_node4(const GraphView& g, uint32_t n, uint32_t a_nc, uint32_t a_il, uint32_t a_ol, uint32_t a_r0, TouchedPtr t) {
   unsigned long long* p = reinterpret_cast<unsigned long long*>(g.cnt4 + 4 * size_t(n));
   const unsigned long long lo = a_nc | (static_cast<unsigned long long>(a_il) << 32);
   const unsigned long long hi = a_ol | (static_cast<unsigned long long>(a_r0) << 32);
   if (lo) atomicAdd(p, lo);
   if (hi) atomicAdd(p + 1, hi);
+  if (lo | hi) mark_touched(t, 4 * uint64_t(n));
+}
+// RC of adjacency slot s
+__device__ __forceinline__ void add_rc(const GraphView& g, uint32_t s, uint32_t v, TouchedPtr t) {
+  atomicAdd(&g.rc[s], v);
+  mark_touched(t, uint64_t(g.rc - g.cnt4) + s);
 }
 
 // the graph as the short walks of walk.h see it: one 8-byte gather per node
@@ -119,7 +148,8 @@ __device__ __forceinline__ uint32_t mix64(uint64_t k) {
 // treat as generic: it would emit flat_ instructions, and a flat access that MAY be outstanding makes every later
 // s_waitcnt in the kernel a vmcnt(0) -- which undoes the software pipeline of the walk loops.  Casting to the global
 // address space keeps them global_ instructions.
-#define PANTAS_GLOBAL_AS __attribute__((address_space(1)))
+// (PANTAS_GLOBAL_AS is defined further up, in front of mark_touched)
+
 
 // count += add, first = min(first, order) for `key`; inserts the key if absent.
 __device__ __forceinline__ void table_update(const TableView& t, uint64_t key, uint32_t add, uint64_t order) {
@@ -190,16 +220,17 @@ struct RareSink {
 struct MainSink {
   const GraphView& g;
   __device__ uint32_t node_word(uint32_t n) const { return g.word[n]; }
-  __device__ void nc(uint32_t n) const { atomicAdd(nc_of(g, n), 1u); }
+  __device__ void nc(uint32_t n) const { atomicAdd(nc_of(g, n), 1u); mark_touched(touched_of(g), 4 * uint64_t(n)); }
   __device__ void common(uint32_t n, uint32_t word, uint32_t side, uint32_t times, uint64_t order) const {
     atomicAdd(side == SIDE_IL ? il0_of(g, n) : oll_of(g, n), times);
+    mark_touched(touched_of(g), 4 * uint64_t(n));
     if (word & (side == SIDE_IL ? FLAG_IL : FLAG_OL)) table_update(g.slow->hist, hist_key(n, side, COMMON_POS), 0u, order);
   }
   __device__ void rare(uint32_t, uint32_t, int32_t, uint64_t) const {}
   __device__ void edge(uint32_t a, uint32_t b, uint64_t order) const {
     const uint32_t lo = g.row_ptr[a], hi = g.row_ptr[a + 1];
     for (uint32_t s = lo; s < hi; ++s) {
-      if (g.col[s] == b) { atomicAdd(&g.rc[s], 1u); return; }
+      if (g.col[s] == b) { add_rc(g, s, 1u, touched_of(g)); return; }
     }
     table_update(g.slow->novel, (uint64_t(a) << 32) | b, 1u, order);
   }
@@ -333,10 +364,15 @@ constexpr uint32_t LDS_EMPTY = 0xFFFFFFFFu;
 // 2048 * 31 < 65536.
 constexpr uint32_t PACKED_MAX_PATH = SHORT_MAX_PATH;
 
-template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, bool PACKED = false>
+// TRACK: the sink's counter updates mark the run's bitmap of touched blocks when one is kept (mark_touched).  false: no such code
+// at all -- the instance the position-parallel kernel runs when nobody asked for the bitmap (a run on one GPU): even never-taken,
+// the marking cost that kernel 1.7 % (profiles/r5_ab_s4_touched_marks.txt)
+template <uint32_t LOG_N, uint32_t LOG_S, uint32_t LOG_F, bool PACKED = false, bool TRACK = true>
 struct AggSink {
   static constexpr uint32_t CN = 1u << LOG_N, CS = 1u << LOG_S, CF = 1u << LOG_F, LOG_N_ = LOG_N;
+  static constexpr bool TRACK_ = TRACK;
   const GraphView& g;
+  __device__ __forceinline__ TouchedPtr touched() const { if constexpr (TRACK) return touched_of(g); else return nullptr; }
   uint32_t* nkey; uint32_t* ncnt;      // ncnt: [NC CN | IL0 CN | OLL CN | RC of the node's first out-slot CN]; PACKED: CN x u64 {NC, IL0, OLL, RC first slot}
   uint32_t* skey; uint32_t* scnt;
   uint32_t* fkey; unsigned long long* fmin;
@@ -423,7 +459,7 @@ struct AggSink {
                                      (static_cast<unsigned long long>(a_ol) << 32) | (static_cast<unsigned long long>(a_r0) << 48);
       atomicAdd(reinterpret_cast<unsigned long long*>(ncnt) + h, inc);
     } else {
-      add_node4(g, n, a_nc, a_il, a_ol, a_r0);
+      add_node4(g, n, a_nc, a_il, a_ol, a_r0, touched());
     }
   }
   // the same, plus the first-seen order of the common IL / OL key where the node is flagged: the line id alone decides
@@ -450,7 +486,7 @@ struct AggSink {
         }
       }
     } else {
-      add_node4(g, n, 1u, a_il, a_ol, a_r0);
+      add_node4(g, n, 1u, a_il, a_ol, a_r0, touched());
     }
     // a line with a '-' op has rare keys of its own on the nodes it flags: its common key needs the exact within-line
     // order, through the order table of the general walk
@@ -484,8 +520,8 @@ struct AggSink {
     if (g.ablate & 8u) return LDS_EMPTY;
     if constexpr (PACKED) {
       // general walk: steps above 1 bypass the 16-bit fields
-      if (a_il > 1u) { atomicAdd(il0_of(g, n), a_il); a_il = 0; }
-      if (a_ol > 1u) { atomicAdd(oll_of(g, n), a_ol); a_ol = 0; }
+      if (a_il > 1u) { atomicAdd(il0_of(g, n), a_il); a_il = 0; mark_touched(touched(), 4 * uint64_t(n)); }
+      if (a_ol > 1u) { atomicAdd(oll_of(g, n), a_ol); a_ol = 0; mark_touched(touched(), 4 * uint64_t(n)); }
       if (a_nc | a_il | a_ol) bump_packed(n, 0u, a_nc, a_il, a_ol, 0u);
       return LDS_EMPTY;
     }
@@ -495,7 +531,7 @@ struct AggSink {
       if (a_il) atomicAdd(&ncnt[CN + h], a_il);
       if (a_ol) atomicAdd(&ncnt[2u * CN + h], a_ol);
     } else {
-      add_node4(g, n, a_nc, a_il, a_ol, 0u);
+      add_node4(g, n, a_nc, a_il, a_ol, 0u, touched());
     }
     return h;
   }
@@ -506,7 +542,7 @@ struct AggSink {
     // the POINTER and emits one flat_atomic_add, and a flat access that may be outstanding turns the waits of the walk
     // loop into vmcnt(0)
     if (h != LDS_EMPTY) __hip_atomic_fetch_add(&scnt[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)g.rc + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else { __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)g.rc + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mark_touched(touched(), uint64_t(g.rc - g.cnt4) + s); }
   }
   __device__ __forceinline__ void order_min(uint32_t n, uint32_t side, uint64_t order) const {
     if (g.ablate & 1u) return;
@@ -554,8 +590,8 @@ struct AggSink {
         if (f_ol && line_id < uint32_t(cur >> 32)) atomicMin(&omin[2u * h + 1u], line_id);
       }
     } else {
-      add_node4(g, n, 1u, a_il, a_ol, code == 1u ? 1u : 0u);
-      if (code >= 2u) __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)g.rc + (g.row_ptr[n] + code - 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      add_node4(g, n, 1u, a_il, a_ol, code == 1u ? 1u : 0u, touched());
+      if (code >= 2u) { const uint32_t sl2 = g.row_ptr[n] + code - 1u; __hip_atomic_fetch_add((PANTAS_GLOBAL_AS uint32_t*)g.rc + sl2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mark_touched(touched(), uint64_t(g.rc - g.cnt4) + sl2); }
     }
     if (exact_order != 0 || h == LDS_EMPTY) {
       const uint64_t ord = exact_order != 0 ? exact_order : event_order(line_id, 0, 1);
@@ -718,6 +754,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       }
       __syncthreads();
     }
+    const TouchedPtr tb = touched_of(g);
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       const uint32_t n = nkey[i];
       if (n == LDS_EMPTY) continue;
@@ -728,7 +765,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
       } else {
         a = ncnt[i]; il = ncnt[CN + i]; ol = ncnt[2 * CN + i]; r0 = ncnt[3 * CN + i];
       }
-      add_node4(g, n, a, il, ol, r0);
+      add_node4(g, n, a, il, ol, r0, tb);
       if constexpr (INFO) {
         if (omin[2 * i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(omin[2 * i], 0, 1));
         if (omin[2 * i + 1] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(omin[2 * i + 1], 0, 1));
@@ -736,7 +773,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_main_agg_kernel(GraphVi
     }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
       const uint32_t s = skey[i];
-      if (s != LDS_EMPTY && scnt[i]) atomicAdd(&g.rc[s], scnt[i]);
+      if (s != LDS_EMPTY && scnt[i]) add_rc(g, s, scnt[i], tb);
     }
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) {
       const uint32_t k = fkey[i];
@@ -833,23 +870,24 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_w_kernel(GraphVie
       }
       __syncthreads();
     }
+    const TouchedPtr tb = touched_of(g);
     for (uint32_t i = threadIdx.x; i < CN; i += THREADS) {
       const uint32_t n = nkey[i];
       if (n == LDS_EMPTY) continue;
       const unsigned long long v = reinterpret_cast<const unsigned long long*>(ncnt)[i];
-      add_node4(g, n, uint32_t(v) & 0xFFFFu, uint32_t(v >> 16) & 0xFFFFu, uint32_t(v >> 32) & 0xFFFFu, uint32_t(v >> 48));
+      add_node4(g, n, uint32_t(v) & 0xFFFFu, uint32_t(v >> 16) & 0xFFFFu, uint32_t(v >> 32) & 0xFFFFu, uint32_t(v >> 48), tb);
       const uint32_t v2 = ncnt2[i];
       if (v2) {
         const uint32_t row = g.row_ptr[n];
-        if (v2 & 0xFFFFu) atomicAdd(&g.rc[row + 1u], v2 & 0xFFFFu);
-        if (v2 >> 16) atomicAdd(&g.rc[row + 2u], v2 >> 16);
+        if (v2 & 0xFFFFu) add_rc(g, row + 1u, v2 & 0xFFFFu, tb);
+        if (v2 >> 16) add_rc(g, row + 2u, v2 >> 16, tb);
       }
       if (omin[2 * i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(omin[2 * i], 0, 1));
       if (omin[2 * i + 1] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(omin[2 * i + 1], 0, 1));
     }
     for (uint32_t i = threadIdx.x; i < CS; i += THREADS) {
       const uint32_t sl = skey[i];
-      if (sl != LDS_EMPTY && scnt[i]) atomicAdd(&g.rc[sl], scnt[i]);
+      if (sl != LDS_EMPTY && scnt[i]) add_rc(g, sl, scnt[i], tb);
     }
     for (uint32_t i = threadIdx.x; i < CF; i += THREADS) {
       const uint32_t k = fkey[i];
@@ -903,23 +941,24 @@ __device__ __forceinline__ void chunk_tables_flush(const GraphView& g, const Sin
     }
     __syncthreads();
   }
+  const TouchedPtr tb = Sink::TRACK_ ? touched_of(g) : nullptr;
   for (uint32_t i = threadIdx.x; i < CN; i += threads) {
     const uint32_t n = k.nkey[i];
     if (n == LDS_EMPTY) continue;
     const unsigned long long v = reinterpret_cast<const unsigned long long*>(k.ncnt)[i];
-    add_node4(g, n, uint32_t(v) & 0xFFFFu, uint32_t(v >> 16) & 0xFFFFu, uint32_t(v >> 32) & 0xFFFFu, uint32_t(v >> 48));
+    add_node4(g, n, uint32_t(v) & 0xFFFFu, uint32_t(v >> 16) & 0xFFFFu, uint32_t(v >> 32) & 0xFFFFu, uint32_t(v >> 48), tb);
     const uint32_t v2 = k.ncnt2[i];
     if (v2) {
       const uint32_t row = g.row_ptr[n];
-      if (v2 & 0xFFFFu) atomicAdd(&g.rc[row + 1u], v2 & 0xFFFFu);
-      if (v2 >> 16) atomicAdd(&g.rc[row + 2u], v2 >> 16);
+      if (v2 & 0xFFFFu) add_rc(g, row + 1u, v2 & 0xFFFFu, tb);
+      if (v2 >> 16) add_rc(g, row + 2u, v2 >> 16, tb);
     }
     if (k.omin[2 * i] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_IL, COMMON_POS), 0u, event_order(k.omin[2 * i], 0, 1));
     if (k.omin[2 * i + 1] != ~0u) table_update(g.slow->hist, hist_key(n, SIDE_OL, COMMON_POS), 0u, event_order(k.omin[2 * i + 1], 0, 1));
   }
   for (uint32_t i = threadIdx.x; i < CS; i += threads) {
     const uint32_t sl = k.skey[i];
-    if (sl != LDS_EMPTY && k.scnt[i]) atomicAdd(&g.rc[sl], k.scnt[i]);
+    if (sl != LDS_EMPTY && k.scnt[i]) add_rc(g, sl, k.scnt[i], tb);
   }
   for (uint32_t i = threadIdx.x; i < CF; i += threads) {
     const uint32_t kk = k.fkey[i];
@@ -938,7 +977,7 @@ __global__ __launch_bounds__(THREADS, MINW) void augment_short_p_kernel(GraphVie
   // (the tile arrays are restrict pointers of their own: nothing the kernel writes aliases them, so the wave-uniform words are read
   // with scalar loads)
   constexpr uint32_t LOG_S = 8;
-  using Sink = AggSink<LOG_N, LOG_S, LOG_F, true>;
+  using Sink = AggSink<LOG_N, LOG_S, LOG_F, true, (OPT & 2048u) != 0u>;       // OPT 2048: the instance that keeps the bitmap of touched blocks
   constexpr uint32_t CN = Sink::CN, CF = Sink::CF, CS = Sink::CS, NW = THREADS / 64u;
   static_assert(CHUNK * PACKED_MAX_PATH < 65536u && CHUNK * (SHORT_MAX_PATH_INDEL + 2u) < 65536u, "a 16-bit field could overflow");
   __shared__ uint32_t skey[CS];
@@ -1300,13 +1339,18 @@ struct DeviceGraph {
   uint64_t hist_boost = 1;        // grown after a TableOverflow("hist") retry
   uint64_t imported_flags = 0;    // node flags received from other ranks this run
   uint64_t reserved_hist = 0;     // caller's bound on distinct IL/OL keys (sharded runs)
+  // the run's bitmap of touched counter blocks (SlowTables::touched): kept when a caller asked for it (read-sharded runs),
+  // valid when it has been kept since the counters were last zeroed
+  uint32_t* touched = nullptr;
+  uint64_t touched_words = 0;
+  bool track_touched = false, touched_valid = false;
   SlowTables* slow_dev = nullptr;   // device copy of {hist, novel, status}
   SlowTables slow_host{};           // what slow_dev holds
   // brings the device copy up to date (table pointers change when a table grows); ordered on `stream`
   TildeEntry* tilde_dev = nullptr;  // walk.h TildeCarry of the run (set_tilde_table), kept until the next one
   uint32_t tilde_n = 0;
   void sync_slow() {
-    SlowTables t{hist.v, novel.v, reinterpret_cast<unsigned long long*>(small), TildeCarry{tilde_dev, tilde_n}};
+    SlowTables t{hist.v, novel.v, reinterpret_cast<unsigned long long*>(small), TildeCarry{tilde_dev, tilde_n}, (track_touched && touched_valid) ? touched : nullptr};
     if (memcmp(&t, &slow_host, sizeof t) != 0) {
       slow_host = t;
       HIP_OK(hipMemcpyAsync(slow_dev, &slow_host, sizeof t, hipMemcpyHostToDevice, stream));
@@ -1624,6 +1668,20 @@ void set_tilde_table(DeviceGraph& d, const std::vector<TildeEntry>& tab) {
 void reset_counters(DeviceGraph& d) {
   HIP_OK(hipSetDevice(d.device));
   HIP_OK(hipMemsetAsync(d.counters, 0, (4 * size_t(d.V) + d.A) * 4, d.stream));
+  d.touched_valid = false;
+  if (d.track_touched) {
+    const uint64_t w = 4 * uint64_t(d.V) + d.A;
+    const uint64_t padded = std::max<uint64_t>(1, (w + COUNTER_PAD_WORDS - 1) / COUNTER_PAD_WORDS) * COUNTER_PAD_WORDS;
+    const uint64_t need = padded / (32ull * TOUCHED_BLOCK_WORDS);
+    if (need != d.touched_words) {
+      if (d.touched) (void)hipFree(d.touched);
+      d.touched = nullptr;
+      HIP_OK(dmalloc(&d.touched, need * 4));
+      d.touched_words = need;
+    }
+    HIP_OK(hipMemsetAsync(d.touched, 0, d.touched_words * 4, d.stream));
+    d.touched_valid = true;       // from here on every site that adds to a counter sets its block's bit
+  }
   HIP_OK(hipMemsetAsync(d.small, 0xFF, 8, d.stream));
   HIP_OK(hipMemsetAsync(d.small + 2, 0, 56, d.stream));
   table_clear(d.hist, d.stream);
@@ -2060,7 +2118,9 @@ static float launch_main_impl(DeviceGraph& d, DeviceBatch& b, bool wait) {
                 break;
               }
 #endif
-              default: PANTAS_P(0); break;
+              default:
+                if (d.track_touched && d.touched_valid) PANTAS_P(2048); else PANTAS_P(0);      // (2048: with the marking of touched counter blocks)
+                break;
             }
 #undef PANTAS_P
           }
@@ -2456,6 +2516,17 @@ void download_result(DeviceGraph& d, const Graph& g, AugmentResult& r) {
   pt.lap("sparse tables to the host");
   finalize_result(r);
   pt.lap("first-seen order of the sparse entries");
+}
+
+void set_track_touched(DeviceGraph& d, bool on) {
+  if (on == d.track_touched) return;
+  d.track_touched = on;
+  d.touched_valid = false;          // (kept from the next zeroing of the counters on)
+}
+TouchedBitmap touched_bitmap_of(DeviceGraph& d) {
+  TouchedBitmap t{};
+  if (d.track_touched && d.touched_valid) { t.bits = d.touched; t.words = d.touched_words; t.block_words = TOUCHED_BLOCK_WORDS; }
+  return t;
 }
 
 CounterPtrs counter_ptrs(DeviceGraph& d) {

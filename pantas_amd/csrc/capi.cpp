@@ -548,6 +548,13 @@ __attribute__((visibility("default"))) int pantas_augment_counters(pantas_graph*
   });
 }
 
+__attribute__((visibility("default"))) int pantas_augment_track_touched(pantas_graph* g, int on) {
+  return guarded([&] {
+    need_device(g);
+    set_track_touched(*g->dev, on != 0);
+  });
+}
+
 __attribute__((visibility("default"))) int pantas_counters_bitmap(pantas_graph* g, uint32_t block_words, void** dev_bitmap, uint64_t* bitmap_words) {
   return guarded([&] {
     need_device(g);

@@ -34,6 +34,7 @@ struct CounterExchange {
   size_t scan_tmp_bytes = 0;
   uint4* staging = nullptr;
   uint64_t staging_blocks = 0;
+  bool from_kernels = false;     // the last bitmap was the one the kernels kept (folded), not a pass over the counters
   ScratchPool* pool = nullptr;
   void drop() {
     for (void* p : {(void*)bitmap, (void*)uni, (void*)cnt, (void*)off, scan_tmp, (void*)staging})
@@ -101,6 +102,33 @@ __global__ __launch_bounds__(256) void move_blocks_kernel(uint4* __restrict__ c,
   }
 }
 
+// the kernels' own bitmap (one bit per `fine` counters) as the exchange's (one bit per fine * FOLD counters): a bit is the OR of FOLD
+template <uint32_t FOLD>
+__global__ __launch_bounds__(256) void fold_bitmap_kernel(const uint32_t* __restrict__ fine, uint64_t fine_words, uint64_t out_words, uint32_t* __restrict__ out) {
+  for (uint64_t w = uint64_t(blockIdx.x) * 256u + threadIdx.x; w < out_words; w += uint64_t(gridDim.x) * 256u) {
+    uint32_t r = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < FOLD; ++k) {
+      const uint64_t i = w * FOLD + k;
+      uint32_t x = i < fine_words ? fine[i] : 0u;
+      // OR of every group of FOLD neighbouring bits, gathered into 32 / FOLD bits
+#pragma unroll
+      for (uint32_t s = 1; s < FOLD; s <<= 1) x |= x >> s;
+      uint32_t packed = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 32u / FOLD; ++j) packed |= ((x >> (j * FOLD)) & 1u) << j;
+      r |= packed << (k * (32u / FOLD));
+    }
+    out[w] = r;
+  }
+}
+// bits of `want` that `have` lacks (PANTAS_EXCHANGE_VERIFY)
+__global__ __launch_bounds__(256) void missing_bits_kernel(const uint32_t* __restrict__ want, const uint32_t* __restrict__ have, uint64_t words, unsigned long long* __restrict__ missing) {
+  unsigned long long n = 0;
+  for (uint64_t w = uint64_t(blockIdx.x) * 256u + threadIdx.x; w < words; w += uint64_t(gridDim.x) * 256u) n += __popc(want[w] & ~have[w]);
+  if (n) atomicAdd(missing, n);
+}
+
 uint32_t grid_for(uint64_t items, uint32_t cap = 1u << 20) { return uint32_t(std::min<uint64_t>((items + 255) / 256, cap)); }
 
 }  // namespace
@@ -124,13 +152,48 @@ void exchange_bitmap(DeviceGraph& dg, CounterExchangePtr& xp, uint32_t block_wor
   const uint64_t waves_needed = x.bitmap_words;
   const uint32_t blocks = uint32_t(std::min<uint64_t>((waves_needed + 3) / 4, 1u << 16));
   const uint4* c = static_cast<const uint4*>(cp.base);
-  switch (x.group) {
-    case 2: hipLaunchKernelGGL(touched_bitmap_kernel<2>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, x.bitmap); break;
-    case 4: hipLaunchKernelGGL(touched_bitmap_kernel<4>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, x.bitmap); break;
-    case 8: hipLaunchKernelGGL(touched_bitmap_kernel<8>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, x.bitmap); break;
-    default: hipLaunchKernelGGL(touched_bitmap_kernel<16>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, x.bitmap); break;
+  auto by_reading_the_counters = [&](uint32_t* out) {
+    switch (x.group) {
+      case 2: hipLaunchKernelGGL(touched_bitmap_kernel<2>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, out); break;
+      case 4: hipLaunchKernelGGL(touched_bitmap_kernel<4>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, out); break;
+      case 8: hipLaunchKernelGGL(touched_bitmap_kernel<8>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, out); break;
+      default: hipLaunchKernelGGL(touched_bitmap_kernel<16>, dim3(blocks), dim3(256), 0, gi.stream, c, x.bitmap_words, out); break;
+    }
+    HIP_OK(hipGetLastError());
+  };
+  // Round 5: when the kernels kept the bitmap themselves (augment.h set_track_touched) it is only folded to this exchange's block
+  // size -- 20 MB read instead of the 5 GB of counters of a whole-genome graph (0.94 ms per replicate).  A kept bitmap may hold a
+  // block whose counters are all zero (a flushed zero): harmless, the block is summed like any other.  PANTAS_EXCHANGE_VERIFY=1 also
+  // reads the counters and refuses to go on when a non-zero block is missing from the kept bitmap -- a counter update site that
+  // does not mark would otherwise be a silently wrong sum.
+  const TouchedBitmap kept = touched_bitmap_of(dg);
+  x.from_kernels = kept.bits != nullptr;
+  if (kept.bits) {
+    const uint32_t fold = block_words / kept.block_words;
+    const uint32_t fb = grid_for(x.bitmap_words, 4096);
+    switch (fold) {
+      case 1: hipLaunchKernelGGL(fold_bitmap_kernel<1>, dim3(fb), dim3(256), 0, gi.stream, kept.bits, kept.words, x.bitmap_words, x.bitmap); break;
+      case 2: hipLaunchKernelGGL(fold_bitmap_kernel<2>, dim3(fb), dim3(256), 0, gi.stream, kept.bits, kept.words, x.bitmap_words, x.bitmap); break;
+      case 4: hipLaunchKernelGGL(fold_bitmap_kernel<4>, dim3(fb), dim3(256), 0, gi.stream, kept.bits, kept.words, x.bitmap_words, x.bitmap); break;
+      default: hipLaunchKernelGGL(fold_bitmap_kernel<8>, dim3(fb), dim3(256), 0, gi.stream, kept.bits, kept.words, x.bitmap_words, x.bitmap); break;
+    }
+    HIP_OK(hipGetLastError());
+    if (const char* v = getenv("PANTAS_EXCHANGE_VERIFY"); v && atoi(v) != 0) {
+      uint32_t* check = static_cast<uint32_t*>(x.pool->take(x.bitmap_words * 4));
+      unsigned long long* missing = static_cast<unsigned long long*>(x.pool->take(8));
+      HIP_OK(hipMemsetAsync(missing, 0, 8, gi.stream));
+      by_reading_the_counters(check);
+      hipLaunchKernelGGL(missing_bits_kernel, dim3(grid_for(x.bitmap_words, 4096)), dim3(256), 0, gi.stream, check, x.bitmap, x.bitmap_words, missing);
+      HIP_OK(hipGetLastError());
+      unsigned long long m = 0;
+      HIP_OK(hipMemcpyAsync(&m, missing, 8, hipMemcpyDeviceToHost, gi.stream));
+      HIP_OK(hipStreamSynchronize(gi.stream));
+      x.pool->give(check); x.pool->give(missing);
+      if (m) throw Error("InternalError", std::to_string(m) + " counter blocks hold counts but are missing from the bitmap the kernels kept (a counter update site that does not mark)");
+    }
+  } else {
+    by_reading_the_counters(x.bitmap);
   }
-  HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(gi.stream));     // the caller's collective runs on another stream
   *dev_bitmap = x.bitmap;
   *bitmap_words = x.bitmap_words;

@@ -38,6 +38,10 @@ class LibBackend:
             self.g.to_device(device)
         else:
             self.g = Graph(gfa_path, cache=cache).to_device(device)
+        # a read-sharded run ends with the exchange of the touched counter blocks: the kernels keep that bitmap themselves
+        # (PANTAS_TRACK_TOUCHED=0: the exchange reads the counters to find the blocks, as until round 4)
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1 and os.environ.get("PANTAS_TRACK_TOUCHED", "1") != "0":
+            self.g.track_touched(True)
         self.g.augment_reset()
         self.batch = None
 

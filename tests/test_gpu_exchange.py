@@ -102,6 +102,61 @@ def test_block_sparse_sum_equals_dense():
     assert out.strip().endswith("ok"), out
 
 
+TRACKED = r"""
+import ctypes as C, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, ROOT)
+from pantas_amd.engine import Graph, Synth
+torch.cuda.set_device(0)
+os.environ["PANTAS_EXCHANGE_VERIFY"] = "1"        # touched_bitmap also reads the counters and refuses a kept bitmap that misses a block
+syn = Synth(p_two_indels=0.1, **PARAMS)            # (records of the general-walk class among them)
+plain, kept = Graph(text=syn.gfa).to_device(0), Graph(text=syn.gfa).to_device(0)
+kept.track_touched(True)
+for variant in ("120", "110", "101", "0"):
+    os.environ["PANTAS_MAIN_KERNEL"] = variant
+    out = []
+    for g in (plain, kept):
+        g.augment_reset()
+        b = g.load_gaf_mem(syn.gaf)
+        g.launch(b)
+        g.launch(b)
+        out.append(b)
+    cp, ck = plain.counters_tensor(0), kept.counters_tensor(0)
+    assert torch.equal(cp.cpu(), ck.cpu())                  # marking changes no counter
+    for block in (8, 16, 32, 64):
+        a = np.unpackbits(plain.touched_bitmap(block, 0).cpu().numpy().view(np.uint8), bitorder="little").astype(bool)    # by reading the counters
+        k = np.unpackbits(kept.touched_bitmap(block, 0).cpu().numpy().view(np.uint8), bitorder="little").astype(bool)     # the kernels' own, folded
+        assert not (a & ~k).any(), (variant, block)          # every block that holds a count is in the kept bitmap ...
+        assert k.sum() <= a.sum() * 1.02 + 8, (variant, block, int(a.sum()), int(k.sum()))      # ... and hardly anything else
+        # and the exchange built on it leaves the same counters: one "rank", pack + unpack
+        st = kept.counters_pack(kept.touched_bitmap(block, 0), 1, 0)
+        assert st.numel() > 0
+        kept.counters_unpack()
+        assert torch.equal(kept.counters_tensor(0).cpu(), cp.cpu())
+    print("variant", variant, "ok")
+    del out
+# tracking asked for in the middle of a run only starts at the next reset: until then the counters are read
+late = Graph(text=syn.gfa).to_device(0)
+late.augment_reset()
+b = late.load_gaf_mem(syn.gaf)
+late.launch(b)
+late.track_touched(True)
+late.launch(b)
+a = late.touched_bitmap(16, 0).cpu()
+late.augment_reset(); b = late.load_gaf_mem(syn.gaf); late.launch(b); late.launch(b)
+assert torch.equal(a, late.touched_bitmap(16, 0).cpu())
+print("ok")
+"""
+
+
+def test_bitmap_kept_by_the_kernels_covers_every_touched_block():
+    """round 5 (pantas_augment_track_touched): every site of every main-kernel variant that adds to a counter sets its block's bit --
+    checked against the bitmap made by reading the counters, at every block size, with the library's own cross-check switched on"""
+    out = run_child(f"ROOT = {ROOT!r}\nPARAMS = {PARAMS!r}\n" + TRACKED)
+    assert out.strip().endswith("ok"), out
+
+
 def test_allreduce_counters_one_rank_rccl(tmp_path):
     """the product's exchange routine over a real RCCL communicator (one rank: the sum is the identity)"""
     code = f"""
