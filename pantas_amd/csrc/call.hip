@@ -349,6 +349,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.probe = up(*d, t.probe); c.probe_ok = up(*d, t.probe_ok);
   d->status = dalloc<unsigned long long>(*d, 1);
   d->arena = dalloc<uint32_t>(*d, size_t(ARENA_SLOTS) * ARENA_CAP);
+  HIP_OK(hipMemsetAsync(d->arena, 0, size_t(ARENA_SLOTS) * ARENA_CAP * 4, d->stream));      // (word 0 of a slice: held or free; a search gives its slice back)
   d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
   build_walk_runs(*d, c);

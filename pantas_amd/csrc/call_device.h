@@ -102,11 +102,26 @@ struct CallView {
   uint32_t arena_slots, arena_cap;
 };
 
-PANTAS_HD uint32_t claim_slice(uint32_t* counter) {
+// Overflow room of the intronic search: `slots` slices of `cap` words; word 0 of a slice says whether a lane holds it (round 5:
+// a slice goes back when its search is over -- level order makes many more searches outgrow their registers than the 4 096 slices
+// a pass used to hand out once and for all).  Returns the slice, or `slots` when a whole round of them was busy.
+PANTAS_HD uint32_t claim_slice(uint32_t* counter, uint32_t* arena, uint32_t slots, uint32_t cap) {
+  for (uint32_t tries = 0; tries < slots; ++tries) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return atomicAdd(counter, 1u);
+    const uint32_t s = atomicAdd(counter, 1u) % slots;
+    if (atomicCAS(arena + size_t(s) * cap, 0u, 1u) == 0u) return s;
 #else
-  return (*counter)++;
+    const uint32_t s = (*counter)++ % slots;
+    if (arena[size_t(s) * cap] == 0u) { arena[size_t(s) * cap] = 1u; return s; }
+#endif
+  }
+  return slots;
+}
+PANTAS_HD void release_slice(uint32_t* arena, uint32_t slice, uint32_t cap) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicExch(arena + size_t(slice) * cap, 0u);
+#else
+  arena[size_t(slice) * cap] = 0u;
 #endif
 }
 
@@ -285,7 +300,7 @@ PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit
 // [:734-750, :787-803] level-bounded frontier search; pop() takes the members of a level, in GFA order, before anything the
 // level adds, the hit is the target that comes first in the GFA (rule R3).  dir 0: follow out-links from `start`, targets = {n : (anchor, n) junction};
 // dir 1: follow in-links, targets = {p : (p, anchor) junction}.
-constexpr uint32_t FRONTIER_LOCAL = 24;
+constexpr uint32_t FRONTIER_LOCAL = 64;
 constexpr uint32_t FRONTIER_TARGETS = 8;
 PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t anchor, uint32_t dir, Fault& f) {
   // The targets -- the other ends of the anchor's junction links -- are a handful: taken from the anchor's own row (dir 0) or
@@ -312,62 +327,86 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
     for (uint32_t i = 0; i < FRONTIER_TARGETS; ++i) hit |= i < n_tg && tg[i] == x;
     return hit;
   };
+  // Rule R3 (round 5: level order).  The reference's `visit` is kept as two stretches of one buffer: lev[0 .. nl), the members the
+  // set held when the level began -- its `pvisitl` of them -- sorted by node index and popped in that order, and behind them
+  // nxt[0 .. nn), what the pops of this level add, APPENDED as it comes (a node may stand there more than once).  A node that is
+  // added while it still waits in lev is in the set already and changes nothing; one that was popped and is added again belongs to
+  // the next level, like everything else in nxt.  When the level's last member has been popped, nxt is sorted, made unique and
+  // becomes lev.  (Until the first form of this round the set was ONE sorted array: every insertion shifted half of it, and
+  // level order -- unlike the depth-first pop it replaced, which left a wide frontier quickly -- expands whole levels: a search that
+  // meets a segment with thousands of links added by reads cost n^2 moves; 200 M reads: the novel-link pass 0.75 s instead of 0.2.)
   uint32_t local[FRONTIER_LOCAL];
-  uint32_t* vis = local;      // sorted set of node indices; moves to an arena slice when it outgrows `local`
+  uint32_t* buf = local;      // moves to an arena slice when it outgrows `local`
   uint32_t cap = FRONTIER_LOCAL;
-  uint32_t n = 1;
-  // Rule R3 (round 5: level order): the members the set held when the level began -- the reference's `pvisitl` of them --
-  // carry FRONTIER_LEVEL and are popped in ascending order before anything added since (a node popped and added again comes
-  // back without the bit: it belongs to the next level).  Node indices stay below 2^31 (the loader refuses more).
-  constexpr uint32_t FRONTIER_LEVEL = 0x80000000u;
-  vis[0] = start | FRONTIER_LEVEL;
-  // the first member of the (sorted) set that is a target = the smallest target in it; members only leave by the pop below,
-  // which is not reached while there is one
+  struct Held {               // the slice goes back wherever the search ends
+    uint32_t* arena; uint32_t slice, cap;
+    PANTAS_HD ~Held() { if (slice != CNONE) release_slice(arena, slice, cap); }
+  } held{c.arena, CNONE, c.arena_cap};
+  uint32_t nl = 1, nn = 0, pos = 0;
+  buf[0] = start;
+  // the smallest target that has entered the set; members only leave by the pop below, which is not reached while there is one
   uint32_t tmin = is_target(start) ? start : CNONE;
-  int32_t left = 1;          // members with the bit
   int32_t level = 0;
-  uint32_t cur = 0;          // nothing in front of `cur` carries the bit
+  // nxt in place: heapsort, then unique; returns the new count
+  auto sort_unique = [&](uint32_t* a, uint32_t m) -> uint32_t {
+    if (m < 2u) return m;
+    auto sift = [&](uint32_t root, uint32_t size) {
+      const uint32_t v = a[root];
+      for (;;) {
+        uint32_t ch = 2u * root + 1u;
+        if (ch >= size) break;
+        if (ch + 1u < size && a[ch + 1u] > a[ch]) ++ch;
+        if (a[ch] <= v) break;
+        a[root] = a[ch];
+        root = ch;
+      }
+      a[root] = v;
+    };
+    for (uint32_t i = m / 2u; i-- > 0u;) sift(i, m);
+    for (uint32_t size = m; size-- > 1u;) { const uint32_t t = a[0]; a[0] = a[size]; a[size] = t; sift(0u, size); }
+    uint32_t k = 1;
+    for (uint32_t i = 1; i < m; ++i) if (a[i] != a[k - 1u]) a[k++] = a[i];
+    return k;
+  };
   for (;;) {
     if (tmin != CNONE) return level < c.isw ? tmin : CNONE;
     if (level >= c.isw) return CNONE;
-    if (n == 0) return CNONE;
-    while (!(vis[cur] & FRONTIER_LEVEL)) ++cur;
-    const uint32_t x = vis[cur] & ~FRONTIER_LEVEL;
-    for (uint32_t i = cur + 1; i < n; ++i) vis[i - 1] = vis[i];
-    --n;
-    --left;
+    if (pos == nl) {
+      // the level is through: what it added is the next one
+      const uint32_t m = sort_unique(buf + nl, nn);
+      if (m == 0u) return CNONE;                                // (the set is empty)
+      for (uint32_t i = 0; i < m; ++i) buf[i] = buf[nl + i];
+      nl = m; nn = 0; pos = 0;
+    }
+    const uint32_t x = buf[pos++];
     const uint32_t b = dir == 0 ? c.row_ptr[x] : c.irow_ptr[x];
     const uint32_t e = dir == 0 ? c.row_ptr[x + 1] : c.irow_ptr[x + 1];
     for (uint32_t s = b; s < e; ++s) {
       const uint32_t y = dir == 0 ? c.col[s] : c.icol[s];
-      // binary search for the insertion point
-      uint32_t lo = 0, hi = n;
+      // still waiting in lev (behind pos): in the set already
+      uint32_t lo = pos, hi = nl;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((vis[mid] & ~FRONTIER_LEVEL) < y) lo = mid + 1; else hi = mid;
+        if (buf[mid] < y) lo = mid + 1; else hi = mid;
       }
-      if (lo < n && (vis[lo] & ~FRONTIER_LEVEL) == y) continue;
-      if (n == cap) {
-        if (vis != local || c.arena == nullptr) { f.raise(CE_FRONTIER); return CNONE; }
-        const uint32_t slice = claim_slice(c.arena_next);
-        if (slice >= c.arena_slots) { f.raise(CE_FRONTIER); return CNONE; }
-        uint32_t* big = c.arena + size_t(slice) * c.arena_cap;
-        for (uint32_t i = 0; i < n; ++i) big[i] = vis[i];
-        vis = big;
-        cap = c.arena_cap;
+      if (lo < nl && buf[lo] == y) continue;
+      if (nl + nn == cap) {
+        nn = sort_unique(buf + nl, nn);                         // copies of one node give their room back first
+        if (nl + nn == cap) {
+          if (buf != local || c.arena == nullptr) { f.raise(CE_FRONTIER); return CNONE; }
+          const uint32_t slice = claim_slice(c.arena_next, c.arena, c.arena_slots, c.arena_cap);
+          if (slice >= c.arena_slots) { f.raise(CE_FRONTIER); return CNONE; }
+          held.slice = slice;
+          uint32_t* big = c.arena + size_t(slice) * c.arena_cap + 1u;      // (word 0 is the slice's flag)
+          for (uint32_t i = 0; i < nl + nn; ++i) big[i] = buf[i];
+          buf = big;
+          cap = c.arena_cap - 1u;
+        }
       }
-      for (uint32_t i = n; i > lo; --i) vis[i] = vis[i - 1];
-      vis[lo] = y;
-      ++n;
-      if (lo <= cur) ++cur;
+      buf[nl + nn++] = y;
       if (y < tmin && is_target(y)) tmin = y;
     }
-    if (left == 0) {
-      ++level;
-      left = int32_t(n);
-      cur = 0;
-      for (uint32_t i = 0; i < n; ++i) vis[i] |= FRONTIER_LEVEL;
-    }
+    if (pos == nl) ++level;            // the reference counts the level when its last member has been popped [:746-749]
   }
 }
 

@@ -93,9 +93,9 @@ def test_fast_form_on_mutated_plain_lines(tokenize_sim, tmp_path):
     rng = random.Random(5)
     alphabet = "\t\t\t  >><<**::++--==~~0123456789acgtZsdvf.c_"
     taken = 0
-    for trial in range(40):
+    for trial in range(12):         # (the round's campaign ran 40 x 120 lines here and 3 000 fuzzed files beside: no difference)
         out_lines = []
-        for l in rng.sample(lines, 120):
+        for l in rng.sample(lines, 100):
             for _ in range(rng.choice([1, 1, 2])):
                 at = rng.randrange(len(l) + 1)
                 kind = rng.random()
@@ -112,5 +112,5 @@ def test_fast_form_on_mutated_plain_lines(tokenize_sim, tmp_path):
                 f.write(l + "\n" + "\n".join(lines[k * 3:k * 3 + 3]) + "\n")
             out = run(tokenize_sim, pre + ".m.gaf", pre + ".gfa")
             taken += int(out.split("fast=")[1])
-    assert taken > 10000        # (most mutations leave a line plain, or touch a free-text column)
+    assert taken > 2500         # (most mutations leave a line plain, or touch a free-text column)
 
