@@ -266,13 +266,16 @@ static T* dalloc(DeviceCall& d, size_t n) {
 
 // ---- the intron walks' runs (call_device.h CallView::run_end_rev / pl / pnc), made on the device from the arrays that are there:
 // a whole-genome graph has 2.5e8 segments, and the host has the command line's wall time to lose
-__global__ __launch_bounds__(256) void run_breaks_kernel(uint32_t V, const uint32_t* nxt1, const uint32_t* nflags, uint32_t* key_rev, uint32_t* no_nc) {
-  uint32_t missing = 0;
+// no_nc[0]: segments without an NC tag; no_nc[1]: places where the names' string order is not the S-line order
+__global__ __launch_bounds__(256) void run_breaks_kernel(uint32_t V, const uint32_t* nxt1, const uint32_t* nflags, const uint32_t* rank, uint32_t* key_rev, uint32_t* no_nc) {
+  uint32_t missing = 0, descents = 0;
   for (uint32_t n = blockIdx.x * 256u + threadIdx.x; n < V; n += gridDim.x * 256u) {
     key_rev[V - 1u - n] = nxt1[n] != n + 1u ? n : 0xFFFFFFFFu;        // (the last segment always ends its run: nxt1 < V)
     missing += (nflags[n] & N_HAS_NC) ? 0u : 1u;
+    descents += (n + 1u < V && rank[n + 1u] <= rank[n]) ? 1u : 0u;
   }
-  if (__ballot(missing != 0u) && missing) atomicAdd(no_nc, missing);
+  if (missing) atomicAdd(no_nc, missing);
+  if (descents) atomicAdd(no_nc + 1, descents);
 }
 __global__ void run_totals_kernel(uint32_t V, const uint32_t* ln, const int32_t* nc, uint64_t* pl, uint64_t* pnc) {
   pl[V] = pl[V - 1u] + ln[V - 1u];
@@ -282,17 +285,19 @@ struct U32To64 { __host__ __device__ uint64_t operator()(uint32_t x) const { ret
 struct I32To64 { __host__ __device__ uint64_t operator()(int32_t x) const { return uint64_t(uint32_t(x)); } };    // (counts are below 2^31)
 
 static void build_walk_runs(DeviceCall& d, CallView& c) {
-  c.run_end_rev = nullptr; c.pl = nullptr; c.pnc = nullptr;
+  c.run_end_rev = nullptr; c.pl = nullptr; c.pnc = nullptr; c.rank_monotone = 0;
   const uint32_t V = c.V;
   if (V == 0 || getenv("PANTAS_CALL_NO_RUNS")) return;
   uint32_t* key = dalloc<uint32_t>(d, V);
-  uint32_t* no_nc = dalloc<uint32_t>(d, 1);
-  HIP_OK(hipMemsetAsync(no_nc, 0, 4, d.stream));
-  hipLaunchKernelGGL(run_breaks_kernel, dim3(uint32_t(std::min<uint64_t>((uint64_t(V) + 255) / 256, 1u << 16))), dim3(256), 0, d.stream, V, c.nxt1, c.nflags, key, no_nc);
+  uint32_t* no_nc = dalloc<uint32_t>(d, 2);
+  HIP_OK(hipMemsetAsync(no_nc, 0, 8, d.stream));
+  hipLaunchKernelGGL(run_breaks_kernel, dim3(uint32_t(std::min<uint64_t>((uint64_t(V) + 255) / 256, 1u << 16))), dim3(256), 0, d.stream, V, c.nxt1, c.nflags, c.rank, key, no_nc);
   HIP_OK(hipGetLastError());
-  uint32_t missing = 0;
-  HIP_OK(hipMemcpyAsync(&missing, no_nc, 4, hipMemcpyDeviceToHost, d.stream));
+  uint32_t counts[2] = {0, 0};
+  HIP_OK(hipMemcpyAsync(counts, no_nc, 8, hipMemcpyDeviceToHost, d.stream));
   HIP_OK(hipStreamSynchronize(d.stream));
+  const uint32_t missing = counts[0];
+  c.rank_monotone = counts[1] == 0 ? 1u : 0u;
   if (missing) return;         // a segment without NC: the walks step through it one by one (and raise KeyError when a row needs its NC)
   uint64_t* pl = dalloc<uint64_t>(d, size_t(V) + 1);
   uint64_t* pnc = dalloc<uint64_t>(d, size_t(V) + 1);

@@ -82,6 +82,8 @@ struct CallView {
   const uint32_t* run_end_rev;  // [V] at V - 1 - n: the first segment m >= n with nxt1[m] != m + 1 (n .. m is walked in one step)
   const uint64_t* pl;           // [V + 1] sums of ln[0 .. n)
   const uint64_t* pnc;          // [V + 1] sums of nc[0 .. n); the three are only offered when EVERY segment has an NC tag
+  uint32_t rank_monotone;       // the names' string order is the order of the S lines (rank[n] < rank[n + 1] throughout): what lets the
+                                // greedy walk, whose step asks "name <= v's name", take a run as well
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
   // JN data hangs off the junction links only (5e5 of 2.6e8 slots at whole-genome scale): jrow[s] = ordinal of slot s
   // among the junction slots or CNONE, the four offset arrays are per junction ordinal (+ 1)
@@ -274,6 +276,24 @@ PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit
     if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;
     if (cur == v) return true;
     if (cur != u) ln_inner += c.ln[cur];
+    if (c.run_end_rev && c.rank_monotone && n_path > 1u && cur != u && v > cur) {
+      // Round 5, the run that begins at cur in one step (see walk_exon).  A segment x of the run has ONE out-neighbour, x + 1: the
+      // greedy rule goes to v when that is v, and else takes it -- it is no later than v by name (string order = S-line order here,
+      // and x + 1 < v), it has an out-neighbour itself (it is inside the run) and an NC tag (all segments have).  The step INTO the
+      // run's last segment m is left to the rule below: m may be a dead end.
+      const uint32_t m = c.run_end_rev[c.V - 1u - cur];
+      const uint32_t last = v <= m ? v : (m > cur ? m - 1u : cur);
+      if (last > cur) {
+        if (emit) emit->push_range(cur + 1u, last);
+        n_path += last - cur;
+        nc_sum += c.pnc[last + 1u] - c.pnc[cur + 1u];
+        ln_inner += c.pl[last == v ? v : last + 1u] - c.pl[cur + 1u];       // (v itself is no inner segment)
+        if (guard <= last - cur) { f.raise(CE_HANG); return false; }
+        guard -= last - cur;
+        cur = last;
+        if (cur == v) return true;
+      }
+    }
     const uint32_t b = c.row_ptr[cur], e = c.row_ptr[cur + 1];
     uint32_t occ = 0;
     for (uint32_t s = b; s < e; ++s) occ += (c.col[s] == v) ? 1u : 0u;

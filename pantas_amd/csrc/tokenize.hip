@@ -542,14 +542,26 @@ __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned
   __shared__ uint32_t s_slot[TPB], s_k[TPB], s_noff[TPB + 1], s_ooff[TPB + 1];
   __shared__ uint32_t s_tpos[TPB];       // tile * 64 + first lane of the record (0xFFFFFFFF: no tile)
   __shared__ uint8_t s_ord[TPB];         // the record's ordinal in its tile
+  // Round 5: the first GATHER_STAGE words of every record are read ONCE, by the record's own lane, into LDS (a record of the synthetic
+  // workloads is 14 words: header 6, six path nodes, two ops), and the word-wise moves below take them from there.  The records stand at
+  // random places of an array as large as the text: read three times -- header, then node and op words one by one, then again for the
+  // op summary -- every record dragged its one or two 128-byte lines from memory again and again (24 GB of read requests for 2.8 GB of
+  // records by the L2's counters); what a workgroup's 256 records touch is 32 KB, more than its share of an L2 that 128 workgroups use.
+  constexpr uint32_t GATHER_STAGE = 16, GATHER_STRIDE = GATHER_STAGE + 1u;     // (the odd stride spreads the lanes' rows over the banks)
+  __shared__ uint32_t s_rec[TPB * GATHER_STRIDE];
   const uint32_t r0 = blockIdx.x * TPB, t = threadIdx.x, i = r0 + t;
   const uint32_t cnt = min(TPB, n - r0);
   uint32_t slot = 0, k = 0, c = 0, flags = 0;
   if (t < cnt) {
     slot = uint32_t(val[i] & 0xFFFFFFFFull);
     const uint32_t* w = prov + slot;
-    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-    flags = w[3]; k = w[4]; c = w[5];
+    uint32_t head[GATHER_STAGE];
+#pragma unroll
+    for (uint32_t j = 0; j < GATHER_STAGE; ++j) head[j] = w[j];       // (behind a short record: words of the next line's room, or of the arena, or of the sixteen spare words behind it)
+#pragma unroll
+    for (uint32_t j = 0; j < GATHER_STAGE; ++j) s_rec[t * GATHER_STRIDE + j] = head[j];
+    const uint32_t w0 = head[0], w1 = head[1], w2 = head[2];
+    flags = head[3]; k = head[4]; c = head[5];
     hdr[i] = LineHdr{int32_t(w0), int32_t(w1), w2, flags};
     s_slot[t] = slot;
     s_k[t] = k;
@@ -577,18 +589,20 @@ __global__ void __launch_bounds__(TPB) gather2_kernel(uint32_t n, const unsigned
   };
   for (uint32_t p = s_noff[0] + t; p < s_noff[cnt]; p += TPB) {
     const uint32_t r = owner(s_noff, p), j = p - s_noff[r];
-    const uint32_t id = prov[s_slot[r] + PROV_HDR + j];
+    const uint32_t id = PROV_HDR + j < GATHER_STAGE ? s_rec[r * GATHER_STRIDE + PROV_HDR + j] : prov[s_slot[r] + PROV_HDR + j];
     nodes[p] = id;
     const uint32_t tpos = s_tpos[r];
     if (tpos != 0xFFFFFFFFu) { to.pnodes[size_t(tpos) + j] = id; to.pmeta[size_t(tpos) + j] = uint16_t(pos_meta(j, s_k[r], s_ord[r])); }
   }
   for (uint32_t p = s_ooff[0] + t; p < s_ooff[cnt]; p += TPB) {
-    const uint32_t r = owner(s_ooff, p);
-    ops[p] = prov[s_slot[r] + PROV_HDR + s_k[r] + (p - s_ooff[r])];
+    const uint32_t r = owner(s_ooff, p), q = PROV_HDR + s_k[r] + (p - s_ooff[r]);
+    ops[p] = q < GATHER_STAGE ? s_rec[r * GATHER_STRIDE + q] : prov[s_slot[r] + q];
   }
   if (t < cnt) {
     if (flags & LINE_HAS_DEL) del_idx[del_scan[i]] = i;
-    const uint32_t* w = prov + slot;
+    // (a record that fits the staged words is read from them; a longer one from the array)
+    const bool staged = PROV_HDR + k + c <= GATHER_STAGE;
+    const uint32_t* w = staged ? s_rec + t * GATHER_STRIDE : prov + slot;
     ShortOps so;
     make_rec_entry(rec, i, s_noff[t], k, s_ooff[t], c, w + PROV_HDR, w + PROV_HDR + k, &so);
     const uint32_t tpos = s_tpos[t];
@@ -862,7 +876,7 @@ static DeviceBatchPtr tokenize_one_pass(const DeviceGraphInfo& gi, ScratchPool& 
   if (bits > 30 || prov_words + arena_words >= 0xFFFFFFF0ull || n_lines == 0) return nullptr;
   double t0 = now();
   DevBuf prov(pool), key(pool), val(pool), key2(pool), val2(pool), partial(pool), small(pool), sort_tmp(pool);
-  prov.alloc((prov_words + arena_words) * 4);
+  prov.alloc((prov_words + arena_words + 16) * 4);      // (+ 16: the gather reads sixteen words from every record's start, also the arena's last)
   key.alloc(size_t(n_lines) * 4); val.alloc(size_t(n_lines) * 8);
   // as many single-wave workgroups as the GPU holds at once (a grid that needs a second round of them waits for the first: 4096
   // workgroups where 3328 fit took 39 ms instead of 27), each walking groups of 64 lines

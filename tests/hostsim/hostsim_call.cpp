@@ -115,6 +115,8 @@ int main(int argc, char** argv) {
         }
         for (uint32_t n = 0; n < c.V; ++n) { pl[n + 1] = pl[n] + c.ln[n]; pnc[n + 1] = pnc[n] + uint64_t(uint32_t(c.nc[n])); }
         c.run_end_rev = run_end_rev.data(); c.pl = pl.data(); c.pnc = pnc.data();
+        c.rank_monotone = 1;
+        for (uint32_t n = 0; n + 1 < c.V; ++n) if (c.rank[n + 1] <= c.rank[n]) c.rank_monotone = 0;
       }
     }
     std::vector<uint32_t> arena(size_t(64) * 4096);

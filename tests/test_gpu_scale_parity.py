@@ -5,9 +5,11 @@
 * `test_whole_s3_vs_cpp_oracle`: ALL of S3 (human chr1 scale, 10 M lines) through `pantas augment` against the independent C++
   form of the oracle (oracle/augment_oracle.cpp, pinned to the reference's goldens by tests/test_oracle_cpp.py) on the host
   cores: the two augmented GFAs are the same file; then `pantas call --rca 3 --novel` on that file against
-  oracle/call_oracle.cpp: the same rows (round 3).  (The same check of ALL of S4 -- 50 M lines, 2.5e8 segments, 23 GB of output --
-  takes minutes of single-thread GFA indexing in the oracle: `test_whole_s4_vs_cpp_oracle`, run with PANTAS_WHOLE_S4=1 once per round:
-  profiles/r2_e2e_s4_cpp_oracle.json.)
+  oracle/call_oracle.cpp: the same rows (round 3).
+* `test_whole_s4_and_s5_vs_cpp_oracles` (round 5; part of the default run): ALL of S4 -- 50 M lines, 2.5e8 segments, 23 GB of output --
+  the same way, the GFA compared through the oracle's byte digest (every phase of the oracle runs on all cores and nothing is written:
+  586 s became 160), then three more blocks of the read stream behind the first: S5, 200 M reads, 241 M event rows.  Until round 4 these
+  were opt-in tests, run by hand once per round.
 * `test_full_graph_slice_vs_oracle[s3|s4]`: the FULL human-chr1 / human whole-genome graph (2.5e8 segments, ids in the
   1e9 range, the dense name table, counter offsets beyond 2^30 words) with a slice of the read stream spread over every
   chromosome.  The Python oracle cannot hold such a graph, and it does not have to: what it prints for a segment or a
