@@ -321,6 +321,28 @@ static void build_walk_runs(DeviceCall& d, CallView& c) {
   c.run_end_rev = key; c.pl = pl; c.pnc = pnc;
 }
 
+// CallView::share_ex: a thread makes one word of it (32 link slots)
+__global__ __launch_bounds__(256) void share_bits_kernel(uint64_t A, const uint32_t* src, const uint32_t* col, const uint32_t* ex_ptr, const uint32_t* ex_tag, uint32_t* out) {
+  const uint64_t words = (A + 31u) / 32u;
+  for (uint64_t w = uint64_t(blockIdx.x) * 256u + threadIdx.x; w < words; w += uint64_t(gridDim.x) * 256u) {
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+      const uint64_t t = w * 32u + b;
+      if (t < A && ends_share_exon(ex_ptr, ex_tag, src[t], col[t])) bits |= 1u << b;
+    }
+    out[w] = bits;
+  }
+}
+static void build_share_bits(DeviceCall& d, CallView& c, uint64_t A) {
+  c.share_ex = nullptr;
+  if (A == 0 || getenv("PANTAS_CALL_NO_SHARE_BITS")) return;
+  uint32_t* bits = dalloc<uint32_t>(d, (A + 31) / 32);
+  hipLaunchKernelGGL(share_bits_kernel, dim3(uint32_t(std::min<uint64_t>(((A + 31) / 32 + 255) / 256, 1u << 16))), dim3(256), 0, d.stream, A, c.src, c.col, c.ex_ptr, c.ex_tag, bits);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(d.stream));
+  c.share_ex = bits;
+}
+
 DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device)
@@ -358,7 +380,8 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
   build_walk_runs(*d, c);
-  pt.lap("walk runs (device)");
+  build_share_bits(*d, c, t.A);
+  pt.lap("walk runs, shared-exon bits (device)");
   if (pt.on) fprintf(stderr, "[timing] upload_call: %.2f GB: hipMalloc %.3f s, copies %.3f s (%.1f GB/s)\n", g_up_bytes / 1e9, g_up_malloc_s, g_up_copy_s,
                      g_up_copy_s > 0 ? g_up_bytes / 1e9 / g_up_copy_s : 0.0);
   pt.lap("tables in HBM");

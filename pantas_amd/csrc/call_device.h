@@ -82,6 +82,12 @@ struct CallView {
   const uint32_t* run_end_rev;  // [V] at V - 1 - n: the first segment m >= n with nxt1[m] != m + 1 (n .. m is walked in one step)
   const uint64_t* pl;           // [V + 1] sums of ln[0 .. n)
   const uint64_t* pnc;          // [V + 1] sums of nc[0 .. n); the three are only offered when EVERY segment has an NC tag
+  // Round 5: one bit per link slot, set when source and target of the slot share an exon tag (nullptr: not offered).  The rows of an
+  // expressed gene's segments hold thousands of links the reads added, nearly all of them into OTHER exons; loops that ask every
+  // neighbour of a row "do you carry one of my exon tags?" read this bit -- sixteen slots per cache line, in row order -- before
+  // they chase the neighbour's tag list through three dependent loads (the stage kernels are one round of waves: their time is
+  // their slowest lane, and that lane was walking such a row).
+  const uint32_t* share_ex;
   uint32_t rank_monotone;       // the names' string order is the order of the S lines (rank[n] < rank[n + 1] throughout): what lets the
                                 // greedy walk, whose step asks "name <= v's name", take a run as well
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
@@ -144,6 +150,18 @@ PANTAS_HD Ex ex_of(const CallView& c, uint32_t node) {
   return Ex{c.ex_tag + b, c.ex_tx + b, c.ex_gene + b, c.ex_ptr[node + 1] - b};
 }
 PANTAS_HD bool ex_has(const Ex& s, uint32_t tag) { return sorted_has(s.tag, s.n, tag); }
+// false: the two ends of link slot t have no exon tag in common (true: they may -- or the bits are not offered)
+PANTAS_HD bool may_share_exon(const CallView& c, uint32_t t) { return c.share_ex == nullptr || ((c.share_ex[t >> 5] >> (t & 31u)) & 1u) != 0u; }
+// the bit of slot t, by merging the two sorted tag lists (what makes CallView::share_ex)
+PANTAS_HD bool ends_share_exon(const uint32_t* ex_ptr, const uint32_t* ex_tag, uint32_t u, uint32_t v) {
+  uint32_t a = ex_ptr[u], ae = ex_ptr[u + 1], b = ex_ptr[v], be = ex_ptr[v + 1];
+  while (a < ae && b < be) {
+    const uint32_t x = ex_tag[a], y = ex_tag[b];
+    if (x == y) return true;
+    if (x < y) ++a; else ++b;
+  }
+  return false;
+}
 // index of tag in s, or CNONE
 PANTAS_HD uint32_t ex_find(const Ex& s, uint32_t tag) {
   uint32_t lo = 0, hi = s.n;
@@ -557,6 +575,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     if (n_tails) {
       for (uint32_t t = ob; t < oe; ++t) {          // every out-link line of u, duplicates included
         if (!in_out_list(c, t)) continue;
+        if (!may_share_exon(c, t)) continue;        // (the neighbour carries none of u's exons: `cont` below would stay false)
         const uint32_t n = c.col[t];
         if (n == v) continue;
         const Ex en = ex_of(c, n);
@@ -588,6 +607,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     if (n_heads) {
       for (uint32_t q0 = ib; q0 < ie; ++q0) {        // every in-link line of v
         if (!in_in_list(c, c.islot[q0])) continue;
+        if (!may_share_exon(c, c.islot[q0])) continue;
         const uint32_t n = c.icol[q0];
         if (n == u) continue;
         const Ex en = ex_of(c, n);
@@ -624,6 +644,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     bool done = !both_any;
     for (uint32_t t = ob; t < oe && !done; ++t) {
       if (!in_out_list(c, t)) continue;
+      if (!may_share_exon(c, t)) continue;          // (n1_any below needs a tag of n1 that is also u's)
       const uint32_t n1 = c.col[t];
       if (n1 == v) continue;
       const Ex e1 = ex_of(c, n1);
@@ -632,6 +653,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
       if (!n1_any) continue;
       for (uint32_t q = ib; q < ie && !done; ++q) {
         if (!in_in_list(c, c.islot[q])) continue;
+        if (!may_share_exon(c, c.islot[q])) continue;      // (`pick` below is a tag of n2 that is also v's)
         const uint32_t n2 = c.icol[q];
         if (n2 == u) continue;
         if (c.rank[n2] < c.rank[n1]) continue;
@@ -718,6 +740,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
         for (uint32_t t = b; t < e; ++t) {
           const uint32_t n = side == 0 ? c.col[t] : c.icol[t];
           const uint32_t jj = c.first_slot[side == 0 ? t : c.islot[t]];
+          if (!(c.lflags[jj] & L_JUNC)) continue;       // (asked last until round 5: the rows are long, the junctions in them few)
           const Ex en = ex_of(c, n);
           bool shared = false;
           uint32_t gene = CNONE;
@@ -831,12 +854,12 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
     // exons of gene g that END at u (no out-neighbour carries them) and START at v
     auto ends_at_u = [&](uint32_t i) {
       if (exu.gene[i] != g) return false;
-      for (uint32_t t = ob; t < oe; ++t) if (ex_has(ex_of(c, c.col[t]), exu.tag[i])) return false;
+      for (uint32_t t = ob; t < oe; ++t) if (may_share_exon(c, t) && ex_has(ex_of(c, c.col[t]), exu.tag[i])) return false;
       return true;
     };
     auto starts_at_v = [&](uint32_t k) {
       if (exv.gene[k] != g) return false;
-      for (uint32_t q = ib; q < ie; ++q) if (ex_has(ex_of(c, c.icol[q]), exv.tag[k])) return false;
+      for (uint32_t q = ib; q < ie; ++q) if (may_share_exon(c, c.islot[q]) && ex_has(ex_of(c, c.icol[q]), exv.tag[k])) return false;
       return true;
     };
     // Each test walks a whole row of u / v (thousands of links the reads added on an expressed gene): it is made ONCE per exon

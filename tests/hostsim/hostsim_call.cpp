@@ -119,6 +119,13 @@ int main(int argc, char** argv) {
         for (uint32_t n = 0; n + 1 < c.V; ++n) if (c.rank[n + 1] <= c.rank[n]) c.rank_monotone = 0;
       }
     }
+    // ... and the shared-exon bit per link slot (CallView::share_ex; HOSTSIM_CALL_NO_SHARE_BITS=1: every neighbour's tags are read)
+    std::vector<uint32_t> share((t.A + 31) / 32 + 1, 0u);
+    if (!getenv("HOSTSIM_CALL_NO_SHARE_BITS")) {
+      for (size_t sl = 0; sl < t.A; ++sl)
+        if (ends_share_exon(c.ex_ptr, c.ex_tag, c.src[sl], c.col[sl])) share[sl >> 5] |= 1u << (sl & 31);
+      c.share_ex = share.data();
+    }
     std::vector<uint32_t> arena(size_t(64) * 4096);
     uint32_t arena_next = 0;
     c.arena = arena.data(); c.arena_next = &arena_next; c.arena_slots = 64; c.arena_cap = 4096;
