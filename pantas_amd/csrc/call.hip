@@ -73,7 +73,20 @@ __global__ __launch_bounds__(256) void call_stage_kernel(CallView c, const uint3
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     StageEmit e{stage_rec + size_t(i) * STAGE_RECS, stage_side + size_t(i) * STAGE_WORDS};
     Fault f;
+#ifdef PANTAS_EXPERIMENTS
+    // timing only (PANTAS_CALL_STAMPS): shader clocks per item into a log2 histogram behind the status word, the slowest item beside it
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
     run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
+#ifdef PANTAS_EXPERIMENTS
+    if (c.events & 0x8000u) {
+      const unsigned long long dt = __builtin_amdgcn_s_memtime() - t0_;
+      uint32_t b = 0;
+      while ((dt >> b) > 1ull && b < 39u) ++b;
+      atomicAdd(status + 1 + b, 1ull);
+      atomicMax(status + 41, (dt << 24) | i);
+    }
+#endif
     if (f.bad()) {
       atomicMin(status, (static_cast<unsigned long long>(PASS) << 40) | (static_cast<unsigned long long>(i) << 8) | f.code);
       e.recs = 0;
@@ -333,14 +346,93 @@ __global__ __launch_bounds__(256) void share_bits_kernel(uint64_t A, const uint3
     out[w] = bits;
   }
 }
+// CallView::iflags: a thread per in-slot
+__global__ __launch_bounds__(256) void in_slot_flags_kernel(uint64_t A, const uint32_t* islot, const uint32_t* first_slot, const uint32_t* lflags, const uint32_t* share, uint8_t* out) {
+  for (uint64_t q = uint64_t(blockIdx.x) * 256u + threadIdx.x; q < A; q += uint64_t(gridDim.x) * 256u) {
+    const uint32_t t = islot[q], fs = first_slot[t], fl = lflags[fs];
+    out[q] = uint8_t((fs == t ? I_CANON : 0u) | ((fl & L_JUNC) ? I_JUNC : 0u) | ((fl & L_NOVEL) ? I_NOVEL : 0u) | (((share[t >> 5] >> (t & 31u)) & 1u) ? I_SHARE : 0u));
+  }
+}
+// CallView::j_ht_n / j_ht / j_carried: a WAVE per junction walks the out-row of its head and the in-row of its tail, 64 links at a time
+__global__ __launch_bounds__(256) void junction_rows_kernel(CallView c, const uint32_t* junctions, uint32_t nJ, uint32_t* ht_n, uint32_t* ht, unsigned long long* carried) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+  for (uint32_t w = wave0; w < nJ; w += n_waves) {
+    const uint32_t s = junctions[w], j = c.jrow[s];
+    const uint32_t u = c.src[s], v = c.col[s];
+    const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1], ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+    const Set genes = jg_of(c, s);
+    const bool one_gene = genes.n == 1u;
+    const uint32_t g = one_gene ? genes.p[0] : CNONE;
+    const Ex exu = ex_of(c, u), exv = ex_of(c, v);
+    // ---- heads (out-row of u) and tails (in-row of v): junction links of gene g other than s, in row order
+    for (uint32_t side = 0; side < 2u; ++side) {
+      const uint32_t b = side == 0 ? ob : ib, e = side == 0 ? oe : ie;
+      uint32_t n = 0;
+      bool keyerr = false;
+      for (uint32_t base = b; base < e; base += 64u) {
+        const uint32_t q = base + lane;
+        bool is = false;
+        uint32_t t = CNONE;
+        if (q < e) {
+          t = side == 0 ? q : c.islot[q];
+          if (c.first_slot[t] == t && t != s && (c.lflags[t] & L_JUNC)) {
+            keyerr |= (c.lflags[t] & L_GENE_KEYERR) != 0u;
+            is = one_gene && set_has(jg_of(c, t), g);
+          }
+        }
+        const unsigned long long m = __ballot(is);
+        if (is) {
+          const uint32_t at = n + __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+          if (at < J_HT_MAX) ht[size_t(2u * J_HT_MAX) * j + side * J_HT_MAX + at] = t;
+        }
+        n += uint32_t(__popcll(m));
+      }
+      const bool any_keyerr = __ballot(keyerr) != 0ull;
+      if (lane == 0) ht_n[2u * j + side] = n | (any_keyerr ? J_KEYERR : 0u);
+    }
+    // ---- which exon tags of u an out-neighbour carries, which of v an in-neighbour
+    for (uint32_t side = 0; side < 2u; ++side) {
+      const Ex mine = side == 0 ? exu : exv;
+      const uint32_t b = side == 0 ? ob : ib, e = side == 0 ? oe : ie;
+      unsigned long long m = 0;
+      if (mine.n != 0u && mine.n <= 64u) {
+        for (uint32_t q = b + lane; q < e; q += 64u) {
+          const uint32_t t = side == 0 ? q : c.islot[q];
+          if (!may_share_exon(c, t)) continue;
+          const Ex en = ex_of(c, side == 0 ? c.col[q] : c.icol[q]);
+          for (uint32_t i = 0; i < mine.n; ++i) if (ex_has(en, mine.tag[i])) m |= 1ull << i;
+        }
+      }
+      for (int d = 32; d > 0; d >>= 1) m |= __shfl_xor(m, d, 64);
+      if (lane == 0) carried[2u * j + side] = m;
+    }
+  }
+}
+static void build_junction_rows(DeviceCall& d, CallView& c, const uint32_t* d_junctions, uint32_t nJ) {
+  c.j_ht_n = nullptr; c.j_ht = nullptr; c.j_carried = nullptr;
+  if (nJ == 0 || getenv("PANTAS_CALL_NO_SHARE_BITS")) return;
+  uint32_t* ht_n = dalloc<uint32_t>(d, size_t(2) * nJ);
+  uint32_t* ht = dalloc<uint32_t>(d, size_t(2) * J_HT_MAX * nJ);
+  unsigned long long* carried = dalloc<unsigned long long>(d, size_t(2) * nJ);
+  hipLaunchKernelGGL(junction_rows_kernel, dim3(uint32_t(std::min<uint64_t>((uint64_t(nJ) + 3) / 4, 1u << 16))), dim3(256), 0, d.stream, c, d_junctions, nJ, ht_n, ht, carried);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(d.stream));
+  c.j_ht_n = ht_n; c.j_ht = ht; c.j_carried = carried;
+}
+
 static void build_share_bits(DeviceCall& d, CallView& c, uint64_t A) {
-  c.share_ex = nullptr;
+  c.share_ex = nullptr; c.iflags = nullptr;
   if (A == 0 || getenv("PANTAS_CALL_NO_SHARE_BITS")) return;
   uint32_t* bits = dalloc<uint32_t>(d, (A + 31) / 32);
   hipLaunchKernelGGL(share_bits_kernel, dim3(uint32_t(std::min<uint64_t>(((A + 31) / 32 + 255) / 256, 1u << 16))), dim3(256), 0, d.stream, A, c.src, c.col, c.ex_ptr, c.ex_tag, bits);
   HIP_OK(hipGetLastError());
+  uint8_t* ifl = dalloc<uint8_t>(d, A);
+  hipLaunchKernelGGL(in_slot_flags_kernel, dim3(uint32_t(std::min<uint64_t>((A + 255) / 256, 1u << 20))), dim3(256), 0, d.stream, A, c.islot, c.first_slot, c.lflags, bits, ifl);
+  HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(d.stream));
   c.share_ex = bits;
+  c.iflags = ifl;
 }
 
 DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
@@ -374,14 +466,15 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.jg_ptr = up(*d, t.jg_ptr); c.jg = up(*d, t.jg);
   c.tx_gene = up(*d, t.tx_gene);
   c.probe = up(*d, t.probe); c.probe_ok = up(*d, t.probe_ok);
-  d->status = dalloc<unsigned long long>(*d, 1);
+  d->status = dalloc<unsigned long long>(*d, 48);       // (word 0: the status; the rest: timing experiments)
   d->arena = dalloc<uint32_t>(*d, size_t(ARENA_SLOTS) * ARENA_CAP);
   HIP_OK(hipMemsetAsync(d->arena, 0, size_t(ARENA_SLOTS) * ARENA_CAP * 4, d->stream));      // (word 0 of a slice: held or free; a search gives its slice back)
   d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
   build_walk_runs(*d, c);
   build_share_bits(*d, c, t.A);
-  pt.lap("walk runs, shared-exon bits (device)");
+  build_junction_rows(*d, c, up(*d, t.junctions), uint32_t(t.junctions.size()));
+  pt.lap("walk runs, shared-exon bits, junction rows (device)");
   if (pt.on) fprintf(stderr, "[timing] upload_call: %.2f GB: hipMalloc %.3f s, copies %.3f s (%.1f GB/s)\n", g_up_bytes / 1e9, g_up_malloc_s, g_up_copy_s,
                      g_up_copy_s > 0 ? g_up_bytes / 1e9 / g_up_copy_s : 0.0);
   pt.lap("tables in HBM");
@@ -438,7 +531,39 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
     stage_side = u32(size_t(n) * STAGE_WORDS);
   }
   HIP_OK(hipEventRecord(d.ev0, d.stream));
+#ifdef PANTAS_EXPERIMENTS
+  CallView cs = c;
+  cs.stamps = d.status + 43;
+  if (getenv("PANTAS_CALL_STAMPS")) { cs.events |= 0x8000u; HIP_OK(hipMemsetAsync(d.status + 1, 0, 47 * 8, d.stream)); }
+  if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, cs, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status);
+  if (staged && getenv("PANTAS_CALL_STAMPS")) {
+    unsigned long long h[47];
+    HIP_OK(hipMemcpyAsync(h, d.status + 1, sizeof h, hipMemcpyDeviceToHost, d.stream));
+    HIP_OK(hipStreamSynchronize(d.stream));
+    {
+      const uint32_t sl = slots[size_t(h[40] & 0xFFFFFFull) % slots.size()];
+      auto rd = [&](const uint32_t* p, uint64_t i) { uint32_t v = 0; HIP_OK(hipMemcpy(&v, p + i, 4, hipMemcpyDeviceToHost)); return v; };
+      {
+        // the lanes of a wave leave together: the heavy item is one of the 64 of that wave
+        const size_t i0 = size_t(h[40] & 0xFFFFFFull) & ~size_t(63);
+        for (size_t k = i0; k < i0 + 64 && k < slots.size(); ++k) {
+          const uint32_t s2 = slots[k], u2 = rd(c.src, s2), v2 = rd(c.col, s2);
+          const uint32_t od = rd(c.row_ptr, u2 + 1) - rd(c.row_ptr, u2), id = rd(c.irow_ptr, v2 + 1) - rd(c.irow_ptr, v2);
+          const uint32_t oi = rd(c.irow_ptr, u2 + 1) - rd(c.irow_ptr, u2), io = rd(c.row_ptr, v2 + 1) - rd(c.row_ptr, v2);
+          if (od > 16 || id > 16 || oi > 16 || io > 16) fprintf(stderr, "[call stamps]   item %zu: u out %u in %u, v out %u in %u, exons %u / %u\n", k, od, oi, io, id, rd(c.ex_ptr, u2 + 1) - rd(c.ex_ptr, u2), rd(c.ex_ptr, v2 + 1) - rd(c.ex_ptr, v2));
+        }
+      }
+      const uint32_t u = rd(c.src, sl), v = rd(c.col, sl);
+      fprintf(stderr, "[call stamps] pass %d: slowest item %llu clocks (item %llu, slot %u: u %u out-degree %u in-degree %u exons %u; v %u out-degree %u in-degree %u exons %u)\n", PASS,
+              h[40] >> 24, h[40] & 0xFFFFFFull, sl, u, rd(c.row_ptr, u + 1) - rd(c.row_ptr, u), rd(c.irow_ptr, u + 1) - rd(c.irow_ptr, u), rd(c.ex_ptr, u + 1) - rd(c.ex_ptr, u),
+              v, rd(c.row_ptr, v + 1) - rd(c.row_ptr, v), rd(c.irow_ptr, v + 1) - rd(c.irow_ptr, v), rd(c.ex_ptr, v + 1) - rd(c.ex_ptr, v));
+    }
+    for (int b = 0; b < 40; ++b) if (h[b]) fprintf(stderr, "[call stamps]   2^%d clocks: %llu items\n", b, h[b]);
+    fprintf(stderr, "[call stamps]   sections of the items with a row of more than 500 links, clocks summed: %llu %llu %llu %llu\n", h[42], h[43], h[44], h[45]);
+  }
+#else
   if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status);
+#endif
   else hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d.status);
   HIP_OK(hipGetLastError());
   exclusive_scan(d, nrec, rec_off, n);

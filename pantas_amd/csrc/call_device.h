@@ -88,6 +88,21 @@ struct CallView {
   // they chase the neighbour's tag list through three dependent loads (the stage kernels are one round of waves: their time is
   // their slowest lane, and that lane was walking such a row).
   const uint32_t* share_ex;
+  // ... and what the loops over an IN-row ask of every slot, in in-row order (nullptr: not offered): a byte per in-slot q with
+  // I_CANON (islot[q] is the first slot of its pair), I_JUNC / I_NOVEL (the pair's first slot carries L_JUNC / L_NOVEL) and I_SHARE
+  // (share_ex of islot[q]).  The in-row of a segment lists slots scattered all over the out-CSR: asking first_slot[islot[q]] and
+  // lflags[...] per link of a row of thousands was two cache misses per link, and the one junction at such a segment was the
+  // whole run time of its kernel (36 M clocks for one item, 2 M for every other: profiles/r5_call_stamps_s4.txt).
+  const uint8_t* iflags;
+  // Per junction ordinal j = jrow[slot] (nullptr: not offered), made once per table set by a WAVE per junction (call.hip
+  // junction_rows_kernel) -- what annotated_junction and novel_around used to find by walking the whole out-row of the junction's
+  // head and in-row of its tail, one lane per junction: a lane's pass over a row costs a third of a microsecond per link whatever it
+  // does there, the junctions of an expressed gene stand at rows of a thousand links the reads added, and a stage kernel is one
+  // round of waves -- its time was the time of the wave that held those junctions (profiles/r5_call_stamps_s4.txt).
+  const uint32_t* j_ht_n;                 // [2 nJ] heads / tails of gene g among the junction links at u / v (annotated_junction), | J_KEYERR
+  const uint32_t* j_ht;                   // [2 J_HT_MAX nJ] the first J_HT_MAX heads, then tails, in row order
+  const unsigned long long* j_carried;    // [2 nJ] bit i: an out-neighbour of u carries u's exon tag i / an in-neighbour of v carries v's tag i
+  unsigned long long* stamps;   // timing experiments only (EXPERIMENTS builds)
   uint32_t rank_monotone;       // the names' string order is the order of the S lines (rank[n] < rank[n + 1] throughout): what lets the
                                 // greedy walk, whose step asks "name <= v's name", take a run as well
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
@@ -150,6 +165,12 @@ PANTAS_HD Ex ex_of(const CallView& c, uint32_t node) {
   return Ex{c.ex_tag + b, c.ex_tx + b, c.ex_gene + b, c.ex_ptr[node + 1] - b};
 }
 PANTAS_HD bool ex_has(const Ex& s, uint32_t tag) { return sorted_has(s.tag, s.n, tag); }
+enum : uint32_t { I_CANON = 1, I_JUNC = 2, I_NOVEL = 4, I_SHARE = 8 };
+constexpr uint32_t J_HT_MAX = 16;
+constexpr uint32_t J_KEYERR = 0x80000000u;     // a junction link of the row has a transcript the GTF lacks (the row scan raised there)
+constexpr uint32_t J_NO_MASK = 0x40000000u;    // more than 64 exon tags at this end: no carried mask
+// in-slot q cannot pass a test that needs ALL bits of `need` (true: it may -- or the bytes are not offered)
+PANTAS_HD bool in_slot_may(const CallView& c, uint32_t q, uint32_t need) { return c.iflags == nullptr || (c.iflags[q] & need) == need; }
 // false: the two ends of link slot t have no exon tag in common (true: they may -- or the bits are not offered)
 PANTAS_HD bool may_share_exon(const CallView& c, uint32_t t) { return c.share_ex == nullptr || ((c.share_ex[t >> 5] >> (t & 31u)) & 1u) != 0u; }
 // the bit of slot t, by merging the two sorted tag lists (what makes CallView::share_ex)
@@ -489,6 +510,15 @@ PANTAS_HD void gene_accumulate(const CallView& c, uint32_t tx, uint32_t& gene, F
   else if (gene != g) gene = GENE_MULTI;
 }
 
+// timing only (EXPERIMENTS builds, PANTAS_CALL_STAMPS): shader clocks of the sections of a HEAVY item (a row of more than 500 links) summed
+// into words 43 .. 47 behind the status word
+#if defined(PANTAS_EXPERIMENTS) && defined(__HIP_DEVICE_COMPILE__)
+#define PANTAS_SECTION_BEGIN(HEAVY) const bool sec_on_ = (c.events & 0x8000u) && (HEAVY); unsigned long long sec_t_ = sec_on_ ? __builtin_amdgcn_s_memtime() : 0ull
+#define PANTAS_SECTION(K) do { if (sec_on_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(c.stamps + (K), n_ - sec_t_); sec_t_ = n_; } } while (0)
+#else
+#define PANTAS_SECTION_BEGIN(HEAVY) do {} while (0)
+#define PANTAS_SECTION(K) do {} while (0)
+#endif
 #define PANTAS_DBG(TYPE, SLOT) do { if (c.debug) { emit.begin(TYPE, CNONE, SLOT, CNONE, CNONE); emit.end(0); } } while (0)
 
 // ---- pass 1: annotated junctions (:239-524) ----------------------------------------------------------------
@@ -514,15 +544,29 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
   // The rows of u and v also hold every link the reads added (thousands on expressed genes); the
   // junctions among them are few, so they are listed once and the pair loops below run over the lists.
-  constexpr uint32_t HT_MAX = 16;
+  constexpr uint32_t HT_MAX = J_HT_MAX;
   uint32_t heads[HT_MAX], tails[HT_MAX];
   uint32_t n_heads = 0, n_tails = 0;
-  for (uint32_t t = ob; t < oe; ++t) {
+  PANTAS_SECTION_BEGIN(oe - ob > 500u || ie - ib > 500u);
+  const bool listed = c.j_ht_n != nullptr;
+  if (listed) {
+    const uint32_t j = c.jrow[s];
+    const uint32_t nh = c.j_ht_n[2u * j], nt = c.j_ht_n[2u * j + 1u];
+    if ((nh | nt) & J_KEYERR) { f.raise(CE_KEY_TX); return; }
+    n_heads = nh & ~(J_KEYERR | J_NO_MASK);
+    n_tails = nt & ~(J_KEYERR | J_NO_MASK);
+    for (uint32_t i = 0; i < HT_MAX; ++i) {
+      heads[i] = i < n_heads ? c.j_ht[2u * HT_MAX * j + i] : CNONE;
+      tails[i] = i < n_tails ? c.j_ht[2u * HT_MAX * j + HT_MAX + i] : CNONE;
+    }
+  }
+  for (uint32_t t = ob; t < oe && !listed; ++t) {
     if (c.first_slot[t] != t || t == s || !(c.lflags[t] & L_JUNC)) continue;
     if (c.lflags[t] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
     if (set_has(jg_of(c, t), g)) { if (n_heads < HT_MAX) heads[n_heads] = t; ++n_heads; }
   }
-  for (uint32_t q = ib; q < ie; ++q) {
+  for (uint32_t q = ib; q < ie && !listed; ++q) {
+    if (!in_slot_may(c, q, I_CANON | I_JUNC)) continue;
     const uint32_t t = c.islot[q];
     if (c.first_slot[t] != t || t == s || !(c.lflags[t] & L_JUNC)) continue;
     if (c.lflags[t] & L_GENE_KEYERR) { f.raise(CE_KEY_TX); return; }
@@ -541,10 +585,11 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   auto tail_at = [&](uint32_t i) -> uint32_t {
     if (i < HT_MAX) return tails[i];
     uint32_t k = 0;
-    for (uint32_t q = ib; q < ie; ++q) { const uint32_t t = c.islot[q]; if (is_head(t)) { if (k == i) return t; ++k; } }
+    for (uint32_t q = ib; q < ie; ++q) { if (!in_slot_may(c, q, I_CANON | I_JUNC)) continue; const uint32_t t = c.islot[q]; if (is_head(t)) { if (k == i) return t; ++k; } }
     return CNONE;
   };
 
+  PANTAS_SECTION(0);
   if (c.events & EV_ES) {
     PANTAS_DBG(T_DBG_ANN_ES, s);                    // :317
     for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
@@ -570,6 +615,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     }
   }
 
+  PANTAS_SECTION(1);
   if (c.events & EV_SS) {
     PANTAS_DBG(T_DBG_ANN_SS, s);                    // :378
     if (n_tails) {
@@ -606,6 +652,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     }
     if (n_heads) {
       for (uint32_t q0 = ib; q0 < ie; ++q0) {        // every in-link line of v
+        if (!in_slot_may(c, q0, I_SHARE)) continue;        // (the neighbour carries none of v's exons: `cont` below would stay false)
         if (!in_in_list(c, c.islot[q0])) continue;
         if (!may_share_exon(c, c.islot[q0])) continue;
         const uint32_t n = c.icol[q0];
@@ -635,6 +682,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     }
   }
 
+  PANTAS_SECTION(2);
   if (c.events & EV_IR) {
     PANTAS_DBG(T_DBG_ANN_IR, s);                    // :466
     // exons (of gene g) that lie on both ends of the junction: only they can retain the intron.  Testing
@@ -652,6 +700,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
       for (uint32_t i = 0; i < e1.n && !n1_any; ++i) n1_any = ex_has_gene(exu, e1.tag[i], g) && ex_has_gene(exv, e1.tag[i], g);
       if (!n1_any) continue;
       for (uint32_t q = ib; q < ie && !done; ++q) {
+        if (!in_slot_may(c, q, I_SHARE)) continue;
         if (!in_in_list(c, c.islot[q])) continue;
         if (!may_share_exon(c, c.islot[q])) continue;      // (`pick` below is a tag of n2 that is also v's)
         const uint32_t n2 = c.icol[q];
@@ -675,6 +724,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
       }
     }
   }
+  PANTAS_SECTION(3);
 }
 
 // ---- pass 2: links seen only in reads (:531-893) ------------------------------------------------------------
@@ -709,6 +759,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
           const uint32_t j1 = c.first_slot[t];
           if (!(c.lflags[j1] & L_JUNC)) continue;
           for (uint32_t q = ib; q < ie; ++q) {
+            if (!in_slot_may(c, q, I_JUNC)) continue;
             const uint32_t j2 = c.first_slot[c.islot[q]];
             if (!(c.lflags[j2] & L_JUNC)) continue;
             const Set x1 = jx_of(c, j1), x2 = jx_of(c, j2);
@@ -738,6 +789,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
         if (spl.n == 0) continue;
         const uint32_t b = side == 0 ? ob : ib, e = side == 0 ? oe : ie;
         for (uint32_t t = b; t < e; ++t) {
+          if (side == 1 && !in_slot_may(c, t, I_JUNC)) continue;
           const uint32_t n = side == 0 ? c.col[t] : c.icol[t];
           const uint32_t jj = c.first_slot[side == 0 ? t : c.islot[t]];
           if (!(c.lflags[jj] & L_JUNC)) continue;       // (asked last until round 5: the rows are long, the junctions in them few)
@@ -820,6 +872,7 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
   const Ex exu = ex_of(c, u), exv = ex_of(c, v);
   const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+  PANTAS_SECTION_BEGIN(oe - ob > 500u || ie - ib > 500u);
 
   // cassette exons (:954-984) are enumerated by cassette_item, one (junction, novel head link) per thread
   if (c.debug && (c.events & EV_ES)) {
@@ -859,20 +912,28 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
     };
     auto starts_at_v = [&](uint32_t k) {
       if (exv.gene[k] != g) return false;
-      for (uint32_t q = ib; q < ie; ++q) if (may_share_exon(c, c.islot[q]) && ex_has(ex_of(c, c.icol[q]), exv.tag[k])) return false;
+      for (uint32_t q = ib; q < ie; ++q) if (in_slot_may(c, q, I_SHARE) && may_share_exon(c, c.islot[q]) && ex_has(ex_of(c, c.icol[q]), exv.tag[k])) return false;
       return true;
     };
     // Each test walks a whole row of u / v (thousands of links the reads added on an expressed gene): it is made ONCE per exon
     // and kept as a bit -- the pair loops below asked it up to (exons of u) x (exons of v) times, twice over
+    PANTAS_SECTION(0);
     uint64_t end_ok = 0, start_ok = 0;
     const bool masks = exu.n <= 64u && exv.n <= 64u;
-    if (masks) {
+    if (masks && c.j_carried != nullptr) {
+      // (exon i of u ends at u: it is of gene g and no out-neighbour carries it)
+      const uint32_t j = c.jrow[s];
+      const unsigned long long co = c.j_carried[2u * j], ci = c.j_carried[2u * j + 1u];
+      for (uint32_t i = 0; i < exu.n; ++i) if (exu.gene[i] == g && !((co >> i) & 1ull)) end_ok |= 1ull << i;
+      for (uint32_t k = 0; k < exv.n; ++k) if (exv.gene[k] == g && !((ci >> k) & 1ull)) start_ok |= 1ull << k;
+    } else if (masks) {
       for (uint32_t i = 0; i < exu.n; ++i) if (ends_at_u(i)) end_ok |= 1ull << i;
       if (end_ok)
         for (uint32_t k = 0; k < exv.n; ++k) if (starts_at_v(k)) start_ok |= 1ull << k;
     }
     auto is_end = [&](uint32_t i) { return masks ? ((end_ok >> i) & 1ull) != 0ull : ends_at_u(i); };
     auto is_start = [&](uint32_t k) { return masks ? ((start_ok >> k) & 1ull) != 0ull : starts_at_v(k); };
+    PANTAS_SECTION(1);
     uint32_t n_pairs = 0;
     uint32_t gene2 = CNONE;
     Fault gf;
@@ -897,6 +958,7 @@ PANTAS_HD void novel_around(const CallView& c, uint32_t s, uint32_t jidx, Emit& 
       }
     }
     emit.end(0);
+    PANTAS_SECTION(2);
   }
 }
 
@@ -919,6 +981,7 @@ PANTAS_HD void cassette_item(const CallView& c, uint32_t s, uint32_t t1, Emit& e
   const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
   const uint32_t es_rank = c.rank[c.col[t1]];
   for (uint32_t q = ib; q < ie; ++q) {
+    if (!in_slot_may(c, q, I_CANON | I_NOVEL)) continue;
     const uint32_t t2 = c.islot[q];
     if (c.first_slot[t2] != t2 || t2 == s || !(c.lflags[t2] & L_NOVEL)) continue;
     if (es_rank <= c.rank[c.src[t2]]) {

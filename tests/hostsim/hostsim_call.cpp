@@ -126,6 +126,47 @@ int main(int argc, char** argv) {
         if (ends_share_exon(c.ex_ptr, c.ex_tag, c.src[sl], c.col[sl])) share[sl >> 5] |= 1u << (sl & 31);
       c.share_ex = share.data();
     }
+    std::vector<uint8_t> iflags(t.A + 1, 0);
+    if (!getenv("HOSTSIM_CALL_NO_SHARE_BITS")) {
+      for (size_t q = 0; q < t.A; ++q) {
+        const uint32_t sl = c.islot[q], fs = c.first_slot[sl], fl = c.lflags[fs];
+        iflags[q] = uint8_t((fs == sl ? I_CANON : 0u) | ((fl & L_JUNC) ? I_JUNC : 0u) | ((fl & L_NOVEL) ? I_NOVEL : 0u) | (((share[sl >> 5] >> (sl & 31)) & 1u) ? I_SHARE : 0u));
+      }
+      c.iflags = iflags.data();
+    }
+    // ... and the per-junction lists and masks (CallView::j_ht_n / j_ht / j_carried), by the loops they replace
+    const size_t nJ = t.junctions.size();
+    std::vector<uint32_t> j_ht_n(2 * nJ + 1, 0u), j_ht(2 * J_HT_MAX * nJ + 1, CNONE);
+    std::vector<unsigned long long> j_carried(2 * nJ + 1, 0ull);
+    if (!getenv("HOSTSIM_CALL_NO_SHARE_BITS")) {
+      for (size_t w = 0; w < nJ; ++w) {
+        const uint32_t sl = t.junctions[w], j = c.jrow[sl], u = c.src[sl], v = c.col[sl];
+        const Set genes = jg_of(c, sl);
+        const bool one = genes.n == 1;
+        const uint32_t g = one ? genes.p[0] : CNONE;
+        for (uint32_t side = 0; side < 2; ++side) {
+          const uint32_t b = side == 0 ? c.row_ptr[u] : c.irow_ptr[v], e = side == 0 ? c.row_ptr[u + 1] : c.irow_ptr[v + 1];
+          uint32_t n = 0;
+          bool keyerr = false;
+          for (uint32_t q = b; q < e; ++q) {
+            const uint32_t tt = side == 0 ? q : c.islot[q];
+            if (c.first_slot[tt] != tt || tt == sl || !(c.lflags[tt] & L_JUNC)) continue;
+            keyerr = keyerr || (c.lflags[tt] & L_GENE_KEYERR);
+            if (one && set_has(jg_of(c, tt), g)) { if (n < J_HT_MAX) j_ht[2 * J_HT_MAX * j + side * J_HT_MAX + n] = tt; ++n; }
+          }
+          j_ht_n[2 * j + side] = n | (keyerr ? J_KEYERR : 0u);
+          const Ex mine = ex_of(c, side == 0 ? u : v);
+          unsigned long long m = 0;
+          if (mine.n && mine.n <= 64)
+            for (uint32_t q = b; q < e; ++q) {
+              const Ex en = ex_of(c, side == 0 ? c.col[q] : c.icol[q]);
+              for (uint32_t i = 0; i < mine.n; ++i) if (ex_has(en, mine.tag[i])) m |= 1ull << i;
+            }
+          j_carried[2 * j + side] = m;
+        }
+      }
+      c.j_ht_n = j_ht_n.data(); c.j_ht = j_ht.data(); c.j_carried = j_carried.data();
+    }
     std::vector<uint32_t> arena(size_t(64) * 4096);
     uint32_t arena_next = 0;
     c.arena = arena.data(); c.arena_next = &arena_next; c.arena_slots = 64; c.arena_cap = 4096;
