@@ -618,13 +618,51 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
   PANTAS_SECTION(1);
   if (c.events & EV_SS) {
     PANTAS_DBG(T_DBG_ANN_SS, s);                    // :378
+    // Round 5.  Both SS loops ask, for every neighbour n of a row and every tail (head) of the junction, whether an exon tag of
+    // the junction's end is carried by n AND by the tail's far end -- a tag list walked per (neighbour, tail) pair, at the rows of
+    // an expressed gene hundreds of neighbours times a dozen tails.  With at most 64 exon tags at the end the answers are bit
+    // masks over its tag list: one per tail (made once), one per neighbour, a pair is two ANDs.
+    // (PANTAS_CALL_NO_SHARE_BITS leaves the pair-by-pair loops below, the A/B the parity tests compare.)
+    const bool by_masks = c.share_ex && exu.n <= 64u && exv.n <= 64u && n_tails <= HT_MAX && n_heads <= HT_MAX;
+    unsigned long long far_has[HT_MAX], far_new[HT_MAX];       // per tail / head: tags of gene g its far end carries; those of a transcript the junction lacks
     if (n_tails) {
+      unsigned long long of_gene = 0;
+      if (by_masks) {
+        for (uint32_t k = 0; k < exu.n; ++k) if (exu.gene[k] == g) of_gene |= 1ull << k;
+        for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
+          far_has[ti_] = 0; far_new[ti_] = 0;
+          const uint32_t from = c.src[tails[ti_]];
+          if (from == u) continue;
+          const Ex ef = ex_of(c, from);
+          for (uint32_t i = 0; i < ef.n; ++i) {
+            const uint32_t k = ex_find(exu, ef.tag[i]);
+            if (k == CNONE || exu.gene[k] != g) continue;
+            far_has[ti_] |= 1ull << k;
+            if (!set_has(txs, ef.tx[i])) far_new[ti_] |= 1ull << k;
+          }
+        }
+      }
       for (uint32_t t = ob; t < oe; ++t) {          // every out-link line of u, duplicates included
         if (!in_out_list(c, t)) continue;
         if (!may_share_exon(c, t)) continue;        // (the neighbour carries none of u's exons: `cont` below would stay false)
         const uint32_t n = c.col[t];
         if (n == v) continue;
         const Ex en = ex_of(c, n);
+        if (by_masks) {
+          unsigned long long mine = 0;               // tags of u that n carries
+          for (uint32_t i = 0; i < en.n; ++i) { const uint32_t k = ex_find(exu, en.tag[i]); if (k != CNONE) mine |= 1ull << k; }
+          if (!(mine & of_gene)) continue;
+          for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
+            if (!(far_has[ti_] & mine) || !(far_new[ti_] & mine)) continue;
+            const uint32_t t2 = tails[ti_];
+            const Set ta = jt_of(c, s), tb = jt_of(c, t2);
+            for (uint32_t i = 0; i < ta.n; ++i)
+              if (set_has(tb, ta.p[i])) { f.raise(CE_ASSERT_JN); return; }
+            emit.begin(T_SS_ANN_A, g, s, t2, CNONE);
+            emit.end(0);
+          }
+          continue;
+        }
         bool cont = false;
         for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exu, en.tag[i], g);
         if (!cont) continue;
@@ -651,6 +689,22 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
       }
     }
     if (n_heads) {
+      unsigned long long of_gene = 0;
+      if (by_masks) {
+        for (uint32_t k = 0; k < exv.n; ++k) if (exv.gene[k] == g) of_gene |= 1ull << k;
+        for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
+          far_has[hi_] = 0; far_new[hi_] = 0;
+          const uint32_t to = c.col[heads[hi_]];
+          if (to == v) continue;
+          const Ex et = ex_of(c, to);
+          for (uint32_t i = 0; i < et.n; ++i) {
+            const uint32_t k = ex_find(exv, et.tag[i]);
+            if (k == CNONE || exv.gene[k] != g) continue;
+            far_has[hi_] |= 1ull << k;
+            if (!set_has(txs, et.tx[i])) far_new[hi_] |= 1ull << k;
+          }
+        }
+      }
       for (uint32_t q0 = ib; q0 < ie; ++q0) {        // every in-link line of v
         if (!in_slot_may(c, q0, I_SHARE)) continue;        // (the neighbour carries none of v's exons: `cont` below would stay false)
         if (!in_in_list(c, c.islot[q0])) continue;
@@ -658,6 +712,17 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
         const uint32_t n = c.icol[q0];
         if (n == u) continue;
         const Ex en = ex_of(c, n);
+        if (by_masks) {
+          unsigned long long mine = 0;               // tags of v that n carries
+          for (uint32_t i = 0; i < en.n; ++i) { const uint32_t k = ex_find(exv, en.tag[i]); if (k != CNONE) mine |= 1ull << k; }
+          if (!(mine & of_gene)) continue;
+          for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
+            if (!(far_has[hi_] & mine) || !(far_new[hi_] & mine)) continue;
+            emit.begin(T_SS_ANN_B, g, s, heads[hi_], CNONE);
+            emit.end(0);
+          }
+          continue;
+        }
         bool cont = false;
         for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exv, en.tag[i], g);
         if (!cont) continue;
