@@ -566,11 +566,13 @@ def main():
             runs.append((time.perf_counter() - t1, cs))
         os.close(fd)
         wall, cs = min(runs, key=lambda x: x[0])
-        k_ms = cs.annotated_ms + cs.novel_ms + cs.around_ms
+        # the passes run side by side since round 5 (PANTAS_CALL_SERIAL=1: in turn): their window on the device, not the sum of the lanes
+        k_ms = cs.passes_ms or (cs.annotated_ms + cs.novel_ms + cs.around_ms)
         call = {"events": cs.events, "junctions": cs.junctions, "novel_links": cs.novel_links,
                 "evaluated": cs.evaluated, "flags": f"--rca {rca} --novel (= --rca 3 per pass over the batch)",
                 "events_per_s": cs.events / wall, "wall_s": wall, "kernel_ms": k_ms,
-                "kernel_ms_by_pass": {"annotated": cs.annotated_ms, "novel_links": cs.novel_ms, "novel_around": cs.around_ms},
+                "kernel_ms_by_pass": {"annotated": cs.annotated_ms, "novel_links": cs.novel_ms, "novel_around": cs.around_ms,
+                                      "note": "lanes that overlap: their sum exceeds kernel_ms"},
                 "junction_evals_per_s_kernel": cs.evaluated / (k_ms * 1e-3) if k_ms else None,
                 # SURVEY 8-d "achieved bytes for completeness": one pass over the link flags and the CSR rows, 4 (V + A), plus a nominal
                 # 64 bytes per evaluated item (a row of up to eight neighbours and four tag triples); the kernels are chains of dependent

@@ -289,7 +289,9 @@ typedef struct {
   double parse_seconds;     /* tag + GTF parsing and interning (host) */
   double upload_seconds;
   double render_seconds;
-  float annotated_ms, novel_ms, around_ms;   /* kernels of each pass, HIP events */
+  float annotated_ms, novel_ms, around_ms;   /* kernels of each pass, HIP events; the passes run side by side on streams of their own (PANTAS_CALL_SERIAL=1: one after
+                                              * the other), so these overlap -- around_ms = the pass around the novel links + the cassette items */
+  float passes_ms;                           /* (ABI 8) all passes on the device: first launch to the last pass's end */
 } pantas_call_stats;
 
 /* :145-216: parse the tags of the (augmented) GFA behind `g` and the GTF, intern them, copy the

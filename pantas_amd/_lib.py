@@ -84,7 +84,7 @@ class CallStats(_Sized):
     _fields_ = _HEAD + [("junctions", C.c_uint64), ("novel_links", C.c_uint64), ("evaluated", C.c_uint64),
                 ("events", C.c_uint64), ("ex_entries", C.c_uint64), ("jn_entries", C.c_uint64),
                 ("parse_seconds", C.c_double), ("upload_seconds", C.c_double), ("render_seconds", C.c_double),
-                ("annotated_ms", C.c_float), ("novel_ms", C.c_float), ("around_ms", C.c_float)]
+                ("annotated_ms", C.c_float), ("novel_ms", C.c_float), ("around_ms", C.c_float), ("passes_ms", C.c_float)]
 
 
 class SynthParams(_Sized):

@@ -11,6 +11,7 @@ using DeviceCallPtr = std::unique_ptr<DeviceCall, DeviceCallDeleter>;
 
 struct CallTimes {
   float annotated_ms = 0, novel_ms = 0, around_ms = 0;   // count + scan + write kernels of each pass (HIP events)
+  float passes_ms = 0;                                   // all passes, first launch to last end: they run side by side (round 5)
   uint64_t junctions = 0;                                // junction evaluations launched
 };
 

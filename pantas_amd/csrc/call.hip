@@ -11,6 +11,8 @@
 // any sort or atomic cursor.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <exception>
+#include <thread>
 
 #include "call_host.h"
 #include "call.h"
@@ -200,27 +202,42 @@ __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* a, uint32_t*
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t ARENA_SLOTS = 4096, ARENA_CAP = 16384;   // 256 MB of overflow frontiers per kernel
 
+// What one junction pass needs to itself while the passes of a call run side by side (run_call): a stream, the events around its
+// launches, its own error word (lowest failing item of THIS pass), its own ring counter of the search arena, scan scratch.
+struct PassLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long* status = nullptr;     // 48 words: word 0 the status, the rest timing experiments
+  uint32_t* arena_next = nullptr;
+  void* scan_tmp = nullptr;                 // hipcub temporary storage, grown on demand
+  size_t scan_tmp_bytes = 0;
+};
+constexpr int PASS_LANES = 4;
+
 struct DeviceCall {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  PassLane lane[PASS_LANES];                // lane 0 works on `stream`
   std::vector<void*> allocs;
   CallView view{};
   uint32_t* d_junctions = nullptr;
   uint32_t* d_novels = nullptr;
   uint32_t nJ = 0, nN = 0;
-  unsigned long long* status = nullptr;
   uint32_t* arena = nullptr;
-  uint32_t* arena_next = nullptr;
-  void* scan_tmp = nullptr;       // hipcub temporary storage, grown on demand
-  size_t scan_tmp_bytes = 0;
 };
 
 void DeviceCallDeleter::operator()(DeviceCall* d) const {
   if (!d) return;
   (void)hipSetDevice(d->device);
   for (void* p : d->allocs) (void)hipFree(p);
-  if (d->scan_tmp) (void)hipFree(d->scan_tmp);
+  for (int k = 0; k < PASS_LANES; ++k) {
+    PassLane& l = d->lane[k];
+    if (l.scan_tmp) (void)hipFree(l.scan_tmp);
+    if (l.ev0) (void)hipEventDestroy(l.ev0);
+    if (l.ev1) (void)hipEventDestroy(l.ev1);
+    if (k && l.stream) (void)hipStreamDestroy(l.stream);
+  }
   if (d->ev0) (void)hipEventDestroy(d->ev0);
   if (d->ev1) (void)hipEventDestroy(d->ev1);
   if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -231,7 +248,7 @@ __global__ void scan_total_kernel(const uint32_t* a, uint32_t* out, uint32_t n) 
 
 // out[0..n] = exclusive prefix sums of a[0..n), out[n] = total.  The single-workgroup scan_kernel took 0.85 ms per scan at
 // whole-genome scale (15 scans per call); the device-wide scan is a few tens of microseconds.
-static void exclusive_scan(DeviceCall& d, const uint32_t* a, uint32_t* out, uint32_t n) {
+static void exclusive_scan(PassLane& d, const uint32_t* a, uint32_t* out, uint32_t n) {
   if (n < 65536u || n > 0x7FFFFFFFu) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, d.stream, a, out, n);
     return;
@@ -466,10 +483,20 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   c.jg_ptr = up(*d, t.jg_ptr); c.jg = up(*d, t.jg);
   c.tx_gene = up(*d, t.tx_gene);
   c.probe = up(*d, t.probe); c.probe_ok = up(*d, t.probe_ok);
-  d->status = dalloc<unsigned long long>(*d, 48);       // (word 0: the status; the rest: timing experiments)
+  {
+    unsigned long long* status = dalloc<unsigned long long>(*d, size_t(48) * PASS_LANES);
+    uint32_t* ring = dalloc<uint32_t>(*d, PASS_LANES);
+    for (int k = 0; k < PASS_LANES; ++k) {
+      PassLane& l = d->lane[k];
+      l.stream = k ? take_stream(device) : d->stream;
+      HIP_OK(hipEventCreate(&l.ev0));
+      HIP_OK(hipEventCreate(&l.ev1));
+      l.status = status + size_t(48) * k;
+      l.arena_next = ring + k;
+    }
+  }
   d->arena = dalloc<uint32_t>(*d, size_t(ARENA_SLOTS) * ARENA_CAP);
   HIP_OK(hipMemsetAsync(d->arena, 0, size_t(ARENA_SLOTS) * ARENA_CAP * 4, d->stream));      // (word 0 of a slice: held or free; a search gives its slice back)
-  d->arena_next = dalloc<uint32_t>(*d, 1);
   HIP_OK(hipStreamSynchronize(d->stream));
   build_walk_runs(*d, c);
   build_share_bits(*d, c, t.A);
@@ -496,10 +523,11 @@ struct PassOut {
 };
 
 template <int PASS>
-static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_t>& slots, const std::vector<uint32_t>* jidx,
+static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots, const std::vector<uint32_t>* jidx,
                      PassOut& po, float& ms) {
   const uint32_t n = uint32_t(slots.size());
   if (!n) return;
+  c.arena_next = d.arena_next;
   auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(dmalloc(&p, std::max<size_t>(bytes, 4))); po.tmp.push_back(p); return p; };
   auto u32 = [&](size_t count) { return static_cast<uint32_t*>(dev(count * 4)); };
   uint32_t* d_slots = u32(n);
@@ -518,6 +546,7 @@ static void run_pass(DeviceCall& d, const CallView& c, const std::vector<uint32_
       throw Error(call_error_kind(code), call_error_text(code));
     }
   };
+  HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));
   HIP_OK(hipMemsetAsync(d.arena_next, 0, 4, d.stream));
   // the junction passes are evaluated once (staged); the cassette items are a row scan that writes as many records as it
   // visits links -- nothing to gain from staging them
@@ -647,25 +676,54 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   HIP_OK(hipSetDevice(d.device));
   CallView c = d.view;
   c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events; c.debug = o.debug ? 1u : 0u;
-  c.arena = d.arena; c.arena_next = d.arena_next; c.arena_slots = ARENA_SLOTS; c.arena_cap = ARENA_CAP;
+  c.arena = d.arena; c.arena_slots = ARENA_SLOTS; c.arena_cap = ARENA_CAP;
   PhaseTimer pt("run_call");
   std::vector<uint32_t> ann, nov, around, around_j;
   pass_lists(g, t, o, ann, nov, around, around_j);
   pt.lap("pass lists");
-  HIP_OK(hipMemsetAsync(d.status, 0xFF, 8, d.stream));
   out = CallOutput();
   times = CallTimes();
   size_t extra_items = 0;
   PassOut po[4];
-  run_pass<0>(d, c, ann, nullptr, po[0], times.annotated_ms);
-  run_pass<1>(d, c, nov, nullptr, po[1], times.novel_ms);
-  run_pass<2>(d, c, around, &around_j, po[2], times.around_ms);
+  std::vector<uint32_t> cj, ch;
   if (o.novel && (o.events & EV_ES)) {
-    std::vector<uint32_t> cj, ch;
     cassette_items(t, around, cj, ch);
-    run_pass<3>(d, c, cj, &ch, po[3], times.around_ms);
     extra_items = cj.size();
   }
+  // The four passes share nothing but the tables they read, and each is a chain of short launches with a host decision between
+  // them whose launches end in a tail at whole-genome scale (the hub junction of a row of a thousand links, the longest intron of
+  // the batch: walk_once_kernel takes the same 4 ms at S3 and at S4).  Side by side, each on its lane (stream, error word, arena
+  // counter), the tails overlap: round 5, PANTAS_CALL_SERIAL=1 = one after the other as before.  An error is reported as the
+  // serial order would have met it: the lowest pass that failed.
+  float pass_ms[4] = {0, 0, 0, 0};
+  auto one = [&](int k) {
+    HIP_OK(hipSetDevice(d.device));
+    switch (k) {
+      case 0: run_pass<0>(d.lane[0], c, ann, nullptr, po[0], pass_ms[0]); break;
+      case 1: run_pass<1>(d.lane[1], c, nov, nullptr, po[1], pass_ms[1]); break;
+      case 2: run_pass<2>(d.lane[2], c, around, &around_j, po[2], pass_ms[2]); break;
+      default: if (!cj.empty()) run_pass<3>(d.lane[3], c, cj, &ch, po[3], pass_ms[3]);
+    }
+  };
+  HIP_OK(hipEventRecord(d.ev0, d.stream));
+  if (getenv("PANTAS_CALL_SERIAL")) {
+    for (int k = 0; k < 4; ++k) one(k);
+  } else {
+    std::exception_ptr err[4];
+    std::thread th[3];
+    for (int k = 1; k < 4; ++k)
+      th[k - 1] = std::thread([&, k] { try { one(k); } catch (...) { err[k] = std::current_exception(); } });
+    try { one(0); } catch (...) { err[0] = std::current_exception(); }
+    for (std::thread& x : th) x.join();
+    for (const std::exception_ptr& e : err) if (e) std::rethrow_exception(e);
+  }
+  // the window of all four on the device: from before the first launch to the last lane's end
+  const bool ran[4] = {!ann.empty(), !nov.empty(), !around.empty(), !cj.empty()};
+  for (int k = 1; k < 4; ++k) if (ran[k]) HIP_OK(hipStreamWaitEvent(d.stream, d.lane[k].ev1, 0));
+  HIP_OK(hipEventRecord(d.ev1, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  HIP_OK(hipEventElapsedTime(&times.passes_ms, d.ev0, d.ev1));
+  times.annotated_ms = pass_ms[0]; times.novel_ms = pass_ms[1]; times.around_ms = pass_ms[2] + pass_ms[3];
   times.junctions = ann.size() + nov.size() + around.size() + extra_items;
   pt.lap("kernels");
   // ---- one copy to the host: the arrays are sized once (no value-initialising fill, pages touched by many threads), the

@@ -1112,6 +1112,7 @@ __attribute__((visibility("default"))) int pantas_call_run(pantas_graph* g, cons
       stats->annotated_ms = times.annotated_ms;
       stats->novel_ms = times.novel_ms;
       stats->around_ms = times.around_ms;
+      stats->passes_ms = times.passes_ms;
       put_out(stats_out, st_local, "pantas_call_stats");
     }
   });

@@ -168,6 +168,8 @@ def test_walks_by_runs_equal_walks_by_steps(hostsim, mid):
 def test_engine_walks_by_runs_equal_walks_by_steps(mid):
     cmd = [sys.executable, "-m", "pantas_amd.call", *META["calls"][1]["flags"], f"{mid}/expected.aug.gfa", f"{mid}/in.gtf"]
     runs = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)
-    steps = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env={**os.environ, "PANTAS_CALL_NO_RUNS": "1", "PANTAS_CALL_NO_SHARE_BITS": "1"})
+    # ... and the passes one after the other on one stream against side by side on four (call.hip run_call)
+    steps = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT,
+                           env={**os.environ, "PANTAS_CALL_NO_RUNS": "1", "PANTAS_CALL_NO_SHARE_BITS": "1", "PANTAS_CALL_SERIAL": "1"})
     assert runs.returncode == 0 and steps.returncode == 0, runs.stderr + steps.stderr
     assert runs.stdout == steps.stdout and runs.stdout.count("\nIR,") > 500
