@@ -403,6 +403,9 @@ def main():
     if world > 1 and "PANTAS_THREADS" not in os.environ:
         os.environ["PANTAS_THREADS"] = str(max(4, (os.cpu_count() or 8) // world))
     dist = None
+    # what the library asks the HIP runtime for when it is loaded (pantas_amd/csrc/capi.cpp ask_for_more_hardware_queues: the lanes of
+    # the call passes on hardware queues of their own) -- here torch comes first and may start the runtime before the library is there
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     if world > 1:
         import torch.distributed as dist

@@ -528,7 +528,18 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
   const uint32_t n = uint32_t(slots.size());
   if (!n) return;
   c.arena_next = d.arena_next;
-  auto dev = [&](size_t bytes) { void* p = nullptr; HIP_OK(dmalloc(&p, std::max<size_t>(bytes, 4))); po.tmp.push_back(p); return p; };
+  const bool timing = getenv("PANTAS_TIMING") != nullptr;
+  const double t_in = timing ? now_s() : 0;
+  double malloc_s = 0;
+  size_t malloc_bytes = 0;
+  auto dev = [&](size_t bytes) {
+    void* p = nullptr;
+    const double t0 = timing ? now_s() : 0;
+    HIP_OK(dmalloc(&p, std::max<size_t>(bytes, 4)));
+    if (timing) { malloc_s += now_s() - t0; malloc_bytes += bytes; }
+    po.tmp.push_back(p);
+    return p;
+  };
   auto u32 = [&](size_t count) { return static_cast<uint32_t*>(dev(count * 4)); };
   uint32_t* d_slots = u32(n);
   uint32_t* d_jidx = jidx ? u32(n) : nullptr;
@@ -668,6 +679,8 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
   float t = 0;
   HIP_OK(hipEventElapsedTime(&t, d.ev0, d.ev1));
   ms += t;
+  if (timing) fprintf(stderr, "[timing] run_pass<%d>: %u items, %.3f ms on the device, %.3f ms on the host of which %.3f in %zu hipMalloc (%.2f GB)\n", PASS, n, t,
+                      (now_s() - t_in) * 1e3, malloc_s * 1e3, po.tmp.size(), malloc_bytes / 1e9);
   po.recs = d_recs; po.side = d_side; po.tasks = d_tout; po.paths = d_paths;
   po.n_recs = totals[0]; po.n_words = totals[1]; po.n_tasks = nt; po.n_paths = path_total;
 }
@@ -685,11 +698,8 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   times = CallTimes();
   size_t extra_items = 0;
   PassOut po[4];
-  std::vector<uint32_t> cj, ch;
-  if (o.novel && (o.events & EV_ES)) {
-    cassette_items(t, around, cj, ch);
-    extra_items = cj.size();
-  }
+  std::vector<uint32_t> cj, ch;       // (the cassette items are listed by the thread of their lane, beside the other passes)
+  const bool cassettes = o.novel && (o.events & EV_ES);
   // The four passes share nothing but the tables they read, and each is a chain of short launches with a host decision between
   // them whose launches end in a tail at whole-genome scale (the hub junction of a row of a thousand links, the longest intron of
   // the batch: walk_once_kernel takes the same 4 ms at S3 and at S4).  Side by side, each on its lane (stream, error word, arena
@@ -702,7 +712,11 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
       case 0: run_pass<0>(d.lane[0], c, ann, nullptr, po[0], pass_ms[0]); break;
       case 1: run_pass<1>(d.lane[1], c, nov, nullptr, po[1], pass_ms[1]); break;
       case 2: run_pass<2>(d.lane[2], c, around, &around_j, po[2], pass_ms[2]); break;
-      default: if (!cj.empty()) run_pass<3>(d.lane[3], c, cj, &ch, po[3], pass_ms[3]);
+      default:
+        if (cassettes) {
+          cassette_items(t, around, cj, ch);
+          run_pass<3>(d.lane[3], c, cj, &ch, po[3], pass_ms[3]);
+        }
     }
   };
   HIP_OK(hipEventRecord(d.ev0, d.stream));
@@ -724,6 +738,7 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   HIP_OK(hipStreamSynchronize(d.stream));
   HIP_OK(hipEventElapsedTime(&times.passes_ms, d.ev0, d.ev1));
   times.annotated_ms = pass_ms[0]; times.novel_ms = pass_ms[1]; times.around_ms = pass_ms[2] + pass_ms[3];
+  extra_items = cj.size();
   times.junctions = ann.size() + nov.size() + around.size() + extra_items;
   pt.lap("kernels");
   // ---- one copy to the host: the arrays are sized once (no value-initialising fill, pages touched by many threads), the

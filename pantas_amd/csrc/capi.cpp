@@ -173,6 +173,12 @@ __attribute__((visibility("default"))) int pantas_remap_run(const char* csv_path
   });
 }
 __attribute__((visibility("default"))) void pantas_device_warmup(int device) { try { warm_up_device(device); } catch (...) {} }
+// The call passes run on four streams beside the graph's own (call.hip run_call).  The HIP runtime spreads a process's streams over
+// four hardware queues unless told otherwise, and two lanes that land on one queue run in turn (S4: 31 ms for the passes against
+// 24 with eight queues).  The variable is read when the runtime starts, i.e. at the first HIP call: set here, when this library is
+// loaded, unless the user has chosen a value.
+__attribute__((constructor)) static void ask_for_more_hardware_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 static std::atomic<int> g_init_device{-1};      // the device of the last pantas_device_init: where a GFA is parsed when a GPU is there
 __attribute__((visibility("default"))) void pantas_device_init(int device) { try { init_device(device); g_init_device.store(device); } catch (...) {} }
 
