@@ -438,6 +438,51 @@ static void build_junction_rows(DeviceCall& d, CallView& c, const uint32_t* d_ju
   c.j_ht_n = ht_n; c.j_ht = ht; c.j_carried = carried;
 }
 
+// CallView::oj / ij: a thread per node.  WRITE false: the number of junction slots in its out-row and in its in-row; true: the
+// slots themselves at the scanned offsets.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void junction_slot_lists_kernel(CallView c, uint32_t* n_out, uint32_t* n_in, uint32_t* oj, uint32_t* ij) {
+  for (uint64_t n = blockIdx.x * 256ull + threadIdx.x; n < c.V; n += gridDim.x * 256ull) {
+    uint32_t k = WRITE ? c.oj_ptr[n] : 0u;
+    for (uint32_t t = c.row_ptr[n]; t < c.row_ptr[n + 1]; ++t)
+      if (c.lflags[c.first_slot[t]] & L_JUNC) { if (WRITE) oj[k] = t; ++k; }
+    if (!WRITE) n_out[n] = k;
+    k = WRITE ? c.ij_ptr[n] : 0u;
+    for (uint32_t q = c.irow_ptr[n]; q < c.irow_ptr[n + 1]; ++q)
+      if (c.lflags[c.first_slot[c.islot[q]]] & L_JUNC) { if (WRITE) ij[k] = q; ++k; }
+    if (!WRITE) n_in[n] = k;
+  }
+}
+static void build_junction_slot_lists(DeviceCall& d, CallView& c) {
+  c.oj_ptr = c.oj = c.ij_ptr = c.ij = nullptr;
+  if (c.V == 0 || getenv("PANTAS_CALL_NO_SHARE_BITS")) return;
+  const uint32_t V = c.V;
+  const uint32_t blocks = uint32_t(std::min<uint64_t>((uint64_t(V) + 255) / 256, 1u << 16));
+  uint32_t* n_out = nullptr;
+  uint32_t* n_in = nullptr;
+  HIP_OK(dmalloc(&n_out, size_t(V) * 4));
+  HIP_OK(dmalloc(&n_in, size_t(V) * 4));
+  uint32_t* op = dalloc<uint32_t>(d, size_t(V) + 1);
+  uint32_t* ip = dalloc<uint32_t>(d, size_t(V) + 1);
+  hipLaunchKernelGGL(junction_slot_lists_kernel<false>, dim3(blocks), dim3(256), 0, d.stream, c, n_out, n_in, nullptr, nullptr);
+  HIP_OK(hipGetLastError());
+  exclusive_scan(d.lane[0], n_out, op, V);
+  exclusive_scan(d.lane[0], n_in, ip, V);
+  uint32_t tot[2] = {0, 0};
+  HIP_OK(hipMemcpyAsync(&tot[0], op + V, 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipMemcpyAsync(&tot[1], ip + V, 4, hipMemcpyDeviceToHost, d.stream));
+  HIP_OK(hipStreamSynchronize(d.stream));
+  (void)hipFree(n_out);
+  (void)hipFree(n_in);
+  uint32_t* oj = dalloc<uint32_t>(d, tot[0]);
+  uint32_t* ij = dalloc<uint32_t>(d, tot[1]);
+  c.oj_ptr = op; c.ij_ptr = ip;
+  hipLaunchKernelGGL(junction_slot_lists_kernel<true>, dim3(blocks), dim3(256), 0, d.stream, c, nullptr, nullptr, oj, ij);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipStreamSynchronize(d.stream));
+  c.oj = oj; c.ij = ij;
+}
+
 static void build_share_bits(DeviceCall& d, CallView& c, uint64_t A) {
   c.share_ex = nullptr; c.iflags = nullptr;
   if (A == 0 || getenv("PANTAS_CALL_NO_SHARE_BITS")) return;
@@ -501,6 +546,7 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
   build_walk_runs(*d, c);
   build_share_bits(*d, c, t.A);
   build_junction_rows(*d, c, up(*d, t.junctions), uint32_t(t.junctions.size()));
+  build_junction_slot_lists(*d, c);
   pt.lap("walk runs, shared-exon bits, junction rows (device)");
   if (pt.on) fprintf(stderr, "[timing] upload_call: %.2f GB: hipMalloc %.3f s, copies %.3f s (%.1f GB/s)\n", g_up_bytes / 1e9, g_up_malloc_s, g_up_copy_s,
                      g_up_copy_s > 0 ? g_up_bytes / 1e9 / g_up_copy_s : 0.0);

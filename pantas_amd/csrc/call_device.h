@@ -102,6 +102,12 @@ struct CallView {
   const uint32_t* j_ht_n;                 // [2 nJ] heads / tails of gene g among the junction links at u / v (annotated_junction), | J_KEYERR
   const uint32_t* j_ht;                   // [2 J_HT_MAX nJ] the first J_HT_MAX heads, then tails, in row order
   const unsigned long long* j_carried;    // [2 nJ] bit i: an out-neighbour of u carries u's exon tag i / an in-neighbour of v carries v's tag i
+  // Per node, the slots of its out-row (oj: slot indices) and of its in-row (ij: in-slot positions) whose link is a junction, in
+  // row order, duplicates included (nullptr: not offered; call.hip junction_slot_lists_kernel).  What novel_link and the search
+  // of rule R3 ask a row for is its few junction links, the rows the reads made are thousands of novel links long, and every
+  // novel link of such a row asked again: 78 % of the novel-link pass at S5 was the search reading its anchor's row for its targets.
+  const uint32_t* oj_ptr; const uint32_t* oj;       // [V + 1], [oj_ptr[V]]
+  const uint32_t* ij_ptr; const uint32_t* ij;       // [V + 1], [ij_ptr[V]]
   unsigned long long* stamps;   // timing experiments only (EXPERIMENTS builds)
   uint32_t rank_monotone;       // the names' string order is the order of the S lines (rank[n] < rank[n + 1] throughout): what lets the
                                 // greedy walk, whose step asks "name <= v's name", take a run as well
@@ -370,9 +376,12 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
   uint32_t n_tg = 0;
   bool tg_all = true;           // false: more targets than tg holds -- every test asks is_junction
   {
-    const uint32_t b = dir == 0 ? c.row_ptr[anchor] : c.irow_ptr[anchor];
-    const uint32_t e = dir == 0 ? c.row_ptr[anchor + 1] : c.irow_ptr[anchor + 1];
-    for (uint32_t s = b; s < e && tg_all; ++s) {
+    const bool lst = c.oj_ptr != nullptr;            // the junction slots of the row alone
+    const uint32_t* ptr = lst ? (dir == 0 ? c.oj_ptr : c.ij_ptr) : (dir == 0 ? c.row_ptr : c.irow_ptr);
+    const uint32_t* at = dir == 0 ? c.oj : c.ij;
+    const uint32_t b = ptr[anchor], e = ptr[anchor + 1];
+    for (uint32_t a = b; a < e && tg_all; ++a) {
+      const uint32_t s = lst ? at[a] : a;
       const uint32_t slot = dir == 0 ? s : c.islot[s];
       const uint32_t fs = c.first_slot[slot];
       if (fs != slot || !(c.lflags[fs] & L_JUNC)) continue;      // (a later duplicate of a pair: its first slot is listed too)
@@ -801,8 +810,10 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
   const Ex ex0 = ex_of(c, u), ex1 = ex_of(c, v);
   if (ex0.n == 0 && ex1.n == 0) return;
   PANTAS_DBG(T_DBG_NOV_J, s);                       // :541
-  const uint32_t ob = c.row_ptr[u], oe = c.row_ptr[u + 1];
-  const uint32_t ib = c.irow_ptr[v], ie = c.irow_ptr[v + 1];
+  // (every loop below keeps the junction links of a row and drops the rest: with the per-node lists it runs over those alone)
+  const bool lst = c.oj_ptr != nullptr;
+  const uint32_t ojb = lst ? c.oj_ptr[u] : c.row_ptr[u], oje = lst ? c.oj_ptr[u + 1] : c.row_ptr[u + 1];
+  const uint32_t ijb = lst ? c.ij_ptr[v] : c.irow_ptr[v], ije = lst ? c.ij_ptr[v + 1] : c.irow_ptr[v + 1];
   // cap = transcripts with an exon on both ends
   auto in_cap = [&](uint32_t tx) {
     bool a = false, b = false;
@@ -814,16 +825,19 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
   for (uint32_t i = 0; i < ex0.n && !cap_any; ++i)
     for (uint32_t k = 0; k < ex1.n && !cap_any; ++k) cap_any = ex0.tx[i] == ex1.tx[k];
 
+  PANTAS_SECTION_BEGIN(true);
   if (c.events & EV_ES) {
     PANTAS_DBG(T_DBG_NOV_ES, s);                    // :551
     if (ex0.n && ex1.n) {
       uint32_t both = 0;
       for (uint32_t i = 0; i < ex0.n; ++i) both += ex_has(ex1, ex0.tag[i]) ? 1u : 0u;
       if (both != ex0.n) {
-        for (uint32_t t = ob; t < oe; ++t) {
+        for (uint32_t a = ojb; a < oje; ++a) {
+          const uint32_t t = lst ? c.oj[a] : a;
           const uint32_t j1 = c.first_slot[t];
           if (!(c.lflags[j1] & L_JUNC)) continue;
-          for (uint32_t q = ib; q < ie; ++q) {
+          for (uint32_t a2 = ijb; a2 < ije; ++a2) {
+            const uint32_t q = lst ? c.ij[a2] : a2;
             if (!in_slot_may(c, q, I_JUNC)) continue;
             const uint32_t j2 = c.first_slot[c.islot[q]];
             if (!(c.lflags[j2] & L_JUNC)) continue;
@@ -845,6 +859,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
     }
   }
 
+  PANTAS_SECTION(0);
   if (c.events & EV_SS) {
     if (cap_any) PANTAS_DBG(T_DBG_NOV_SS1, s);      // :618
     if (cap_any) {
@@ -852,8 +867,9 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
       for (uint32_t side = 0; side < 2; ++side) {
         const Ex spl = side == 0 ? ex1 : ex0;
         if (spl.n == 0) continue;
-        const uint32_t b = side == 0 ? ob : ib, e = side == 0 ? oe : ie;
-        for (uint32_t t = b; t < e; ++t) {
+        const uint32_t b = side == 0 ? ojb : ijb, e = side == 0 ? oje : ije;
+        for (uint32_t a = b; a < e; ++a) {
+          const uint32_t t = lst ? (side == 0 ? c.oj[a] : c.ij[a]) : a;
           if (side == 1 && !in_slot_may(c, t, I_JUNC)) continue;
           const uint32_t n = side == 0 ? c.col[t] : c.icol[t];
           const uint32_t jj = c.first_slot[side == 0 ? t : c.islot[t]];
@@ -877,6 +893,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
         }
       }
     }
+    PANTAS_SECTION(1);
     PANTAS_DBG(T_DBG_NOV_SS2, s);                   // :728
     uint32_t j1 = CNONE;
     if (ex0.n && !ex1.n) {
@@ -896,6 +913,7 @@ PANTAS_HD void novel_link(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
     }
   }
 
+  PANTAS_SECTION(2);
   if ((c.events & EV_IR) && cap_any) {
     PANTAS_DBG(T_DBG_NOV_IR1, s);                   // :839
     bool inside_any = false;

@@ -134,6 +134,20 @@ int main(int argc, char** argv) {
       }
       c.iflags = iflags.data();
     }
+    // ... the junction slots of every out-row and in-row (CallView::oj / ij), by the filter they replace
+    std::vector<uint32_t> oj_ptr(size_t(c.V) + 1, 0u), ij_ptr(size_t(c.V) + 1, 0u), oj, ij;
+    if (!getenv("HOSTSIM_CALL_NO_SHARE_BITS")) {
+      for (uint32_t n = 0; n < c.V; ++n) {
+        for (uint32_t s2 = c.row_ptr[n]; s2 < c.row_ptr[n + 1]; ++s2)
+          if (c.lflags[c.first_slot[s2]] & L_JUNC) oj.push_back(s2);
+        oj_ptr[n + 1] = uint32_t(oj.size());
+        for (uint32_t q = c.irow_ptr[n]; q < c.irow_ptr[n + 1]; ++q)
+          if (c.lflags[c.first_slot[c.islot[q]]] & L_JUNC) ij.push_back(q);
+        ij_ptr[n + 1] = uint32_t(ij.size());
+      }
+      oj.push_back(0); ij.push_back(0);       // (data() of an empty vector may be null: the view tests the pointers)
+      c.oj_ptr = oj_ptr.data(); c.oj = oj.data(); c.ij_ptr = ij_ptr.data(); c.ij = ij.data();
+    }
     // ... and the per-junction lists and masks (CallView::j_ht_n / j_ht / j_carried), by the loops they replace
     const size_t nJ = t.junctions.size();
     std::vector<uint32_t> j_ht_n(2 * nJ + 1, 0u), j_ht(2 * J_HT_MAX * nJ + 1, CNONE);
