@@ -436,6 +436,19 @@ static void build_junction_rows(DeviceCall& d, CallView& c, const uint32_t* d_ju
   HIP_OK(hipGetLastError());
   HIP_OK(hipStreamSynchronize(d.stream));
   c.j_ht_n = ht_n; c.j_ht = ht; c.j_carried = carried;
+  if (getenv("PANTAS_CALL_HIST")) {
+    // how many heads / tails the junctions have (tuning aid: J_HT_MAX of them are listed, the rest are found by walking the row)
+    std::vector<uint32_t> h(size_t(2) * nJ);
+    HIP_OK(hipMemcpy(h.data(), ht_n, h.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t hist[8] = {0};
+    for (uint32_t x : h) {
+      const uint32_t n = x & ~(J_KEYERR | J_NO_MASK);
+      ++hist[n == 0 ? 0 : n <= 4 ? 1 : n <= 8 ? 2 : n <= 16 ? 3 : n <= 32 ? 4 : n <= 64 ? 5 : n <= 256 ? 6 : 7];
+    }
+    fprintf(stderr, "[call hist] heads / tails per junction side: 0: %llu, <=4: %llu, <=8: %llu, <=16: %llu, <=32: %llu, <=64: %llu, <=256: %llu, more: %llu\n",
+            (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4],
+            (unsigned long long)hist[5], (unsigned long long)hist[6], (unsigned long long)hist[7]);
+  }
 }
 
 // CallView::oj / ij: a thread per node.  WRITE false: the number of junction slots in its out-row and in its in-row; true: the

@@ -530,6 +530,35 @@ PANTAS_HD void gene_accumulate(const CallView& c, uint32_t tx, uint32_t& gene, F
 #endif
 #define PANTAS_DBG(TYPE, SLOT) do { if (c.debug) { emit.begin(TYPE, CNONE, SLOT, CNONE, CNONE); emit.end(0); } } while (0)
 
+// The exon tags of a junction's end, held by the lane (up to 16 of them; every end of the whole-genome workloads has at most 12):
+// which of them a neighbour carries is then a compare per pair in registers.  Looked up tag by tag in the end's list -- a binary
+// search of dependent loads per tag of the neighbour -- the neighbours of a row of a few thousand links that do share an exon with
+// the end cost 12 us each, and their lane held its wave for the length of the kernel.
+struct EndTags {
+  static constexpr uint32_t N = 16;
+  uint32_t t[N];
+  bool held;
+  Ex ex;
+  PANTAS_HD explicit EndTags(const Ex& e) : held(e.n <= N), ex(e) {
+    for (uint32_t k = 0; k < N; ++k) t[k] = (held && k < e.n) ? e.tag[k] : CNONE;
+  }
+  // bit k: the end's tag k is among the tags of `en`
+  PANTAS_HD unsigned long long carried_by(const Ex& en) const {
+    unsigned long long m = 0;
+    if (held) {
+      for (uint32_t i = 0; i < en.n; ++i) {
+        const uint32_t tg = en.tag[i];
+        uint32_t hit = 0;
+        for (uint32_t k = 0; k < N; ++k) if (t[k] == tg) hit |= 1u << k;
+        m |= hit;
+      }
+    } else {
+      for (uint32_t i = 0; i < en.n; ++i) { const uint32_t k = ex_find(ex, en.tag[i]); if (k != CNONE) m |= 1ull << k; }
+    }
+    return m;
+  }
+};
+
 // ---- pass 1: annotated junctions (:239-524) ----------------------------------------------------------------
 template <class Emit>
 PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
@@ -636,6 +665,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     unsigned long long far_has[HT_MAX], far_new[HT_MAX];       // per tail / head: tags of gene g its far end carries; those of a transcript the junction lacks
     if (n_tails) {
       unsigned long long of_gene = 0;
+      const EndTags end_tags(exu);
       if (by_masks) {
         for (uint32_t k = 0; k < exu.n; ++k) if (exu.gene[k] == g) of_gene |= 1ull << k;
         for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
@@ -658,8 +688,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
         if (n == v) continue;
         const Ex en = ex_of(c, n);
         if (by_masks) {
-          unsigned long long mine = 0;               // tags of u that n carries
-          for (uint32_t i = 0; i < en.n; ++i) { const uint32_t k = ex_find(exu, en.tag[i]); if (k != CNONE) mine |= 1ull << k; }
+          const unsigned long long mine = end_tags.carried_by(en);      // tags of u that n carries
           if (!(mine & of_gene)) continue;
           for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
             if (!(far_has[ti_] & mine) || !(far_new[ti_] & mine)) continue;
@@ -699,6 +728,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
     }
     if (n_heads) {
       unsigned long long of_gene = 0;
+      const EndTags end_tags(exv);
       if (by_masks) {
         for (uint32_t k = 0; k < exv.n; ++k) if (exv.gene[k] == g) of_gene |= 1ull << k;
         for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
@@ -722,8 +752,7 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
         if (n == u) continue;
         const Ex en = ex_of(c, n);
         if (by_masks) {
-          unsigned long long mine = 0;               // tags of v that n carries
-          for (uint32_t i = 0; i < en.n; ++i) { const uint32_t k = ex_find(exv, en.tag[i]); if (k != CNONE) mine |= 1ull << k; }
+          const unsigned long long mine = end_tags.carried_by(en);      // tags of v that n carries
           if (!(mine & of_gene)) continue;
           for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
             if (!(far_has[hi_] & mine) || !(far_new[hi_] & mine)) continue;
