@@ -211,6 +211,10 @@ struct PassLane {
   uint32_t* arena_next = nullptr;
   void* scan_tmp = nullptr;                 // hipcub temporary storage, grown on demand
   size_t scan_tmp_bytes = 0;
+  // the buffers of the lane's pass, kept for the next run on this handle (several replicates on one graph; the benchmark): a pass
+  // asks for the same twenty buffers in the same order every time, and hipMalloc is 50 us on a good day, 5 ms -- or 200 -- on others
+  std::vector<std::pair<void*, size_t>> blocks;
+  size_t next_block = 0;
 };
 constexpr int PASS_LANES = 4;
 
@@ -234,6 +238,7 @@ void DeviceCallDeleter::operator()(DeviceCall* d) const {
   for (int k = 0; k < PASS_LANES; ++k) {
     PassLane& l = d->lane[k];
     if (l.scan_tmp) (void)hipFree(l.scan_tmp);
+    for (auto& b : l.blocks) (void)hipFree(b.first);
     if (l.ev0) (void)hipEventDestroy(l.ev0);
     if (l.ev1) (void)hipEventDestroy(l.ev1);
     if (k && l.stream) (void)hipStreamDestroy(l.stream);
@@ -568,17 +573,12 @@ DeviceCallPtr upload_call(const Graph& g, const CallTables& t, int device) {
 }
 
 // what one pass leaves on the device until run_call has the totals of all passes and copies everything to the host once
-struct PassOut {
-  std::vector<void*> tmp;            // every device buffer of the pass
+struct PassOut {                     // (the buffers themselves belong to the pass's lane)
   EventRec* recs = nullptr;
   uint32_t* side = nullptr;
   TaskOut* tasks = nullptr;
   uint32_t* paths = nullptr;
   uint32_t n_recs = 0, n_words = 0, n_tasks = 0, n_paths = 0;
-  PassOut() = default;
-  PassOut(const PassOut&) = delete;
-  PassOut& operator=(const PassOut&) = delete;
-  ~PassOut() { for (void* p : tmp) (void)hipFree(p); }
 };
 
 template <int PASS>
@@ -591,12 +591,24 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
   const double t_in = timing ? now_s() : 0;
   double malloc_s = 0;
   size_t malloc_bytes = 0;
+  d.next_block = 0;
+  size_t n_malloc = 0;
   auto dev = [&](size_t bytes) {
-    void* p = nullptr;
+    bytes = std::max<size_t>(bytes, 4);
+    if (d.next_block < d.blocks.size() && d.blocks[d.next_block].second >= bytes) return d.blocks[d.next_block++].first;
     const double t0 = timing ? now_s() : 0;
-    HIP_OK(dmalloc(&p, std::max<size_t>(bytes, 4)));
-    if (timing) { malloc_s += now_s() - t0; malloc_bytes += bytes; }
-    po.tmp.push_back(p);
+    if (d.next_block < d.blocks.size()) {          // (this run needs more here than the last one did)
+      HIP_OK(hipStreamSynchronize(d.stream));
+      (void)hipFree(d.blocks[d.next_block].first);
+      d.blocks[d.next_block] = {nullptr, 0};
+    } else {
+      d.blocks.push_back({nullptr, 0});
+    }
+    void* p = nullptr;
+    HIP_OK(dmalloc(&p, bytes));
+    d.blocks[d.next_block] = {p, bytes};
+    ++d.next_block;
+    if (timing) { malloc_s += now_s() - t0; malloc_bytes += bytes; ++n_malloc; }
     return p;
   };
   auto u32 = [&](size_t count) { return static_cast<uint32_t*>(dev(count * 4)); };
@@ -739,7 +751,7 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
   HIP_OK(hipEventElapsedTime(&t, d.ev0, d.ev1));
   ms += t;
   if (timing) fprintf(stderr, "[timing] run_pass<%d>: %u items, %.3f ms on the device, %.3f ms on the host of which %.3f in %zu hipMalloc (%.2f GB)\n", PASS, n, t,
-                      (now_s() - t_in) * 1e3, malloc_s * 1e3, po.tmp.size(), malloc_bytes / 1e9);
+                      (now_s() - t_in) * 1e3, malloc_s * 1e3, n_malloc, malloc_bytes / 1e9);
   po.recs = d_recs; po.side = d_side; po.tasks = d_tout; po.paths = d_paths;
   po.n_recs = totals[0]; po.n_words = totals[1]; po.n_tasks = nt; po.n_paths = path_total;
 }

@@ -559,6 +559,54 @@ struct EndTags {
   }
 };
 
+// A row scanned ROW_BATCH neighbours at a time: which neighbours the filters leave (node_at: CNONE = dropped), where their tag lists
+// stand and the lists themselves are asked for TOGETHER -- one trip to memory per batch and step instead of two per neighbour -- and
+// each(position, tags of the end the neighbour carries) is then called in row order (false = stop, scan_row returns false).  A lane's
+// pass over a row of thousands of links of which hundreds share an exon with the end was a chain of dependent loads per neighbour.
+constexpr uint32_t ROW_BATCH = 8;
+template <class NodeAt, class Each>
+PANTAS_HD bool scan_row(const CallView& c, uint32_t b, uint32_t e, const EndTags& end, NodeAt node_at, Each each) {
+  for (uint32_t p0 = b; p0 < e; p0 += ROW_BATCH) {
+    uint32_t nd[ROW_BATCH], lo[ROW_BATCH], len[ROW_BATCH];
+    unsigned long long mine[ROW_BATCH];
+    uint32_t longest = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ROW_BATCH; ++k) nd[k] = p0 + k < e ? node_at(p0 + k) : CNONE;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t k = 0; k < ROW_BATCH; ++k) {
+      const uint32_t n = nd[k] == CNONE ? 0u : nd[k];
+      lo[k] = c.ex_ptr[n];
+      len[k] = nd[k] == CNONE ? 0u : c.ex_ptr[n + 1u] - lo[k];
+      mine[k] = 0;
+      if (len[k] > longest) longest = len[k];
+    }
+    if (end.held) {
+      for (uint32_t i = 0; i < longest; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t k = 0; k < ROW_BATCH; ++k) {
+          if (i >= len[k]) continue;
+          const uint32_t tg = c.ex_tag[lo[k] + i];
+          uint32_t hit = 0;
+          for (uint32_t j = 0; j < EndTags::N; ++j) if (end.t[j] == tg) hit |= 1u << j;
+          mine[k] |= hit;
+        }
+      }
+    } else {
+      for (uint32_t k = 0; k < ROW_BATCH; ++k)
+        if (len[k]) mine[k] = end.carried_by(Ex{c.ex_tag + lo[k], c.ex_tx + lo[k], c.ex_gene + lo[k], len[k]});
+    }
+    for (uint32_t k = 0; k < ROW_BATCH; ++k)
+      if (nd[k] != CNONE && !each(p0 + k, mine[k])) return false;
+  }
+  return true;
+}
+
 // ---- pass 1: annotated junctions (:239-524) ----------------------------------------------------------------
 template <class Emit>
 PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fault& f) {
@@ -681,26 +729,37 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
           }
         }
       }
-      for (uint32_t t = ob; t < oe; ++t) {          // every out-link line of u, duplicates included
+      if (by_masks) {
+        // a tail that shares a transcript with the junction [the assert of :405] stops the run where its first row would be written
+        uint32_t clash = 0;
+        for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
+          const Set ta = jt_of(c, s), tb = jt_of(c, tails[ti_]);
+          for (uint32_t i = 0; i < ta.n; ++i) if (set_has(tb, ta.p[i])) clash |= 1u << ti_;
+        }
+        const bool through = scan_row(c, ob, oe, end_tags,
+          [&](uint32_t t) -> uint32_t {               // every out-link line of u, duplicates included
+            if (!in_out_list(c, t) || !may_share_exon(c, t)) return CNONE;
+            const uint32_t n = c.col[t];
+            return n == v ? CNONE : n;
+          },
+          [&](uint32_t, unsigned long long mine) -> bool {      // mine: tags of u that the neighbour carries
+            if (!(mine & of_gene)) return true;
+            for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
+              if (!(far_has[ti_] & mine) || !(far_new[ti_] & mine)) continue;
+              if ((clash >> ti_) & 1u) { f.raise(CE_ASSERT_JN); return false; }
+              emit.begin(T_SS_ANN_A, g, s, tails[ti_], CNONE);
+              emit.end(0);
+            }
+            return true;
+          });
+        if (!through) return;
+      }
+      for (uint32_t t = ob; t < oe && !by_masks; ++t) {          // every out-link line of u, duplicates included
         if (!in_out_list(c, t)) continue;
         if (!may_share_exon(c, t)) continue;        // (the neighbour carries none of u's exons: `cont` below would stay false)
         const uint32_t n = c.col[t];
         if (n == v) continue;
         const Ex en = ex_of(c, n);
-        if (by_masks) {
-          const unsigned long long mine = end_tags.carried_by(en);      // tags of u that n carries
-          if (!(mine & of_gene)) continue;
-          for (uint32_t ti_ = 0; ti_ < n_tails; ++ti_) {
-            if (!(far_has[ti_] & mine) || !(far_new[ti_] & mine)) continue;
-            const uint32_t t2 = tails[ti_];
-            const Set ta = jt_of(c, s), tb = jt_of(c, t2);
-            for (uint32_t i = 0; i < ta.n; ++i)
-              if (set_has(tb, ta.p[i])) { f.raise(CE_ASSERT_JN); return; }
-            emit.begin(T_SS_ANN_A, g, s, t2, CNONE);
-            emit.end(0);
-          }
-          continue;
-        }
         bool cont = false;
         for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exu, en.tag[i], g);
         if (!cont) continue;
@@ -744,23 +803,32 @@ PANTAS_HD void annotated_junction(const CallView& c, uint32_t s, Emit& emit, Fau
           }
         }
       }
-      for (uint32_t q0 = ib; q0 < ie; ++q0) {        // every in-link line of v
+      if (by_masks) {
+        scan_row(c, ib, ie, end_tags,
+          [&](uint32_t q0) -> uint32_t {              // every in-link line of v
+            if (!in_slot_may(c, q0, I_SHARE)) return CNONE;
+            const uint32_t sl = c.islot[q0];
+            if (!in_in_list(c, sl) || !may_share_exon(c, sl)) return CNONE;
+            const uint32_t n = c.icol[q0];
+            return n == u ? CNONE : n;
+          },
+          [&](uint32_t, unsigned long long mine) -> bool {      // mine: tags of v that the neighbour carries
+            if (!(mine & of_gene)) return true;
+            for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
+              if (!(far_has[hi_] & mine) || !(far_new[hi_] & mine)) continue;
+              emit.begin(T_SS_ANN_B, g, s, heads[hi_], CNONE);
+              emit.end(0);
+            }
+            return true;
+          });
+      }
+      for (uint32_t q0 = ib; q0 < ie && !by_masks; ++q0) {        // every in-link line of v
         if (!in_slot_may(c, q0, I_SHARE)) continue;        // (the neighbour carries none of v's exons: `cont` below would stay false)
         if (!in_in_list(c, c.islot[q0])) continue;
         if (!may_share_exon(c, c.islot[q0])) continue;
         const uint32_t n = c.icol[q0];
         if (n == u) continue;
         const Ex en = ex_of(c, n);
-        if (by_masks) {
-          const unsigned long long mine = end_tags.carried_by(en);      // tags of v that n carries
-          if (!(mine & of_gene)) continue;
-          for (uint32_t hi_ = 0; hi_ < n_heads; ++hi_) {
-            if (!(far_has[hi_] & mine) || !(far_new[hi_] & mine)) continue;
-            emit.begin(T_SS_ANN_B, g, s, heads[hi_], CNONE);
-            emit.end(0);
-          }
-          continue;
-        }
         bool cont = false;
         for (uint32_t i = 0; i < en.n && !cont; ++i) cont = ex_has_gene(exv, en.tag[i], g);
         if (!cont) continue;
