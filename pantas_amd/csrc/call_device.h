@@ -198,6 +198,19 @@ PANTAS_HD uint32_t ex_find(const Ex& s, uint32_t tag) {
   }
   return (lo < s.n && s.tag[lo] == tag) ? lo : CNONE;
 }
+// ex_has for a walk's step: the list's tags four at a time, all asked for at once -- the binary search is three or four trips to
+// memory, one behind the other, and a walk's time is its number of trips.
+PANTAS_HD bool ex_has_flat(const CallView& c, uint32_t node, uint32_t tag) {
+  const uint32_t b = c.ex_ptr[node], n = c.ex_ptr[node + 1] - b;
+  bool hit = false;
+  for (uint32_t i = 0; i < n; i += 4u) {
+    const uint32_t last = n - 1u;
+    const uint32_t t0 = c.ex_tag[b + i], t1 = c.ex_tag[b + (i + 1u < n ? i + 1u : last)], t2 = c.ex_tag[b + (i + 2u < n ? i + 2u : last)],
+                   t3 = c.ex_tag[b + (i + 3u < n ? i + 3u : last)];
+    hit |= t0 == tag || t1 == tag || t2 == tag || t3 == tag;
+  }
+  return hit;
+}
 // tag is an exon of `s` that belongs to gene g
 PANTAS_HD bool ex_has_gene(const Ex& s, uint32_t tag, uint32_t g) {
   uint32_t i = ex_find(s, tag);
@@ -1224,12 +1237,21 @@ PANTAS_HD void run_walk_task(const CallView& c, const EventRec& r, const uint32_
   const uint32_t u = c.src[r.j0], v = c.col[r.j0];
   if (r.type == T_IR_ANN) {
     const uint32_t n1 = side[r.side_off], n2 = side[r.side_off + 1], pick = side[r.side_off + 2];
-    auto ok = [&](uint32_t nn) { return ex_has(ex_of(c, nn), pick); };
+    auto ok = [&](uint32_t nn) { return ex_has_flat(c, nn, pick); };
     if (!walk_exon<Emit>(c, n1, n2, ok, path, np, ncs, ln, nc_ok, f)) return;
   } else if (r.type == T_IR1_NOV) {
     const Ex ex0 = ex_of(c, u), ex1 = ex_of(c, v);
+    // the tags on BOTH ends, found once and held by the lane (a step then compares the neighbour's tags with them in registers
+    // instead of looking each of them up in both lists); more than EndTags holds: the lists are asked as before
+    uint32_t both[EndTags::N];
+    uint32_t n_both = 0;
+    bool held = true;
+    for (uint32_t i = 0; i < ex0.n && held; ++i)
+      if (ex_has(ex1, ex0.tag[i])) { if (n_both == EndTags::N) held = false; else both[n_both++] = ex0.tag[i]; }
+    const EndTags on_both(Ex{both, both, both, held ? n_both : 0u});
     auto ok = [&](uint32_t nn) {
       const Ex en = ex_of(c, nn);
+      if (held) return on_both.carried_by(en) != 0ull;
       for (uint32_t i = 0; i < en.n; ++i)
         if (ex_has(ex0, en.tag[i]) && ex_has(ex1, en.tag[i])) return true;
       return false;
