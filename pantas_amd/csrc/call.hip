@@ -39,6 +39,7 @@ template <int PASS>
 __global__ __launch_bounds__(256) void call_count_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx,
                                                          uint32_t n, uint32_t* nrec, uint32_t* nword, uint32_t* ntask,
                                                          unsigned long long* status) {
+  frontier_lds_init();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     CountEmit e;
     Fault f;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void call_write_kernel(CallView c, const uint3
                                                          uint32_t n, const uint32_t* rec_off, const uint32_t* word_off,
                                                          const uint32_t* task_off, EventRec* recs, uint32_t* side,
                                                          uint32_t* task_list) {
+  frontier_lds_init();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     if (rec_off[i + 1] == rec_off[i]) continue;   // nothing to emit: skip the second evaluation
     WriteEmit e{recs, side, rec_off[i], word_off[i], task_list, task_off[i]};
@@ -72,6 +74,7 @@ __global__ __launch_bounds__(256) void call_write_kernel(CallView c, const uint3
 template <int PASS>
 __global__ __launch_bounds__(256) void call_stage_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx, uint32_t n, uint32_t* nrec, uint32_t* nword,
                                                          uint32_t* ntask, uint8_t* fits, EventRec* stage_rec, uint32_t* stage_side, unsigned long long* status) {
+  frontier_lds_init();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     StageEmit e{stage_rec + size_t(i) * STAGE_RECS, stage_side + size_t(i) * STAGE_WORDS};
     Fault f;
@@ -106,6 +109,7 @@ template <int PASS>
 __global__ __launch_bounds__(256) void call_place_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx, uint32_t n, const uint32_t* rec_off,
                                                          const uint32_t* word_off, const uint32_t* task_off, const uint8_t* fits, const EventRec* stage_rec,
                                                          const uint32_t* stage_side, EventRec* recs, uint32_t* side, uint32_t* task_list) {
+  frontier_lds_init();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t r0 = rec_off[i], nr = rec_off[i + 1] - r0;
     if (nr == 0) continue;
@@ -645,7 +649,7 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
 #ifdef PANTAS_EXPERIMENTS
   CallView cs = c;
   cs.stamps = d.status + 43;
-  if (getenv("PANTAS_CALL_STAMPS")) { cs.events |= 0x8000u; HIP_OK(hipMemsetAsync(d.status + 1, 0, 47 * 8, d.stream)); }
+  if (getenv("PANTAS_CALL_STAMPS")) { cs.events |= getenv("PANTAS_CALL_STAMPS_FRONTIER") ? 0x4000u : 0x8000u; HIP_OK(hipMemsetAsync(d.status + 1, 0, 47 * 8, d.stream)); }
   if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, cs, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status);
   if (staged && getenv("PANTAS_CALL_STAMPS")) {
     unsigned long long h[47];
@@ -761,6 +765,8 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
   CallView c = d.view;
   c.rca = o.rca; c.isw = o.isw; c.minintron = o.minintron; c.events = o.events; c.debug = o.debug ? 1u : 0u;
   c.arena = d.arena; c.arena_slots = ARENA_SLOTS; c.arena_cap = ARENA_CAP;
+  // (PANTAS_CALL_LDS_FRONTIER=0: registers, then the arena, as until round 5; a small number: the tests' way through all three)
+  c.frontier_lds = getenv("PANTAS_CALL_LDS_FRONTIER") ? uint32_t(std::max(0, atoi(getenv("PANTAS_CALL_LDS_FRONTIER")))) : FRONTIER_LDS;
   PhaseTimer pt("run_call");
   std::vector<uint32_t> ann, nov, around, around_j;
   pass_lists(g, t, o, ann, nov, around, around_j);

@@ -109,6 +109,7 @@ struct CallView {
   const uint32_t* oj_ptr; const uint32_t* oj;       // [V + 1], [oj_ptr[V]]
   const uint32_t* ij_ptr; const uint32_t* ij;       // [V + 1], [ij_ptr[V]]
   unsigned long long* stamps;   // timing experiments only (EXPERIMENTS builds)
+  uint32_t frontier_lds;        // words of the workgroup's LDS the R3 search may use between its registers and the arena (0: none; frontier_search)
   uint32_t rank_monotone;       // the names' string order is the order of the S lines (rank[n] < rank[n + 1] throughout): what lets the
                                 // greedy walk, whose step asks "name <= v's name", take a run as well
   const uint32_t* ex_ptr; const uint32_t* ex_tag; const uint32_t* ex_tx; const uint32_t* ex_gene;  // per node, sorted by tag id
@@ -380,6 +381,88 @@ PANTAS_HD bool walk_greedy(const CallView& c, uint32_t u, uint32_t v, Emit* emit
 // dir 1: follow in-links, targets = {p : (p, anchor) junction}.
 constexpr uint32_t FRONTIER_LOCAL = 64;
 constexpr uint32_t FRONTIER_TARGETS = 8;
+// Between the lane's 64 words and a slice of the arena in HBM: 32 KB of the workgroup's LDS, for ONE search of the workgroup at a
+// time (frontier_lds_held; a second one that outgrows its registers while the first holds it goes to the arena).  A search that
+// runs into a segment with thousands of links is a lane alone with a sort and a copy per level -- every step a dependent access,
+// half a microsecond each in HBM (S5: one such search was 20 of the novel-link pass's 22 ms), a few tens of nanoseconds in LDS.
+constexpr uint32_t FRONTIER_LDS = 8192;
+#if defined(__HIP_DEVICE_COMPILE__)
+__shared__ uint32_t frontier_lds[FRONTIER_LDS];
+__shared__ uint32_t frontier_lds_held;
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void frontier_lds_init() {      // every kernel that may search calls this first
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (threadIdx.x == 0) frontier_lds_held = 0u;
+  __syncthreads();
+#endif
+}
+#endif
+#if defined(PANTAS_EXPERIMENTS) && defined(__HIP_DEVICE_COMPILE__)
+#define PANTAS_FRONTIER_T0() const unsigned long long ft0_ = ((c.events & 0x4000u) && buf != local) ? __builtin_amdgcn_s_memtime() : 0ull
+#define PANTAS_FRONTIER_T(K) do { if (ft0_) { fph_[K] += __builtin_amdgcn_s_memtime() - ft0_; atomicMax(c.stamps + (K), fph_[K]); } } while (0)
+#define PANTAS_FRONTIER_SIZE(N) do { if (c.events & 0x4000u) atomicMax(c.stamps + 3, (unsigned long long)(N)); } while (0)
+#else
+#define PANTAS_FRONTIER_SIZE(N) do {} while (0)
+#define PANTAS_FRONTIER_T0() do {} while (0)
+#define PANTAS_FRONTIER_T(K) do {} while (0)
+#endif
+// Where the words of a search stand -- the lane's own 64, the workgroup's LDS, a slice of the arena in HBM -- is SAID to the
+// compiler in the two loops that are all dependent accesses (the sort of a level, its move to the front): through a generic
+// pointer every access is a flat one that waits for both memory counters before the next is issued.
+struct AnyWords {
+  uint32_t* p;
+  PANTAS_HD uint32_t get(uint32_t i) const { return p[i]; }
+  PANTAS_HD void set(uint32_t i, uint32_t v) const { p[i] = v; }
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+struct LdsWords {
+  uint32_t off;
+  __device__ __forceinline__ uint32_t get(uint32_t i) const { return frontier_lds[off + i]; }
+  __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { frontier_lds[off + i] = v; }
+};
+struct HbmWords {
+  __attribute__((address_space(1))) uint32_t* p;
+  __device__ __forceinline__ uint32_t get(uint32_t i) const { return p[i]; }
+  __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { p[i] = v; }
+};
+#endif
+// a[0 .. m) sorted (heapsort: in place) and made unique; returns the new count
+template <class W>
+PANTAS_HD uint32_t sort_unique_words(const W a, uint32_t m) {
+  if (m < 2u) return m;
+  auto sift = [&](uint32_t root, uint32_t size) {
+    const uint32_t v = a.get(root);
+    for (;;) {
+      uint32_t ch = 2u * root + 1u;
+      if (ch >= size) break;
+      uint32_t cv = a.get(ch);
+      if (ch + 1u < size) { const uint32_t c1 = a.get(ch + 1u); if (c1 > cv) { cv = c1; ++ch; } }
+      if (cv <= v) break;
+      a.set(root, cv);
+      root = ch;
+    }
+    a.set(root, v);
+  };
+  for (uint32_t i = m / 2u; i-- > 0u;) sift(i, m);
+  for (uint32_t size = m; size-- > 1u;) { const uint32_t t = a.get(0u); a.set(0u, a.get(size)); a.set(size, t); sift(0u, size); }
+  uint32_t k = 1;
+  uint32_t prev = a.get(0u);
+  for (uint32_t i = 1; i < m; ++i) { const uint32_t v = a.get(i); if (v != prev) { a.set(k++, v); prev = v; } }
+  return k;
+}
+// dst[0 .. n) = src[0 .. n), eight words asked for at a time (dst may lie below src in the same buffer)
+template <class D, class S>
+PANTAS_HD void move_words(const D dst, const S src, uint32_t n) {
+  uint32_t i = 0;
+  for (; i + 8u <= n; i += 8u) {
+    const uint32_t a = src.get(i), b = src.get(i + 1u), c2 = src.get(i + 2u), d = src.get(i + 3u), e = src.get(i + 4u), g = src.get(i + 5u), h = src.get(i + 6u),
+                   k = src.get(i + 7u);
+    dst.set(i, a); dst.set(i + 1u, b); dst.set(i + 2u, c2); dst.set(i + 3u, d); dst.set(i + 4u, e); dst.set(i + 5u, g); dst.set(i + 6u, h); dst.set(i + 7u, k);
+  }
+  for (; i < n; ++i) dst.set(i, src.get(i));
+}
+
 PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t anchor, uint32_t dir, Fault& f) {
   // The targets -- the other ends of the anchor's junction links -- are a handful: taken from the anchor's own row (dir 0) or
   // in-list (dir 1) once, so that a node is tested when it ENTERS the set and against that handful, instead of every member of
@@ -419,74 +502,113 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
   uint32_t local[FRONTIER_LOCAL];
   uint32_t* buf = local;      // moves to an arena slice when it outgrows `local`
   uint32_t cap = FRONTIER_LOCAL;
-  struct Held {               // the slice goes back wherever the search ends
-    uint32_t* arena; uint32_t slice, cap;
-    PANTAS_HD ~Held() { if (slice != CNONE) release_slice(arena, slice, cap); }
-  } held{c.arena, CNONE, c.arena_cap};
+  struct Held {               // the LDS and the slice go back wherever the search ends
+    uint32_t* arena; uint32_t slice, cap; bool lds;
+    PANTAS_HD ~Held() {
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (lds) atomicExch(&frontier_lds_held, 0u);
+#endif
+      if (slice != CNONE) release_slice(arena, slice, cap);
+    }
+  } held{c.arena, CNONE, c.arena_cap, false};
   uint32_t nl = 1, nn = 0, pos = 0;
   buf[0] = start;
   // the smallest target that has entered the set; members only leave by the pop below, which is not reached while there is one
   uint32_t tmin = is_target(start) ? start : CNONE;
   int32_t level = 0;
-  // nxt in place: heapsort, then unique; returns the new count
-  auto sort_unique = [&](uint32_t* a, uint32_t m) -> uint32_t {
-    if (m < 2u) return m;
-    auto sift = [&](uint32_t root, uint32_t size) {
-      const uint32_t v = a[root];
-      for (;;) {
-        uint32_t ch = 2u * root + 1u;
-        if (ch >= size) break;
-        if (ch + 1u < size && a[ch + 1u] > a[ch]) ++ch;
-        if (a[ch] <= v) break;
-        a[root] = a[ch];
-        root = ch;
-      }
-      a[root] = v;
-    };
-    for (uint32_t i = m / 2u; i-- > 0u;) sift(i, m);
-    for (uint32_t size = m; size-- > 1u;) { const uint32_t t = a[0]; a[0] = a[size]; a[size] = t; sift(0u, size); }
-    uint32_t k = 1;
-    for (uint32_t i = 1; i < m; ++i) if (a[i] != a[k - 1u]) a[k++] = a[i];
-    return k;
+#if defined(PANTAS_EXPERIMENTS) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long fph_[3] = {0, 0, 0};      // this search's clocks per phase (the slowest search's show in the stamps)
+#endif
+  // nxt (buf[from .. from + m)) in place: sorted, then unique; returns the new count
+  auto sort_unique = [&](uint32_t from, uint32_t m) -> uint32_t {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (held.lds) return sort_unique_words(LdsWords{from}, m);
+    if (held.slice != CNONE) return sort_unique_words(HbmWords{(__attribute__((address_space(1))) uint32_t*)(buf + from)}, m);
+#endif
+    return sort_unique_words(AnyWords{buf + from}, m);
+  };
+  // the level's additions move to the front
+  auto to_front = [&](uint32_t from, uint32_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (held.lds) { move_words(LdsWords{0u}, LdsWords{from}, m); return; }
+    if (held.slice != CNONE) {
+      move_words(HbmWords{(__attribute__((address_space(1))) uint32_t*)buf}, HbmWords{(__attribute__((address_space(1))) uint32_t*)(buf + from)}, m);
+      return;
+    }
+#endif
+    move_words(AnyWords{buf}, AnyWords{buf + from}, m);
   };
   for (;;) {
     if (tmin != CNONE) return level < c.isw ? tmin : CNONE;
     if (level >= c.isw) return CNONE;
     if (pos == nl) {
       // the level is through: what it added is the next one
-      const uint32_t m = sort_unique(buf + nl, nn);
+      PANTAS_FRONTIER_T0();
+      PANTAS_FRONTIER_SIZE(nl + nn);
+      const uint32_t m = sort_unique(nl, nn);
+      PANTAS_FRONTIER_T(0);
       if (m == 0u) return CNONE;                                // (the set is empty)
-      for (uint32_t i = 0; i < m; ++i) buf[i] = buf[nl + i];
+      to_front(nl, m);
+      PANTAS_FRONTIER_T(1);
       nl = m; nn = 0; pos = 0;
     }
+    PANTAS_FRONTIER_T0();
     const uint32_t x = buf[pos++];
     const uint32_t b = dir == 0 ? c.row_ptr[x] : c.irow_ptr[x];
     const uint32_t e = dir == 0 ? c.row_ptr[x + 1] : c.irow_ptr[x + 1];
+    // what still waits in lev lies in [wait_lo, wait_hi]: a neighbour outside that range -- against the links' direction nearly
+    // every one: the waiting members come after x, its in-neighbours before it -- is not looked up (the lookup is a binary search
+    // of dependent loads in the arena: twelve trips per neighbour on a level of thousands)
+    const uint32_t wait_lo = pos < nl ? buf[pos] : CNONE, wait_hi = pos < nl ? buf[nl - 1u] : 0u;
     for (uint32_t s = b; s < e; ++s) {
       const uint32_t y = dir == 0 ? c.col[s] : c.icol[s];
       // still waiting in lev (behind pos): in the set already
-      uint32_t lo = pos, hi = nl;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (buf[mid] < y) lo = mid + 1; else hi = mid;
+      if (y >= wait_lo && y <= wait_hi) {
+        uint32_t lo = pos, hi = nl;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (buf[mid] < y) lo = mid + 1; else hi = mid;
+        }
+        if (lo < nl && buf[lo] == y) continue;
       }
-      if (lo < nl && buf[lo] == y) continue;
       if (nl + nn == cap) {
-        nn = sort_unique(buf + nl, nn);                         // copies of one node give their room back first
-        if (nl + nn == cap) {
-          if (buf != local || c.arena == nullptr) { f.raise(CE_FRONTIER); return CNONE; }
-          const uint32_t slice = claim_slice(c.arena_next, c.arena, c.arena_slots, c.arena_cap);
-          if (slice >= c.arena_slots) { f.raise(CE_FRONTIER); return CNONE; }
-          held.slice = slice;
-          uint32_t* big = c.arena + size_t(slice) * c.arena_cap + 1u;      // (word 0 is the slice's flag)
-          for (uint32_t i = 0; i < nl + nn; ++i) big[i] = buf[i];
-          buf = big;
-          cap = c.arena_cap - 1u;
+        nn = sort_unique(nl, nn);                               // copies of one node give their room back first
+        // ... but a buffer that stays three quarters full would be sorted again a few nodes later, and again: the next room up while
+        // there is one (the top one is only given up when it is full)
+        const bool top = held.slice != CNONE || c.arena == nullptr;
+        if (nl + nn == cap || (!top && nl + nn > cap - cap / 4u)) {
+          uint32_t* big = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (buf == local && c.frontier_lds > 2u * FRONTIER_LOCAL && atomicCAS(&frontier_lds_held, 0u, 1u) == 0u) {
+            held.lds = true;
+            big = frontier_lds;
+            cap = c.frontier_lds < FRONTIER_LDS ? c.frontier_lds : FRONTIER_LDS;
+          }
+#endif
+          if (!big && !top) {
+            const uint32_t slice = claim_slice(c.arena_next, c.arena, c.arena_slots, c.arena_cap);
+            if (slice < c.arena_slots) {
+              held.slice = slice;
+              big = c.arena + size_t(slice) * c.arena_cap + 1u;      // (word 0 is the slice's flag)
+              cap = c.arena_cap - 1u;
+            }
+          }
+          if (big) {
+            move_words(AnyWords{big}, AnyWords{buf}, nl + nn);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (held.lds && big != frontier_lds) { held.lds = false; atomicExch(&frontier_lds_held, 0u); }      // (outgrown as well)
+#endif
+            buf = big;
+          } else if (nl + nn == cap) {                               // nowhere to go and no word left
+            f.raise(CE_FRONTIER);
+            return CNONE;
+          }
         }
       }
       buf[nl + nn++] = y;
       if (y < tmin && is_target(y)) tmin = y;
     }
+    PANTAS_FRONTIER_T(2);
     if (pos == nl) ++level;            // the reference counts the level when its last member has been popped [:746-749]
   }
 }

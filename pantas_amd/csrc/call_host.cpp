@@ -1076,7 +1076,7 @@ CallView host_view(const Graph& g, const CallTables& t, const CallOptions& o) {
   c.first_slot = t.first_slot.data(); c.src = t.src.data(); c.lflags = t.lflags.data();
   c.hid = t.hidden.empty() ? nullptr : t.hidden.data();
   c.nxt1 = t.nxt1.data();
-  c.run_end_rev = nullptr; c.pl = nullptr; c.pnc = nullptr; c.rank_monotone = 0; c.share_ex = nullptr; c.iflags = nullptr; c.stamps = nullptr; c.j_ht_n = nullptr; c.j_ht = nullptr; c.j_carried = nullptr; c.oj_ptr = c.oj = c.ij_ptr = c.ij = nullptr;      // (made on the device, call.hip build_walk_runs / build_share_bits; the CPU harness makes its own)
+  c.run_end_rev = nullptr; c.pl = nullptr; c.pnc = nullptr; c.rank_monotone = 0; c.share_ex = nullptr; c.iflags = nullptr; c.stamps = nullptr; c.j_ht_n = nullptr; c.j_ht = nullptr; c.j_carried = nullptr; c.oj_ptr = c.oj = c.ij_ptr = c.ij = nullptr; c.frontier_lds = 0;      // (made on the device, call.hip build_walk_runs / build_share_bits; the CPU harness makes its own)
   c.rc = t.rc.data(); c.nc = t.nc.data(); c.nflags = t.nflags.data(); c.ln = g.seg_len.data(); c.rank = t.rank.data();
   c.ex_ptr = t.ex_ptr.data(); c.ex_tag = t.ex_tag.data(); c.ex_tx = t.ex_tx.data(); c.ex_gene = t.ex_gene.data();
   c.jrow = t.jrow.data();

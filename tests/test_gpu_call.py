@@ -125,13 +125,18 @@ def test_fused_equals_text_round_trip(tmp_path):
 
 
 @pytest.mark.parametrize("fan", [10, 40, 300, 5000])
-def test_intronic_search_beyond_local_frontier(tmp_path, fan):
+def test_intronic_search_beyond_local_frontier(tmp_path, fan, monkeypatch):
     from hub_case import write_hub_case
     pre = str(tmp_path / "hub")
     write_hub_case(pre, fan)
     flags = ["--novel", "--rca", "0"]
-    want = call_oracle.call(pre + ".gfa", pre + ".gtf", None, **_flags_to_opts(flags))
-    assert sorted(engine_call(pre + ".gfa", pre + ".gtf", flags)) == sorted(want)
+    want = sorted(call_oracle.call(pre + ".gfa", pre + ".gtf", None, **_flags_to_opts(flags)))
+    assert sorted(engine_call(pre + ".gfa", pre + ".gtf", flags)) == want
+    # the search's three rooms (call_device.h frontier_search): the lane's 64 words, the workgroup's LDS, a slice of the arena --
+    # without the LDS, and with so little of it that the search outgrows it on its way
+    for words in ("0", "200"):
+        monkeypatch.setenv("PANTAS_CALL_LDS_FRONTIER", words)
+        assert sorted(engine_call(pre + ".gfa", pre + ".gtf", flags)) == want
 
 
 def test_sharded_call_driver_nccl_single_rank(tmp_path):
