@@ -64,6 +64,29 @@ def test_crash_inputs():
         assert ei.value.kind == c["exception"], c["name"]
 
 
+def test_two_failing_passes_report_the_first(tmp_path):
+    """The passes run side by side (call.hip run_call); the reference runs them in turn and dies in the first that fails.  A transcript the
+    GTF lacks (annotated pass) AND a novel link without RC (novel-link pass): the error is the annotated pass's, whichever lane is
+    through first -- and the novel-link pass's without the annotated pass.  The oracle says which is which."""
+    import re
+    from pantas_amd.engine import PantasError
+    d = os.path.join(GOLDEN, "synth_a")
+    gfa = open(f"{d}/expected.aug.gfa").read().splitlines()
+    k = next(i for i, l in enumerate(gfa) if l.startswith("L") and "ID:Z:N" in l)
+    gfa[k] = re.sub(r"\tRC:i:\d+", "", gfa[k])
+    gtf = [l for l in open(f"{d}/in.gtf").read().splitlines() if 'transcript_id "G10T1"' not in l]
+    open(tmp_path / "a.gfa", "w").write("\n".join(gfa) + "\n")
+    open(tmp_path / "a.gtf", "w").write("\n".join(gtf) + "\n")
+    for flags, word in ((["--novel", "--rca", "0"], "transcript"), (["--novel", "--rca", "0", "--no-annotated"], "RC")):
+        with pytest.raises(augment_oracle.ReferenceCrash) as want:
+            call_oracle.call(str(tmp_path / "a.gfa"), str(tmp_path / "a.gtf"), None, **_flags_to_opts(flags))
+        assert str(want.value).startswith("KeyError") and word in str(want.value)
+        for _ in range(4):
+            with pytest.raises(PantasError) as got:
+                engine_call(str(tmp_path / "a.gfa"), str(tmp_path / "a.gtf"), flags)
+            assert got.value.kind == "KeyError" and word in str(got.value), str(got.value)
+
+
 @pytest.mark.parametrize("seed,genes,lines,kw,flags", [
     (31, 120, 30000, {}, ["--rca", "2", "--novel", "--minintronsize", "30"]),
     (32, 60, 30000, dict(bubble_rate=0.15, p_novel_skip=0.1, p_novel_ce=0.06, p_intron=0.15, p_novel_ss=0.1),
