@@ -73,10 +73,11 @@ __global__ __launch_bounds__(256) void call_write_kernel(CallView c, const uint3
 // ---- evaluate once: count into a staging area per item, then move (call_host.h StageEmit) --------------------------------
 template <int PASS>
 __global__ __launch_bounds__(256) void call_stage_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx, uint32_t n, uint32_t* nrec, uint32_t* nword,
-                                                         uint32_t* ntask, uint8_t* fits, EventRec* stage_rec, uint32_t* stage_side, unsigned long long* status) {
+                                                         uint32_t* ntask, uint8_t* fits, EventRec* stage_rec, uint32_t* stage_side, unsigned long long* status,
+                                                         StagePool pool, uint32_t* chunk_of) {
   frontier_lds_init();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-    StageEmit e{stage_rec + size_t(i) * STAGE_RECS, stage_side + size_t(i) * STAGE_WORDS};
+    StageEmit e{stage_rec + size_t(i) * STAGE_RECS, stage_side + size_t(i) * STAGE_WORDS, pool};
     Fault f;
 #ifdef PANTAS_EXPERIMENTS
     // timing only (PANTAS_CALL_STAMPS): shader clocks per item into a log2 histogram behind the status word, the slowest item beside it
@@ -101,19 +102,21 @@ __global__ __launch_bounds__(256) void call_stage_kernel(CallView c, const uint3
     nrec[i] = e.recs;
     nword[i] = e.words;
     ntask[i] = e.tasks;
-    fits[i] = e.fits ? 1 : 0;
+    fits[i] = e.fits ? e.where : uint8_t(FITS_NO);
+    if (chunk_of) chunk_of[i] = e.chunk;
   }
 }
 
 template <int PASS>
 __global__ __launch_bounds__(256) void call_place_kernel(CallView c, const uint32_t* slots, const uint32_t* jidx, uint32_t n, const uint32_t* rec_off,
                                                          const uint32_t* word_off, const uint32_t* task_off, const uint8_t* fits, const EventRec* stage_rec,
-                                                         const uint32_t* stage_side, EventRec* recs, uint32_t* side, uint32_t* task_list) {
+                                                         const uint32_t* stage_side, EventRec* recs, uint32_t* side, uint32_t* task_list, StagePool pool,
+                                                         const uint32_t* chunk_of) {
   frontier_lds_init();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
     const uint32_t r0 = rec_off[i], nr = rec_off[i + 1] - r0;
     if (nr == 0) continue;
-    if (!fits[i]) {                               // more than the staging area holds: evaluated again, straight to its place
+    if (fits[i] == FITS_NO) {                     // more than the staging areas hold: evaluated again, straight to its place
       WriteEmit e{recs, side, r0, word_off[i], task_list, task_off[i]};
       Fault f;
       run_junction<PASS>(c, slots[i], jidx ? jidx[i] : 0u, e, f);
@@ -122,6 +125,8 @@ __global__ __launch_bounds__(256) void call_place_kernel(CallView c, const uint3
     const uint32_t w0 = word_off[i], nw = word_off[i + 1] - w0, t0 = task_off[i];
     const EventRec* sr = stage_rec + size_t(i) * STAGE_RECS;
     const uint32_t* ss = stage_side + size_t(i) * STAGE_WORDS;
+    if (fits[i] == FITS_MID) { sr = pool.mid_rec + size_t(chunk_of[i]) * STAGE_MID_RECS; ss = pool.mid_side + size_t(chunk_of[i]) * STAGE_MID_WORDS; }
+    else if (fits[i] == FITS_BIG) { sr = pool.big_rec + size_t(chunk_of[i]) * STAGE_BIG_RECS; ss = pool.big_side + size_t(chunk_of[i]) * STAGE_BIG_WORDS; }
     for (uint32_t k = 0; k < nr; ++k) {
       EventRec r = sr[k];
       r.side_off += w0;
@@ -640,17 +645,32 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
   uint8_t* d_fits = nullptr;
   EventRec* stage_rec = nullptr;
   uint32_t* stage_side = nullptr;
+  StagePool pool{};
+  uint32_t* chunk_of = nullptr;
   if (staged) {
     d_fits = static_cast<uint8_t*>(dev(n));
     stage_rec = static_cast<EventRec*>(dev(size_t(n) * STAGE_RECS * sizeof(EventRec)));
     stage_side = u32(size_t(n) * STAGE_WORDS);
+    if (!getenv("PANTAS_CALL_NO_STAGE_POOL")) {
+      // (PANTAS_CALL_STAGE_POOL = "mid,big" chunks: the tests' way to an exhausted pool)
+      uint32_t mid_n = std::min<uint32_t>(n, 65536u), big_n = std::min<uint32_t>(n, 1024u);      // 400 MB + 200 MB at whole-genome scale
+      if (const char* e = getenv("PANTAS_CALL_STAGE_POOL")) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2) { mid_n = std::min(mid_n, a); big_n = std::min(big_n, b); } }
+      pool.mid_n = mid_n; pool.big_n = big_n;
+      pool.mid_rec = static_cast<EventRec*>(dev(size_t(mid_n) * STAGE_MID_RECS * sizeof(EventRec)));
+      pool.mid_side = u32(size_t(mid_n) * STAGE_MID_WORDS);
+      pool.big_rec = static_cast<EventRec*>(dev(size_t(big_n) * STAGE_BIG_RECS * sizeof(EventRec)));
+      pool.big_side = u32(size_t(big_n) * STAGE_BIG_WORDS);
+      pool.taken = u32(2);
+      chunk_of = u32(n);
+      HIP_OK(hipMemsetAsync(pool.taken, 0, 8, d.stream));
+    }
   }
   HIP_OK(hipEventRecord(d.ev0, d.stream));
 #ifdef PANTAS_EXPERIMENTS
   CallView cs = c;
   cs.stamps = d.status + 43;
   if (getenv("PANTAS_CALL_STAMPS")) { cs.events |= getenv("PANTAS_CALL_STAMPS_FRONTIER") ? 0x4000u : 0x8000u; HIP_OK(hipMemsetAsync(d.status + 1, 0, 47 * 8, d.stream)); }
-  if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, cs, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status);
+  if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, cs, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status, pool, chunk_of);
   if (staged && getenv("PANTAS_CALL_STAMPS")) {
     unsigned long long h[47];
     HIP_OK(hipMemcpyAsync(h, d.status + 1, sizeof h, hipMemcpyDeviceToHost, d.stream));
@@ -677,7 +697,7 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
     fprintf(stderr, "[call stamps]   sections of the items with a row of more than 500 links, clocks summed: %llu %llu %llu %llu\n", h[42], h[43], h[44], h[45]);
   }
 #else
-  if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status);
+  if (staged) hipLaunchKernelGGL(call_stage_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d_fits, stage_rec, stage_side, d.status, pool, chunk_of);
 #endif
   else hipLaunchKernelGGL(call_count_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, nrec, nword, ntask, d.status);
   HIP_OK(hipGetLastError());
@@ -710,7 +730,7 @@ static void run_pass(PassLane& d, CallView c, const std::vector<uint32_t>& slots
   uint32_t* d_side = u32(totals[1]);
   uint32_t* d_tasks = u32(totals[2]);
   if (staged) hipLaunchKernelGGL(call_place_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, task_off, d_fits, stage_rec,
-                                 stage_side, d_recs, d_side, d_tasks);
+                                 stage_side, d_recs, d_side, d_tasks, pool, chunk_of);
   else hipLaunchKernelGGL(call_write_kernel<PASS>, dim3(blocks), dim3(256), 0, d.stream, c, d_slots, d_jidx, n, rec_off, word_off, task_off,
                      d_recs, d_side, d_tasks);
   HIP_OK(hipGetLastError());

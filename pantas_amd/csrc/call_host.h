@@ -124,27 +124,67 @@ struct CountEmit {
 // words) while it is counted; the write pass then only moves it to its scanned place.  An item that emits more than fits is
 // counted in full all the same (`fits` cleared) and evaluated a second time by the write pass, as every item was before.
 constexpr uint32_t STAGE_RECS = 4, STAGE_WORDS = 96;
+// Round 5: an item that outgrows its own area moves on to a chunk of a pool -- 64 records / 1 024 words, then 4 096 / 16 384 -- and
+// is still evaluated once; only an item that finds no chunk (or outgrows the large one) is evaluated again.  The items that did not
+// fit were the expensive ones: the junctions at rows of thousands of links write thousands of rows, and the second evaluation
+// was a tail as long as the first.
+constexpr uint32_t STAGE_MID_RECS = 64, STAGE_MID_WORDS = 1024, STAGE_BIG_RECS = 4096, STAGE_BIG_WORDS = 16384;
+struct StagePool {
+  EventRec* mid_rec; uint32_t* mid_side; uint32_t mid_n;       // mid_n chunks of STAGE_MID_RECS / STAGE_MID_WORDS
+  EventRec* big_rec; uint32_t* big_side; uint32_t big_n;
+  uint32_t* taken;                                             // [2]: chunks handed out (mid, big)
+};
+// what the stage kernel leaves per item: where its records stand
+enum : uint8_t { FITS_NO = 0, FITS_OWN = 1, FITS_MID = 2, FITS_BIG = 3 };
 struct StageEmit {
-  EventRec* rec;          // STAGE_RECS slots
-  uint32_t* side;         // STAGE_WORDS slots
+  EventRec* rec;          // cap_r slots
+  uint32_t* side;         // cap_w slots
+  StagePool pool;
+  uint32_t cap_r = STAGE_RECS, cap_w = STAGE_WORDS;
   uint32_t recs = 0, words = 0, tasks = 0;
+  uint32_t chunk = 0;     // of the pool, once where == FITS_MID / FITS_BIG
+  uint8_t where = FITS_OWN;
   bool fits = true;
+  // room for one more record / word: the next chunk up, with what is staged so far (an open record included)
+  PANTAS_HD bool grow() {
+    if (!fits || where == FITS_BIG || pool.taken == nullptr) return false;
+    const bool to_mid = where == FITS_OWN;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t k = atomicAdd(pool.taken + (to_mid ? 0 : 1), 1u);
+#else
+    const uint32_t k = pool.taken[to_mid ? 0 : 1]++;
+#endif
+    if (k >= (to_mid ? pool.mid_n : pool.big_n)) return false;
+    EventRec* nr = to_mid ? pool.mid_rec + size_t(k) * STAGE_MID_RECS : pool.big_rec + size_t(k) * STAGE_BIG_RECS;
+    uint32_t* ns = to_mid ? pool.mid_side + size_t(k) * STAGE_MID_WORDS : pool.big_side + size_t(k) * STAGE_BIG_WORDS;
+    const uint32_t nrec = recs < cap_r ? recs + 1u : cap_r;      // (the record that is open, if it has a slot)
+    for (uint32_t i = 0; i < nrec; ++i) nr[i] = rec[i];
+    const uint32_t nw = words < cap_w ? words : cap_w;
+    for (uint32_t i = 0; i < nw; ++i) ns[i] = side[i];
+    rec = nr; side = ns;
+    cap_r = to_mid ? STAGE_MID_RECS : STAGE_BIG_RECS;
+    cap_w = to_mid ? STAGE_MID_WORDS : STAGE_BIG_WORDS;
+    where = to_mid ? FITS_MID : FITS_BIG;
+    chunk = k;
+    return true;
+  }
   PANTAS_HD void begin(uint32_t type, uint32_t gene, uint32_t j0, uint32_t j1, uint32_t j2) {
-    if (recs < STAGE_RECS) {
-      EventRec& r = rec[recs];
-      r.type = type; r.gene = gene; r.j0 = j0; r.j1 = j1; r.j2 = j2; r.side_off = words; r.side_len = 0; r.mean = 0;
-    } else fits = false;
+    if (fits && recs >= cap_r && !grow()) fits = false;
+    if (!fits) return;
+    EventRec& r = rec[recs];
+    r.type = type; r.gene = gene; r.j0 = j0; r.j1 = j1; r.j2 = j2; r.side_off = words; r.side_len = 0; r.mean = 0;
   }
   PANTAS_HD void task() {
-    if (recs < STAGE_RECS) rec[recs].j1 = tasks;       // the item's own task ordinal; the write pass adds the item's task offset
+    if (fits) rec[recs].j1 = tasks;       // the item's own task ordinal; the write pass adds the item's task offset
     ++tasks;
   }
   PANTAS_HD void push(uint32_t w) {
-    if (words < STAGE_WORDS) side[words] = w; else fits = false;
+    if (fits && words >= cap_w && !grow()) fits = false;
+    if (fits) side[words] = w;
     ++words;
   }
   PANTAS_HD void end(uint32_t mean) {
-    if (recs < STAGE_RECS) {
+    if (fits) {
       EventRec& r = rec[recs];
       r.side_len = words - r.side_off;
       r.mean = mean;

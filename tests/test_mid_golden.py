@@ -173,3 +173,7 @@ def test_engine_walks_by_runs_equal_walks_by_steps(mid):
                            env={**os.environ, "PANTAS_CALL_NO_RUNS": "1", "PANTAS_CALL_NO_SHARE_BITS": "1", "PANTAS_CALL_SERIAL": "1"})
     assert runs.returncode == 0 and steps.returncode == 0, runs.stderr + steps.stderr
     assert runs.stdout == steps.stdout and runs.stdout.count("\nIR,") > 500
+    # the staging pool of the junction passes (call_host.h StageEmit): none, and one that runs out after three chunks
+    for pool in ({"PANTAS_CALL_NO_STAGE_POOL": "1"}, {"PANTAS_CALL_STAGE_POOL": "3,1"}):
+        alt = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env={**os.environ, **pool})
+        assert alt.returncode == 0 and alt.stdout == runs.stdout, alt.stderr
