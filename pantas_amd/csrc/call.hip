@@ -880,6 +880,25 @@ void run_call(DeviceCall& d, const Graph& g, const CallTables& t, const CallOpti
     if (bp) for (size_t i = 0; i < p.n_tasks; ++i) out.tasks[base[k][2] + i].path_off += bp;
   }
   pt.lap("offset fix-ups");
+  if (getenv("PANTAS_CALL_HIST")) {
+    // the walks: segments and path words (a run of consecutive segments is two words) of the longest, and how many are long
+    uint64_t longest = 0, words_longest = 0, n1k = 0, total = 0;
+    for (size_t i = 0; i < out.tasks.size(); ++i) {
+      const TaskOut& t = out.tasks[i];
+      if (t.status != 1) continue;
+      total += t.np;
+      if (t.np >= 1000) ++n1k;
+      if (t.np > longest) {
+        longest = t.np;
+        const size_t b = t.path_off;
+        size_t w = 0, seg = 0;
+        while (seg < t.np && b + w < out.paths.size()) { const uint32_t x = out.paths[b + w]; if (x & PATH_RANGE) { seg += out.paths[b + w + 1] - (x & ~PATH_RANGE) + 1; w += 2; } else { ++seg; ++w; } }
+        words_longest = w;
+      }
+    }
+    fprintf(stderr, "[call hist] walks: %zu tasks, %llu segments in all, longest %llu segments in %llu path words, %llu walks of 1000 segments or more\n", out.tasks.size(),
+            (unsigned long long)total, (unsigned long long)longest, (unsigned long long)words_longest, (unsigned long long)n1k);
+  }
 }
 
 // loads this file's code object ahead of its first real kernel (warm_up_device, on a thread beside the graph parse)
