@@ -316,6 +316,20 @@ PANTAS_HD bool walk_exon(const CallView& c, uint32_t start, uint32_t goal, Ok ok
     if (nxt == CNONE) { f.raise(CE_ASSERT_PATH); return false; }
     cur = nxt;
     if (--guard == 0) { f.raise(CE_HANG); return false; }
+    // The segment chosen at a fork is as a rule one allele of a bubble: no run begins there and one way leads on.  Its turn of the
+    // loop is taken HERE -- the same bookkeeping -- so that a bubble is one turn for every lane of the wave (lanes that take the
+    // fork's turn and the allele's turn out of step with each other pay for both every time).
+    if (c.run_end_rev && c.run_end_rev[c.V - 1u - cur] == cur && cur != goal) {
+      const uint32_t one2 = c.nxt1[cur];
+      if (one2 != CNONE) {
+        if (emit) emit->push(cur);
+        ++n_path;
+        if (c.nflags[cur] & N_HAS_NC) nc_sum += uint64_t(int64_t(c.nc[cur])); else nc_ok = false;
+        ln_sum += c.ln[cur];
+        cur = one2;
+        if (--guard == 0) { f.raise(CE_HANG); return false; }
+      }
+    }
   }
 }
 
