@@ -4,7 +4,7 @@ novel-link queue overflows into the inline insertion), indel-heavy reads (one-in
 (paths beyond the short-walk class), a handful of genes under a million reads (every lane of a wave on the same node, the 16-bit
 LDS fields near their bound), wide graphs with flat expression (node tables overflow into memory atomics), tiny batches of a
 streamed run, '~' ops planted in front of one cs in forty (their length leaks in from the line before).  The augmented GFAs must be
-the same file.
+the same file; since round 5 `pantas call` with drawn flags follows on every augmented GFA, against oracle/call_oracle.cpp (call_leg).
 
 PANTAS_FUZZ_RUNS=<n> draws n parameter sets instead of the four of the default run (a campaign of 40 was run at the end of round 2:
 profiles/r2_fuzz_cpp_oracle.txt)."""
@@ -81,7 +81,40 @@ def one(kind, kw, env, tmp):
     assert r.returncode == 0, what + r.stderr.decode()[-1500:]
     same = open(pre + ".gpu.gfa", "rb").read() == open(pre + ".or.gfa", "rb").read()
     assert same, what
-    return os.path.getsize(pre + ".gpu.gfa")
+    rows = call_leg(pre, random.Random(kw["seed"] + 1), what) if os.environ.get("PANTAS_FUZZ_CALL", "1") != "0" else None
+    return os.path.getsize(pre + ".gpu.gfa"), rows
+
+
+def call_leg(pre, rng, what):
+    """round 5: `pantas call` on the augmented GFA of the run, with drawn flags, against oracle/call_oracle.cpp -- the same rows as a
+    multiset (the oracle's 128-bit digest of the normalised rows), or the same exception where the reference raises.  The rows the
+    reads made thousands of links long (kind "hub"), the searches of rule R3 under small and large --isw, the staging pool, the
+    lists and masks made once per table set: every table and switch of DESIGN 3's call row meets graphs of other shapes here."""
+    import json
+    flags = ["--rca", str(rng.choice([0, 1, 3, 8])), "--isw", str(rng.choice([1, 2, 3, 5, 8])), "--minintronsize", str(rng.choice([1, 20, 100]))]
+    if rng.random() < 0.85:
+        flags.append("--novel")
+    if rng.random() < 0.15:
+        flags.append("--no-annotated")
+    if rng.random() < 0.3:          # (in front: the list takes every word up to the next option, as the reference's parser does)
+        flags = ["--events", *rng.sample(["ES", "SS", "IR"], rng.choice([1, 2]))] + flags
+    exe = os.path.join(ROOT, "oracle", "bin", "call_oracle_cpp")
+    what = f"{what} call {flags}"
+    with open(pre + ".gpu.csv", "wb") as f:
+        r = subprocess.run([sys.executable, "-m", "pantas_amd.call", *flags, pre + ".or.gfa", pre + ".gtf"], stdout=f, stderr=subprocess.PIPE, cwd=ROOT)
+    o = subprocess.run([exe, "--threads", "8", "--digest", "--no-out", *flags, pre + ".or.gfa", pre + ".gtf"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    if o.returncode != 0:           # the reference raises here: the same exception class, no rows compared
+        want = o.stderr.decode().strip().splitlines()[-1].split(":", 1)[0]
+        assert r.returncode != 0 and r.stderr.decode().strip().splitlines()[-1].startswith(want), what + r.stderr.decode()[-800:] + o.stderr.decode()[-800:]
+        return f"both raise {want}"
+    if r.returncode != 0 and r.stderr.decode().strip().splitlines()[-1].startswith("Unsupported"):
+        return "engine refuses: " + r.stderr.decode().strip().splitlines()[-1][:160]      # (DESIGN 4: inputs whose rows depend on the reference's hash order)
+    assert r.returncode == 0, what + r.stderr.decode()[-1500:]
+    want = json.loads(o.stderr.decode().strip().splitlines()[-1])
+    got = json.loads(subprocess.run([exe, "--threads", "8", "--digest-csv", pre + ".gpu.csv"], capture_output=True, check=True).stdout)
+    keys = ("rows", "s1", "s2", "x")
+    assert {k: got[k] for k in keys} == {k: want[k] for k in keys}, what + f" {got} {want}"
+    return f"{want['rows']} rows {' '.join(flags)}"
 
 
 def test_generated_workloads_against_the_cpp_oracle():
@@ -93,9 +126,9 @@ def test_generated_workloads_against_the_cpp_oracle():
         kind, kw, env = draw(rng)
         tmp = tempfile.mkdtemp(prefix="pantas_fuzz_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
         try:
-            size = one(kind, kw, env, tmp)
+            size, rows = one(kind, kw, env, tmp)
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
         if log:
             with open(log, "a") as f:
-                f.write(f"run {i}: {kind} same file ({size} bytes) {kw} {env}\n")
+                f.write(f"run {i}: {kind} same file ({size} bytes); call: {rows}; {kw} {env}\n")
