@@ -514,7 +514,7 @@ PANTAS_HD uint32_t frontier_search(const CallView& c, uint32_t start, uint32_t a
   // level order -- unlike the depth-first pop it replaced, which left a wide frontier quickly -- expands whole levels: a search that
   // meets a segment with thousands of links added by reads cost n^2 moves; 200 M reads: the novel-link pass 0.75 s instead of 0.2.)
   uint32_t local[FRONTIER_LOCAL];
-  uint32_t* buf = local;      // moves to an arena slice when it outgrows `local`
+  uint32_t* buf = local;      // moves to the workgroup's LDS, then to an arena slice, as it outgrows its room
   uint32_t cap = FRONTIER_LOCAL;
   struct Held {               // the LDS and the slice go back wherever the search ends
     uint32_t* arena; uint32_t slice, cap; bool lds;
