@@ -27,6 +27,13 @@ static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, Out&
     ntask[i + 1] = ntask[i] + e.tasks;
   }
   const size_t r0 = o.recs.size(), w0 = o.side.size(), t0 = o.tasks.size();
+  const bool stage_check = getenv("HOSTSIM_CALL_STAGE_CHECK") != nullptr;
+  const uint32_t MID_N = 48, BIG_N = 2;
+  std::vector<EventRec> mid_r(stage_check ? size_t(MID_N) * STAGE_MID_RECS : 0), big_r(stage_check ? size_t(BIG_N) * STAGE_BIG_RECS : 0);
+  std::vector<uint32_t> mid_w(stage_check ? size_t(MID_N) * STAGE_MID_WORDS : 0), big_w(stage_check ? size_t(BIG_N) * STAGE_BIG_WORDS : 0);
+  uint32_t taken[2] = {0, 0};
+  const StagePool pool{mid_r.data(), mid_w.data(), MID_N, big_r.data(), big_w.data(), BIG_N, taken};
+  size_t staged_items[4] = {0, 0, 0, 0};
   o.recs.resize(r0 + nrec.back());
   o.side.resize(w0 + nword.back());
   std::vector<uint32_t> task_list(ntask.back());
@@ -36,7 +43,32 @@ static void run_pass(const CallView& c, const std::vector<uint32_t>& slots, Out&
     Fault f;
     fn(c, slots[i], uint32_t(i), e, f);
     if (e.rec_i != nrec[i + 1] || e.word_i != nword[i + 1] || e.task_i != ntask[i + 1]) throw Error("InternalError", "count/write mismatch");
+    if (stage_check) {
+      // HOSTSIM_CALL_STAGE_CHECK=1: the item once more through the stage kernel's emitter (call_host.h StageEmit: its own four
+      // records, then chunks of a pool -- a small one here, so that some items find none): what it staged is what was written
+      EventRec own_r[STAGE_RECS];
+      uint32_t own_w[STAGE_WORDS];
+      StageEmit se{own_r, own_w, pool};
+      Fault f2;
+      fn(c, slots[i], uint32_t(i), se, f2);
+      if (se.recs != nrec[i + 1] - nrec[i] || se.words != nword[i + 1] - nword[i] || se.tasks != ntask[i + 1] - ntask[i]) throw Error("InternalError", "stage: counts differ");
+      if (se.fits) {
+        ++staged_items[se.where];
+        for (uint32_t k = 0; k < se.recs; ++k) {
+          const EventRec& a = se.rec[k];
+          const EventRec& b = o.recs[r0 + nrec[i] + k];
+          const bool task = rec_is_task(a.type);
+          if (a.type != b.type || a.gene != b.gene || a.j0 != b.j0 || a.j2 != b.j2 || a.side_len != b.side_len || a.mean != b.mean ||
+              a.side_off + nword[i] != b.side_off || (task ? a.j1 + ntask[i] != b.j1 : a.j1 != b.j1))
+            throw Error("InternalError", "stage: a staged record differs from the written one");
+        }
+        for (uint32_t k = 0; k < se.words; ++k)
+          if (se.side[k] != o.side[w0 + nword[i] + k]) throw Error("InternalError", "stage: a staged payload word differs");
+      } else ++staged_items[FITS_NO];
+    }
   }
+  if (stage_check) fprintf(stderr, "[hostsim stage check] %zu items: %zu evaluated again, %zu in their own area, %zu in a chunk of 64 records, %zu in a chunk of 4096\n", slots.size(),
+                           staged_items[FITS_NO], staged_items[FITS_OWN], staged_items[FITS_MID], staged_items[FITS_BIG]);
   // deferred walks: decide + measure, then write at the scanned offsets
   o.tasks.resize(t0 + task_list.size());
   std::vector<uint32_t> poff(task_list.size() + 1, 0);

@@ -294,6 +294,18 @@ def test_short_walk_node_summary_vs_piece_compaction():
     assert r.stdout.startswith("ok ") and " tiles" in r.stdout.splitlines()[0]
 
 
+def test_stage_emitter_against_the_write_emitter():
+    """call_host.h StageEmit (what the call stage kernels emit through, round 5: an item's own four records, then a chunk of 64 of a
+    pool, then one of 4 096, then "evaluate again") against WriteEmit on made-up items of every size around those steps, with a
+    pool, without one and with one that has run out: the same records and payload words wherever an item is staged."""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "hostsim_stage")
+    subprocess.check_call(CXX + ["-o", exe, os.path.join(ROOT, "tests/hostsim/hostsim_stage.cpp")])
+    r = run([exe])
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    assert r.stdout.startswith("evaluated again ")
+
+
 @pytest.mark.parametrize("seed", [5, 6])
 def test_walk_source_around_the_short_walk_bounds(hostsim, tmp_path, seed):
     """tests/long_path_case.py: paths of 27 .. 40 nodes (the short-walk class ends at 31, at 29 with an indel), one

@@ -157,11 +157,17 @@ def test_walks_by_runs_equal_walks_by_steps(hostsim, mid):
     walk that steps segment by segment (HOSTSIM_CALL_NO_RUNS=1) -- IR rows carry the whole path and its mean coverage"""
     flags = META["calls"][1]["flags"]
     cmd = [hostsim["call"], *flags, f"{mid}/expected.aug.gfa", f"{mid}/in.gtf"]
-    runs = subprocess.run(cmd, capture_output=True, text=True)
+    # (HOSTSIM_CALL_STAGE_CHECK: every item also goes through the stage kernel's emitter -- its own four records, then chunks of a pool
+    # that runs out here -- and what it staged is held against what was written: call_host.h StageEmit on the CPU)
+    runs = subprocess.run(cmd, capture_output=True, text=True, env={**os.environ, "HOSTSIM_CALL_STAGE_CHECK": "1"})
     steps = subprocess.run(cmd, capture_output=True, text=True, env={**os.environ, "HOSTSIM_CALL_NO_RUNS": "1", "HOSTSIM_CALL_NO_SHARE_BITS": "1"})
     assert runs.returncode == 0 and steps.returncode == 0, runs.stderr + steps.stderr
     assert runs.stdout == steps.stdout
     assert sum(1 for l in runs.stdout.splitlines() if l.startswith("IR,")) > 500
+    import re
+    checks = [tuple(map(int, m.groups())) for m in re.finditer(
+        r"stage check\] (\d+) items: (\d+) evaluated again, (\d+) in their own area, (\d+) in a chunk of 64 records, (\d+) in a chunk of 4096", runs.stderr)]
+    assert len(checks) >= 3 and sum(c[1] for c in checks) > 0 and sum(c[3] for c in checks) > 0, runs.stderr[-600:]
 
 
 @pytest.mark.gpu
